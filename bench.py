@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""bench.py -- FS-EEND frame-wise diarization forward on MI355X.
+
+One "step" = one pass of the hot path (OnlineTransformerDADiarization.test: causal encoder ->
+look-ahead conv -> attractor decoder -> head) over one batch of B synthetic 500-frame
+utterances already resident in HBM.  Metric = audio frames / s (1 frame = 100 ms of 8 kHz
+audio), whole job (all ranks).  Multi-GPU = utterances sharded over ranks, no data-path
+collective (weak scaling: per-GPU batch fixed).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+FS_CFG = dict(n_units=256, n_heads=4, enc_n_layers=4, dec_n_layers=2, dropout=0.1, has_mask=True,
+              max_seqlen=500, dec_dim_feedforward=2048, mask_delay=0)     # conf/spk_onl_tfm_enc_dec_nonautoreg.yaml
+PEAK_MFMA_TFLOPS = 2500.0     # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_launch(name, shape, T):
+    """Algorithmic flops of one launch."""
+    if name == "attn_causal":          # 2*D*T*(T+1) causal-useful flops per sequence, D = H*64
+        nseq, H = shape
+        return nseq * 2.0 * (H * 64) * T * (T + 1)
+    if name in ("linear", "linear_res_ln", "linear_res_scale", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
+        M, N, K = shape
+        return 2.0 * M * N * K
+    return 0.0
+
+
+class OpTimer:
+    """Brackets every C-ABI call with HIP events on the launch stream (instrumented steps only)."""
+
+    def __init__(self, ops_mod, T):
+        self.ops, self.T, self.rec, self.orig = ops_mod, T, [], {}
+
+    def _wrap(self, name, fn):
+        def w(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            if name == "attn_causal":
+                shape = (a[4], a[5])
+            elif name in ("linear", "linear_res_ln", "linear_res_scale"):
+                shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
+            elif name == "inproj_heads":
+                shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
+            elif name == "convert_fanout":
+                shape = (a[0].shape[0], 256, 256)
+            elif name == "conv1d_l2norm":
+                shape = (a[0].shape[0], 256, a[1].shape[1])
+            else:
+                shape = ()
+            self.rec.append((name, shape, s, e))
+            return r
+        return w
+
+    def __enter__(self):
+        for n in ("bn_cast_pad", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+                  "convert_fanout", "attn_causal", "spk_attn", "head_l2dot"):
+            self.orig[n] = getattr(self.ops, n)
+            setattr(self.ops, n, self._wrap(n, self.orig[n]))
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.ops, n, f)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, shape, s, e in self.rec:
+            key = (name, shape)
+            d = agg.setdefault(key, [0.0, 0])
+            d[0] += s.elapsed_time(e)
+            d[1] += 1
+        out = []
+        for (name, shape), (ms, n) in agg.items():
+            fl = flops_per_launch(name, shape, self.T)
+            out.append(dict(kernel=name, shape=list(shape), launches=n, avg_ms=ms / n, total_ms=ms,
+                            tflops=(fl / (ms / n * 1e-3) / 1e12) if fl else None))
+        return sorted(out, key=lambda d: -d["total_ms"])
+
+
+def cpu_baseline(T, C, threads, batch=16, warm=2, runs=5):
+    """The oracle (CPU restatement of the reference, validated against it) timed on the host cores."""
+    from oracle import fs_eend_ref as R
+    from fs_eend_amd.fs_model import OnlineTransformerDADiarization
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **FS_CFG).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(777)
+    src = [torch.randn(T, 345, generator=g) * 2 - 3 for _ in range(batch)]
+    ts = []
+    with torch.no_grad():
+        for i in range(warm + runs):
+            t0 = time.perf_counter()
+            R.fs_test(src, [T] * batch, sd, n_heads=4, enc_n_layers=4, dec_n_layers=2, max_nspks=C)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return dict(value=batch * T / med, unit="frames/s", cores=threads, kind="port",
+                sample=f"oracle fs_test fp32, B={batch} x T={T}, C={C}, median of {runs} after {warm} warm-up "
+                       f"({sum(ts):.1f} s timed)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--slots", type=int, default=6, help="speaker slots C = data.max_speakers + 2")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from fs_eend_amd import build as _build, ops
+    if rank == 0:
+        _build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from fs_eend_amd.fs_model import OnlineTransformerDADiarization
+
+    B, T, C = args.batch, args.frames, args.slots
+    torch.manual_seed(0)
+    model = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **FS_CFG).eval().to(dev)
+    g = torch.Generator().manual_seed(777 + rank)
+    src = [(torch.randn(T, 345, generator=g) * 2 - 3).to(dev) for _ in range(B)]      # resident in HBM
+    ilens = [T] * B
+
+    def step():
+        return model.test(src, ilens, C)
+
+    step()                                       # allocate the workspace, prepare f16 weights
+    torch.cuda.synchronize()
+    run = step
+    graph_used = False
+    if args.graph:
+        try:
+            gr = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(gr):
+                static_out = step()
+            run = gr.replay
+            graph_used = True
+        except Exception as e:                   # capture is an optimisation of launch overhead only
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            run = step
+
+    for _ in range(args.warmup):
+        run()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames_per_step = world * B * T
+    value = frames_per_step * args.steps / dt
+
+    out = {
+        "metric": "audio frames/sec (T=500 chunks)", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "dtype_detail": "QK^T/PV bf16 MFMA; linear layers + conv f16 MFMA; fp32 accumulate, residual, LayerNorm, softmax",
+        "data": "synthetic",
+        "config": {"workload": f"FS-EEND conf/spk_onl_tfm_enc_dec_nonautoreg.yaml model.test: {B} utterances/GPU x "
+                               f"T={T} frames x 345 log-mel, d_model 256, 4 heads, 4 enc + 2 dec layers, "
+                               f"max_nspks={C}, random init (seed 0), eval",
+                   "batch_per_gpu": B, "frames": T, "speaker_slots": C, "parallelism": f"utterance-sharded x{world}",
+                   "launch": "hipGraph replay" if graph_used else "eager ctypes launches"},
+        "rtf": dt / args.steps / (B * T * 0.1),
+    }
+
+    if rank == 0 and not args.no_breakdown:
+        with OpTimer(ops, T) as tm:
+            for _ in range(3):
+                step()
+            ksum = tm.summary()
+        tot = sum(k["total_ms"] for k in ksum)
+        out["kernel_breakdown"] = [dict(kernel=k["kernel"], shape=k["shape"], launches_per_step=k["launches"] // 3,
+                                        avg_ms=round(k["avg_ms"], 4), share=round(k["total_ms"] / tot, 4),
+                                        tflops=None if k["tflops"] is None else round(k["tflops"], 1))
+                                   for k in ksum]
+        dom = next(k for k in ksum if k["tflops"] is not None)
+        fl = flops_per_launch(dom["kernel"], tuple(dom["shape"]), T)
+        out["roofline"] = {"kernel": f"{dom['kernel']} {dom['shape']}", "bound": "mfma",
+                           "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                           "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+        att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
+        if att:
+            a = att[0]
+            fl = flops_per_launch("attn_causal", tuple(a["shape"]), T)
+            byt = a["shape"][0] * 4.0 * T * 256 * 2            # Q,K,V read + O written once, 2-byte elements
+            out["roofline_attention"] = {
+                "kernel": f"encoder attn_causal nseq={a['shape'][0]} H=4 T={T}", "bound": "mfma",
+                "achieved": fl / (a["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                "hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9, "hbm_frac": byt / (a["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": None, "avg_launch_ms": a["avg_ms"]}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(T, C, threads=os.cpu_count() or 1)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

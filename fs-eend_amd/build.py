@@ -1,0 +1,57 @@
+"""Build libeend_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery:
+the library is a plain C-ABI shared object loaded with ctypes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["gemm.hip", "attn.hip", "misc.hip", "retention.hip", "api.hip"]
+LIB = os.path.join(CSRC, "libeend_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "eend_hip.h"))
+    objs = [s[:-4] + ".o" for s in srcs]
+    hipcc = _hipcc()
+
+    def cc(pair):
+        src, obj = pair
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        list(ex.map(cc, zip(srcs, objs)))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,113 @@
+// C-ABI shim: validates arguments, fills the launch structs, forwards to the kernels.
+// The exported surface is exactly include/eend_hip.h.
+#include "../../include/eend_hip.h"
+#include "kernels.h"
+#include <string.h>
+
+namespace {
+GemmParams base_params(const void* A, int lda, const void* W, int ldw, const float* bias, int M, int N, int K) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.ldo = N; p.Tp = 64; p.H = 4; p.dh = 64; p.C = 1;
+    p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0;
+    return p;
+}
+}  // namespace
+
+extern "C" {
+
+int eend_abi_version(void) { return 1; }
+
+int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                         const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,
+                         int Fpad, int apply_bn, void* stream) {
+    if (!x || !out_f16 || (Tp % 64) != 0 || (Fpad % 64) != 0) return EEND_EINVAL;
+    if (apply_bn && (!bn_weight || !bn_bias || !bn_mean || !bn_var)) return EEND_EINVAL;
+    return eend_launch_bn_cast_pad(x, bn_weight, bn_bias, bn_mean, bn_var, eps, out_f16, B, T, Tp, Fin, Fpad,
+                                   apply_bn, (hipStream_t)stream);
+}
+
+int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
+                    int M, int N, int K, int relu, void* stream) {
+    if (!A || !W || !out_f16 || (ldo & 3)) return EEND_EINVAL;
+    GemmParams p = base_params(A, lda, W, ldw, bias, M, N, K);
+    p.out16 = out_f16; p.ldo = ldo;
+    return eend_launch_gemm(p, relu ? EPI_PLAIN_RELU_F16 : EPI_PLAIN_F16, (hipStream_t)stream);
+}
+
+int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* Q_bf16,
+                           void* K_bf16, void* Vt_bf16, int nseq, int Tp, int H, int dh, int K, void* stream) {
+    if (!A || !W || !bias || !Q_bf16 || !K_bf16 || !Vt_bf16) return EEND_EINVAL;
+    if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || dh != 64 || H <= 0 || ((H * dh) % 128) != 0) return EEND_EINVAL;
+    const int D = H * dh;
+    GemmParams p = base_params(A, lda, W, ldw, bias, nseq * Tp, 2 * D, K);
+    p.Tp = Tp; p.H = H; p.dh = dh; p.out16 = Q_bf16; p.out16b = K_bf16;
+    int rc = eend_launch_gemm(p, EPI_QK_HEADS, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    GemmParams v = base_params(A, lda, (const char*)W + (size_t)2 * D * ldw * 2, ldw, bias + 2 * D, nseq * Tp, D, K);
+    v.Tp = Tp; v.H = H; v.dh = dh; v.out16 = Vt_bf16;
+    return eend_launch_gemm(v, EPI_VT_HEADS, (hipStream_t)stream);
+}
+
+int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
+                           const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16,
+                           int M, int K, void* stream) {
+    if (!A || !W || (!out_f32 && !out_f16) || ((gamma == nullptr) != (beta == nullptr))) return EEND_EINVAL;
+    GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
+    p.res = res; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
+    return eend_launch_gemm(p, EPI_RES_LN, (hipStream_t)stream);
+}
+
+int eend_linear_res_scale_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                              const float* res, float alpha, float* out_f32, void* out_f16, int M, int K,
+                              void* stream) {
+    if (!A || !W || (!out_f32 && !out_f16)) return EEND_EINVAL;
+    GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
+    p.res = res; p.alpha = alpha; p.out32 = out_f32; p.out16 = out_f16;
+    return eend_launch_gemm(p, EPI_RES_SCALE, (hipStream_t)stream);
+}
+
+int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, const int* ilens, float* out_f32,
+                           void* out_f16, int nseq, int Tp, int cin, int ktaps, int pad, void* stream) {
+    if (!X || !Wr || !ilens || (!out_f32 && !out_f16)) return EEND_EINVAL;
+    if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || cin <= 0 || (cin % 64) != 0 || ktaps <= 0 || pad < 0 ||
+        pad >= ktaps)
+        return EEND_EINVAL;
+    GemmParams p = base_params(X, cin, Wr, ktaps * cin, bias, nseq * Tp, 256, ktaps * cin);
+    p.Tp = Tp; p.ilens = ilens; p.conv_cin = cin; p.conv_pad = pad; p.out32 = out_f32; p.out16 = out_f16;
+    return eend_launch_gemm(p, EPI_L2NORM, (hipStream_t)stream);
+}
+
+int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
+                            int B, int Tp, int C, void* stream) {
+    if (!E || !W1 || !pc || !out_f32 || !out_f16 || B <= 0 || C <= 0 || Tp <= 0 || (Tp % 64) != 0)
+        return EEND_EINVAL;
+    GemmParams p = base_params(E, 256, W1, 256, nullptr, B * Tp, 256, 256);
+    p.Tp = Tp; p.C = C; p.pc = pc; p.out32 = out_f32; p.out16 = out_f16;
+    return eend_launch_gemm(p, EPI_CONVERT, (hipStream_t)stream);
+}
+
+int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, int nseq, int H, int Tp,
+                          int ldo, int mask_delay, int kv_len, float scale, void* stream) {
+    if (!Q || !K || !Vt || !O_f16 || nseq > 65535 || H > 65535) return EEND_EINVAL;
+    AttnParams p;
+    p.Q = Q; p.K = K; p.Vt = Vt; p.O = O_f16; p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo;
+    p.mask_delay = mask_delay; p.kv_len = kv_len; p.scale_log2 = scale * 1.4426950408889634f;
+    return eend_launch_attn_causal(p, (hipStream_t)stream);
+}
+
+int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale, void* stream) {
+    if (!qkv || !O_f16) return EEND_EINVAL;
+    SpkAttnParams p;
+    p.qkv = qkv; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.H = H; p.scale = scale;
+    return eend_launch_spk_attn(p, (hipStream_t)stream);
+}
+
+int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
+                        int Tp, int C, int D, void* stream) {
+    if (!emb || !attr || !attr_out || !logits) return EEND_EINVAL;
+    return eend_launch_head(emb, attr, attr_out, logits, B, T, Tp, C, D, (hipStream_t)stream);
+}
+
+}  // extern "C"

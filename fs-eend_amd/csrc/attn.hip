@@ -1,0 +1,273 @@
+// Fused causal multi-head attention (QK^T -> index-predicate mask -> online
+// softmax -> PV) on bf16 MFMA, for the time axis of the FS-EEND encoder
+// (nn.TransformerEncoderLayer, model :147) and attractor decoder (_sa_block1,
+// modules/merge_tfm_encoder.py:379-385).  dh = 64.
+//
+// Everything is computed transposed so that one lane owns one query row:
+//   S^T = K Q^T   : v_mfma_f32_32x32x16_bf16(A = K tile, B = Q^T) -> lane (q, hi) holds 16 keys
+//   O^T = V^T P^T : v_mfma_f32_32x32x16_bf16(A = V^T tile, B = P^T) -> lane (q, hi) holds 16 d's
+// so the running max / sum / rescale are per-lane scalars (one cross-lane step
+// with lane^32), P is fed back as the B operand straight from registers, and V
+// arrives pre-transposed ([d][t], written by the in-proj GEMM epilogue).  K rows
+// are fed with bits 2<->3 of the row index swapped, which makes the 8 keys a
+// lane holds per k-step contiguous (keys 8*hi..8*hi+7), so the matching V^T
+// fragment is a single ds_read_b128.
+//
+// The {0,-inf} (T,T) mask tensor of the reference (model :107-110,:152-155) is
+// never materialised: allowed(i,j) <=> j - i <= mask_delay is evaluated on the
+// indices (and j < kv_len), only in tiles that straddle the boundary; fully masked tiles are
+// skipped (that is the "causal-useful" 2*D*T*(T+1) flop count).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int QB = 128;   // query rows per workgroup (4 waves x 32)
+constexpr int KB = 64;    // keys per LDS tile
+constexpr int TILE = KB * 128;   // bytes of one [64][64] bf16 tile
+
+DEV int swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+__global__ __launch_bounds__(256)
+void attn_causal_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], Vt[2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqt = (p.Tp + QB - 1) / QB;
+    const int qt = nqt - 1 - (int)blockIdx.x;            // heavy (late) query tiles first
+    const int h = blockIdx.y, seq = blockIdx.z;
+    const int q0 = qt * QB;
+    const int qw0 = q0 + wave * 32;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int q = qw0 + lq;
+    const int qc = q < p.Tp ? q : p.Tp - 1;
+
+    const size_t sh = (size_t)seq * p.H + h;
+    const __bf16* __restrict__ Qg = (const __bf16*)p.Q + sh * p.Tp * 64;
+    const __bf16* __restrict__ Kg = (const __bf16*)p.K + sh * p.Tp * 64;
+    const __bf16* __restrict__ Vg = (const __bf16*)p.Vt + sh * 64 * p.Tp;
+
+    int last_key = q0 + QB - 1 + p.mask_delay;
+    last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
+    const int ntiles = last_key < 0 ? 0 : last_key / KB + 1;
+
+    // Q^T fragments (B operand of S^T): elems j <-> d = ks*16 + hi*8 + j
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qc * 64 + ks * 16 + hi * 8);
+
+    // register staging of the next K / V^T tile (two 16-B chunks of each per thread)
+    uint4 kr0, kr1, vr0, vr1;
+    const int c0row = tid >> 3, c0ch = tid & 7, c1row = (tid + 256) >> 3;
+#define ATT_GLOAD(j)                                                                  \
+    do {                                                                              \
+        kr0 = *(const uint4*)(Kg + (size_t)((j) * KB + c0row) * 64 + c0ch * 8);       \
+        kr1 = *(const uint4*)(Kg + (size_t)((j) * KB + c1row) * 64 + c0ch * 8);       \
+        vr0 = *(const uint4*)(Vg + (size_t)c0row * p.Tp + (j) * KB + c0ch * 8);       \
+        vr1 = *(const uint4*)(Vg + (size_t)c1row * p.Tp + (j) * KB + c0ch * 8);       \
+    } while (0)
+#define ATT_LSTORE(buf)                                                               \
+    do {                                                                              \
+        *(uint4*)(smem + (buf) * TILE + swz128(c0row, c0ch)) = kr0;                   \
+        *(uint4*)(smem + (buf) * TILE + swz128(c1row, c0ch)) = kr1;                   \
+        *(uint4*)(smem + (2 + (buf)) * TILE + swz128(c0row, c0ch)) = vr0;             \
+        *(uint4*)(smem + (2 + (buf)) * TILE + swz128(c1row, c0ch)) = vr1;             \
+    } while (0)
+
+    f32x16 oT[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (ntiles > 0) {
+        ATT_GLOAD(0);
+        ATT_LSTORE(0);
+    }
+    __syncthreads();
+
+    const int krow = swap23(lq);
+    for (int j = 0; j < ntiles; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < ntiles) ATT_GLOAD(j + 1);
+        const int key0 = j * KB;
+        // wave-uniform: does any (q, key) pair of this wave x tile pass the mask?
+        if (key0 <= qw0 + 31 + p.mask_delay) {
+            const char* kb_ = smem + buf * TILE;
+            const char* vb_ = smem + (2 + buf) * TILE;
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                }
+            }
+            // reg i of s[kb] in lane (q, hi) <-> key = key0 + kb*32 + (i&7) + 8*hi + 16*(i>>3)
+            const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
+            const bool diag = key0 + KB - 1 > wlim;                 // some element may be masked
+            if (diag) {
+                const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
+                        if (key > lim) s[kb][i] = -INFINITY;
+                    }
+            }
+            float tmax = s[0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[1][i]);
+            tmax = wave_xor_max(tmax, 32);
+            const float m_new = __builtin_fmaxf(m_run, tmax * p.scale_log2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], p.scale_log2, -m_use));
+                    s[kb][i] = pv;
+                    lsum += pv;
+                }
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
+            // P^T fragments (B operand of O^T): elem j of k-step (kb,kk) = reg kk*8 + j
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][kk * 8 + jj];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(db * 32 + lq, kb * 4 + kk * 2 + hi));
+                        oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                    }
+                }
+        }
+        if (j + 1 < ntiles) ATT_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // O[q][h*64 + d] = O^T[d][q] / l ; reg i of oT[db] <-> d = db*32 + 8*(i>>2) + 4*hi + (i&3)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (q < p.Tp) {
+        const float inv = 1.0f / l_tot;
+        _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * p.Tp + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 o;
+                o[0] = to_f16_sat(oT[db][g * 4 + 0] * inv);
+                o[1] = to_f16_sat(oT[db][g * 4 + 1] * inv);
+                o[2] = to_f16_sat(oT[db][g * 4 + 2] * inv);
+                o[3] = to_f16_sat(oT[db][g * 4 + 3] * inv);
+                *(f16x4*)(Og + db * 32 + g * 8 + hi * 4) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Speaker-axis attention (_sa_block2, modules/merge_tfm_encoder.py:388-394): unmasked MHA
+// over the C <= 16 attractor slots of ONE frame.  C*C*dh is far too small for the matrix
+// pipe and the op is bound by reading qkv once, so: one wave per frame, lane = (head,
+// 4-wide d slice), K and V of all slots live in registers, scores are reduced inside each
+// 16-lane row with DPP, softmax + PV in registers.  Rows of the (b,c)-major slab are
+// gathered with stride Tp -- no physical transpose between the time and speaker stages.
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256)
+void spk_attn_kernel(const SpkAttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long frame = (long)blockIdx.x * 4 + wave;       // b*Tp + t
+    const long nframes = (long)p.B * p.Tp;
+    if (frame >= nframes) return;
+    const int b = (int)(frame / p.Tp), t = (int)(frame - (long)b * p.Tp);
+    const int D = p.H * 64;
+    const int col = lane * 4;                              // (head = lane>>4, d = (lane&15)*4)
+    const _Float16* __restrict__ base = (const _Float16*)p.qkv;
+    _Float16* __restrict__ out = (_Float16*)p.O;
+
+    float kf[C][4], vf[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t row = ((size_t)b * C + c) * p.Tp + t;
+        const f16x4 k4 = *(const f16x4*)(base + row * 3 * D + D + col);
+        const f16x4 v4 = *(const f16x4*)(base + row * 3 * D + 2 * D + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kf[c][e] = (float)k4[e]; vf[c][e] = (float)v4[e]; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t row = ((size_t)b * C + c) * p.Tp + t;
+        const f16x4 q4 = *(const f16x4*)(base + row * 3 * D + col);
+        float s[C];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c2 = 0; c2 < C; ++c2) {
+            float d = (float)q4[0] * kf[c2][0];
+            d = __builtin_fmaf((float)q4[1], kf[c2][1], d);
+            d = __builtin_fmaf((float)q4[2], kf[c2][2], d);
+            d = __builtin_fmaf((float)q4[3], kf[c2][3], d);
+            s[c2] = row16_allreduce_add(d) * p.scale;
+            mx = __builtin_fmaxf(mx, s[c2]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < C; ++c2) { s[c2] = __expf(s[c2] - mx); den += s[c2]; }
+        const float inv = 1.0f / den;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c2 = 0; c2 < C; ++c2) {
+            const float pw = s[c2] * inv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(pw, vf[c2][e], o[e]);
+        }
+        f16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = to_f16_sat(o[e]);
+        *(f16x4*)(out + row * D + col) = o4;
+    }
+}
+
+template <int C>
+int launch_spk(const SpkAttnParams& p, hipStream_t stream) {
+    const long nframes = (long)p.B * p.Tp;
+    hipLaunchKernelGGL(spk_attn_kernel<C>, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+}  // namespace
+
+int eend_launch_attn_causal(const AttnParams& p, hipStream_t stream) {
+    if (p.nseq <= 0 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || (p.ldo & 3) || p.kv_len <= 0 || p.kv_len > p.Tp)
+        return EEND_EINVAL;
+    const int nqt = (p.Tp + QB - 1) / QB;
+    hipLaunchKernelGGL(attn_causal_kernel, dim3(nqt, p.H, p.nseq), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_spk_attn(const SpkAttnParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.Tp <= 0 || p.H != 4) return EEND_EINVAL;    // lane map assumes 4 heads x 64
+    switch (p.C) {
+#define SPK_CASE(n) case n: return launch_spk<n>(p, stream);
+        SPK_CASE(1) SPK_CASE(2) SPK_CASE(3) SPK_CASE(4) SPK_CASE(5) SPK_CASE(6) SPK_CASE(7) SPK_CASE(8)
+        SPK_CASE(9) SPK_CASE(10) SPK_CASE(11) SPK_CASE(12)
+#undef SPK_CASE
+        default: return EEND_EINVAL;
+    }
+}

@@ -1,0 +1,59 @@
+// Shared device-side helpers for the gfx950 (CDNA4 / MI355X) EEND kernels.
+// wave = 64 lanes, MFMA 16x16x32 (f16 linears) and 32x32x16 (bf16 attention).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define EEND_OK 0
+#define EEND_EINVAL (-1)
+#define EEND_ELAUNCH (-2)
+
+#define DEV __device__ __forceinline__
+
+// fp16 saturating round-to-nearest conversion (keeps +-inf out of the f16 MFMA operands)
+DEV _Float16 to_f16_sat(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
+    return (_Float16)x;
+}
+
+// Byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][128 B] LDS tile.
+// XOR swizzle with (row>>1)&7: any 16 distinct consecutive-ish rows reading the
+// same logical chunk hit 16 distinct 16-B slots of the 256-B bank row, so the
+// ds_read_b128 of an MFMA fragment (16x16x32: lane = row, 32x32x16: lane&31 =
+// row) is conflict-free; ds_write_b128 of a contiguous row is conflict-free too.
+DEV int swz128(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+
+DEV float wave_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
+DEV float wave_xor_max(float v, int m) { return __builtin_fmaxf(v, __shfl_xor(v, m, 64)); }
+
+// All-reduce (sum) inside each aligned group of 16 lanes with DPP moves
+// (quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror).
+DEV float row16_allreduce_add(float v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false);
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false);
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false);
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false);
+    v += __builtin_bit_cast(float, t);
+    return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: hardware places block b on XCD
+// b % 8; give each XCD one contiguous range of logical tile ids so tiles that
+// share an activation panel are served by the same (non-coherent) 4 MiB L2.
+DEV int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,402 @@
+// Y = epilogue(X[M,K] * W[N,K]^T): the dense linear layers of the EEND hot path
+// on f16 MFMA (v_mfma_f32_16x16x32_f16, fp32 accumulate).
+//
+// Both operands are K-contiguous, so both MFMA fragments are one ds_read_b128
+// per lane out of XOR-swizzled [rows][64-elem] LDS tiles.  Global -> register
+// -> LDS staging is double buffered (loads of k-tile i+1 are in flight while
+// k-tile i feeds the matrix pipe, one barrier per k-tile).
+//
+// SWAP=true feeds W as the MFMA "A" operand, so a lane owns 4 *consecutive
+// output features* of one token: row-major outputs are written as 8-byte
+// (f16x4) / 16-byte (float4) pieces and per-token LayerNorm / L2-norm
+// statistics are lane-local + 2 cross-lane steps.  SWAP=false gives a lane 4
+// consecutive *tokens* of one feature, which is exactly the transposed V layout
+// ([seq][head][d][t]) the attention kernel wants -- the layout change is fused
+// into the producer's epilogue instead of being a kernel of its own.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1 };
+
+template <class OT> struct OutCvt;
+template <> struct OutCvt<_Float16> {
+    static DEV f16x4 cvt(float a, float b, float c, float d) {
+        f16x4 r; r[0] = to_f16_sat(a); r[1] = to_f16_sat(b); r[2] = to_f16_sat(c); r[3] = to_f16_sat(d); return r;
+    }
+};
+template <> struct OutCvt<__bf16> {
+    static DEV bf16x4 cvt(float a, float b, float c, float d) {
+        bf16x4 r; r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d; return r;
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
+__global__ __launch_bounds__(WGM * WGN * 64)
+void gemm_f16_kernel(const GemmParams p) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int WR = SWAP ? WN : WM;          // wave extent along MFMA rows (register dim)
+    constexpr int WL = SWAP ? WM : WN;          // wave extent along MFMA cols (lane dim)
+    constexpr int FR = WR / 16, FL = WL / 16;
+    constexpr int XCH = BM * 8 / NT;            // 16-B chunks of the X tile per thread
+    constexpr int WCH = BN * 8 / NT;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int ntn = p.N / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (L / ntn) * BM;
+    const int n0 = (L % ntn) * BN;
+    const int nk = p.K >> 6;
+
+    const _Float16* __restrict__ A = (const _Float16*)p.A;
+    const _Float16* __restrict__ W = (const _Float16*)p.W;
+
+    // ---- per-thread staging coordinates --------------------------------------------------
+    uint4 xr[XCH], wr[WCH];
+    const _Float16* xsrc[XCH];
+    int xseq_t[XCH];            // conv: frame index t inside its slab
+    int xilen[XCH];             // conv: valid length of that sequence
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int q = tid + i * NT;
+        int m = m0 + (q >> 3);
+        m = m < p.M ? m : p.M - 1;
+        if (ALOAD == ALOAD_CONV) {
+            const int seq = m / p.Tp;
+            xseq_t[i] = m - seq * p.Tp;
+            xilen[i] = p.ilens[seq];
+            xsrc[i] = A + (size_t)seq * p.Tp * p.lda + (q & 7) * 8;
+        } else {
+            xsrc[i] = A + (size_t)m * p.lda + (q & 7) * 8;
+        }
+    }
+    const _Float16* wsrc[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int q = tid + i * NT;
+        wsrc[i] = W + (size_t)(n0 + (q >> 3)) * p.ldw + (q & 7) * 8;
+    }
+
+    // (macros, not lambdas: by-reference closures over the staging arrays end up in scratch)
+#define GEMM_GLOAD(kt_)                                                                          \
+    do {                                                                                         \
+        const int kt__ = (kt_);                                                                  \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                        \
+            if (ALOAD == ALOAD_CONV) {                                                           \
+                /* implicit GEMM for Conv1d: k-tile kt covers input channels cin0..cin0+63 of   \
+                   tap `tap`; source frame t + tap - pad, zero outside [0, ilen) (reference:    \
+                   truncate to ilen, zero re-pad, then the conv's own zero padding). */         \
+                const int kpt = p.conv_cin >> 6;                                                 \
+                const int tap = kt__ / kpt;                                                      \
+                const int cin0 = (kt__ - tap * kpt) << 6;                                        \
+                const int ts = xseq_t[i] + tap - p.conv_pad;                                     \
+                if (ts >= 0 && ts < xilen[i])                                                    \
+                    xr[i] = *(const uint4*)(xsrc[i] + (size_t)ts * p.lda + cin0);                \
+                else                                                                             \
+                    xr[i] = make_uint4(0, 0, 0, 0);                                              \
+            } else {                                                                             \
+                xr[i] = *(const uint4*)(xsrc[i] + kt__ * 64);                                    \
+            }                                                                                    \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i) wr[i] = *(const uint4*)(wsrc[i] + kt__ * 64); \
+    } while (0)
+#define GEMM_LSTORE(buf_)                                                                        \
+    do {                                                                                         \
+        char* xb__ = smem + (buf_) * TILE_BYTES;                                                 \
+        char* wb__ = xb__ + BM * 128;                                                            \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                        \
+            const int q = tid + i * NT;                                                          \
+            *(uint4*)(xb__ + swz128(q >> 3, q & 7)) = xr[i];                                     \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                        \
+            const int q = tid + i * NT;                                                          \
+            *(uint4*)(wb__ + swz128(q >> 3, q & 7)) = wr[i];                                     \
+        }                                                                                        \
+    } while (0)
+
+    f32x4 acc[FR][FL];
+#pragma unroll
+    for (int i = 0; i < FR; ++i)
+#pragma unroll
+        for (int j = 0; j < FL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // tile-local row offsets of this wave's R (register-dim) and L (lane-dim) operands
+    const int r_tile_row0 = SWAP ? wn * WN : wm * WM;     // inside W tile if SWAP else X tile
+    const int l_tile_row0 = SWAP ? wm * WM : wn * WN;
+    const int frow = lane & 15, fkg = lane >> 4;
+
+    GEMM_GLOAD(0);
+    GEMM_LSTORE(0);
+    __syncthreads();
+
+#define GEMM_COMPUTE(buf_)                                                                       \
+    do {                                                                                         \
+        const char* xb__ = smem + (buf_) * TILE_BYTES;                                           \
+        const char* wb__ = xb__ + BM * 128;                                                      \
+        const char* rb__ = SWAP ? wb__ : xb__;                                                   \
+        const char* lb__ = SWAP ? xb__ : wb__;                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                       \
+            f16x8 rf[FR], lf[FL];                                                                \
+            _Pragma("unroll") for (int i = 0; i < FR; ++i)                                       \
+                rf[i] = *(const f16x8*)(rb__ + swz128(r_tile_row0 + i * 16 + frow, ks * 4 + fkg)); \
+            _Pragma("unroll") for (int j = 0; j < FL; ++j)                                       \
+                lf[j] = *(const f16x8*)(lb__ + swz128(l_tile_row0 + j * 16 + frow, ks * 4 + fkg)); \
+            _Pragma("unroll") for (int i = 0; i < FR; ++i)                                       \
+                _Pragma("unroll") for (int j = 0; j < FL; ++j)                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf[i], lf[j], acc[i][j], 0, 0, 0); \
+        }                                                                                        \
+    } while (0)
+
+    // k-tile kt+1 is in flight (registers) while k-tile kt feeds the matrix pipe; the last
+    // k-tile is peeled so the steady-state body has no conditionals.
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        const int buf = kt & 1;
+        GEMM_GLOAD(kt + 1);
+        GEMM_COMPUTE(buf);
+        GEMM_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+    GEMM_COMPUTE((nk - 1) & 1);
+    __syncthreads();
+
+    // ---- epilogues -----------------------------------------------------------------------
+    // acc[i][j][r]: R index = R0 + i*16 + (lane>>4)*4 + r ; L index = L0 + j*16 + (lane&15)
+    const int R0 = (SWAP ? n0 + wn * WN : m0 + wm * WM) + fkg * 4;
+    const int L0 = (SWAP ? m0 + wm * WM : n0 + wn * WN) + frow;
+
+    if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16) {
+        static_assert(SWAP, "plain epilogue expects SWAP");
+        _Float16* __restrict__ out = (_Float16*)p.out16;
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+            const int n = R0 + i * 16;
+            const float4 b = p.bias ? *(const float4*)(p.bias + n) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int m = L0 + j * 16;
+                if (m >= p.M) continue;
+                float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+                if (EPI == EPI_PLAIN_RELU_F16) {
+                    v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
+                    v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
+                }
+                *(f16x4*)(out + (size_t)m * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
+            }
+        }
+    } else if constexpr (EPI == EPI_QK_HEADS) {
+        // n in [0, 2D): Q then K of the packed in-proj; bf16 [which][seq][H][Tp][dh]
+        static_assert(SWAP, "QK epilogue expects SWAP");
+        const int D = p.H * p.dh;
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+            const int n = R0 + i * 16;
+            const float4 b = *(const float4*)(p.bias + n);
+            const int which = n / D;
+            const int nn = n - which * D;
+            const int h = nn / p.dh, d = nn - h * p.dh;
+            __bf16* __restrict__ dst = (__bf16*)(which ? p.out16b : p.out16);
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int m = L0 + j * 16;
+                if (m >= p.M) continue;
+                const int seq = m / p.Tp, t = m - seq * p.Tp;
+                *(bf16x4*)(dst + (((size_t)seq * p.H + h) * p.Tp + t) * p.dh + d) =
+                    OutCvt<__bf16>::cvt(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
+            }
+        }
+    } else if constexpr (EPI == EPI_VT_HEADS) {
+        // n in [0, D): V of the packed in-proj, written transposed: bf16 [seq][H][dh][Tp]
+        static_assert(!SWAP, "Vt epilogue expects !SWAP");
+        __bf16* __restrict__ dst = (__bf16*)p.out16;
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+            const int n = L0 + j * 16;
+            const float b = p.bias[n];
+            const int h = n / p.dh, d = n - h * p.dh;
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                const int m = R0 + i * 16;         // 4 consecutive frames m..m+3 (same slab: Tp % 4 == 0)
+                if (m >= p.M) continue;
+                const int seq = m / p.Tp, t = m - seq * p.Tp;
+                *(bf16x4*)(dst + (((size_t)seq * p.H + h) * p.dh + d) * p.Tp + t) =
+                    OutCvt<__bf16>::cvt(acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b);
+            }
+        }
+    } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE) {
+        // The block owns complete rows (BN == N, WGM == 1): per-token statistics.
+        static_assert(SWAP && WGM == 1, "row-stat epilogues expect SWAP and one wave row");
+        float* red = (float*)smem;                        // [WGN][BM] (main loop is done with LDS)
+        float4 bias4[FR];
+#pragma unroll
+        for (int i = 0; i < FR; ++i)
+            bias4[i] = p.bias ? *(const float4*)(p.bias + R0 + i * 16) : make_float4(0, 0, 0, 0);
+        // v = acc + bias (+ residual)
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+            const int m = L0 + j * 16;
+            const bool ok = m < p.M;
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                float4 r = make_float4(0, 0, 0, 0);
+                if (EPI != EPI_L2NORM && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
+                const float s = (EPI == EPI_RES_SCALE) ? p.alpha : 1.0f;
+                acc[i][j][0] = (acc[i][j][0] + bias4[i].x) * s + r.x;
+                acc[i][j][1] = (acc[i][j][1] + bias4[i].y) * s + r.y;
+                acc[i][j][2] = (acc[i][j][2] + bias4[i].z) * s + r.z;
+                acc[i][j][3] = (acc[i][j][3] + bias4[i].w) * s + r.w;
+            }
+        }
+        float mean[FL], scale[FL];
+        if constexpr (EPI == EPI_RES_SCALE) {
+#pragma unroll
+            for (int j = 0; j < FL; ++j) { mean[j] = 0.f; scale[j] = 1.f; }
+        } else {
+            auto block_rowsum = [&](float (&part)[FL]) {
+#pragma unroll
+                for (int j = 0; j < FL; ++j) {
+                    part[j] = wave_xor_add(part[j], 16);
+                    part[j] = wave_xor_add(part[j], 32);
+                }
+                __syncthreads();
+                if (fkg == 0) {
+#pragma unroll
+                    for (int j = 0; j < FL; ++j) red[wn * BM + j * 16 + frow] = part[j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < FL; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WGN; ++w) s += red[w * BM + j * 16 + frow];
+                    part[j] = s;
+                }
+            };
+            const float invN = 1.0f / (float)p.N;
+            float part[FL];
+            if constexpr (EPI == EPI_RES_LN) {
+#pragma unroll
+                for (int j = 0; j < FL; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < FR; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+                    part[j] = s;
+                }
+                block_rowsum(part);
+#pragma unroll
+                for (int j = 0; j < FL; ++j) mean[j] = part[j] * invN;
+            } else {
+#pragma unroll
+                for (int j = 0; j < FL; ++j) mean[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < FR; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
+                part[j] = s;
+            }
+            block_rowsum(part);
+#pragma unroll
+            for (int j = 0; j < FL; ++j)
+                scale[j] = (EPI == EPI_RES_LN) ? 1.0f / __builtin_sqrtf(part[j] * invN + p.eps)
+                                               : 1.0f / __builtin_sqrtf(part[j]);
+        }
+        float* __restrict__ o32 = (float*)p.out32;
+        _Float16* __restrict__ o16 = (_Float16*)p.out16;
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+            const int n = R0 + i * 16;
+            float4 g = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
+            if (EPI == EPI_RES_LN && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int m = L0 + j * 16;
+                if (m >= p.M) continue;
+                const float v0 = (acc[i][j][0] - mean[j]) * scale[j] * g.x + be.x;
+                const float v1 = (acc[i][j][1] - mean[j]) * scale[j] * g.y + be.y;
+                const float v2 = (acc[i][j][2] - mean[j]) * scale[j] * g.z + be.z;
+                const float v3 = (acc[i][j][3] - mean[j]) * scale[j] * g.w + be.w;
+                if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
+                if (o16) *(f16x4*)(o16 + (size_t)m * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
+            }
+        }
+    } else if constexpr (EPI == EPI_CONVERT) {
+        // attr0[(b,c), t, :] = acc[(b,t), :] + pc[c, :]   (FS model :113-114 factored:
+        // convert([emb; pe_c]) = W[:, :D] emb + (W[:, D:] pe_c + b)); rows fan out to the
+        // decoder's (sequence = (b,c)) slab layout.
+        static_assert(SWAP, "convert epilogue expects SWAP");
+        float* __restrict__ o32 = (float*)p.out32;
+        _Float16* __restrict__ o16 = (_Float16*)p.out16;
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+            const int m = L0 + j * 16;
+            if (m >= p.M) continue;
+            const int b = m / p.Tp, t = m - b * p.Tp;
+            for (int c = 0; c < p.C; ++c) {
+                const size_t row = ((size_t)b * p.C + c) * p.Tp + t;
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    const int n = R0 + i * 16;
+                    const float4 pc = *(const float4*)(p.pc + (size_t)c * p.N + n);
+                    const float v0 = acc[i][j][0] + pc.x, v1 = acc[i][j][1] + pc.y, v2 = acc[i][j][2] + pc.z, v3 = acc[i][j][3] + pc.w;
+                    *(float4*)(o32 + row * p.ldo + n) = make_float4(v0, v1, v2, v3);
+                    *(f16x4*)(o16 + row * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
+    if (p.N % BN != 0 || p.K % 64 != 0 || (p.lda & 7) || (p.ldw & 7)) return EEND_EINVAL;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    auto kern = gemm_f16_kernel<BM, BN, WGM, WGN, SWAP, ALOAD, EPI>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return EEND_ELAUNCH;
+        attr_done = true;
+    }
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WGM * WGN * 64), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+}  // namespace
+
+int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
+    switch (epi) {
+        case EPI_PLAIN_F16:      return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_F16>(p, stream);
+        case EPI_PLAIN_RELU_F16: return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_RELU_F16>(p, stream);
+        case EPI_QK_HEADS:       return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS>(p, stream);
+        case EPI_VT_HEADS:       return launch<128, 128, 2, 2, false, ALOAD_PLAIN, EPI_VT_HEADS>(p, stream);
+        case EPI_RES_LN:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN>(p, stream);
+        case EPI_RES_SCALE:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
+        case EPI_L2NORM:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<64, 256, 1, 4, true, ALOAD_CONV, EPI_L2NORM>(p, stream);
+        case EPI_CONVERT:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_CONVERT>(p, stream);
+        default: return EEND_EINVAL;
+    }
+}

@@ -1,0 +1,67 @@
+// Internal (C++) launch interface shared by the .hip translation units and the
+// C-ABI shim (api.hip).  Nothing here is exported; the exported surface is
+// include/eend_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum GemmEpilogue {
+    EPI_PLAIN_F16 = 0,       // out16[m][n] = f16(acc + bias)
+    EPI_PLAIN_RELU_F16 = 1,  // out16[m][n] = f16(relu(acc + bias))
+    EPI_QK_HEADS = 2,        // bf16 Q -> out16, K -> out16b, layout [seq][H][Tp][dh]
+    EPI_VT_HEADS = 3,        // bf16 V^T -> out16, layout [seq][H][dh][Tp]
+    EPI_RES_LN = 4,          // LN(acc + bias + res) -> out32 (f32) and out16 (f16); N == 256
+    EPI_L2NORM = 5,          // implicit-GEMM Conv1d + bias, then x/||x||_2 -> out32, out16; N == 256
+    EPI_CONVERT = 6,         // attr0 fan-out over C speaker slots (+pc[c]) -> out32, out16; N == 256
+    EPI_RES_SCALE = 7,       // (acc + bias)*alpha + res -> out32, out16 (no norm); N == 256
+};
+
+struct GemmParams {
+    const void* A;      // activations, f16 [M][lda]
+    const void* W;      // weights, f16 [N][ldw]
+    const float* bias;  // [N] or null
+    int M, N, K;        // K % 64 == 0
+    int lda, ldw, ldo;
+    void* out16;        // f16 / bf16 output (see epilogue)
+    void* out16b;       // second half-precision output (K for EPI_QK_HEADS)
+    void* out32;        // f32 output or null
+    const float* res;   // f32 residual [M][ldo] or null
+    const float* gamma; // LN affine
+    const float* beta;
+    const float* pc;    // EPI_CONVERT: [C][N] per-speaker-slot constant
+    const int* ilens;   // ALOAD_CONV: valid frames per sequence
+    float eps;
+    float alpha;        // EPI_RES_SCALE
+    int Tp;             // frames per sequence slab (Tp % 64 == 0)
+    int H, dh;          // heads layout
+    int C;              // speaker slots (EPI_CONVERT)
+    int conv_cin;       // ALOAD_CONV: input channels (multiple of 64)
+    int conv_pad;       // ALOAD_CONV: left padding (taps before the centre)
+};
+
+struct AttnParams {
+    const void* Q;   // bf16 [nseq][H][Tp][64]
+    const void* K;   // bf16 [nseq][H][Tp][64]
+    const void* Vt;  // bf16 [nseq][H][64][Tp]
+    void* O;         // f16 [nseq*Tp][ldo], head h at columns h*64..
+    int nseq, H, Tp, ldo;
+    int mask_delay;  // allowed(i,j) <=> j - i <= mask_delay && j < kv_len
+    int kv_len;      // number of real key frames (<= Tp)
+    float scale_log2;  // (1/sqrt(dh)) * log2(e)
+};
+
+struct SpkAttnParams {
+    const void* qkv;  // f16 [nrows][3*D], row = (b*C + c)*Tp + t
+    void* O;          // f16 [nrows][D]
+    int B, C, Tp, H;  // D = H*64
+    float scale;      // 1/sqrt(dh)
+};
+
+int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+int eend_launch_attn_causal(const AttnParams& p, hipStream_t stream);
+int eend_launch_spk_attn(const SpkAttnParams& p, hipStream_t stream);
+int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b, const float* bn_mean,
+                            const float* bn_var, float eps, void* out16, int B, int T, int Tp, int Fin,
+                            int Fpad, int apply_bn, hipStream_t stream);
+int eend_launch_head(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
+                     int Tp, int C, int D, hipStream_t stream);

@@ -1,0 +1,335 @@
+"""Host-side mirror of the reference's FS-EEND batch ("masked") model.
+
+Drop-in for ``nnet.model.onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm``
+(reference FS-EEND/nnet/model/...l2norm.py): same class names, constructor
+arguments, attribute tree (what utils/copy_params.py:7-57 walks) and
+``state_dict`` keys (106 entries incl. the dead ``dec.encoder*`` / ``norm12``
+tensors and the ``dec.pos_enc.pe`` buffer), so reference checkpoints load with
+``load_state_dict`` and default initialisation under a given
+``torch.manual_seed`` is bit-identical (modules are created in the reference's
+order with the same torch.nn initialisers).
+
+The torch.nn modules here are *parameter containers only*: ``forward`` /
+``test`` never call them.  All arithmetic runs in libeend_hip.so (ops.py).
+"""
+import copy
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .lib import EendHipError
+
+_D_SUPPORTED = 256
+_H_SUPPORTED = 4
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table, rows indexed by *speaker slot* (reference model :190-224)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+
+class TransformerEncoder(nn.Module):
+    """Layer-stack container (reference modules/merge_tfm_encoder.py:17-43): N deep copies."""
+
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+
+
+class TransformerEncoderFusionLayer(nn.Module):
+    """Parameters of the time x speaker fusion layer (merge_tfm_encoder.py:197-233)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, layer_norm_eps=1e-5,
+                 batch_first=True):
+        super().__init__()
+        self.self_attn1 = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=batch_first)
+        self.self_attn2 = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=batch_first)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm11 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm12 = nn.LayerNorm(d_model, eps=layer_norm_eps)      # unused by the reference too (:361)
+        self.norm21 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm22 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.dropout11 = nn.Dropout(dropout)
+        self.dropout21 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+
+class MaskedTransformerEncoderModel(nn.Module):
+    """Parameters of the embedding encoder (reference model :120-160)."""
+
+    def __init__(self, in_size, n_heads, n_units, n_layers, dim_feedforward=2048, dropout=0.5,
+                 has_mask=False, max_seqlen=500, has_pos=False, mask_delay=0):
+        super().__init__()
+        self.in_size, self.n_heads, self.n_units, self.n_layers = in_size, n_heads, n_units, n_layers
+        self.has_pos, self.has_mask, self.max_seqlen, self.mask_delay = has_pos, has_mask, max_seqlen, mask_delay
+        if has_pos:
+            raise NotImplementedError("has_pos=True is not used by any reference config")
+        self.bn = nn.BatchNorm1d(in_size)
+        self.encoder = nn.Linear(in_size, n_units)
+        self.encoder_norm = nn.LayerNorm(n_units)
+        encoder_layers = nn.TransformerEncoderLayer(n_units, n_heads, dim_feedforward, dropout)
+        self.transformer_encoder = TransformerEncoder(encoder_layers, n_layers)
+        self.init_weights()
+
+    def init_weights(self):
+        initrange = 0.1
+        self.encoder.bias.data.zero_()
+        self.encoder.weight.data.uniform_(-initrange, initrange)
+
+
+class MaskedTransformerDecoderModel(nn.Module):
+    """Parameters of the attractor decoder (reference model :87-105)."""
+
+    def __init__(self, in_size, n_heads, n_units, n_layers, dim_feedforward, dropout=0.5, has_mask=False,
+                 max_seqlen=500, has_pos=False, mask_delay=0):
+        super().__init__()
+        self.in_size, self.n_heads, self.n_units, self.n_layers = in_size, n_heads, n_units, n_layers
+        self.has_pos, self.has_mask, self.max_seqlen, self.mask_delay = has_pos, has_mask, max_seqlen, mask_delay
+        self.encoder = nn.Linear(in_size, n_units)          # dead in the reference, kept for checkpoints
+        self.encoder_norm = nn.LayerNorm(n_units)           # dead
+        self.pos_enc = PositionalEncoding(n_units, dropout)
+        self.convert = nn.Linear(n_units * 2, n_units)
+        decoder_layers = TransformerEncoderFusionLayer(n_units, n_heads, dim_feedforward, dropout, batch_first=True)
+        self.attractor_decoder = TransformerEncoder(decoder_layers, n_layers)
+
+
+def _f16(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float16).contiguous()
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Workspace:
+    """Device buffers for one (B, Tp, C) problem shape (allocated once, reused)."""
+
+    def __init__(self, dev, B, Tp, C, D, F_enc, F_dec, Fin_pad, H):
+        f16, bf16, f32 = torch.float16, torch.bfloat16, torch.float32
+        Me, Md = B * Tp, B * C * Tp
+        Mx = max(Me, Md)
+        e = lambda *s, dt: torch.empty(*s, dtype=dt, device=dev)
+        self.xin16 = torch.zeros(Me, Fin_pad, dtype=f16, device=dev)
+        self.h32, self.h16 = e(Me, D, dt=f32), e(Me, D, dt=f16)
+        self.q = e(Mx * D, dt=bf16)
+        self.k = e(Mx * D, dt=bf16)
+        self.vt = e(Mx * D, dt=bf16)
+        self.o16 = e(Mx, D, dt=f16)
+        self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
+        self.emb32, self.emb16 = e(Me, D, dt=f32), e(Me, D, dt=f16)
+        self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
+        self.qkv16 = e(Md, 3 * D, dt=f16)
+
+
+class OnlineTransformerDADiarization(nn.Module):
+    """FS-EEND batch model on MI355X (reference model :10-84)."""
+
+    def __init__(self, n_speakers, in_size, n_units, n_heads, enc_n_layers, dec_n_layers, dropout, has_mask,
+                 max_seqlen, dec_dim_feedforward, conv_delay=9, mask_delay=0, decom_kernel_size=64):
+        super().__init__()
+        if n_units != _D_SUPPORTED or n_heads != _H_SUPPORTED:
+            raise NotImplementedError("HIP kernels are specialised for n_units=256, n_heads=4 (all reference configs)")
+        self.n_speakers = n_speakers
+        self.delay = conv_delay
+        self.enc = MaskedTransformerEncoderModel(in_size, n_heads, n_units, enc_n_layers, dropout=dropout,
+                                                 has_mask=has_mask, max_seqlen=max_seqlen, mask_delay=mask_delay)
+        self.dec = MaskedTransformerDecoderModel(in_size, n_heads, n_units, dec_n_layers,
+                                                 dim_feedforward=dec_dim_feedforward, dropout=dropout,
+                                                 has_mask=has_mask, max_seqlen=max_seqlen, mask_delay=mask_delay)
+        # NB padding is hard-coded 9 in the reference (model :30), whatever conv_delay is
+        self.cnn = nn.Conv1d(n_units, n_units, kernel_size=2 * conv_delay + 1, padding=9)
+        self._prep = None
+        self._prep_key = None
+        self._ws = {}
+        self._pc = {}
+
+    # ------------------------------------------------------------------ weight preparation
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _prepare(self):
+        """f16 MFMA-operand copies of the weights in kernel layouts (rebuilt when parameters change)."""
+        key = self._fingerprint()
+        if self._prep is not None and key == self._prep_key:
+            return self._prep
+        dev = self.cnn.weight.device
+        if dev.type != "cuda":
+            raise EendHipError("model parameters must live on the GPU: the HIP path has no CPU fallback")
+        P = {}
+        enc = self.enc
+        Fin = enc.in_size
+        Fin_pad = (Fin + 63) // 64 * 64
+        w = torch.zeros(enc.n_units, Fin_pad, dtype=torch.float16, device=dev)
+        w[:, :Fin] = enc.encoder.weight.detach().to(torch.float16)
+        P["enc.in.w"], P["enc.in.b"] = w, _f32(enc.encoder.bias)
+        P["enc.in.g"], P["enc.in.beta"] = _f32(enc.encoder_norm.weight), _f32(enc.encoder_norm.bias)
+        P["enc.in.eps"] = enc.encoder_norm.eps
+        P["bn"] = tuple(_f32(t) for t in (enc.bn.weight, enc.bn.bias, enc.bn.running_mean, enc.bn.running_var))
+        P["bn.eps"] = enc.bn.eps
+        P["Fin_pad"] = Fin_pad
+        layers = []
+        for l in enc.transformer_encoder.layers:
+            layers.append(dict(
+                in_w=_f16(l.self_attn.in_proj_weight), in_b=_f32(l.self_attn.in_proj_bias),
+                out_w=_f16(l.self_attn.out_proj.weight), out_b=_f32(l.self_attn.out_proj.bias),
+                w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
+                g1=_f32(l.norm1.weight), be1=_f32(l.norm1.bias), eps1=l.norm1.eps,
+                g2=_f32(l.norm2.weight), be2=_f32(l.norm2.bias), eps2=l.norm2.eps))
+        P["enc.layers"] = layers
+        cw = self.cnn.weight.detach()                       # (Dout, Din, k)
+        P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
+        P["cnn.b"] = _f32(self.cnn.bias)
+        P["cnn.k"], P["cnn.pad"] = cw.shape[2], self.cnn.padding[0]
+        D = enc.n_units
+        P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
+        dl = []
+        for l in self.dec.attractor_decoder.layers:
+            dl.append(dict(
+                in1_w=_f16(l.self_attn1.in_proj_weight), in1_b=_f32(l.self_attn1.in_proj_bias),
+                out1_w=_f16(l.self_attn1.out_proj.weight), out1_b=_f32(l.self_attn1.out_proj.bias),
+                in2_w=_f16(l.self_attn2.in_proj_weight), in2_b=_f32(l.self_attn2.in_proj_bias),
+                out2_w=_f16(l.self_attn2.out_proj.weight), out2_b=_f32(l.self_attn2.out_proj.bias),
+                w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
+                g11=_f32(l.norm11.weight), be11=_f32(l.norm11.bias), eps11=l.norm11.eps,
+                g21=_f32(l.norm21.weight), be21=_f32(l.norm21.bias), eps21=l.norm21.eps,
+                g22=_f32(l.norm22.weight), be22=_f32(l.norm22.bias), eps22=l.norm22.eps))
+        P["dec.layers"] = dl
+        self._prep, self._prep_key = P, key
+        self._pc = {}
+        return P
+
+    def _convert_const(self, C):
+        """pc[c] = convert.weight[:, D:] pe[c] + convert.bias  (a (C, D) constant of the weights)."""
+        if C not in self._pc:
+            D = self.enc.n_units
+            pe = self.dec.pos_enc.pe[0, :C].to(torch.float32)
+            w2 = self.dec.convert.weight.detach()[:, D:].to(torch.float32)
+            self._pc[C] = (pe @ w2.t() + self.dec.convert.bias.detach().to(torch.float32)).contiguous()
+        return self._pc[C]
+
+    def _workspace(self, dev, B, Tp, C):
+        key = (str(dev), B, Tp, C)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 8:
+                self._ws.clear()
+            P = self._prep
+            F_enc = P["enc.layers"][0]["w1"].shape[0] if P["enc.layers"] else 0
+            F_dec = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
+            ws = _Workspace(dev, B, Tp, C, self.enc.n_units, F_enc, F_dec, P["Fin_pad"], self.enc.n_heads)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ the hot path
+    def _run(self, src: Sequence[Tensor], ilens: Sequence[int], C: int):
+        """encoder -> look-ahead conv + L2 -> attractor decoder -> head, all in HIP.
+        Returns (logits (B,T,C), emb slab (B,Tp,D) f32, attractors (B,T,C,D), T, Tp)."""
+        P = self._prepare()
+        dev = self.cnn.weight.device
+        D, H = self.enc.n_units, self.enc.n_heads
+        x = nn.utils.rnn.pad_sequence([s.to(device=dev, dtype=torch.float32) for s in src],
+                                      padding_value=-1.0, batch_first=True).contiguous()   # model :165
+        B, T, _ = x.shape
+        Tp = ops.frames_pad(T)
+        ws = self._workspace(dev, B, Tp, C)
+        il_key = tuple(min(int(l), T) for l in ilens)
+        if getattr(ws, "il_key", None) != il_key:           # cached: no H2D copy inside a captured step
+            ws.il = torch.tensor(il_key, dtype=torch.int32, device=dev)
+            ws.il_key = il_key
+        il = ws.il
+        Me, Md = B * Tp, B * C * Tp
+        delay_e = self.enc.mask_delay if self.enc.has_mask else Tp
+        kv_e = Tp if self.enc.has_mask else T
+
+        # ---- embedding encoder (model :162-188)
+        ops.bn_cast_pad(x, P["bn"], ws.xin16, T, Tp, True, P["bn.eps"])
+        ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"],
+                          ws.h32, ws.h16, P["enc.in.eps"])
+        q, k, vt = ws.q[:Me * D], ws.k[:Me * D], ws.vt[:Me * D]
+        o16 = ws.o16[:Me]
+        for L in P["enc.layers"]:
+            F = L["w1"].shape[0]
+            ff = ws.ff16[:Me * F].view(Me, F)
+            ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
+            ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e)
+            ops.linear_res_ln(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], ws.h32, ws.h16, L["eps1"])
+            ops.linear(ws.h16, L["w1"], L["b1"], ff, relu=True)
+            ops.linear_res_ln(ff, L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16, L["eps2"])
+
+        # ---- truncate to ilen / zero re-pad, look-ahead conv, L2 norm (model :38-41)
+        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, ws.emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+
+        # ---- attractor decoder (model :112-118, merge_tfm_encoder.py:356-376)
+        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
+        q, k, vt = ws.q[:Md * D], ws.k[:Md * D], ws.vt[:Md * D]
+        o16 = ws.o16[:Md]
+        for L in P["dec.layers"]:
+            F = L["w1"].shape[0]
+            ff = ws.ff16[:Md * F].view(Md, F)
+            ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
+            ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, Tp)
+            ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
+            ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
+            ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            ops.linear_res_ln(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], ws.a32, ws.a16, L["eps21"])
+            ops.linear(ws.a16, L["w1"], L["b1"], ff, relu=True)
+            ops.linear_res_ln(ff, L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16, L["eps22"])
+
+        # ---- attractor L2 norm + embedding . attractor head (model :43,:60)
+        attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
+        ops.head_l2dot(ws.emb32, ws.a32, attr, logits, B, T, Tp, C, D)
+        emb = ws.emb32.view(B, Tp, D)
+        return logits, emb, attr, T, Tp
+
+    @torch.no_grad()
+    def test(self, src, ilens, max_nspks=6):
+        """reference model :67-84 -> (logits [ (T_i,C) ], emb [ (T_i,D) ], attractors [ (T_i,C,D) ])."""
+        logits, emb, attr, T, Tp = self._run(src, ilens, max_nspks)
+        output = [logits[b, :l] for b, l in enumerate(ilens)]
+        embs = [emb[b, :l].clone() for b, l in enumerate(ilens)]
+        attractors = [attr[b, :l] for b, l in enumerate(ilens)]
+        return output, embs, attractors
+
+    def forward(self, src, tgt, ilens):
+        """reference model :32-65 (values only: the HIP path is forward-only this round, so this
+        must run under torch.no_grad(); training backward is not implemented yet)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("fs-eend_amd: backward kernels are not implemented yet; "
+                                      "call under torch.no_grad()")
+        n_speakers = [t.shape[1] for t in tgt]
+        C = max(n_speakers)
+        logits, emb, attr, T, Tp = self._run(src, ilens, C)
+        dev = logits.device
+        # embedding-consistency loss (model :46-57); (B,T,T) cosine maps, training-time diagnostic
+        e = emb[:, :max(int(l) for l in ilens)]
+        attn_map = e @ e.transpose(-1, -2)
+        n = torch.linalg.vector_norm(e, dim=-1, keepdim=True)
+        attn_map = attn_map / (n @ n.transpose(-1, -2) + 1e-6)
+        tgt_pad = [nn.functional.pad(t.to(dev, torch.float32), (0, C - t.shape[1])) for t in tgt]
+        tgt_pad = nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True)
+        label_map = tgt_pad @ tgt_pad.transpose(-1, -2)
+        tn = torch.linalg.vector_norm(tgt_pad, dim=-1, keepdim=True)
+        label_map = label_map / (tn @ tn.transpose(-1, -2) + 1e-6)
+        emb_consis_loss = nn.functional.mse_loss(attn_map, label_map)
+        output = [logits[b, :l, :n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
+        embs = [emb[b, :l].clone() for b, l in enumerate(ilens)]
+        attractors = [attr[b, :l, 1:n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
+        return output, emb_consis_loss, embs, attractors

@@ -1,0 +1,59 @@
+"""ctypes binding of libeend_hip.so (C-ABI: include/eend_hip.h).
+
+Fails loudly: if the shared object is missing or a symbol is absent the import
+of the product path raises -- there is no CPU / eager fallback anywhere."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libeend_hip.so")
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes, exactly the prototypes of include/eend_hip.h
+PROTOTYPES = {
+    "eend_abi_version": [],
+    "eend_bn_cast_pad_f16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "eend_linear_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "eend_inproj_heads_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "eend_linear_res_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_linear_res_scale_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_conv1d_l2norm_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "eend_convert_fanout_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "eend_attn_causal_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "eend_spk_attn_f16": [_vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "eend_head_l2dot_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+}
+
+_lib = None
+
+
+class EendHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once) and type every exported entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EendHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EendHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise EendHipError(f"{name} failed with code {rc} "
+                           f"({'invalid argument' if rc == -1 else 'HIP launch failure' if rc == -2 else 'unknown'})")

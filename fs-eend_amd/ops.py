@@ -1,0 +1,134 @@
+"""Tensor-level wrappers over the C-ABI (include/eend_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every
+arithmetic op of the hot path is one call into libeend_hip.so.  All wrappers
+require CUDA(ROCm) tensors and raise on anything else -- there is no eager or
+CPU fallback.
+"""
+import math
+
+import torch
+
+from . import lib as _lib
+
+F16, BF16, F32 = torch.float16, torch.bfloat16, torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.EendHipError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.EendHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.EendHipError(f"{name}: expected a contiguous tensor")
+
+
+def frames_pad(T: int) -> int:
+    """Frames per sequence slab: T rounded up to a multiple of 64."""
+    return (T + 63) // 64 * 64
+
+
+def bn_cast_pad(x, bn, out16, T, Tp, apply_bn=True, eps=1e-5):
+    """x f32 (B,T,Fin) -> out16 f16 (B*Tp, Fpad).  bn = (weight, bias, mean, var) or None."""
+    L = _lib.load()
+    _chk(x, F32, "x"); _chk(out16, F16, "out16")
+    B, Fin = x.shape[0], x.shape[2]
+    Fpad = out16.shape[-1]
+    w = b = m = v = None
+    if apply_bn:
+        w, b, m, v = bn
+        for t, n in ((w, "bn.weight"), (b, "bn.bias"), (m, "bn.mean"), (v, "bn.var")):
+            _chk(t, F32, n)
+    _lib.check(L.eend_bn_cast_pad_f16(_p(x), _p(w), _p(b), _p(m), _p(v), eps, _p(out16), B, T, Tp, Fin, Fpad,
+                                      1 if apply_bn else 0, _stream()), "eend_bn_cast_pad_f16")
+    return out16
+
+
+def linear(a16, w16, bias, out16, relu=False):
+    """out16 = act(a16 @ w16.T + bias); a16 (M,K) f16, w16 (N,K) f16."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(out16, F16, "out16")
+    M, K = a16.shape
+    N = w16.shape[0]
+    _lib.check(L.eend_linear_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(out16),
+                                 out16.stride(0), M, N, K, 1 if relu else 0, _stream()), "eend_linear_f16")
+    return out16
+
+
+def inproj_heads(a16, w16, bias, q, k, vt, nseq, Tp, H):
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias")
+    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt")
+    K = a16.shape[1]
+    _lib.check(L.eend_inproj_heads_bf16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(q), _p(k),
+                                        _p(vt), nseq, Tp, H, 64, K, _stream()), "eend_inproj_heads_bf16")
+
+
+def linear_res_ln(a16, w16, bias, res, gamma, beta, out32, out16, eps=1e-5):
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(res, F32, "res")
+    _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = a16.shape
+    if w16.shape[0] != 256:
+        raise _lib.EendHipError("linear_res_ln: N must be 256")
+    _lib.check(L.eend_linear_res_ln_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(res),
+                                        _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, K, _stream()),
+               "eend_linear_res_ln_f16")
+
+
+def linear_res_scale(a16, w16, bias, res, alpha, out32, out16):
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(res, F32, "res")
+    _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = a16.shape
+    if w16.shape[0] != 256:
+        raise _lib.EendHipError("linear_res_scale: N must be 256")
+    _lib.check(L.eend_linear_res_scale_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(res),
+                                           float(alpha), _p(out32), _p(out16), M, K, _stream()),
+               "eend_linear_res_scale_f16")
+
+
+def conv1d_l2norm(x16, wr16, bias, ilens_i32, out32, out16, nseq, Tp, cin, ktaps, pad):
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(wr16, F16, "wr16"); _chk(bias, F32, "bias"); _chk(ilens_i32, torch.int32, "ilens")
+    _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_conv1d_l2norm_f16(_p(x16), _p(wr16), _p(bias), _p(ilens_i32), _p(out32), _p(out16), nseq,
+                                        Tp, cin, ktaps, pad, _stream()), "eend_conv1d_l2norm_f16")
+
+
+def convert_fanout(e16, w1_16, pc, out32, out16, B, Tp, C):
+    L = _lib.load()
+    _chk(e16, F16, "e16"); _chk(w1_16, F16, "w1"); _chk(pc, F32, "pc"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_convert_fanout_f16(_p(e16), _p(w1_16), _p(pc), _p(out32), _p(out16), B, Tp, C, _stream()),
+               "eend_convert_fanout_f16")
+
+
+def attn_causal(q, k, vt, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
+    L = _lib.load()
+    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt"); _chk(o16, F16, "o16")
+    _lib.check(L.eend_attn_causal_bf16(_p(q), _p(k), _p(vt), _p(o16), nseq, H, Tp, o16.stride(0), mask_delay,
+                                       Tp if kv_len is None else kv_len, 1.0 / math.sqrt(64.0), _stream()), "eend_attn_causal_bf16")
+
+
+def spk_attn(qkv16, o16, B, C, Tp, H):
+    L = _lib.load()
+    _chk(qkv16, F16, "qkv16"); _chk(o16, F16, "o16")
+    _lib.check(L.eend_spk_attn_f16(_p(qkv16), _p(o16), B, C, Tp, H, 1.0 / math.sqrt(64.0), _stream()),
+               "eend_spk_attn_f16")
+
+
+def head_l2dot(emb32, attr32, attr_out, logits, B, T, Tp, C, D):
+    L = _lib.load()
+    _chk(emb32, F32, "emb32"); _chk(attr32, F32, "attr32"); _chk(attr_out, F32, "attr_out"); _chk(logits, F32, "logits")
+    _lib.check(L.eend_head_l2dot_f32(_p(emb32), _p(attr32), _p(attr_out), _p(logits), B, T, Tp, C, D, _stream()),
+               "eend_head_l2dot_f32")

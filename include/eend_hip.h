@@ -1,0 +1,112 @@
+/*
+ * eend_hip.h -- C-ABI of libeend_hip.so: the MI355X (gfx950) kernels behind the
+ * FS-EEND / LS-EEND frame-wise diarization forward.
+ *
+ * The reference (Audio-WestlakeU/FS-EEND) is pure Python on torch.nn and has no FFI of
+ * its own; each entry point below replaces the stock ATen kernels that one group of
+ * reference lines dispatches, and cites those lines (paths relative to the reference
+ * root).  The Python host (fs-eend_amd/) binds them with ctypes; INTEGRATION.md shows
+ * the stub.
+ *
+ * Conventions (every entry point):
+ *   - returns 0 on success, EEND_EINVAL (-1) for a rejected argument, EEND_ELAUNCH (-2)
+ *     when the HIP launch failed; never throws, never allocates, never synchronises;
+ *   - all pointers are DEVICE pointers owned by the caller and must stay alive until the
+ *     stream has executed the call; `stream` is a hipStream_t passed as void*;
+ *   - kernels are stateless and stream ordered (safe under hipGraph capture);
+ *   - "slab" layout: activations of `nseq` sequences are stored [nseq][Tp][D] with
+ *     Tp % 64 == 0 >= T (frames t >= T are padding the caller never reads);
+ *   - f16 = IEEE binary16, bf16 = bfloat16, f32 = IEEE binary32; accumulation is f32.
+ */
+#ifndef EEND_HIP_H
+#define EEND_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EEND_OK 0
+#define EEND_EINVAL (-1)
+#define EEND_ELAUNCH (-2)
+
+/* ABI version of this header (bumped on any signature change). */
+int eend_abi_version(void);
+
+/* Eval-mode BatchNorm1d over features + cast + zero pad to the frame slab.
+ * Replaces FS-EEND/nnet/model/onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm.py:165-166
+ * (pad_sequence(-1) is done by the host; BN uses running stats) and, with apply_bn = 0,
+ * the plain cast in front of LS-EEND's input projection (LS-EEND/nnet/conformer/encoder.py:195).
+ * x f32 [B][T][Fin] -> out f16 [B][Tp][Fpad] (Fpad % 64 == 0, zero filled beyond Fin / T). */
+int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias,
+                         const float* bn_mean, const float* bn_var, float eps, void* out_f16,
+                         int B, int T, int Tp, int Fin, int Fpad, int apply_bn, void* stream);
+
+/* out = act(A W^T + bias), f16 in / f16 out, f32 accumulate.  torch.nn.Linear call sites:
+ * FFN linear1+ReLU of nn.TransformerEncoderLayer (FS model :147) and of the fusion layer
+ * (FS-EEND/nnet/modules/merge_tfm_encoder.py:397-399), packed in-proj of the speaker MHA
+ * (merge_tfm_encoder.py:388-394).  A [M][lda], W [N][ldw], N % 128 == 0, K % 64 == 0. */
+int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16,
+                    int ldo, int M, int N, int K, int relu, void* stream);
+
+/* Packed MHA in-projection (3D x D) whose epilogue scatters Q, K (bf16 [nseq][H][Tp][dh]) and
+ * V transposed (bf16 [nseq][H][dh][Tp]) for eend_attn_causal_bf16.  Replaces the in-proj half of
+ * nn.MultiheadAttention in nn.TransformerEncoderLayer (FS model :147) and _sa_block1
+ * (merge_tfm_encoder.py:379-385).  A f16 [nseq*Tp][lda], W f16 [3*H*dh][ldw], bias f32 [3*H*dh]. */
+int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* Q_bf16,
+                           void* K_bf16, void* Vt_bf16, int nseq, int Tp, int H, int dh, int K, void* stream);
+
+/* out = LayerNorm(A W^T + bias + res) * gamma + beta, N = 256; writes f32 (residual stream) and
+ * f16 (next MFMA operand) copies; res / out32 / out16 / gamma may be null.  Replaces
+ * Linear -> LayerNorm (FS model :173-174), out-proj + residual + norm1 / norm11 / norm21 and
+ * linear2 + residual + norm2 / norm22 (torch TransformerEncoderLayer; merge_tfm_encoder.py:364,373-374). */
+int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                           const float* res, const float* gamma, const float* beta, float eps,
+                           float* out_f32, void* out_f16, int M, int K, void* stream);
+
+/* out = (A W^T + bias) * alpha + res, N = 256, f32 + f16 copies (no normalisation).  Replaces the
+ * LS-EEND residual wrappers: ResidualConnectionModule with module_factor 0.5 / 1
+ * (LS-EEND/nnet/conformer/modules.py:32-33) around the second Linear of FeedForwardModule
+ * (feed_forward.py:47-57), the retention out_proj (LS-EEND/nnet/modules/retention.py:226) and the
+ * last pointwise conv of ConformerConvModule (convolution.py:138-149). */
+int eend_linear_res_scale_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                              const float* res, float alpha, float* out_f32, void* out_f16, int M, int K,
+                              void* stream);
+
+/* Look-ahead Conv1d(cin -> 256, ktaps, padding = pad) as an implicit GEMM, + bias, then
+ * x / ||x||_2 (no eps).  Frames >= ilens[seq] read as zero (the reference truncates to ilen and
+ * zero re-pads before the conv).  Replaces FS model :38-41 / LS model :80-87.
+ * X f16 [nseq][Tp][cin]; Wr f16 [256][ktaps*cin] with Wr[o][tap*cin + i] = conv.weight[o][i][tap]. */
+int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, const int* ilens,
+                           float* out_f32, void* out_f16, int nseq, int Tp, int cin, int ktaps, int pad,
+                           void* stream);
+
+/* attr0[(b,c)][t][:] = W1 emb[b][t][:] + pc[c][:], the factored form of
+ * convert(cat(emb, pe[c])) (FS model :113-114, LS model :216-217): W1 = convert.weight[:, :D],
+ * pc[c] = convert.weight[:, D:] pe[c] + convert.bias.  E f16 [B][Tp][256] ->
+ * out f32/f16 [B*C][Tp][256] (decoder slab, sequence index = b*C + c). */
+int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
+                            int B, int Tp, int C, void* stream);
+
+/* Fused causal MHA core: softmax(mask(Q K^T / sqrt(dh))) V with
+ * allowed(i,j) <=> j - i <= mask_delay && j < kv_len evaluated on indices (the (T,T) {0,-inf} tensor
+ * of FS model :107-110,:152-155 is never built; has_mask=False is mask_delay >= Tp, kv_len = T).
+ * dh = 64.  Q,K bf16 [nseq][H][Tp][64], Vt bf16 [nseq][H][64][Tp] -> O f16 [nseq*Tp][ldo]. */
+int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, int nseq, int H,
+                          int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream);
+
+/* Unmasked MHA core over the C (<= 12) attractor slots of each frame (_sa_block2,
+ * merge_tfm_encoder.py:388-394; LS-EEND/nnet/modules/merge_retnet_layer.py:301-306).
+ * qkv f16 [B*C*Tp][768] (row = (b*C + c)*Tp + t) -> O f16 [B*C*Tp][256].  H = 4, dh = 64. */
+int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
+                      void* stream);
+
+/* attractors / ||attractors||_2 and logits[b,t,c] = <emb[b,t], attractors[b,t,c]>
+ * (FS model :43,:60 / :76,:79; LS model :89,:117).  emb f32 [B][Tp][D], attr f32 [B*C][Tp][D]
+ * -> attr_out f32 [B][T][C][D], logits f32 [B][T][C]. */
+int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
+                        int Tp, int C, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEND_HIP_H */

@@ -1,0 +1,132 @@
+"""GPU: the HIP FS-EEND forward (through the C-ABI) against (a) the golden vectors produced
+by the reference itself and (b) the fp32 oracle, plus size-independent properties at the
+BASELINE batch size.
+
+Tolerance (stated by BASELINE.json north_star): per-frame activity logits within 1e-3 of the
+reference's fp32 forward.  emb / attractors are unit vectors compared at 2e-3 per component.
+The linear layers run on f16 MFMA and QK^T / PV on bf16 MFMA, both with fp32 accumulation,
+fp32 residual stream / LayerNorm / softmax statistics.
+"""
+import pytest
+import torch
+
+from oracle import fixtures as FX
+from oracle import fs_eend_ref as R
+from tests.helpers import build_fs_mirror, fs_kwargs, max_abs
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3
+VEC_TOL = 2e-3
+FS_TEST = [c for c in FX.list_cases("fs_") if FX.load_case(c)[0]["kind"] == "fs_test"]
+
+
+@pytest.mark.parametrize("name", FS_TEST)
+def test_fs_test_vs_golden_and_oracle(hip_lib, dev, name):
+    meta, arr = FX.load_case(name)
+    m = build_fs_mirror(meta)
+    src = FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])
+    with torch.no_grad():
+        want = R.fs_test(src, meta["lengths"], m.state_dict(), max_nspks=meta["C"], **fs_kwargs(meta))
+    m = m.to(dev)
+    got = m.test([s.to(dev) for s in src], meta["lengths"], max_nspks=meta["C"])
+    torch.cuda.synchronize()
+    r = meta["rows"]
+    worst = 0.0
+    for i in range(len(src)):
+        assert got[0][i].shape == arr[f"logits{i}"].shape
+        assert torch.isfinite(got[0][i]).all()
+        e_gold = max_abs(got[0][i], arr[f"logits{i}"])
+        e_orc = max_abs(got[0][i], want[0][i])
+        worst = max(worst, e_gold)
+        assert e_gold < LOGIT_TOL, f"{name}[{i}]: logits vs reference golden {e_gold:.2e}"
+        assert e_orc < LOGIT_TOL, f"{name}[{i}]: logits vs oracle {e_orc:.2e}"
+        assert max_abs(got[1][i][::r], arr[f"emb{i}"]) < VEC_TOL
+        assert max_abs(got[2][i][::r], arr[f"attr{i}"]) < VEC_TOL
+        assert max_abs(got[1][i], want[1][i]) < VEC_TOL
+        assert max_abs(got[2][i], want[2][i]) < VEC_TOL
+    print(f"{name}: max |logits - reference| = {worst:.2e}")
+
+
+def test_fs_forward_vs_golden(hip_lib, dev):
+    meta, arr = FX.load_case("fs_fwd_train")
+    m = build_fs_mirror(meta).to(dev)
+    src = [s.to(dev) for s in FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])]
+    tgt = [t.to(dev) for t in FX.make_labels(meta["lengths"], meta["ncols"], meta["lseed"])]
+    with torch.no_grad():
+        logits, loss, emb, attr = m(src, tgt, meta["lengths"])
+    assert abs(float(loss) - float(arr["emb_loss"][0])) < 1e-4
+    r = meta["rows"]
+    for i in range(len(src)):
+        assert logits[i].shape == arr[f"logits{i}"].shape
+        assert max_abs(logits[i], arr[f"logits{i}"]) < LOGIT_TOL
+        assert attr[i].shape[1] == meta["ncols"][i] - 1
+        assert max_abs(attr[i][::r], arr[f"attr{i}"]) < VEC_TOL
+        assert max_abs(emb[i][::r], arr[f"emb{i}"]) < VEC_TOL
+    with pytest.raises(NotImplementedError):
+        m(src, tgt, meta["lengths"])                      # grad-enabled call must refuse, not fake it
+
+
+def test_der_counters_identical_to_oracle(hip_lib, dev):
+    """DER parity: frame-level counters (loss.py:198-236) on HIP vs oracle logits for the same labels."""
+    meta, arr = FX.load_case("fs_full_T500_c6")
+    m = build_fs_mirror(meta)
+    src = FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])
+    with torch.no_grad():
+        want = R.fs_test(src, meta["lengths"], m.state_dict(), max_nspks=meta["C"], **fs_kwargs(meta))[0]
+    got = m.to(dev).test([s.to(dev) for s in src], meta["lengths"], max_nspks=meta["C"])[0]
+    labels = FX.make_labels(meta["lengths"], [meta["C"] - 1] * len(src), 4242)
+    for g, w, l in zip(got, want, labels):
+        # the silence slot is dropped before scoring (dia_pred.py:56)
+        a = R.calc_diarization_error(g.cpu()[:, 1:], l)
+        b = R.calc_diarization_error(w[:, 1:], l)
+        flips = int(((torch.sigmoid(g.cpu()) > 0.5) != (torch.sigmoid(w) > 0.5)).sum())
+        # a decision can only differ where |logit| < tolerance
+        assert flips <= int((w.abs() < LOGIT_TOL).sum())
+        if flips == 0:
+            assert a == b
+
+
+def test_full_batch_properties(hip_lib, dev):
+    """BASELINE size (B=64, T=500, C=6): properties that need no oracle run.
+    1. batch independence: utterance b's logits do not depend on its batch mates (bit exact);
+    2. causality up to the look-ahead: frames <= t - 10 are unchanged (bit exact) when the input
+       changes only after frame t (the conv sees +-9 frames);
+    3. logits are cosines: |logit| <= 1 + eps; attractors / emb rows have unit norm."""
+    meta, _ = FX.load_case("fs_full_T500_c6")
+    m = build_fs_mirror(meta).to(dev)
+    B, T, C = 64, 500, 6
+    src = [s.to(dev) for s in FX.make_src([T] * B, 345, 999)]
+    out = m.test(src, [T] * B, C)
+    lg = torch.stack(out[0])
+    assert torch.isfinite(lg).all() and lg.abs().max() <= 1 + 1e-4
+    assert (torch.stack(out[1]).norm(dim=-1) - 1).abs().max() < 1e-4
+    assert (torch.stack(out[2]).norm(dim=-1) - 1).abs().max() < 1e-4
+    # 1. batch independence
+    sub = m.test(src[5:7], [T, T], C)
+    assert torch.equal(sub[0][0], out[0][5]) and torch.equal(sub[0][1], out[0][6])
+    # 2. causality with a 9-frame look-ahead
+    t0 = 300
+    src2 = [s.clone() for s in src[:2]]
+    for s in src2:
+        s[t0:] = s[t0:] * -0.5 + 1.0
+    out2 = m.test(src2, [T, T], C)
+    assert torch.equal(out2[0][0][: t0 - 9], out[0][0][: t0 - 9])
+    assert not torch.equal(out2[0][0][t0:], out[0][0][t0:])
+    # golden rows still match inside the big batch (first utterance of the golden case is seed-777 data)
+    gsrc = [s.to(dev) for s in FX.make_src(meta["lengths"], 345, meta["xseed"])]
+    big = m.test([gsrc[0]] + src[:63], [T] * 64, C)
+    _, arr = FX.load_case("fs_full_T500_c6")
+    assert max_abs(big[0][0], arr["logits0"]) < LOGIT_TOL
+
+
+def test_weights_update_is_seen(hip_lib, dev):
+    """The f16 weight cache must follow parameter updates (load_state_dict / in-place edits)."""
+    meta, _ = FX.load_case("fs_small_ragged")
+    m = build_fs_mirror(meta).to(dev)
+    src = [s.to(dev) for s in FX.make_src(meta["lengths"], 345, meta["xseed"])]
+    a = m.test(src, meta["lengths"], 4)[0][0].clone()
+    with torch.no_grad():
+        m.dec.convert.bias.add_(0.5)
+    b = m.test(src, meta["lengths"], 4)[0][0]
+    assert not torch.equal(a, b)

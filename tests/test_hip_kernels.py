@@ -1,0 +1,254 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 reference of the same op, on the
+same (already f16/bf16-quantised) inputs.  Inputs are asymmetric random data so that a
+transposed fragment or swapped operand cannot pass."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F16, BF16, F32 = torch.float16, torch.bfloat16, torch.float32
+
+
+def rnd(shape, dev, seed, dtype=F32, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def close(got, want, atol, rtol, what):
+    got, want = got.float(), want.float()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - want).abs()
+    bound = atol + rtol * want.abs()
+    bad = (err > bound)
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements off, max err {err.max().item():.3e} "
+                           f"(first bad index {bad.nonzero()[0].tolist()})")
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(1, 128, 64, False), (100, 768, 256, False), (333, 2048, 256, True),
+                                        (128, 128, 2048, True), (4100, 256, 384, False)])
+def test_linear(hip_lib, dev, M, N, K, relu):
+    from fs_eend_amd import ops
+    a, w, b = rnd((M, K), dev, 1, F16), rnd((N, K), dev, 2, F16, 0.1), rnd((N,), dev, 3)
+    out = torch.full((M, N), float("nan"), dtype=F16, device=dev)
+    ops.linear(a, w, b, out, relu=relu)
+    want = a.float() @ w.float().t() + b
+    if relu:
+        want = want.relu()
+    close(out, want, 2e-3, 2e-3, f"linear {M}x{N}x{K}")
+
+
+def test_linear_strided_output(hip_lib, dev):
+    from fs_eend_amd import ops
+    a, w = rnd((70, 256), dev, 4, F16), rnd((128, 256), dev, 5, F16, 0.1)
+    big = torch.zeros(70, 384, dtype=F16, device=dev)
+    out = big[:, 128:256]
+    L = __import__("fs_eend_amd.lib", fromlist=["x"]).load()
+    rc = L.eend_linear_f16(a.data_ptr(), 256, w.data_ptr(), 256, None, out.data_ptr(), 384, 70, 128, 256, 0,
+                           torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    close(big[:, 128:256], a.float() @ w.float().t(), 2e-3, 2e-3, "strided linear")
+    assert (big[:, :128] == 0).all() and (big[:, 256:] == 0).all()
+
+
+def test_invalid_arguments_are_rejected(hip_lib, dev):
+    L = hip_lib
+    a = torch.zeros(64, 64, dtype=F16, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.eend_linear_f16(a.data_ptr(), 64, a.data_ptr(), 64, None, a.data_ptr(), 64, 64, 100, 64, 0, s) == -1  # N%128
+    assert L.eend_linear_f16(a.data_ptr(), 64, a.data_ptr(), 64, None, a.data_ptr(), 64, 64, 128, 60, 0, s) == -1  # K%64
+    assert L.eend_linear_f16(None, 64, a.data_ptr(), 64, None, a.data_ptr(), 64, 64, 128, 64, 0, s) == -1
+    assert L.eend_attn_causal_bf16(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), 1, 4, 100, 256, 0, 100,
+                                   0.125, s) == -1                                                    # Tp%64
+    assert L.eend_spk_attn_f16(a.data_ptr(), a.data_ptr(), 1, 13, 64, 4, 0.125, s) == -1               # C>12
+
+
+@pytest.mark.parametrize("nseq,Tp", [(1, 64), (3, 192), (2, 512)])
+def test_inproj_heads(hip_lib, dev, nseq, Tp):
+    from fs_eend_amd import ops
+    H, D = 4, 256
+    M = nseq * Tp
+    a, w, b = rnd((M, D), dev, 6, F16), rnd((3 * D, D), dev, 7, F16, 0.1), rnd((3 * D,), dev, 8)
+    q = torch.full((M * D,), float("nan"), dtype=BF16, device=dev)
+    k, vt = q.clone(), q.clone()
+    ops.inproj_heads(a, w, b, q, k, vt, nseq, Tp, H)
+    y = (a.float() @ w.float().t() + b).view(nseq, Tp, 3, H, 64)
+    wq = y[:, :, 0].permute(0, 2, 1, 3)               # (nseq,H,Tp,64)
+    wk = y[:, :, 1].permute(0, 2, 1, 3)
+    wv = y[:, :, 2].permute(0, 2, 3, 1)               # (nseq,H,64,Tp)
+    close(q.view(nseq, H, Tp, 64), wq, 1e-2, 1e-2, "Q heads")
+    close(k.view(nseq, H, Tp, 64), wk, 1e-2, 1e-2, "K heads")
+    close(vt.view(nseq, H, 64, Tp), wv, 1e-2, 1e-2, "V^T heads")
+
+
+@pytest.mark.parametrize("M,K,res", [(64, 256, True), (200, 2048, True), (130, 384, False), (1, 256, True)])
+def test_linear_res_ln(hip_lib, dev, M, K, res):
+    from fs_eend_amd import ops
+    a, w, b = rnd((M, K), dev, 9, F16), rnd((256, K), dev, 10, F16, 0.1), rnd((256,), dev, 11)
+    r = rnd((M, 256), dev, 12) + 0.7 if res else None
+    g, be = rnd((256,), dev, 13) * 0.2 + 1, rnd((256,), dev, 14) * 0.1
+    o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+    ops.linear_res_ln(a, w, b, r, g, be, o32, o16, 1e-5)
+    y = a.float() @ w.float().t() + b + (r if res else 0)
+    want = torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5)
+    close(o32, want, 2e-4, 2e-4, "res+LN f32")
+    close(o16, want, 3e-3, 2e-3, "res+LN f16")
+
+
+def test_linear_res_ln_inplace_residual(hip_lib, dev):
+    from fs_eend_amd import ops
+    M, K = 300, 256
+    a, w, b = rnd((M, K), dev, 15, F16), rnd((256, K), dev, 16, F16, 0.1), rnd((256,), dev, 17)
+    r = rnd((M, 256), dev, 18)
+    g, be = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    want = torch.nn.functional.layer_norm(a.float() @ w.float().t() + b + r, (256,), g, be, 1e-5)
+    o16 = torch.empty((M, 256), dtype=F16, device=dev)
+    ops.linear_res_ln(a, w, b, r, g, be, r, o16, 1e-5)       # out32 aliases res (how the model calls it)
+    close(r, want, 2e-4, 2e-4, "in-place res+LN")
+
+
+def test_linear_res_scale(hip_lib, dev):
+    from fs_eend_amd import ops
+    M, K = 150, 1024
+    a, w, b = rnd((M, K), dev, 19, F16), rnd((256, K), dev, 20, F16, 0.05), rnd((256,), dev, 21)
+    r = rnd((M, 256), dev, 22)
+    o32 = torch.empty((M, 256), dtype=F32, device=dev)
+    o16 = torch.empty((M, 256), dtype=F16, device=dev)
+    ops.linear_res_scale(a, w, b, r, 0.5, o32, o16)
+    want = (a.float() @ w.float().t() + b) * 0.5 + r
+    close(o32, want, 2e-4, 2e-4, "res+scale f32")
+    close(o16, want, 3e-3, 2e-3, "res+scale f16")
+
+
+@pytest.mark.parametrize("nseq,Tp,ilens", [(2, 64, [64, 30]), (3, 128, [100, 128, 1]), (1, 512, [500])])
+def test_conv1d_l2norm(hip_lib, dev, nseq, Tp, ilens):
+    from fs_eend_amd import ops
+    D, k, pad = 256, 19, 9
+    x = rnd((nseq, Tp, D), dev, 23, F16)
+    w = rnd((D, D, k), dev, 24, F32, 0.05)
+    b = rnd((D,), dev, 25)
+    wr = w.permute(0, 2, 1).reshape(D, k * D).to(F16).contiguous()
+    il = torch.tensor(ilens, dtype=torch.int32, device=dev)
+    o32 = torch.empty((nseq * Tp, D), dtype=F32, device=dev)
+    o16 = torch.empty((nseq * Tp, D), dtype=F16, device=dev)
+    ops.conv1d_l2norm(x.view(-1, D), wr, b, il, o32, o16, nseq, Tp, D, k, pad)
+    xm = x.float().clone()
+    for i, l in enumerate(ilens):
+        xm[i, l:] = 0                                   # truncate to ilen, zero re-pad
+    y = torch.nn.functional.conv1d(xm.transpose(1, 2), wr.view(D, k, D).permute(0, 2, 1).float(), b, padding=pad)
+    y = y.transpose(1, 2)
+    want = y / torch.linalg.vector_norm(y, dim=-1, keepdim=True)
+    close(o32.view(nseq, Tp, D), want, 2e-4, 1e-3, "conv+l2 f32")
+    close(o16.view(nseq, Tp, D), want, 1e-3, 2e-3, "conv+l2 f16")
+
+
+@pytest.mark.parametrize("B,Tp,C", [(2, 64, 4), (1, 128, 10), (3, 64, 1)])
+def test_convert_fanout(hip_lib, dev, B, Tp, C):
+    from fs_eend_amd import ops
+    e, w1 = rnd((B * Tp, 256), dev, 26, F16), rnd((256, 256), dev, 27, F16, 0.1)
+    pc = rnd((C, 256), dev, 28)
+    o32 = torch.full((B * C * Tp, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((B * C * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.convert_fanout(e, w1, pc, o32, o16, B, Tp, C)
+    y = (e.float() @ w1.float().t()).view(B, 1, Tp, 256) + pc.view(1, C, 1, 256)
+    close(o32.view(B, C, Tp, 256), y, 2e-4, 2e-4, "convert fan-out f32")
+    close(o16.view(B, C, Tp, 256), y, 3e-3, 2e-3, "convert fan-out f16")
+
+
+def attn_ref(q, k, v, delay, kv_len):
+    """q,k,v (nseq,H,Tp,64) fp32 -> (nseq,Tp,H*64)."""
+    Tp = q.shape[2]
+    s = q @ k.transpose(-1, -2) / 8.0
+    i = torch.arange(Tp, device=q.device)[:, None]
+    j = torch.arange(Tp, device=q.device)[None, :]
+    allowed = ((j - i) <= delay) & (j < kv_len)
+    s = s.masked_fill(~allowed, float("-inf"))
+    o = torch.softmax(s, -1) @ v
+    return o.permute(0, 2, 1, 3).reshape(q.shape[0], Tp, -1)
+
+
+@pytest.mark.parametrize("nseq,Tp,delay,kv_len,scale", [(1, 64, 0, 64, 1.0), (2, 128, 0, 128, 1.0), (1, 192, 0, 192, 3.0),
+                                                        (2, 512, 0, 512, 1.0), (1, 256, 2, 256, 1.0),
+                                                        (1, 128, 128, 100, 1.0), (1, 512, 0, 512, 6.0)])
+def test_attn_causal(hip_lib, dev, nseq, Tp, delay, kv_len, scale):
+    from fs_eend_amd import ops
+    H = 4
+    q = rnd((nseq, H, Tp, 64), dev, 29, BF16, scale)
+    k = rnd((nseq, H, Tp, 64), dev, 30, BF16, scale)
+    v = rnd((nseq, H, Tp, 64), dev, 31, BF16)
+    vt = v.transpose(-1, -2).contiguous()
+    o = torch.full((nseq * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.attn_causal(q.view(-1), k.view(-1), vt.view(-1), o, nseq, H, Tp, delay, kv_len)
+    want = attn_ref(q.float(), k.float(), v.float(), delay, kv_len)
+    valid = min(Tp, kv_len) if delay >= Tp else Tp       # rows that see >= 1 key are all rows here
+    # P is rounded to bf16 before PV: tolerance ~ 2^-8 relative on O(1) values
+    close(o.view(nseq, Tp, 256)[:, :valid], want[:, :valid], 1.5e-2, 1e-2, f"attention Tp={Tp} delay={delay}")
+    # bit-exact mask indexing: row 0 with delay 0 attends only key 0 -> O[0] == V[0] exactly (p = 1)
+    if delay == 0:
+        o0 = o.view(nseq, Tp, H, 64)[:, 0]
+        assert torch.equal(o0.float(), v[:, :, 0].float().to(F16).float()), "row 0 must equal V[0] exactly"
+
+
+def test_attn_causality_property(hip_lib, dev):
+    """Changing keys/values at frames > t must not change output rows <= t (bit exact)."""
+    from fs_eend_amd import ops
+    nseq, H, Tp = 1, 4, 256
+    q, k, v = (rnd((nseq, H, Tp, 64), dev, s, BF16) for s in (32, 33, 34))
+    o1 = torch.empty((Tp, 256), dtype=F16, device=dev)
+    o2 = torch.empty((Tp, 256), dtype=F16, device=dev)
+    ops.attn_causal(q.view(-1), k.view(-1), v.transpose(-1, -2).contiguous().view(-1), o1, nseq, H, Tp, 0, Tp)
+    k2, v2 = k.clone(), v.clone()
+    k2[:, :, 150:] = 7.0
+    v2[:, :, 150:] = -3.0
+    ops.attn_causal(q.view(-1), k2.view(-1), v2.transpose(-1, -2).contiguous().view(-1), o2, nseq, H, Tp, 0, Tp)
+    assert torch.equal(o1[:150], o2[:150])
+    assert not torch.equal(o1[150:], o2[150:])
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 6, 10, 12])
+def test_spk_attn(hip_lib, dev, C):
+    from fs_eend_amd import ops
+    B, Tp, H, D = 2, 64, 4, 256
+    M = B * C * Tp
+    qkv = rnd((M, 3 * D), dev, 35 + C, F16)
+    o = torch.full((M, D), float("nan"), dtype=F16, device=dev)
+    ops.spk_attn(qkv, o, B, C, Tp, H)
+    x = qkv.float().view(B, C, Tp, 3, H, 64).permute(3, 0, 2, 4, 1, 5)      # (3,B,Tp,H,C,64)
+    s = x[0] @ x[1].transpose(-1, -2) / 8.0
+    want = (torch.softmax(s, -1) @ x[2]).permute(0, 3, 1, 2, 4).reshape(B, C, Tp, D)   # (B,C,Tp,H*64)
+    close(o.view(B, C, Tp, D), want, 3e-3, 3e-3, f"speaker attention C={C}")
+
+
+def test_bn_cast_pad(hip_lib, dev):
+    from fs_eend_amd import ops
+    B, T, Tp, Fin, Fpad = 3, 70, 128, 345, 384
+    x = rnd((B, T, Fin), dev, 50) * 2 - 3
+    w, b = rnd((Fin,), dev, 51) * 0.2 + 1, rnd((Fin,), dev, 52) * 0.1
+    mean, var = rnd((Fin,), dev, 53) - 3, rnd((Fin,), dev, 54).abs() + 0.5
+    out = torch.full((B * Tp, Fpad), float("nan"), dtype=F16, device=dev)
+    ops.bn_cast_pad(x, (w, b, mean, var), out, T, Tp, True, 1e-5)
+    want = torch.zeros(B, Tp, Fpad, device=dev)
+    want[:, :T, :Fin] = (x - mean) / torch.sqrt(var + 1e-5) * w + b
+    close(out.view(B, Tp, Fpad), want, 1e-3, 1e-3, "bn+cast+pad")
+    out2 = torch.full((B * Tp, Fpad), float("nan"), dtype=F16, device=dev)
+    ops.bn_cast_pad(x, None, out2, T, Tp, False)
+    want2 = torch.zeros(B, Tp, Fpad, device=dev)
+    want2[:, :T, :Fin] = x
+    close(out2.view(B, Tp, Fpad), want2, 1e-3, 1e-3, "cast+pad")
+
+
+def test_head_l2dot(hip_lib, dev):
+    from fs_eend_amd import ops
+    B, T, Tp, C, D = 2, 50, 64, 6, 256
+    emb = rnd((B, Tp, D), dev, 55)
+    emb = emb / emb.norm(dim=-1, keepdim=True)
+    attr = rnd((B * C, Tp, D), dev, 56) * 3
+    ao = torch.empty((B, T, C, D), dtype=F32, device=dev)
+    lg = torch.empty((B, T, C), dtype=F32, device=dev)
+    ops.head_l2dot(emb.view(-1, D), attr.view(-1, D), ao, lg, B, T, Tp, C, D)
+    a = attr.view(B, C, Tp, D)[:, :, :T].permute(0, 2, 1, 3)
+    a = a / a.norm(dim=-1, keepdim=True)
+    close(ao, a, 1e-6, 1e-5, "attractor l2norm")
+    close(lg, (emb[:, :T, None, :] * a).sum(-1), 2e-6, 1e-5, "logits")
