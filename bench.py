@@ -94,28 +94,41 @@ class OpTimer:
         return sorted(out, key=lambda d: -d["total_ms"])
 
 
-def cpu_baseline(T, C, threads, batch=16, warm=2, runs=5):
-    """The oracle (CPU restatement of the reference, validated against it) timed on the host cores."""
+def cpu_baseline(T, C, batch=4, budget_s=25.0):
+    """The oracle (CPU restatement of the reference, validated against it) timed on the host cores.
+    Bounded sample: B=4 utterances per run, a few thread counts, ~25 s of CPU work in total; the best
+    thread count is reported (torch oversubscribes badly when given every hardware thread)."""
     from oracle import fs_eend_ref as R
     from fs_eend_amd.fs_model import OnlineTransformerDADiarization
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **FS_CFG).eval()
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(777)
     src = [torch.randn(T, 345, generator=g) * 2 - 3 for _ in range(batch)]
-    ts = []
+    ncpu = os.cpu_count() or 1
+    cands = sorted({1, min(8, ncpu), min(32, ncpu)})
+    t_start, results = time.perf_counter(), {}
     with torch.no_grad():
-        for i in range(warm + runs):
-            t0 = time.perf_counter()
-            R.fs_test(src, [T] * batch, sd, n_heads=4, enc_n_layers=4, dec_n_layers=2, max_nspks=C)
-            if i >= warm:
-                ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return dict(value=batch * T / med, unit="frames/s", cores=threads, kind="port",
-                sample=f"oracle fs_test fp32, B={batch} x T={T}, C={C}, median of {runs} after {warm} warm-up "
-                       f"({sum(ts):.1f} s timed)")
+        for th in cands:
+            torch.set_num_threads(th)
+            ts = []
+            for i in range(4):                      # 1 warm-up + up to 3 timed
+                t0 = time.perf_counter()
+                R.fs_test(src, [T] * batch, sd, n_heads=4, enc_n_layers=4, dec_n_layers=2, max_nspks=C)
+                dt = time.perf_counter() - t0
+                if i > 0:
+                    ts.append(dt)
+                if time.perf_counter() - t_start > budget_s * (cands.index(th) + 1) / len(cands):
+                    if not ts:
+                        ts.append(dt)
+                    break
+            ts.sort()
+            results[th] = batch * T / ts[len(ts) // 2]
+    best = max(results, key=results.get)
+    return dict(value=results[best], unit="frames/s", cores=best, kind="port",
+                sample=f"oracle fs_test fp32 on host CPU ({ncpu} hw threads), B={batch} x T={T}, C={C}; frames/s by "
+                       f"torch threads: " + ", ".join(f"{k}: {v:.0f}" for k, v in results.items()) +
+                       f"; {time.perf_counter() - t_start:.1f} s of CPU work")
 
 
 def main():
@@ -247,7 +260,7 @@ def main():
                 "traffic": None, "avg_launch_ms": a["avg_ms"]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(T, C, threads=os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(T, C)
 
     if world > 1:
         dist.barrier()

@@ -29,11 +29,20 @@ int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn
 }
 
 int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
-                    int M, int N, int K, int relu, void* stream) {
-    if (!A || !W || !out_f16 || (ldo & 3)) return EEND_EINVAL;
+                    int M, int N, int K, int act, void* stream) {
+    if (!A || !W || !out_f16 || (ldo & 3) || act < 0 || act > 2) return EEND_EINVAL;
     GemmParams p = base_params(A, lda, W, ldw, bias, M, N, K);
     p.out16 = out_f16; p.ldo = ldo;
-    return eend_launch_gemm(p, relu ? EPI_PLAIN_RELU_F16 : EPI_PLAIN_F16, (hipStream_t)stream);
+    const int epi = act == 1 ? EPI_PLAIN_RELU_F16 : act == 2 ? EPI_PLAIN_SWISH_F16 : EPI_PLAIN_F16;
+    return eend_launch_gemm(p, epi, (hipStream_t)stream);
+}
+
+int eend_linear_glu_f16(const void* A, int lda, const void* Wi, int ldw, const float* bias_i, void* out_f16,
+                        int ldo, int M, int N2, int K, void* stream) {
+    if (!A || !Wi || !bias_i || !out_f16 || (ldo & 1) || (N2 & 1)) return EEND_EINVAL;
+    GemmParams p = base_params(A, lda, Wi, ldw, bias_i, M, N2, K);
+    p.out16 = out_f16; p.ldo = ldo;
+    return eend_launch_gemm(p, EPI_GLU_F16, (hipStream_t)stream);
 }
 
 int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* Q_bf16,
@@ -51,12 +60,67 @@ int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const
 }
 
 int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
-                           const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16,
-                           int M, int K, void* stream) {
+                           float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
+                           void* out_f16, int M, int K, void* stream) {
     if (!A || !W || (!out_f32 && !out_f16) || ((gamma == nullptr) != (beta == nullptr))) return EEND_EINVAL;
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
-    p.res = res; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
+    p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_LN, (hipStream_t)stream);
+}
+
+int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                                   const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                                   float* out_f32, void* out_f16, int M, int K, void* stream) {
+    if (!A || !W || !out_f32 || !out_f16 || !gamma || !beta) return EEND_EINVAL;
+    GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
+    p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
+    return eend_launch_gemm(p, EPI_RES_SCALE_LN16, (hipStream_t)stream);
+}
+
+int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,
+                            void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim, void* stream) {
+    if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;
+    if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || dh != 64 || H <= 0 || ((H * dh) % 128) != 0) return EEND_EINVAL;
+    const int D = H * dh, M = nseq * Tp;
+    const char* W = (const char*)Wqkvg;
+    const size_t rowb = (size_t)ldw * 2;
+    GemmParams qk = base_params(A, lda, W, ldw, bias, M, 2 * D, Kdim);                      // rows [0, 2D): q, k
+    qk.Tp = Tp; qk.H = H; qk.dh = dh; qk.out16 = Q; qk.out16b = K;
+    int rc = eend_launch_gemm(qk, EPI_QK_HEADS_F16, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    GemmParams kv = base_params(A, lda, W + (size_t)D * rowb, ldw, bias + D, M, 2 * D, Kdim);  // rows [D, 3D): k, v
+    kv.Tp = Tp; kv.H = H; kv.dh = dh; kv.out16 = Kt; kv.out16b = Vt;
+    rc = eend_launch_gemm(kv, EPI_KTVT_HEADS_F16, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    GemmParams g = base_params(A, lda, W + (size_t)3 * D * rowb, ldw, bias + 3 * D, M, D, Kdim);  // rows [3D, 4D): g
+    g.out16 = G; g.ldo = D;
+    return eend_launch_gemm(g, EPI_PLAIN_F16, (hipStream_t)stream);
+}
+
+int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
+                             void* O_f16, void* St_ws, float* cscale_ws, float* sexp_ws, int nseq, int H, int Tp,
+                             int L, int ldo, int ldg, float gn_eps, void* stream) {
+    if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !St_ws || !cscale_ws || !sexp_ws || L <= 0) return EEND_EINVAL;
+    RetParams p;
+    p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tp + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
+    int rc = eend_launch_ret_state_scan(p, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_ret_chunk(p, (hipStream_t)stream);
+}
+
+int eend_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out_f16, int M,
+                       int D, void* stream) {
+    if (!x || !gamma || !beta || !out_f16) return EEND_EINVAL;
+    return eend_launch_layernorm_f16(x, gamma, beta, eps, out_f16, M, D, (hipStream_t)stream);
+}
+
+int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_weight, const float* bn_bias,
+                             const float* bn_mean, const float* bn_var, float eps, void* out_f16, int nseq, int Tp,
+                             int D, int k, void* stream) {
+    if (!x_f16 || !w || !bn_weight || !bn_bias || !bn_mean || !bn_var || !out_f16) return EEND_EINVAL;
+    return eend_launch_dwconv_bn_swish(x_f16, w, bn_weight, bn_bias, bn_mean, bn_var, eps, out_f16, nseq, Tp, D, k,
+                                       (hipStream_t)stream);
 }
 
 int eend_linear_res_scale_f16(const void* A, int lda, const void* W, int ldw, const float* bias,

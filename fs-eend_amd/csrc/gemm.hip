@@ -15,6 +15,7 @@
 // into the producer's epilogue instead of being a kernel of its own.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -175,7 +176,7 @@ void gemm_f16_kernel(const GemmParams p) {
     const int R0 = (SWAP ? n0 + wn * WN : m0 + wm * WM) + fkg * 4;
     const int L0 = (SWAP ? m0 + wm * WM : n0 + wn * WN) + frow;
 
-    if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16) {
+    if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16) {
         static_assert(SWAP, "plain epilogue expects SWAP");
         _Float16* __restrict__ out = (_Float16*)p.out16;
 #pragma unroll
@@ -191,10 +192,36 @@ void gemm_f16_kernel(const GemmParams p) {
                     v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
                     v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
                 }
+                if (EPI == EPI_PLAIN_SWISH_F16) {
+                    v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
+                    v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
+                }
                 *(f16x4*)(out + (size_t)m * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
             }
         }
-    } else if constexpr (EPI == EPI_QK_HEADS) {
+    } else if constexpr (EPI == EPI_GLU_F16) {
+        // W rows interleaved (2n = value_n, 2n+1 = gate_n): a lane's 4 consecutive rows are two
+        // (value, gate) pairs -> out16[m][n], out16[m][n+1] (GLU over channels, activation.py:39-41)
+        static_assert(SWAP, "GLU epilogue expects SWAP");
+        _Float16* __restrict__ out = (_Float16*)p.out16;
+#pragma unroll
+        for (int i = 0; i < FR; ++i) {
+            const int r = R0 + i * 16;
+            const float4 b = *(const float4*)(p.bias + r);
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int m = L0 + j * 16;
+                if (m >= p.M) continue;
+                const float a0 = acc[i][j][0] + b.x, g0 = acc[i][j][1] + b.y;
+                const float a1 = acc[i][j][2] + b.z, g1 = acc[i][j][3] + b.w;
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                f16x2 o;
+                o[0] = to_f16_sat(a0 / (1.0f + __expf(-g0)));
+                o[1] = to_f16_sat(a1 / (1.0f + __expf(-g1)));
+                *(f16x2*)(out + (size_t)m * p.ldo + (r >> 1)) = o;
+            }
+        }
+    } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16) {
         // n in [0, 2D): Q then K of the packed in-proj; bf16 [which][seq][H][Tp][dh]
         static_assert(SWAP, "QK epilogue expects SWAP");
         const int D = p.H * p.dh;
@@ -205,35 +232,41 @@ void gemm_f16_kernel(const GemmParams p) {
             const int which = n / D;
             const int nn = n - which * D;
             const int h = nn / p.dh, d = nn - h * p.dh;
-            __bf16* __restrict__ dst = (__bf16*)(which ? p.out16b : p.out16);
+            using OT = typename std::conditional<EPI == EPI_QK_HEADS, __bf16, _Float16>::type;
+            OT* __restrict__ dst = (OT*)(which ? p.out16b : p.out16);
 #pragma unroll
             for (int j = 0; j < FL; ++j) {
                 const int m = L0 + j * 16;
                 if (m >= p.M) continue;
                 const int seq = m / p.Tp, t = m - seq * p.Tp;
-                *(bf16x4*)(dst + (((size_t)seq * p.H + h) * p.Tp + t) * p.dh + d) =
-                    OutCvt<__bf16>::cvt(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
+                *(decltype(OutCvt<OT>::cvt(0, 0, 0, 0))*)(dst + (((size_t)seq * p.H + h) * p.Tp + t) * p.dh + d) =
+                    OutCvt<OT>::cvt(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
             }
         }
-    } else if constexpr (EPI == EPI_VT_HEADS) {
-        // n in [0, D): V of the packed in-proj, written transposed: bf16 [seq][H][dh][Tp]
+    } else if constexpr (EPI == EPI_VT_HEADS || EPI == EPI_KTVT_HEADS_F16) {
+        // transposed head layout [seq][H][dh][Tp]: V of the packed in-proj (bf16, n in [0, D)) or
+        // K then V of the retention projections (f16, n in [0, 2D): K^T -> out16, V^T -> out16b)
         static_assert(!SWAP, "Vt epilogue expects !SWAP");
-        __bf16* __restrict__ dst = (__bf16*)p.out16;
+        using OT = typename std::conditional<EPI == EPI_VT_HEADS, __bf16, _Float16>::type;
+        const int D = p.H * p.dh;
 #pragma unroll
         for (int j = 0; j < FL; ++j) {
             const int n = L0 + j * 16;
             const float b = p.bias[n];
-            const int h = n / p.dh, d = n - h * p.dh;
+            const int which = n / D;
+            const int nn = n - which * D;
+            OT* __restrict__ dst = (OT*)(which ? p.out16b : p.out16);
+            const int h = nn / p.dh, d = nn - h * p.dh;
 #pragma unroll
             for (int i = 0; i < FR; ++i) {
                 const int m = R0 + i * 16;         // 4 consecutive frames m..m+3 (same slab: Tp % 4 == 0)
                 if (m >= p.M) continue;
                 const int seq = m / p.Tp, t = m - seq * p.Tp;
-                *(bf16x4*)(dst + (((size_t)seq * p.H + h) * p.dh + d) * p.Tp + t) =
-                    OutCvt<__bf16>::cvt(acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b);
+                *(decltype(OutCvt<OT>::cvt(0, 0, 0, 0))*)(dst + (((size_t)seq * p.H + h) * p.dh + d) * p.Tp + t) =
+                    OutCvt<OT>::cvt(acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b);
             }
         }
-    } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE) {
+    } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE || EPI == EPI_RES_SCALE_LN16) {
         // The block owns complete rows (BN == N, WGM == 1): per-token statistics.
         static_assert(SWAP && WGM == 1, "row-stat epilogues expect SWAP and one wave row");
         float* red = (float*)smem;                        // [WGN][BM] (main loop is done with LDS)
@@ -250,7 +283,7 @@ void gemm_f16_kernel(const GemmParams p) {
             for (int i = 0; i < FR; ++i) {
                 float4 r = make_float4(0, 0, 0, 0);
                 if (EPI != EPI_L2NORM && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
-                const float s = (EPI == EPI_RES_SCALE) ? p.alpha : 1.0f;
+                const float s = (EPI == EPI_L2NORM) ? 1.0f : p.alpha;
                 acc[i][j][0] = (acc[i][j][0] + bias4[i].x) * s + r.x;
                 acc[i][j][1] = (acc[i][j][1] + bias4[i].y) * s + r.y;
                 acc[i][j][2] = (acc[i][j][2] + bias4[i].z) * s + r.z;
@@ -284,7 +317,7 @@ void gemm_f16_kernel(const GemmParams p) {
             };
             const float invN = 1.0f / (float)p.N;
             float part[FL];
-            if constexpr (EPI == EPI_RES_LN) {
+            if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_SCALE_LN16) {
 #pragma unroll
                 for (int j = 0; j < FL; ++j) {
                     float s = 0.f;
@@ -311,8 +344,8 @@ void gemm_f16_kernel(const GemmParams p) {
             block_rowsum(part);
 #pragma unroll
             for (int j = 0; j < FL; ++j)
-                scale[j] = (EPI == EPI_RES_LN) ? 1.0f / __builtin_sqrtf(part[j] * invN + p.eps)
-                                               : 1.0f / __builtin_sqrtf(part[j]);
+                scale[j] = (EPI == EPI_L2NORM) ? 1.0f / __builtin_sqrtf(part[j])
+                                               : 1.0f / __builtin_sqrtf(part[j] * invN + p.eps);
         }
         float* __restrict__ o32 = (float*)p.out32;
         _Float16* __restrict__ o16 = (_Float16*)p.out16;
@@ -320,7 +353,7 @@ void gemm_f16_kernel(const GemmParams p) {
         for (int i = 0; i < FR; ++i) {
             const int n = R0 + i * 16;
             float4 g = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
-            if (EPI == EPI_RES_LN && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
+            if ((EPI == EPI_RES_LN || EPI == EPI_RES_SCALE_LN16) && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
 #pragma unroll
             for (int j = 0; j < FL; ++j) {
                 const int m = L0 + j * 16;
@@ -329,7 +362,9 @@ void gemm_f16_kernel(const GemmParams p) {
                 const float v1 = (acc[i][j][1] - mean[j]) * scale[j] * g.y + be.y;
                 const float v2 = (acc[i][j][2] - mean[j]) * scale[j] * g.z + be.z;
                 const float v3 = (acc[i][j][3] - mean[j]) * scale[j] * g.w + be.w;
-                if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
+                if (EPI == EPI_RES_SCALE_LN16) {           // residual stream stays un-normalised
+                    if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
                 if (o16) *(f16x4*)(o16 + (size_t)m * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
             }
         }
@@ -383,11 +418,18 @@ int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     switch (epi) {
         case EPI_PLAIN_F16:      return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_F16>(p, stream);
         case EPI_PLAIN_RELU_F16: return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_RELU_F16>(p, stream);
+        case EPI_PLAIN_SWISH_F16:return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_SWISH_F16>(p, stream);
+        case EPI_GLU_F16:        return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_GLU_F16>(p, stream);
+        case EPI_QK_HEADS_F16:   return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS_F16>(p, stream);
+        case EPI_KTVT_HEADS_F16: return launch<128, 128, 2, 2, false, ALOAD_PLAIN, EPI_KTVT_HEADS_F16>(p, stream);
         case EPI_QK_HEADS:       return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS>(p, stream);
         case EPI_VT_HEADS:       return launch<128, 128, 2, 2, false, ALOAD_PLAIN, EPI_VT_HEADS>(p, stream);
         case EPI_RES_LN:
             if (p.N != 256) return EEND_EINVAL;
             return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN>(p, stream);
+        case EPI_RES_SCALE_LN16:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE_LN16>(p, stream);
         case EPI_RES_SCALE:
             if (p.N != 256) return EEND_EINVAL;
             return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);

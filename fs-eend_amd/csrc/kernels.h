@@ -14,6 +14,11 @@ enum GemmEpilogue {
     EPI_L2NORM = 5,          // implicit-GEMM Conv1d + bias, then x/||x||_2 -> out32, out16; N == 256
     EPI_CONVERT = 6,         // attr0 fan-out over C speaker slots (+pc[c]) -> out32, out16; N == 256
     EPI_RES_SCALE = 7,       // (acc + bias)*alpha + res -> out32, out16 (no norm); N == 256
+    EPI_RES_SCALE_LN16 = 8,  // y = (acc + bias)*alpha + res -> out32 ; LN(y)*gamma+beta -> out16; N == 256
+    EPI_PLAIN_SWISH_F16 = 9, // out16[m][n] = f16(swish(acc + bias))
+    EPI_GLU_F16 = 10,        // rows of W interleaved (value, gate): out16[m][n/2] = v * sigmoid(g)
+    EPI_QK_HEADS_F16 = 11,   // as EPI_QK_HEADS, f16 outputs (retention)
+    EPI_KTVT_HEADS_F16 = 12, // K^T -> out16, V^T -> out16b, f16 [seq][H][dh][Tp] (retention)
 };
 
 struct GemmParams {
@@ -57,7 +62,28 @@ struct SpkAttnParams {
     float scale;      // 1/sqrt(dh)
 };
 
+struct RetParams {
+    const void* Q;    // f16 [nseq][H][Tp][64]
+    const void* K;    // f16 [nseq][H][Tp][64]   (already scaled by dk^-0.5)
+    const void* Kt;   // f16 [nseq][H][64][Tp]
+    const void* Vt;   // f16 [nseq][H][64][Tp]
+    const void* G;    // f16 [nseq*Tp][ldg] gate pre-activation
+    void* O;          // f16 [nseq*Tp][ldo]
+    void* St;         // f16 [nseq][H][nc][2][64 hd][64 kd]: state before each chunk, hi/lo, prescaled
+    float* cscale;    // [nseq][H][nc] reference cross_scale of that state
+    float* sexp;      // [nseq][H][nc] 2^e undoing the prescale
+    int nseq, H, Tp, L, nc, ldo, ldg;
+    float gn_eps;
+};
+
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream);
+int eend_launch_ret_chunk(const RetParams& p, hipStream_t stream);
+int eend_launch_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out16,
+                              long M, int D, hipStream_t stream);
+int eend_launch_dwconv_bn_swish(const void* x16, const float* w, const float* bn_w, const float* bn_b,
+                                const float* bn_mean, const float* bn_var, float eps, void* out16, int nseq,
+                                int Tp, int D, int k, hipStream_t stream);
 int eend_launch_attn_causal(const AttnParams& p, hipStream_t stream);
 int eend_launch_spk_attn(const SpkAttnParams& p, hipStream_t stream);
 int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b, const float* bn_mean,

@@ -68,7 +68,98 @@ void head_kernel(const float* __restrict__ emb, const float* __restrict__ attr, 
     if (lane == 0) logits[idx] = dot * inv;
 }
 
+// Stand-alone LayerNorm f32 [M][D] -> f16 (D <= 1024, D % 4 == 0), one wave per row.  Used where
+// LS-EEND applies two LayerNorms back to back (block-final LN followed by the next module's
+// pre-norm: conformer/encoder.py:104-110 then feed_forward.py:48).
+__global__ __launch_bounds__(256)
+void layernorm_f16_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                          float eps, _Float16* __restrict__ out, long M, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * D;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i * 256;
+        v[i] = (k < D) ? *(const float4*)(xr + k) : make_float4(0, 0, 0, 0);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) s = wave_xor_add(s, m);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i * 256;
+        if (k < D) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) q = wave_xor_add(q, m);
+    const float rstd = 1.0f / __builtin_sqrtf(q / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i * 256;
+        if (k < D) {
+            const float4 g = *(const float4*)(gamma + k), b = *(const float4*)(beta + k);
+            f16x4 o;
+            o[0] = to_f16_sat((v[i].x - mean) * rstd * g.x + b.x);
+            o[1] = to_f16_sat((v[i].y - mean) * rstd * g.y + b.y);
+            o[2] = to_f16_sat((v[i].z - mean) * rstd * g.z + b.z);
+            o[3] = to_f16_sat((v[i].w - mean) * rstd * g.w + b.w);
+            *(f16x4*)(out + row * D + k) = o;
+        }
+    }
+}
+
+// Causal depthwise Conv1d(k taps, left context k-1, no bias) -> BatchNorm1d(eval) -> Swish
+// (LS-EEND/nnet/conformer/convolution.py:65-68,143-147).  x,out f16 [nseq][Tp][D]; w f32 [D][k].
+// One thread per channel, a 64-frame strip per block: reads are 2*D-byte coalesced rows, the k-tap
+// window re-reads hit L1/L2.
+__global__ __launch_bounds__(256)
+void dwconv_bn_swish_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bw,
+                            const float* __restrict__ bb, const float* __restrict__ bm, const float* __restrict__ bv,
+                            float eps, _Float16* __restrict__ out, int Tp, int D, int k) {
+    const int seq = blockIdx.y, t0 = blockIdx.x * 64;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float sc = bw[c] / __builtin_sqrtf(bv[c] + eps);
+        const float sh = bb[c] - bm[c] * sc;
+        const _Float16* xs = x + (size_t)seq * Tp * D + c;
+        const float* wc = w + (size_t)c * k;
+        for (int t = t0; t < t0 + 64 && t < Tp; ++t) {
+            float y = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const int ts = t - (k - 1) + j;
+                if (ts >= 0) y = __builtin_fmaf(wc[j], (float)xs[(size_t)ts * D], y);
+            }
+            y = y * sc + sh;
+            out[((size_t)seq * Tp + t) * D + c] = to_f16_sat(y / (1.0f + __expf(-y)));
+        }
+    }
+}
+
 }  // namespace
+
+int eend_launch_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out16,
+                              long M, int D, hipStream_t stream) {
+    if (M <= 0 || D <= 0 || D > 1024 || (D & 3)) return EEND_EINVAL;
+    hipLaunchKernelGGL(layernorm_f16_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, eps,
+                       (_Float16*)out16, M, D);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_dwconv_bn_swish(const void* x16, const float* w, const float* bn_w, const float* bn_b,
+                                const float* bn_mean, const float* bn_var, float eps, void* out16, int nseq,
+                                int Tp, int D, int k, hipStream_t stream) {
+    if (nseq <= 0 || nseq > 65535 || Tp <= 0 || D <= 0 || k <= 0) return EEND_EINVAL;
+    hipLaunchKernelGGL(dwconv_bn_swish_kernel, dim3((Tp + 63) / 64, nseq), dim3(256), 0, stream, (const _Float16*)x16, w,
+                       bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D, k);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
 
 int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b, const float* bn_mean,
                             const float* bn_var, float eps, void* out16, int B, int T, int Tp, int Fin,

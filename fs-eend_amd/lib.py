@@ -16,7 +16,13 @@ PROTOTYPES = {
     "eend_bn_cast_pad_f16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "eend_linear_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_inproj_heads_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "eend_linear_res_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_linear_glu_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "eend_linear_res_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_linear_res_scale_ln16_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "eend_layernorm_f16": [_vp, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "eend_dwconv_bn_swish_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "eend_linear_res_scale_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_conv1d_l2norm_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_convert_fanout_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -1,0 +1,456 @@
+"""Host-side mirror of the reference's LS-EEND model (Conformer-with-retention encoder,
+retention x speaker-attention attractor decoder).
+
+Drop-in for ``nnet.model.onl_conformer_retention_enc_1dcnn_tfm_retention_enc_linear_non_autoreg_
+pos_enc_l2norm_emb_loss_mask`` (reference LS-EEND/nnet/model/...emb_loss_mask.py): same class
+names, constructor arguments, attribute tree (``enc.encoder.layers[i].sequential[j].module...``,
+``dec.layers[i]``, ``cnn``; what LS-EEND/streaming_infer_dia.py:30-44 reads) and state_dict keys,
+so reference checkpoints load and seeded default init is bit-identical.
+
+The torch.nn modules below are parameter containers only (no forward); the arithmetic runs
+in libeend_hip.so through ops.py.
+"""
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .fs_model import PositionalEncoding, _f16, _f32
+from .lib import EendHipError
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _Tag(nn.Module):
+    """Parameter-less placeholder keeping nn.Sequential indices aligned with the reference
+    (Swish / GLU / Dropout / Transpose slots)."""
+
+    def __init__(self, what: str):
+        super().__init__()
+        self.what = what
+
+
+class Linear(nn.Module):
+    """nn.Linear wrapper with xavier weight / zero bias (reference conformer/modules.py:36-49)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+        nn.init.xavier_uniform_(self.linear.weight)
+        if bias:
+            nn.init.zeros_(self.linear.bias)
+
+
+class ResidualConnectionModule(nn.Module):
+    def __init__(self, module, module_factor=1.0, input_factor=1.0):
+        super().__init__()
+        self.module = module
+        self.module_factor = module_factor
+        self.input_factor = input_factor
+
+
+class FeedForwardModule(nn.Module):
+    def __init__(self, encoder_dim, expansion_factor, dropout_p):
+        super().__init__()
+        self.sequential = nn.Sequential(
+            nn.LayerNorm(encoder_dim),
+            Linear(encoder_dim, encoder_dim * expansion_factor, bias=True),
+            _Tag("swish"), nn.Dropout(p=dropout_p),
+            Linear(encoder_dim * expansion_factor, encoder_dim, bias=True),
+            nn.Dropout(p=dropout_p))
+
+
+class RetNetRelPos(nn.Module):
+    """Buffers only; decay == log(1) (reference modules/retention.py:15-23)."""
+
+    def __init__(self, embed_dim, num_heads, recurrent_chunk_size):
+        super().__init__()
+        angle = 1.0 / (10000 ** torch.linspace(0, 1, embed_dim // num_heads // 2))
+        angle = angle.unsqueeze(-1).repeat(1, 2).flatten()
+        decay = torch.log(torch.tensor([1] * num_heads, dtype=torch.float))
+        self.register_buffer("angle", angle)
+        self.register_buffer("decay", decay)
+        self.recurrent_chunk_size = recurrent_chunk_size
+
+
+class MultiScaleRetention(nn.Module):
+    def __init__(self, embed_dim, num_heads, value_factor=1):
+        super().__init__()
+        self.factor, self.embed_dim, self.num_heads = value_factor, embed_dim, num_heads
+        self.head_dim = embed_dim * value_factor // num_heads
+        self.key_dim = embed_dim // num_heads
+        self.scaling = self.key_dim ** -0.5
+        self.q_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.k_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.v_proj = nn.Linear(embed_dim, embed_dim * value_factor, bias=True)
+        self.g_proj = nn.Linear(embed_dim, embed_dim * value_factor, bias=True)
+        self.out_proj = nn.Linear(embed_dim * value_factor, embed_dim, bias=True)
+        self.group_norm = nn.LayerNorm(self.head_dim, eps=1e-6, elementwise_affine=False)
+        for p in (self.q_proj, self.k_proj, self.v_proj, self.g_proj):
+            nn.init.xavier_uniform_(p.weight, gain=2 ** -2.5)
+        nn.init.xavier_uniform_(self.out_proj.weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class MultiHeadedSelfRetentionModule(nn.Module):
+    def __init__(self, d_model, num_heads, recurrent_chunk_size=500, dropout_p=0.1):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.ret_pos = RetNetRelPos(d_model, num_heads, recurrent_chunk_size)
+        self.self_attn = MultiScaleRetention(d_model, num_heads, value_factor=1)
+        self.dropout = nn.Dropout(p=dropout_p)
+
+
+class PointwiseConv1d(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True)
+
+
+class DepthwiseConv1d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, padding):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, groups=in_channels, stride=1,
+                              padding=padding, bias=False)
+
+
+class ConformerConvModule(nn.Module):
+    def __init__(self, in_channels, kernel_size=31, expansion_factor=2, dropout_p=0.1):
+        super().__init__()
+        assert expansion_factor == 2
+        self.sequential = nn.Sequential(
+            nn.LayerNorm(in_channels), _Tag("transpose"),
+            PointwiseConv1d(in_channels, in_channels * expansion_factor), _Tag("glu"),
+            DepthwiseConv1d(in_channels, in_channels, kernel_size, padding=kernel_size - 1),
+            nn.BatchNorm1d(in_channels), _Tag("swish"),
+            PointwiseConv1d(in_channels, in_channels), nn.Dropout(p=dropout_p))
+
+
+class ConformerEncoderBlock(nn.Module):
+    def __init__(self, encoder_dim, num_attention_heads, feed_forward_expansion_factor, conv_expansion_factor,
+                 feed_forward_dropout_p, attention_dropout_p, conv_dropout_p, conv_kernel_size, half_step_residual,
+                 recurrent_chunk_size):
+        super().__init__()
+        self.feed_forward_residual_factor = 0.5 if half_step_residual else 1
+        f = self.feed_forward_residual_factor
+        self.sequential = nn.Sequential(
+            ResidualConnectionModule(FeedForwardModule(encoder_dim, feed_forward_expansion_factor, feed_forward_dropout_p), f),
+            ResidualConnectionModule(MultiHeadedSelfRetentionModule(encoder_dim, num_attention_heads, recurrent_chunk_size,
+                                                                    attention_dropout_p)),
+            ResidualConnectionModule(ConformerConvModule(encoder_dim, conv_kernel_size, conv_expansion_factor, conv_dropout_p)),
+            ResidualConnectionModule(FeedForwardModule(encoder_dim, feed_forward_expansion_factor, feed_forward_dropout_p), f),
+            nn.LayerNorm(encoder_dim))
+
+
+class ConformerEncoder(nn.Module):
+    def __init__(self, input_dim, encoder_dim, num_layers, num_attention_heads, feed_forward_expansion_factor,
+                 conv_expansion_factor, feed_forward_dropout_p, attention_dropout_p, conv_dropout_p, conv_kernel_size,
+                 half_step_residual, recurrent_chunk_size):
+        super().__init__()
+        self._conv_kernel_size = conv_kernel_size
+        self.input_projection = Linear(input_dim, encoder_dim)
+        self.layer_norm = nn.LayerNorm(encoder_dim)
+        self.layers = nn.ModuleList([ConformerEncoderBlock(
+            encoder_dim, num_attention_heads, feed_forward_expansion_factor, conv_expansion_factor,
+            feed_forward_dropout_p, attention_dropout_p, conv_dropout_p, conv_kernel_size, half_step_residual,
+            recurrent_chunk_size) for _ in range(num_layers)])
+
+
+class EmbeddingEncoderModule(nn.Module):
+    def __init__(self, in_size, n_units, n_heads, n_layers, recurrent_chunk_size, feed_forward_expansion_factor=8,
+                 conv_expansion_factor=2, dropout=0.1, conv_kernel_size=16, half_step_residual=True, max_seqlen=500):
+        super().__init__()
+        self.max_seqlen = max_seqlen
+        self.recurrent_chunk_size = recurrent_chunk_size
+        self.encoder = ConformerEncoder(in_size, n_units, n_layers, n_heads, feed_forward_expansion_factor,
+                                        conv_expansion_factor, dropout, dropout, dropout, conv_kernel_size,
+                                        half_step_residual, recurrent_chunk_size)
+
+
+class TransformerEncoderFusionLayer(nn.Module):
+    """Parameters of the LS decoder layer (reference modules/merge_retnet_layer.py:71-110)."""
+
+    def __init__(self, d_model, nhead, recurrent_chunk_size=500, dim_feedforward=2048, dropout=0.1,
+                 layer_norm_eps=1e-5, batch_first=True):
+        super().__init__()
+        self.ret_pos1 = RetNetRelPos(d_model, nhead, recurrent_chunk_size)
+        self.self_attn1 = MultiScaleRetention(d_model, nhead, value_factor=1)
+        self.self_attn2 = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=batch_first)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm11 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm12 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm21 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm22 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.dropout11, self.dropout21, self.dropout2 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+
+
+class MaskedTransformerDecoderModel(nn.Module):
+    def __init__(self, in_size, n_heads, n_units, n_layers, recurrent_chunk_size, dim_feedforward, dropout=0.5,
+                 max_seqlen=500, has_pos=False, mask_delay=0):
+        super().__init__()
+        self.in_size, self.n_heads, self.n_units, self.n_layers = in_size, n_heads, n_units, n_layers
+        self.has_pos, self.max_seqlen, self.mask_delay = has_pos, max_seqlen, mask_delay
+        self.encoder = nn.Linear(in_size, n_units)            # dead, kept for checkpoints
+        self.encoder_norm = nn.LayerNorm(n_units)             # dead
+        self.pos_enc = PositionalEncoding(n_units, dropout)
+        self.convert = nn.Linear(n_units * 2, n_units)
+        self.layers = nn.ModuleList([TransformerEncoderFusionLayer(n_units, n_heads, recurrent_chunk_size, dim_feedforward,
+                                                                   dropout, batch_first=True) for _ in range(n_layers)])
+
+
+def _ret_pack(msr: MultiScaleRetention):
+    """[q; k * dk^-0.5; v; g] rows (4D, D) f16 + bias (4D,) f32 (retention.py:200-205)."""
+    s = msr.scaling
+    w = torch.cat([msr.q_proj.weight, msr.k_proj.weight * s, msr.v_proj.weight, msr.g_proj.weight], dim=0)
+    b = torch.cat([msr.q_proj.bias, msr.k_proj.bias * s, msr.v_proj.bias, msr.g_proj.bias], dim=0)
+    return _f16(w), _f32(b)
+
+
+class _Workspace:
+    def __init__(self, dev, B, Tp, C, D, F_enc, F_dec, Fin_pad, H, nc):
+        f16, f32 = torch.float16, torch.float32
+        Me, Md = B * Tp, B * C * Tp
+        Mx = max(Me, Md)
+        e = lambda *s, dt: torch.empty(*s, dtype=dt, device=dev)
+        self.xin16 = torch.zeros(Me, Fin_pad, dtype=f16, device=dev)
+        self.h32, self.h16, self.x16 = e(Me, D, dt=f32), e(Me, D, dt=f16), e(Me, D, dt=f16)
+        self.q, self.k, self.kt, self.vt = (e(Mx * D, dt=f16) for _ in range(4))
+        self.g = e(Mx, D, dt=f16)
+        self.o16 = e(Mx, D, dt=f16)
+        self.glu16, self.dw16 = e(Me, D, dt=f16), e(Me, D, dt=f16)
+        self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
+        self.emb32, self.emb16 = e(Me, D, dt=f32), e(Me, D, dt=f16)
+        self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
+        self.qkv16 = e(Md, 3 * D, dt=f16)
+        nseq = max(B, B * C)
+        self.st = e(nseq * H * nc * 2 * 4096, dt=f16)
+        self.cscale, self.sexp = e(nseq * H * nc, dt=f32), e(nseq * H * nc, dt=f32)
+
+
+class OnlineConformerRetentionDADiarization(nn.Module):
+    """LS-EEND on MI355X (reference LS model :14-147)."""
+
+    def __init__(self, n_speakers, in_size, n_units, n_heads, enc_n_layers, dec_n_layers, dropout, max_seqlen,
+                 recurrent_chunk_size: int = 500, feed_forward_expansion_factor: int = 8, dec_dim_feedforward: int = 2048,
+                 conv_expansion_factor: int = 2, conv_kernel_size: int = 16, half_step_residual: bool = True,
+                 conv_delay=9, mask_delay=0):
+        super().__init__()
+        if n_units != 256 or n_heads != 4:
+            raise NotImplementedError("HIP kernels are specialised for n_units=256, n_heads=4 (all reference configs)")
+        self.n_speakers, self.n_units, self.delay = n_speakers, n_units, conv_delay
+        self.max_seqlen, self.recurrent_chunk_size = max_seqlen, recurrent_chunk_size
+        self.enc = EmbeddingEncoderModule(in_size=in_size, n_units=n_units, n_heads=n_heads, n_layers=enc_n_layers,
+                                          recurrent_chunk_size=recurrent_chunk_size,
+                                          feed_forward_expansion_factor=feed_forward_expansion_factor,
+                                          conv_expansion_factor=conv_expansion_factor, dropout=dropout,
+                                          conv_kernel_size=conv_kernel_size, half_step_residual=half_step_residual,
+                                          max_seqlen=max_seqlen)
+        self.dec = MaskedTransformerDecoderModel(in_size, n_heads=n_heads, n_units=n_units, n_layers=dec_n_layers,
+                                                 recurrent_chunk_size=recurrent_chunk_size,
+                                                 dim_feedforward=dec_dim_feedforward, dropout=dropout,
+                                                 max_seqlen=max_seqlen, mask_delay=mask_delay)
+        self.cnn = nn.Conv1d(n_units, n_units, kernel_size=2 * conv_delay + 1, padding=conv_delay)
+        self._in_size, self._n_heads = in_size, n_heads
+        self._prep = self._prep_key = None
+        self._ws, self._pc = {}, {}
+
+    # ------------------------------------------------------------------ weight preparation
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _prepare(self):
+        key = self._fingerprint()
+        if self._prep is not None and key == self._prep_key:
+            return self._prep
+        dev = self.cnn.weight.device
+        if dev.type != "cuda":
+            raise EendHipError("model parameters must live on the GPU: the HIP path has no CPU fallback")
+        D = self.n_units
+        P = {}
+        e = self.enc.encoder
+        Fin = self._in_size
+        Fin_pad = (Fin + 63) // 64 * 64
+        w = torch.zeros(D, Fin_pad, dtype=torch.float16, device=dev)
+        w[:, :Fin] = e.input_projection.linear.weight.detach().to(torch.float16)
+        P["in.w"], P["in.b"] = w, _f32(e.input_projection.linear.bias)
+        P["in.g"], P["in.beta"], P["in.eps"] = _f32(e.layer_norm.weight), _f32(e.layer_norm.bias), e.layer_norm.eps
+        P["Fin_pad"] = Fin_pad
+        blocks = []
+        for blk in e.layers:
+            s = blk.sequential
+            ffa, ret, cm, ffb, ln_e = s[0].module.sequential, s[1].module, s[2].module.sequential, s[3].module.sequential, s[4]
+            pw1 = cm[2].conv.weight.detach()[:, :, 0]                                   # (2D, D)
+            pb1 = cm[2].conv.bias.detach()
+            inter = torch.stack([pw1[:D], pw1[D:]], dim=1).reshape(2 * D, D)            # rows (value_n, gate_n) interleaved
+            interb = torch.stack([pb1[:D], pb1[D:]], dim=1).reshape(2 * D)
+            wq, bq = _ret_pack(ret.self_attn)
+            bn = cm[5]
+            blocks.append(dict(
+                fa=s[0].module_factor, fb=s[3].module_factor,
+                lna=(_f32(ffa[0].weight), _f32(ffa[0].bias), ffa[0].eps),
+                w1a=_f16(ffa[1].linear.weight), b1a=_f32(ffa[1].linear.bias),
+                w2a=_f16(ffa[4].linear.weight), b2a=_f32(ffa[4].linear.bias),
+                lnb=(_f32(ret.layer_norm.weight), _f32(ret.layer_norm.bias), ret.layer_norm.eps),
+                wqkvg=wq, bqkvg=bq, gn_eps=ret.self_attn.group_norm.eps,
+                wo=_f16(ret.self_attn.out_proj.weight), bo=_f32(ret.self_attn.out_proj.bias),
+                lnc=(_f32(cm[0].weight), _f32(cm[0].bias), cm[0].eps),
+                pw1=_f16(inter), pb1=_f32(interb),
+                dw=_f32(cm[4].conv.weight[:, 0, :]),
+                bn=tuple(_f32(t) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)), bn_eps=bn.eps,
+                pw2=_f16(cm[7].conv.weight[:, :, 0]), pb2=_f32(cm[7].conv.bias),
+                lnd=(_f32(ffb[0].weight), _f32(ffb[0].bias), ffb[0].eps),
+                w1b=_f16(ffb[1].linear.weight), b1b=_f32(ffb[1].linear.bias),
+                w2b=_f16(ffb[4].linear.weight), b2b=_f32(ffb[4].linear.bias),
+                lne=(_f32(ln_e.weight), _f32(ln_e.bias), ln_e.eps)))
+        P["blocks"] = blocks
+        cw = self.cnn.weight.detach()
+        P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
+        P["cnn.b"], P["cnn.k"], P["cnn.pad"] = _f32(self.cnn.bias), cw.shape[2], self.cnn.padding[0]
+        P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
+        dl = []
+        for l in self.dec.layers:
+            wq, bq = _ret_pack(l.self_attn1)
+            dl.append(dict(
+                wqkvg=wq, bqkvg=bq, gn_eps=l.self_attn1.group_norm.eps,
+                out1_w=_f16(l.self_attn1.out_proj.weight), out1_b=_f32(l.self_attn1.out_proj.bias),
+                in2_w=_f16(l.self_attn2.in_proj_weight), in2_b=_f32(l.self_attn2.in_proj_bias),
+                out2_w=_f16(l.self_attn2.out_proj.weight), out2_b=_f32(l.self_attn2.out_proj.bias),
+                w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
+                g11=_f32(l.norm11.weight), be11=_f32(l.norm11.bias), eps11=l.norm11.eps,
+                g21=_f32(l.norm21.weight), be21=_f32(l.norm21.bias), eps21=l.norm21.eps,
+                g22=_f32(l.norm22.weight), be22=_f32(l.norm22.bias), eps22=l.norm22.eps))
+        P["dec.layers"] = dl
+        self._prep, self._prep_key, self._pc = P, key, {}
+        return P
+
+    def _convert_const(self, C):
+        if C not in self._pc:
+            D = self.n_units
+            pe = self.dec.pos_enc.pe[0, :C].to(torch.float32)
+            w2 = self.dec.convert.weight.detach()[:, D:].to(torch.float32)
+            self._pc[C] = (pe @ w2.t() + self.dec.convert.bias.detach().to(torch.float32)).contiguous()
+        return self._pc[C]
+
+    def _workspace(self, dev, B, Tp, C, nc):
+        key = (str(dev), B, Tp, C, nc)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 8:
+                self._ws.clear()
+            P = self._prep
+            F_enc = P["blocks"][0]["w1a"].shape[0] if P["blocks"] else 0
+            F_dec = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
+            ws = _Workspace(dev, B, Tp, C, self.n_units, F_enc, F_dec, P["Fin_pad"], self._n_heads, nc)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ the hot path
+    def _run(self, src: Sequence[Tensor], ilens: Sequence[int], C: int):
+        P = self._prepare()
+        dev = self.cnn.weight.device
+        D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
+        x = nn.utils.rnn.pad_sequence([s.to(device=dev, dtype=torch.float32) for s in src],
+                                      padding_value=0.0, batch_first=True).contiguous()    # LS model :280
+        B, T, _ = x.shape
+        Tpad = math.ceil(T / L) * L                        # reference pads to a chunk multiple (:281-283)
+        Tp = ops.frames_pad(Tpad)
+        nc = (Tp + L - 1) // L
+        ws = self._workspace(dev, B, Tp, C, nc)
+        il_key = tuple(min(int(l), T) for l in ilens)
+        if getattr(ws, "il_key", None) != il_key:
+            ws.il = torch.tensor(il_key, dtype=torch.int32, device=dev)
+            ws.il_key = il_key
+        Me, Md = B * Tp, B * C * Tp
+
+        # ---- Conformer-retention encoder (conformer/encoder.py:194-201, :76-113)
+        ops.bn_cast_pad(x, None, ws.xin16, T, Tp, False)
+        ops.linear_res_ln(ws.xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], ws.h32, ws.h16, P["in.eps"])
+        q, k, kt, vt = ws.q[:Me * D], ws.k[:Me * D], ws.kt[:Me * D], ws.vt[:Me * D]
+        g, o16 = ws.g[:Me], ws.o16[:Me]
+        nb = len(P["blocks"])
+        for i, Bk in enumerate(P["blocks"]):
+            if i == 0:
+                ops.layernorm_f16(ws.h32, Bk["lna"][0], Bk["lna"][1], ws.x16, Bk["lna"][2])
+            F = Bk["w1a"].shape[0]
+            ff = ws.ff16[:Me * F].view(Me, F)
+            # x += fa * FFN(LN_a x)                      -> x16 = LN_b(x)
+            ops.linear(ws.x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
+            ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], ws.h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1],
+                                      ws.h32, ws.x16, Bk["lnb"][2])
+            # x += Retention(LN_b x)                     -> x16 = LN_c(x)
+            ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
+            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"])
+            ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
+                                      ws.h32, ws.x16, Bk["lnc"][2])
+            # x += ConvModule(x): 1x1 + GLU, causal depthwise + BN + swish, 1x1   -> x16 = LN_d(x)
+            ops.linear_glu(ws.x16, Bk["pw1"], Bk["pb1"], ws.glu16)
+            ops.dwconv_bn_swish(ws.glu16, Bk["dw"], Bk["bn"], ws.dw16, B, Tp, Bk["bn_eps"])
+            ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
+                                      ws.h32, ws.x16, Bk["lnd"][2])
+            # x = LN_e(x + fb * FFN(LN_d x))
+            ops.linear(ws.x16, Bk["w1b"], Bk["b1b"], ff, act=ops.ACT_SWISH)
+            ops.linear_res_ln(ff, Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1], ws.h32, ws.h16,
+                              Bk["lne"][2], alpha=Bk["fb"])
+            if i + 1 < nb:
+                nx = P["blocks"][i + 1]["lna"]
+                ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
+
+        # ---- truncate / zero re-pad, look-ahead conv, L2 (LS model :80-87)
+        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, ws.emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+
+        # ---- attractor decoder (LS model :215-220; merge_retnet_layer.py:233-253)
+        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
+        q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
+        g, o16 = ws.g[:Md], ws.o16[:Md]
+        for Ld in P["dec.layers"]:
+            F = Ld["w1"].shape[0]
+            ff = ws.ff16[:Md * F].view(Md, F)
+            ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
+            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"])
+            ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
+            ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
+            ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], ws.a32, ws.a16, Ld["eps21"])
+            ops.linear(ws.a16, Ld["w1"], Ld["b1"], ff, relu=True)
+            ops.linear_res_ln(ff, Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16, Ld["eps22"])
+
+        attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
+        ops.head_l2dot(ws.emb32, ws.a32, attr, logits, B, T, Tp, C, D)
+        return logits, ws.emb32.view(B, Tp, D), attr, T, Tp
+
+    @torch.no_grad()
+    def test(self, src, ilens, max_nspks=6):
+        """reference LS model :125-147."""
+        logits, emb, attr, T, Tp = self._run(src, ilens, max_nspks)
+        return ([logits[b, :l] for b, l in enumerate(ilens)], [emb[b, :l].clone() for b, l in enumerate(ilens)],
+                [attr[b, :l] for b, l in enumerate(ilens)])
+
+    def forward(self, src, tgt, ilens):
+        """reference LS model :74-122 (values only; backward kernels are not implemented yet)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("fs-eend_amd: backward kernels are not implemented yet; call under torch.no_grad()")
+        n_speakers = [t.shape[1] for t in tgt]
+        C = max(n_speakers)
+        logits, emb, attr, T, Tp = self._run(src, ilens, C)
+        dev = logits.device
+        seq_len = max(int(l) for l in ilens)
+        len_mask = nn.utils.rnn.pad_sequence([torch.ones(int(l), device=dev) for l in ilens], batch_first=True)[..., None]
+        e = emb[:, :seq_len] * len_mask                                        # :100
+        attn_map = e @ e.transpose(-1, -2)
+        n = torch.linalg.vector_norm(e, dim=-1, keepdim=True)
+        attn_map = attn_map / (n @ n.transpose(-1, -2) + 1e-6)
+        tgt_pad = [nn.functional.pad(t.to(dev, torch.float32), (0, C - t.shape[1])) for t in tgt]
+        tgt_pad = nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True)
+        label_map = tgt_pad @ tgt_pad.transpose(-1, -2)
+        tn = torch.linalg.vector_norm(tgt_pad, dim=-1, keepdim=True)
+        label_map = label_map / (tn @ tn.transpose(-1, -2) + 1e-6)
+        loss = nn.functional.mse_loss(attn_map, label_map, reduction="sum") / sum(int(l) * int(l) for l in ilens)
+        output = [logits[b, :l, :n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
+        embs = [e[b, :l].clone() for b, l in enumerate(ilens)]
+        attractors = [attr[b, :l, 1:n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
+        return output, loss, embs, attractors

@@ -54,14 +54,19 @@ def bn_cast_pad(x, bn, out16, T, Tp, apply_bn=True, eps=1e-5):
     return out16
 
 
-def linear(a16, w16, bias, out16, relu=False):
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+
+
+def linear(a16, w16, bias, out16, relu=False, act=None):
     """out16 = act(a16 @ w16.T + bias); a16 (M,K) f16, w16 (N,K) f16."""
+    if act is None:
+        act = ACT_RELU if relu else ACT_NONE
     L = _lib.load()
     _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(out16, F16, "out16")
     M, K = a16.shape
     N = w16.shape[0]
     _lib.check(L.eend_linear_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(out16),
-                                 out16.stride(0), M, N, K, 1 if relu else 0, _stream()), "eend_linear_f16")
+                                 out16.stride(0), M, N, K, act, _stream()), "eend_linear_f16")
     return out16
 
 
@@ -74,7 +79,68 @@ def inproj_heads(a16, w16, bias, q, k, vt, nseq, Tp, H):
                                         _p(vt), nseq, Tp, H, 64, K, _stream()), "eend_inproj_heads_bf16")
 
 
-def linear_res_ln(a16, w16, bias, res, gamma, beta, out32, out16, eps=1e-5):
+def linear_glu(a16, wi16, bias_i, out16):
+    """GLU(a16 @ W.T + b) with value/gate rows interleaved in wi16 (2N, K); out16 (M, N)."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wi16, F16, "wi16"); _chk(bias_i, F32, "bias_i"); _chk(out16, F16, "out16")
+    M, K = a16.shape
+    _lib.check(L.eend_linear_glu_f16(_p(a16), a16.stride(0), _p(wi16), wi16.stride(0), _p(bias_i), _p(out16),
+                                     out16.stride(0), M, wi16.shape[0], K, _stream()), "eend_linear_glu_f16")
+
+
+def linear_res_scale_ln16(a16, w16, bias, res, alpha, gamma, beta, out32, out16, eps=1e-5):
+    """out32 = (a16 @ w16.T + bias) * alpha + res ; out16 = f16(LN(out32) * gamma + beta)."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(res, F32, "res")
+    _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = a16.shape
+    _lib.check(L.eend_linear_res_scale_ln16_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(res),
+                                                float(alpha), _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, K,
+                                                _stream()), "eend_linear_res_scale_ln16_f16")
+
+
+def retention_proj(a16, wqkvg16, bias, q, k, kt, vt, g, nseq, Tp, H):
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wqkvg16, F16, "wqkvg"); _chk(bias, F32, "bias")
+    for t, n in ((q, "q"), (k, "k"), (kt, "kt"), (vt, "vt"), (g, "g")):
+        _chk(t, F16, n)
+    _lib.check(L.eend_retention_proj_f16(_p(a16), a16.stride(0), _p(wqkvg16), wqkvg16.stride(0), _p(bias), _p(q),
+                                         _p(k), _p(kt), _p(vt), _p(g), nseq, Tp, H, 64, a16.shape[1], _stream()),
+               "eend_retention_proj_f16")
+
+
+def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp, chunk, gn_eps=1e-6):
+    L = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (kt, "kt"), (vt, "vt"), (g, "g"), (o16, "o16"), (st_ws, "st_ws")):
+        _chk(t, F16, n)
+    _chk(cscale_ws, F32, "cscale_ws"); _chk(sexp_ws, F32, "sexp_ws")
+    nc = (Tp + chunk - 1) // chunk
+    if st_ws.numel() < nseq * H * nc * 2 * 4096 or cscale_ws.numel() < nseq * H * nc or sexp_ws.numel() < nseq * H * nc:
+        raise _lib.EendHipError("retention_chunk: workspace too small")
+    _lib.check(L.eend_retention_chunk_f16(_p(q), _p(k), _p(kt), _p(vt), _p(g), _p(o16), _p(st_ws), _p(cscale_ws),
+                                          _p(sexp_ws), nseq, H, Tp, chunk, o16.stride(0), g.stride(0), gn_eps,
+                                          _stream()), "eend_retention_chunk_f16")
+
+
+def layernorm_f16(x32, gamma, beta, out16, eps=1e-5):
+    L = _lib.load()
+    _chk(x32, F32, "x32"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out16, F16, "out16")
+    M, D = x32.shape
+    _lib.check(L.eend_layernorm_f16(_p(x32), _p(gamma), _p(beta), eps, _p(out16), M, D, _stream()), "eend_layernorm_f16")
+
+
+def dwconv_bn_swish(x16, w, bn, out16, nseq, Tp, eps=1e-5):
+    """x16/out16 f16 (nseq*Tp, D); w f32 (D, k); bn = (weight, bias, mean, var)."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(w, F32, "w"); _chk(out16, F16, "out16")
+    for t in bn:
+        _chk(t, F32, "bn")
+    D, k = w.shape
+    _lib.check(L.eend_dwconv_bn_swish_f16(_p(x16), _p(w), _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), eps, _p(out16),
+                                          nseq, Tp, D, k, _stream()), "eend_dwconv_bn_swish_f16")
+
+
+def linear_res_ln(a16, w16, bias, res, gamma, beta, out32, out16, eps=1e-5, alpha=1.0):
     L = _lib.load()
     _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(res, F32, "res")
     _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
@@ -82,7 +148,7 @@ def linear_res_ln(a16, w16, bias, res, gamma, beta, out32, out16, eps=1e-5):
     if w16.shape[0] != 256:
         raise _lib.EendHipError("linear_res_ln: N must be 256")
     _lib.check(L.eend_linear_res_ln_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(res),
-                                        _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, K, _stream()),
+                                        float(alpha), _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, K, _stream()),
                "eend_linear_res_ln_f16")
 
 

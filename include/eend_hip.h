@@ -41,12 +41,19 @@ int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn
                          const float* bn_mean, const float* bn_var, float eps, void* out_f16,
                          int B, int T, int Tp, int Fin, int Fpad, int apply_bn, void* stream);
 
-/* out = act(A W^T + bias), f16 in / f16 out, f32 accumulate.  torch.nn.Linear call sites:
- * FFN linear1+ReLU of nn.TransformerEncoderLayer (FS model :147) and of the fusion layer
- * (FS-EEND/nnet/modules/merge_tfm_encoder.py:397-399), packed in-proj of the speaker MHA
- * (merge_tfm_encoder.py:388-394).  A [M][lda], W [N][ldw], N % 128 == 0, K % 64 == 0. */
+/* out = act(A W^T + bias), f16 in / f16 out, f32 accumulate; act: 0 none, 1 ReLU, 2 Swish.
+ * torch.nn.Linear call sites: FFN linear1+ReLU of nn.TransformerEncoderLayer (FS model :147) and of
+ * the fusion layer (FS-EEND/nnet/modules/merge_tfm_encoder.py:397-399), packed in-proj of the speaker
+ * MHA (merge_tfm_encoder.py:388-394), Linear+Swish of LS-EEND's FeedForwardModule
+ * (LS-EEND/nnet/conformer/feed_forward.py:49-50).  A [M][lda], W [N][ldw], N % 128 == 0, K % 64 == 0. */
 int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16,
-                    int ldo, int M, int N, int K, int relu, void* stream);
+                    int ldo, int M, int N, int K, int act, void* stream);
+
+/* Pointwise Conv1d(D -> 2D) + GLU over channels (LS-EEND/nnet/conformer/convolution.py:141-142,
+ * activation.py:39-41).  Wi / bias_i have the value and gate rows interleaved
+ * (row 2n = W[n], row 2n+1 = W[n + N2/2]); out[m][n] = v_n * sigmoid(g_n), f16 [M][ldo]. */
+int eend_linear_glu_f16(const void* A, int lda, const void* Wi, int ldw, const float* bias_i, void* out_f16,
+                        int ldo, int M, int N2, int K, void* stream);
 
 /* Packed MHA in-projection (3D x D) whose epilogue scatters Q, K (bf16 [nseq][H][Tp][dh]) and
  * V transposed (bf16 [nseq][H][dh][Tp]) for eend_attn_causal_bf16.  Replaces the in-proj half of
@@ -55,13 +62,22 @@ int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float*
 int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* Q_bf16,
                            void* K_bf16, void* Vt_bf16, int nseq, int Tp, int H, int dh, int K, void* stream);
 
-/* out = LayerNorm(A W^T + bias + res) * gamma + beta, N = 256; writes f32 (residual stream) and
- * f16 (next MFMA operand) copies; res / out32 / out16 / gamma may be null.  Replaces
+/* out = LayerNorm((A W^T + bias) * alpha + res) * gamma + beta, N = 256; writes f32 (residual
+ * stream) and f16 (next MFMA operand) copies; res / out32 / out16 / gamma may be null.  Replaces
  * Linear -> LayerNorm (FS model :173-174), out-proj + residual + norm1 / norm11 / norm21 and
- * linear2 + residual + norm2 / norm22 (torch TransformerEncoderLayer; merge_tfm_encoder.py:364,373-374). */
+ * linear2 + residual + norm2 / norm22 (torch TransformerEncoderLayer; merge_tfm_encoder.py:364,373-374),
+ * and with alpha = 0.5 the half-step FFN + block-final LayerNorm of the Conformer block
+ * (LS-EEND/nnet/conformer/encoder.py:104-110). */
 int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
-                           const float* res, const float* gamma, const float* beta, float eps,
+                           const float* res, float alpha, const float* gamma, const float* beta, float eps,
                            float* out_f32, void* out_f16, int M, int K, void* stream);
+
+/* y = (A W^T + bias) * alpha + res -> out_f32 (residual stream, not normalised) and
+ * LayerNorm(y) * gamma + beta -> out_f16: the pre-norm input of the NEXT Conformer sub-module
+ * (feed_forward.py:48, attention.py:100, convolution.py:139) fused into its producer.  N = 256. */
+int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                                   const float* res, float alpha, const float* gamma, const float* beta,
+                                   float eps, float* out_f32, void* out_f16, int M, int K, void* stream);
 
 /* out = (A W^T + bias) * alpha + res, N = 256, f32 + f16 copies (no normalisation).  Replaces the
  * LS-EEND residual wrappers: ResidualConnectionModule with module_factor 0.5 / 1
@@ -93,6 +109,32 @@ int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, floa
  * dh = 64.  Q,K bf16 [nseq][H][Tp][64], Vt bf16 [nseq][H][64][Tp] -> O f16 [nseq*Tp][ldo]. */
 int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, int nseq, int H,
                           int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream);
+
+/* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
+ * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
+ * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */
+int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q,
+                            void* K, void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim,
+                            void* stream);
+
+/* Chunk-recurrent retention with decay 1 (retention.py:146-194 + RetNetRelPos :30-47), the per-head
+ * LayerNorm (eps gn_eps, no affine, :222) and the swish gate (:224) in one pass:
+ * O = swish(G) * LN_head(retention(Q,K,V)).  L = recurrent_chunk_size; workspaces: St_ws f16
+ * [nseq][H][nc][2][64][64], cscale_ws / sexp_ws f32 [nseq][H][nc], nc = ceil(Tp / L). */
+int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
+                             void* O_f16, void* St_ws, float* cscale_ws, float* sexp_ws, int nseq, int H,
+                             int Tp, int L, int ldo, int ldg, float gn_eps, void* stream);
+
+/* Stand-alone LayerNorm f32 [M][D] -> f16 (D <= 1024): second of two back-to-back LayerNorms
+ * (conformer/encoder.py:110 then feed_forward.py:48; encoder.py:196 then feed_forward.py:48). */
+int eend_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out_f16, int M,
+                       int D, void* stream);
+
+/* Causal depthwise Conv1d (k taps, left context k-1, no bias) -> BatchNorm1d(eval) -> Swish
+ * (conformer/convolution.py:65-68,143-147).  x,out f16 [nseq][Tp][D]; w f32 [D][k]. */
+int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_weight, const float* bn_bias,
+                             const float* bn_mean, const float* bn_var, float eps, void* out_f16, int nseq,
+                             int Tp, int D, int k, void* stream);
 
 /* Unmasked MHA core over the C (<= 12) attractor slots of each frame (_sa_block2,
  * merge_tfm_encoder.py:388-394; LS-EEND/nnet/modules/merge_retnet_layer.py:301-306).

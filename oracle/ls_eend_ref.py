@@ -1,0 +1,322 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the LS-EEND
+frame-wise diarization forward (Conformer-with-retention encoder, retention x
+speaker-attention attractor decoder), batch (chunk-recurrent) and one-step
+(recurrent) forms.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Pinned against the reference by tests/golden/ls_*.npz (oracle/gen_golden_ls.py imports
+/root/reference/LS-EEND/nnet here in the build container).
+
+Explicit tensor algebra over the reference's flat ``state_dict`` names; citations are
+file:line under /root/reference/LS-EEND/.  ``q`` is the same optional operand-quantiser
+hook as in fs_eend_ref (precision studies only).
+"""
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .fs_eend_ref import _id, layer_norm, linear, mha
+
+Tensor = torch.Tensor
+GN_EPS = 1e-6      # MultiScaleRetention.group_norm (nnet/modules/retention.py:102)
+BN_EPS = 1e-5
+
+
+def swish(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)                       # conformer/activation.py:27-28
+
+
+# ----------------------------------------------------------------------------
+# retention (nnet/modules/retention.py), decay == 1, rotation disabled
+# ----------------------------------------------------------------------------
+def retention_chunk(qr: Tensor, kr: Tensor, v: Tensor, L: int, q=_id, role="ret") -> Tensor:
+    """chunk_recurrent_forward (retention.py:146-194) with the RetNetRelPos chunkwise
+    tables for decay = log(1) (retention.py:20,36-46):
+        mask[i,j]      = 1/sqrt(i+1) for j <= i else 0
+        cross_decay    = 1
+        inner_decay[i] = sqrt(L)/sqrt(i+1)
+        mask[-1, j]    = 1/sqrt(L)
+    qr, kr: (N, H, T, dk) ; v: (N, T, H*dv).  Returns (N, T, H, dv)."""
+    N, H, T, dk = qr.shape
+    dv = v.shape[-1] // H
+    nc = T // L
+    assert T % L == 0
+    i = torch.arange(L, dtype=qr.dtype)
+    rs = torch.sqrt(i + 1.0)
+    mask = torch.tril(torch.ones(L, L, dtype=qr.dtype)) / rs[:, None]
+    qc = qr.reshape(N, H, nc, L, dk).transpose(1, 2)          # (N,nc,H,L,dk)
+    kc = kr.reshape(N, H, nc, L, dk).transpose(1, 2)
+    vc = v.reshape(N, nc, L, H, dv).transpose(2, 3)           # (N,nc,H,L,dv)
+    qk = (q(qc, role + ".q") @ q(kc, role + ".k").transpose(-1, -2)) * mask            # :161-162
+    inner_scale = qk.abs().sum(dim=-1, keepdim=True).clamp(min=1)                       # :163
+    qk = qk / inner_scale
+    inner = q(qk, role + ".p") @ q(vc, role + ".v")                                     # :165
+    kv = kc.transpose(-1, -2) @ (vc / math.sqrt(L))                                     # :168 (N,nc,H,dk,dv)
+    state = torch.zeros(N, H, dk, dv, dtype=qr.dtype)
+    scale = torch.ones(N, H, 1, 1, dtype=qr.dtype)
+    kv_rec, cross_scale = [], []
+    for c in range(nc):                                                                  # :176-180
+        kv_rec.append(state / scale)
+        cross_scale.append(scale)
+        state = state + kv[:, c]
+        scale = state.abs().sum(dim=-2, keepdim=True).max(dim=-1, keepdim=True).values.clamp(min=1)
+    kv_rec = torch.stack(kv_rec, dim=1)
+    cross_scale = torch.stack(cross_scale, dim=1)
+    all_scale = torch.maximum(inner_scale, cross_scale)                                 # :185
+    inner_decay = (math.sqrt(L) / rs)[:, None]
+    cross = (q(qc * inner_decay, role + ".qc")) @ q(kv_rec, role + ".s")                # :189
+    out = inner / (all_scale / inner_scale) + cross / (all_scale / cross_scale)         # :190
+    return out.transpose(2, 3).reshape(N, T, H, dv)
+
+
+def retention_step(qr: Tensor, kr: Tensor, v: Tensor, state: dict) -> Tensor:
+    """recurrent_forward (retention.py:126-144), decay = 1.  qr,kr: (N,H,1,dk); v: (N,1,H*dv).
+    state: {"prev_key_value": (N,H,dv?,...)}; NB the reference builds kv = kr * v with
+    v viewed (N,H,dv,1) and kr (N,H,1,dk): kv[n,h,a,b] = v[a] * k[b]; output = sum_b q[b] kv[a,b]."""
+    N, H, _, dk = qr.shape
+    dv = v.shape[-1] // H
+    vv = v.reshape(N, H, dv, 1)
+    kv = kr * vv                                          # (N,H,dv,dk)
+    if "prev_key_value" in state:
+        prev_kv, prev_scale = state["prev_key_value"], state["scale"]
+        scale = prev_scale + 1                                                           # decay = 1
+        kv = prev_kv * (prev_scale.sqrt() / scale.sqrt()).view(H, 1, 1) + kv / scale.sqrt().view(H, 1, 1)
+    else:
+        scale = torch.ones(H, dtype=qr.dtype)
+    state["prev_key_value"] = kv
+    state["scale"] = scale
+    return torch.sum(qr * kv, dim=3)                      # (N,H,dv)
+
+
+def msr(x: Tensor, sd: Dict[str, Tensor], pfx: str, H: int, L: int, q=_id, role="ret",
+        state: Optional[dict] = None) -> Tensor:
+    """MultiScaleRetention.forward (retention.py:196-228), value_factor = 1."""
+    N, T, D = x.shape
+    dk = D // H
+    qq = linear(x, sd[pfx + "q_proj.weight"], sd[pfx + "q_proj.bias"], q, role + ".qp")
+    kk = linear(x, sd[pfx + "k_proj.weight"], sd[pfx + "k_proj.bias"], q, role + ".kp") * (dk ** -0.5)
+    vv = linear(x, sd[pfx + "v_proj.weight"], sd[pfx + "v_proj.bias"], q, role + ".vp")
+    gg = linear(x, sd[pfx + "g_proj.weight"], sd[pfx + "g_proj.bias"], q, role + ".gp")
+    qh = qq.reshape(N, T, H, dk).transpose(1, 2)
+    kh = kk.reshape(N, T, H, dk).transpose(1, 2)
+    if state is not None:
+        o = retention_step(qh, kh, vv, state)[:, None]                       # (N,1,H,dv)
+    else:
+        o = retention_chunk(qh, kh, vv, L, q, role)                           # (N,T,H,dv)
+    o = layer_norm(o, None, None, GN_EPS).reshape(N, T, D)                    # per-head LN, no affine (:222)
+    o = swish(gg) * o                                                          # :224
+    return linear(o, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], q, role + ".op")
+
+
+# ----------------------------------------------------------------------------
+# Conformer encoder (nnet/conformer/*)
+# ----------------------------------------------------------------------------
+def ffn_module(x: Tensor, sd, pfx: str, q=_id, role="ffn") -> Tensor:
+    """FeedForwardModule (feed_forward.py:47-57): LN -> Linear -> Swish -> Linear."""
+    h = layer_norm(x, sd[pfx + "sequential.0.weight"], sd[pfx + "sequential.0.bias"])
+    h = swish(linear(h, sd[pfx + "sequential.1.linear.weight"], sd[pfx + "sequential.1.linear.bias"], q, role + "1"))
+    return linear(h, sd[pfx + "sequential.4.linear.weight"], sd[pfx + "sequential.4.linear.bias"], q, role + "2")
+
+
+def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None):
+    """ConformerConvModule (convolution.py:138-167): LN -> 1x1 (D->2D) -> GLU -> causal
+    depthwise k (left context k-1) -> BatchNorm1d(eval) -> Swish -> 1x1.
+    Batch: x (N,T,D).  One-step: x (N,1,D) with cache (N,D,k-1) -> (y, new_cache)."""
+    h = layer_norm(x, sd[pfx + "sequential.0.weight"], sd[pfx + "sequential.0.bias"])
+    w1 = sd[pfx + "sequential.2.conv.weight"][:, :, 0]                        # (2D, D)
+    h = linear(h, w1, sd[pfx + "sequential.2.conv.bias"], q, "conv.pw1")
+    D = h.shape[-1] // 2
+    h = h[..., :D] * torch.sigmoid(h[..., D:])                                # GLU over channels (activation.py:39-41)
+    dw = sd[pfx + "sequential.4.conv.weight"][:, 0, :]                        # (D, k), bias=False
+    k = dw.shape[1]
+    if cache is None:
+        hp = torch.nn.functional.pad(h, (0, 0, k - 1, 0))                     # pad k-1 both sides, keep first T (:65-68)
+        win = hp.unfold(1, k, 1)                                              # (N,T,D,k)
+        y = (win * dw).sum(-1)
+        new_cache = None
+    else:
+        xp = torch.cat([cache, h.transpose(1, 2)], dim=2)                     # (N,D,k)
+        new_cache = xp[:, :, 1:]
+        y = (xp * dw).sum(-1)[:, None, :]
+    bn = pfx + "sequential.5."
+    y = (y - sd[bn + "running_mean"]) / torch.sqrt(sd[bn + "running_var"] + BN_EPS) * sd[bn + "weight"] + sd[bn + "bias"]
+    y = swish(y)
+    w2 = sd[pfx + "sequential.7.conv.weight"][:, :, 0]
+    y = linear(y, w2, sd[pfx + "sequential.7.conv.bias"], q, "conv.pw2")
+    return y, new_cache
+
+
+def conformer_block(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: Optional[dict] = None,
+                    conv_cache: Optional[Tensor] = None):
+    """ConformerEncoderBlock (encoder.py:76-123), half-step residual FFNs."""
+    s = pfx + "sequential."
+    x = x + 0.5 * ffn_module(x, sd, s + "0.module.", q, "enc.ffa")
+    a = s + "1.module."
+    h = layer_norm(x, sd[a + "layer_norm.weight"], sd[a + "layer_norm.bias"])           # attention.py:100,115
+    x = x + msr(h, sd, a + "self_attn.", H, L, q, "enc.ret", ret_state)
+    y, new_cache = conv_module(x, sd, s + "2.module.", q, conv_cache)
+    x = x + y
+    x = x + 0.5 * ffn_module(x, sd, s + "3.module.", q, "enc.ffb")
+    x = layer_norm(x, sd[s + "4.weight"], sd[s + "4.bias"])
+    return x, new_cache
+
+
+def encoder(src: Sequence[Tensor], sd, *, H: int, n_layers: int, L: int, q=_id, dtype=torch.float32,
+            taps: Optional[dict] = None) -> Tensor:
+    """EmbeddingEncoderModule.forward (model :279-285) -> ConformerEncoder.forward (encoder.py:194-201)."""
+    x = torch.nn.utils.rnn.pad_sequence([s.to(dtype) for s in src], padding_value=0.0, batch_first=True)
+    T = x.shape[1]
+    Tpad = math.ceil(T / L) * L
+    x = torch.nn.functional.pad(x, (0, 0, 0, Tpad - T))
+    x = linear(x, sd["enc.encoder.input_projection.linear.weight"], sd["enc.encoder.input_projection.linear.bias"],
+               q, "enc.in")
+    x = layer_norm(x, sd["enc.encoder.layer_norm.weight"], sd["enc.encoder.layer_norm.bias"])
+    for i in range(n_layers):
+        x, _ = conformer_block(x, sd, f"enc.encoder.layers.{i}.", H, L, q)
+        if taps is not None:
+            taps[f"enc_l{i}"] = x
+    return x
+
+
+def lookahead_conv_l2(enc_out: Tensor, ilens, sd, L: int, conv_delay: int, q=_id) -> Tensor:
+    """model :80-87: truncate to ilen, zero re-pad, pad to a chunk multiple, Conv1d(k=2*delay+1,
+    padding=delay), L2 normalise (no eps)."""
+    emb = [e[:l] for e, l in zip(enc_out, ilens)]
+    emb = torch.nn.utils.rnn.pad_sequence(emb, padding_value=0.0, batch_first=True)
+    T = emb.shape[1]
+    Tpad = math.ceil(T / L) * L
+    emb = torch.nn.functional.pad(emb, (0, 0, 0, Tpad - T))
+    w = sd["cnn.weight"]
+    k = w.shape[-1]
+    xp = torch.nn.functional.pad(emb, (0, 0, conv_delay, k - 1 - conv_delay))
+    B, Tp, D = emb.shape
+    win = xp.unfold(1, k, 1)
+    y = q(win.reshape(B, Tp, D * k), "cnn.a") @ q(w.reshape(w.shape[0], D * k), "cnn.w").t() + sd["cnn.bias"]
+    return y / torch.linalg.vector_norm(y, dim=-1, keepdim=True)
+
+
+def dec_layer(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: Optional[dict] = None) -> Tensor:
+    """LS TransformerEncoderFusionLayer (modules/merge_retnet_layer.py:233-253 batch,
+    :255-276 one-step): retention over time per speaker slot, MHA over slots, FFN; post-norm."""
+    B, T, C, D = x.shape
+    y = x.transpose(1, 2).reshape(B * C, T, D)
+    a = msr(y, sd, pfx + "self_attn1.", H, L, q, "dec.ret", ret_state)
+    y = layer_norm(y + a, sd[pfx + "norm11.weight"], sd[pfx + "norm11.bias"])
+    y = y.reshape(B, C, T, D).transpose(1, 2).reshape(B * T, C, D)
+    a = mha(y, sd[pfx + "self_attn2.in_proj_weight"], sd[pfx + "self_attn2.in_proj_bias"],
+            sd[pfx + "self_attn2.out_proj.weight"], sd[pfx + "self_attn2.out_proj.bias"], H, None, q, "dec.mha_s")
+    y = layer_norm(y + a, sd[pfx + "norm21.weight"], sd[pfx + "norm21.bias"])
+    h = torch.relu(linear(y, sd[pfx + "linear1.weight"], sd[pfx + "linear1.bias"], q, "dec.ff1"))
+    f = linear(h, sd[pfx + "linear2.weight"], sd[pfx + "linear2.bias"], q, "dec.ff2")
+    y = layer_norm(y + f, sd[pfx + "norm22.weight"], sd[pfx + "norm22.bias"])
+    return y.reshape(B, T, C, D)
+
+
+def decoder(emb: Tensor, C: int, sd, *, H: int, n_layers: int, L: int, q=_id,
+            ret_states: Optional[List[dict]] = None) -> Tensor:
+    """LS MaskedTransformerDecoderModel.forward / forward_one_step (model :215-220,:235-243)."""
+    B, T, D = emb.shape
+    pe = sd["dec.pos_enc.pe"][0, :C].to(emb.dtype)
+    cat = torch.cat([emb[:, :, None, :].expand(B, T, C, D), pe[None, None].expand(B, T, C, D)], dim=-1)
+    x = linear(cat, sd["dec.convert.weight"], sd["dec.convert.bias"], q, "dec.convert")
+    for i in range(n_layers):
+        x = dec_layer(x, sd, f"dec.layers.{i}.", H, L, q, None if ret_states is None else ret_states[i])
+    return x
+
+
+def ls_test(src: Sequence[Tensor], ilens: Sequence[int], sd, *, n_heads: int, enc_n_layers: int,
+            dec_n_layers: int, max_nspks: int, chunk: int = 500, conv_delay: int = 9, q=_id,
+            dtype=torch.float32, taps: Optional[dict] = None):
+    """OnlineConformerRetentionDADiarization.test (model :125-147)."""
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    enc_out = encoder(src, sd, H=n_heads, n_layers=enc_n_layers, L=chunk, q=q, dtype=dtype, taps=taps)
+    emb = lookahead_conv_l2(enc_out, ilens, sd, chunk, conv_delay, q)
+    if taps is not None:
+        taps["emb"] = emb
+    attr = decoder(emb, max_nspks, sd, H=n_heads, n_layers=dec_n_layers, L=chunk, q=q)
+    attr = attr / torch.linalg.vector_norm(attr, dim=-1, keepdim=True)
+    out = (q(emb, "head.e")[:, :, None, :] * q(attr, "head.a")).sum(-1)
+    return ([o[:l] for o, l in zip(out, ilens)], [e[:l] for e, l in zip(emb, ilens)],
+            [a[:l] for a, l in zip(attr, ilens)])
+
+
+def ls_forward(src, tgt, ilens, sd, *, n_heads: int, enc_n_layers: int, dec_n_layers: int, chunk: int = 500,
+               conv_delay: int = 9, q=_id, dtype=torch.float32):
+    """OnlineConformerRetentionDADiarization.forward (model :74-122), eval numerics."""
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    n_speakers = [t.shape[1] for t in tgt]
+    C = max(n_speakers)
+    enc_out = encoder(src, sd, H=n_heads, n_layers=enc_n_layers, L=chunk, q=q, dtype=dtype)
+    emb = lookahead_conv_l2(enc_out, ilens, sd, chunk, conv_delay, q)
+    attr = decoder(emb, C, sd, H=n_heads, n_layers=dec_n_layers, L=chunk, q=q)
+    attr = attr / torch.linalg.vector_norm(attr, dim=-1, keepdim=True)
+    seq_len = max(ilens)
+    len_mask = torch.nn.utils.rnn.pad_sequence([torch.ones(l, dtype=dtype) for l in ilens], batch_first=True)[..., None]
+    e = emb[:, :seq_len] * len_mask                                            # :100
+    attn_map = e @ e.transpose(-1, -2)
+    n = torch.linalg.vector_norm(e, dim=-1, keepdim=True)
+    attn_map = attn_map / (n @ n.transpose(-1, -2) + 1e-6)
+    tgt_pad = [torch.nn.functional.pad(t.to(dtype), (0, C - t.shape[1])) for t in tgt]
+    tgt_pad = torch.nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True)
+    label_map = tgt_pad @ tgt_pad.transpose(-1, -2)
+    tn = torch.linalg.vector_norm(tgt_pad, dim=-1, keepdim=True)
+    label_map = label_map / (tn @ tn.transpose(-1, -2) + 1e-6)
+    loss = ((attn_map - label_map) ** 2).sum() / sum(l * l for l in ilens)    # :113
+    Tpad = emb.shape[1]
+    e = torch.nn.functional.pad(e, (0, 0, 0, Tpad - e.shape[1]))              # :116 (masked emb is what the head sees)
+    out = (e[:, :, None, :] * attr).sum(-1)
+    logits = [o[:l, :n] for o, l, n in zip(out, ilens, n_speakers)]
+    embs = [x[:l] for x, l in zip(e, ilens)]
+    attrs = [a[:l, 1:n] for a, l, n in zip(attr, ilens, n_speakers)]
+    return logits, loss, embs, attrs
+
+
+class LsStreamingRef:
+    """Frame-by-frame LS-EEND as LS-EEND/streaming_infer_dia.py:52-97 drives it:
+    enc.forward_one_step -> StreamingConv1d -> L2 -> dec.forward_one_step -> L2 -> dot;
+    retention state (N,H,dv,dk)+scale(H) per layer, depthwise-conv cache (B,D,k-1) per layer."""
+
+    def __init__(self, sd, *, n_heads: int, enc_n_layers: int, dec_n_layers: int, conv_delay: int = 9,
+                 conv_kernel_size: int = 16, dtype=torch.float32):
+        self.sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        self.H, self.Le, self.Ld, self.dtype = n_heads, enc_n_layers, dec_n_layers, dtype
+        self.k = 2 * conv_delay + 1
+        self.delay = conv_delay
+        D = self.sd["cnn.weight"].shape[0]
+        self.enc_states = [dict() for _ in range(enc_n_layers)]
+        self.dec_states = [dict() for _ in range(dec_n_layers)]
+        self.caches = [torch.zeros(1, D, conv_kernel_size - 1, dtype=dtype) for _ in range(enc_n_layers)]
+        self.buf: List[Tensor] = []
+        self.t = 0
+
+    def enc_step(self, x_t: Tensor) -> Tensor:
+        sd = self.sd
+        x = linear(x_t.to(self.dtype), sd["enc.encoder.input_projection.linear.weight"],
+                   sd["enc.encoder.input_projection.linear.bias"])
+        x = layer_norm(x, sd["enc.encoder.layer_norm.weight"], sd["enc.encoder.layer_norm.bias"])
+        for i in range(self.Le):
+            x, self.caches[i] = conformer_block(x, sd, f"enc.encoder.layers.{i}.", self.H, 1,
+                                                ret_state=self.enc_states[i], conv_cache=self.caches[i])
+        return x
+
+    def conv_step(self, e_t: Tensor) -> Optional[Tensor]:
+        """StreamingConv1d.forward (model :160-186)."""
+        self.t += 1
+        self.buf = (self.buf + [e_t])[-self.k:]
+        left = self.k - len(self.buf)
+        win = torch.cat([torch.zeros_like(e_t)] * left + self.buf, dim=1)          # (B,k,D)
+        y = torch.einsum("bkd,odk->bo", win, self.sd["cnn.weight"]) + self.sd["cnn.bias"]
+        return y[:, None, :] if self.t >= self.k // 2 + 1 else None
+
+    def step(self, x_t: Optional[Tensor], C: int) -> Optional[Tensor]:
+        """x_t (1,1,in) or None for a flush step (zero *embedding*, streaming_infer_dia.py:91-95)."""
+        D = self.sd["cnn.weight"].shape[0]
+        e = torch.zeros(1, 1, D, dtype=self.dtype) if x_t is None else self.enc_step(x_t)
+        e = self.conv_step(e)
+        if e is None:
+            return None
+        e = e / torch.linalg.vector_norm(e, dim=-1, keepdim=True)
+        a = decoder(e, C, self.sd, H=self.H, n_layers=self.Ld, L=1, ret_states=self.dec_states)
+        a = a / torch.linalg.vector_norm(a, dim=-1, keepdim=True)
+        return (e[:, :, None, :] * a).sum(-1)

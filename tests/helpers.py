@@ -23,3 +23,18 @@ def fs_kwargs(meta):
 
 def max_abs(a, b):
     return (a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max().item()
+
+
+def build_ls_mirror(meta):
+    from fs_eend_amd.ls_model import OnlineConformerRetentionDADiarization
+    torch.manual_seed(meta["seed"])
+    m = OnlineConformerRetentionDADiarization(n_speakers=None, in_size=meta["in_size"], **meta["cfg"]).eval()
+    FX.perturb_(m, meta["pseed"])
+    FX.check_params(m.state_dict(), meta["checksums"])
+    return m
+
+
+def ls_kwargs(meta):
+    c = meta["cfg"]
+    return dict(n_heads=c["n_heads"], enc_n_layers=c["enc_n_layers"], dec_n_layers=c["dec_n_layers"],
+                chunk=c["recurrent_chunk_size"], conv_delay=c["conv_delay"])

@@ -252,3 +252,152 @@ def test_head_l2dot(hip_lib, dev):
     a = a / a.norm(dim=-1, keepdim=True)
     close(ao, a, 1e-6, 1e-5, "attractor l2norm")
     close(lg, (emb[:, :T, None, :] * a).sum(-1), 2e-6, 1e-5, "logits")
+
+
+# ------------------------------------------------------------------------------------ LS-EEND kernels
+def test_linear_swish(hip_lib, dev):
+    from fs_eend_amd import ops
+    a, w, b = rnd((300, 256), dev, 60, F16), rnd((1024, 256), dev, 61, F16, 0.1), rnd((1024,), dev, 62)
+    out = torch.empty((300, 1024), dtype=F16, device=dev)
+    ops.linear(a, w, b, out, act=ops.ACT_SWISH)
+    y = a.float() @ w.float().t() + b
+    close(out, y * torch.sigmoid(y), 2e-3, 2e-3, "linear+swish")
+
+
+def test_linear_glu(hip_lib, dev):
+    from fs_eend_amd import ops
+    M, D = 200, 256
+    a, w, b = rnd((M, D), dev, 63, F16), rnd((2 * D, D), dev, 64, F16, 0.1), rnd((2 * D,), dev, 65)
+    wi = torch.stack([w[:D], w[D:]], dim=1).reshape(2 * D, D).contiguous()
+    bi = torch.stack([b[:D], b[D:]], dim=1).reshape(2 * D).contiguous()
+    out = torch.full((M, D), float("nan"), dtype=F16, device=dev)
+    ops.linear_glu(a, wi, bi, out)
+    y = a.float() @ w.float().t() + b
+    close(out, y[:, :D] * torch.sigmoid(y[:, D:]), 2e-3, 2e-3, "pointwise conv + GLU")
+
+
+def test_linear_res_scale_ln16(hip_lib, dev):
+    from fs_eend_amd import ops
+    M, K = 170, 1024
+    a, w, b = rnd((M, K), dev, 66, F16), rnd((256, K), dev, 67, F16, 0.05), rnd((256,), dev, 68)
+    r = rnd((M, 256), dev, 69)
+    g, be = rnd((256,), dev, 70) * 0.2 + 1, rnd((256,), dev, 71) * 0.1
+    o32 = torch.empty((M, 256), dtype=F32, device=dev)
+    o16 = torch.empty((M, 256), dtype=F16, device=dev)
+    ops.linear_res_scale_ln16(a, w, b, r, 0.5, g, be, o32, o16, 1e-5)
+    y = (a.float() @ w.float().t() + b) * 0.5 + r
+    close(o32, y, 2e-4, 2e-4, "residual stream")
+    close(o16, torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5), 3e-3, 2e-3, "LN for the next module")
+    # alpha on the LN'd variant (block-final half-step FFN)
+    o32b = torch.empty_like(o32)
+    ops.linear_res_ln(a, w, b, r, g, be, o32b, o16, 1e-5, alpha=0.5)
+    close(o32b, torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5), 2e-4, 2e-4, "alpha + LN")
+
+
+def test_layernorm_f16(hip_lib, dev):
+    from fs_eend_amd import ops
+    x = rnd((77, 256), dev, 72) * 3 + 1
+    g, be = rnd((256,), dev, 73) * 0.2 + 1, rnd((256,), dev, 74) * 0.1
+    out = torch.empty((77, 256), dtype=F16, device=dev)
+    ops.layernorm_f16(x, g, be, out, 1e-5)
+    close(out, torch.nn.functional.layer_norm(x, (256,), g, be, 1e-5), 3e-3, 2e-3, "layernorm")
+
+
+@pytest.mark.parametrize("k", [16, 7, 31])
+def test_dwconv_bn_swish(hip_lib, dev, k):
+    from fs_eend_amd import ops
+    nseq, Tp, D = 2, 128, 256
+    x = rnd((nseq * Tp, D), dev, 75, F16)
+    w = rnd((D, k), dev, 76) * 0.3
+    bn = (rnd((D,), dev, 77) * 0.2 + 1, rnd((D,), dev, 78) * 0.1, rnd((D,), dev, 79) * 0.1, rnd((D,), dev, 80).abs() + 0.5)
+    out = torch.empty((nseq * Tp, D), dtype=F16, device=dev)
+    ops.dwconv_bn_swish(x, w, bn, out, nseq, Tp, 1e-5)
+    xi = x.float().view(nseq, Tp, D).transpose(1, 2)
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(xi, (k - 1, 0)), w[:, None, :], groups=D)
+    y = (y - bn[2][:, None]) / torch.sqrt(bn[3][:, None] + 1e-5) * bn[0][:, None] + bn[1][:, None]
+    y = (y * torch.sigmoid(y)).transpose(1, 2).reshape(nseq * Tp, D)
+    close(out, y, 3e-3, 2e-3, f"depthwise conv k={k}")
+
+
+def _ret_inputs(dev, nseq, Tp, seed, qs=1.0):
+    H = 4
+    q = rnd((nseq, H, Tp, 64), dev, seed, F16, qs)
+    k = rnd((nseq, H, Tp, 64), dev, seed + 1, F16, qs / 8)
+    v = rnd((nseq, H, Tp, 64), dev, seed + 2, F16)
+    g = rnd((nseq * Tp, 256), dev, seed + 3, F16)
+    return q, k, v, g
+
+
+def _ret_reference(q, k, v, g, L, T):
+    """oracle retention (validated against the reference) on the first T frames, + LN + gate."""
+    from oracle import ls_eend_ref as R
+    nseq, H = q.shape[0], q.shape[1]
+    qc, kc = q[:, :, :T].float().cpu(), k[:, :, :T].float().cpu()
+    vc = v[:, :, :T].float().cpu().permute(0, 2, 1, 3).reshape(nseq, T, H * 64)
+    o = R.retention_chunk(qc, kc, vc, L)                          # (nseq,T,H,64)
+    o = R.layer_norm(o, None, None, 1e-6).reshape(nseq, T, 256)
+    gg = g.float().cpu().view(nseq, -1, 256)[:, :T]
+    return R.swish(gg) * o
+
+
+@pytest.mark.parametrize("nseq,Tp,L,T,qs", [(2, 128, 64, 128, 1.0), (1, 512, 500, 500, 1.0), (2, 64, 10, 60, 1.0),
+                                            (1, 256, 100, 200, 1.0), (1, 192, 32, 192, 3.0), (1, 1024, 500, 1000, 0.3)])
+def test_retention_chunk(hip_lib, dev, nseq, Tp, L, T, qs):
+    from fs_eend_amd import ops
+    H = 4
+    q, k, v, g = _ret_inputs(dev, nseq, Tp, 81, qs)
+    kt = k.transpose(-1, -2).contiguous()
+    vt = v.transpose(-1, -2).contiguous()
+    nc = (Tp + L - 1) // L
+    st = torch.empty(nseq * H * nc * 2 * 4096, dtype=F16, device=dev)
+    cs = torch.empty(nseq * H * nc, dtype=F32, device=dev)
+    se = torch.empty(nseq * H * nc, dtype=F32, device=dev)
+    o = torch.full((nseq * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.retention_chunk(q.view(-1), k.view(-1), kt.view(-1), vt.view(-1), g, o, st, cs, se, nseq, H, Tp, L)
+    want = _ret_reference(q, k, v, g, L, T)
+    got = o.view(nseq, Tp, 256)[:, :T].float().cpu()
+    assert torch.isfinite(o).all()
+    # per-head LayerNorm output is O(1); S is rounded to f16 before S.V
+    close(got, want, 2e-2, 1e-2, f"retention L={L} Tp={Tp}")
+    # cross_scale of the state before chunk 1 == max(1, max_d sum_k |S|/sqrt(L)) (retention.py:180)
+    if nc > 1 and T >= L:
+        kv = (k[:, :, :L].float().transpose(-1, -2) @ v[:, :, :L].float()) / (L ** 0.5)     # (nseq,H,64,64)
+        ref = kv.abs().sum(dim=-2).max(dim=-1).values.clamp(min=1)
+        close(cs.view(nseq, H, nc)[:, :, 1], ref, 1e-3, 1e-3, "cross_scale")
+
+
+def test_retention_causality(hip_lib, dev):
+    """Frames <= t must be bit-identical when K/V/Q change only after t (chunk-local and cross-chunk)."""
+    from fs_eend_amd import ops
+    nseq, H, Tp, L = 1, 4, 256, 100
+    q, k, v, g = _ret_inputs(dev, nseq, Tp, 90)
+    nc = (Tp + L - 1) // L
+    ws = lambda: (torch.empty(nseq * H * nc * 2 * 4096, dtype=F16, device=dev), torch.empty(nseq * H * nc, dtype=F32, device=dev),
+                  torch.empty(nseq * H * nc, dtype=F32, device=dev))
+    o1 = torch.empty((Tp, 256), dtype=F16, device=dev)
+    o2 = torch.empty((Tp, 256), dtype=F16, device=dev)
+    ops.retention_chunk(q.view(-1), k.view(-1), k.transpose(-1, -2).contiguous().view(-1),
+                        v.transpose(-1, -2).contiguous().view(-1), g, o1, *ws(), nseq, H, Tp, L)
+    k2, v2 = k.clone(), v.clone()
+    k2[:, :, 150:] = 0.7
+    v2[:, :, 150:] = -2.0
+    ops.retention_chunk(q.view(-1), k2.view(-1), k2.transpose(-1, -2).contiguous().view(-1),
+                        v2.transpose(-1, -2).contiguous().view(-1), g, o2, *ws(), nseq, H, Tp, L)
+    assert torch.equal(o1[:150], o2[:150])
+    assert not torch.equal(o1[150:], o2[150:])
+
+
+def test_retention_proj(hip_lib, dev):
+    from fs_eend_amd import ops
+    nseq, Tp, H, D = 2, 128, 4, 256
+    M = nseq * Tp
+    a, w, b = rnd((M, D), dev, 95, F16), rnd((4 * D, D), dev, 96, F16, 0.1), rnd((4 * D,), dev, 97)
+    bufs = [torch.full((M * D,), float("nan"), dtype=F16, device=dev) for _ in range(4)]
+    g = torch.full((M, D), float("nan"), dtype=F16, device=dev)
+    ops.retention_proj(a, w, b, *bufs, g, nseq, Tp, H)
+    y = (a.float() @ w.float().t() + b).view(nseq, Tp, 4, H, 64)
+    close(bufs[0].view(nseq, H, Tp, 64), y[:, :, 0].permute(0, 2, 1, 3), 3e-3, 2e-3, "Q")
+    close(bufs[1].view(nseq, H, Tp, 64), y[:, :, 1].permute(0, 2, 1, 3), 3e-3, 2e-3, "K")
+    close(bufs[2].view(nseq, H, 64, Tp), y[:, :, 1].permute(0, 2, 3, 1), 3e-3, 2e-3, "K^T")
+    close(bufs[3].view(nseq, H, 64, Tp), y[:, :, 2].permute(0, 2, 3, 1), 3e-3, 2e-3, "V^T")
+    close(g, y[:, :, 3].reshape(M, D), 3e-3, 2e-3, "G")

@@ -25,8 +25,7 @@ if [[ "$WHAT" == all || "$WHAT" == *prof* ]]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o fs -- \
       python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --graph 0 ${BENCH_ARGS:-}) > gpurun_out/prof_bench.log 2>&1
   echo "prof rc=$?"; tail -2 gpurun_out/prof_bench.log
-  find gpurun_out/prof -name "*stats*" | head; 
-  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
-  # keep the merge small: drop the raw per-dispatch trace if it is huge
-  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+  db=$(find gpurun_out/prof -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_stats.py "$db" gpurun_out/kernel_stats.csv && head -25 gpurun_out/kernel_stats.csv | cut -c1-200
+  rm -rf gpurun_out/prof
 fi
