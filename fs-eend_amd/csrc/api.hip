@@ -145,8 +145,7 @@ int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, con
 
 int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
                             int B, int Tp, int C, void* stream) {
-    if (!E || !W1 || !pc || !out_f32 || !out_f16 || B <= 0 || C <= 0 || Tp <= 0 || (Tp % 64) != 0)
-        return EEND_EINVAL;
+    if (!E || !W1 || !pc || !out_f32 || !out_f16 || B <= 0 || C <= 0 || Tp <= 0) return EEND_EINVAL;
     GemmParams p = base_params(E, 256, W1, 256, nullptr, B * Tp, 256, 256);
     p.Tp = Tp; p.C = C; p.pc = pc; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_CONVERT, (hipStream_t)stream);
@@ -172,6 +171,20 @@ int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, fl
                         int Tp, int C, int D, void* stream) {
     if (!emb || !attr || !attr_out || !logits) return EEND_EINVAL;
     return eend_launch_head(emb, attr, attr_out, logits, B, T, Tp, C, D, (hipStream_t)stream);
+}
+
+int eend_retention_step_f16(const void* qkvg, float* kv_state, const float* scale_in, float* scale_out,
+                            void* out_f16, int N, int H, float gn_eps, void* stream) {
+    if (!qkvg || !kv_state || !scale_in || !scale_out || !out_f16) return EEND_EINVAL;
+    return eend_launch_ret_step(qkvg, kv_state, scale_in, scale_out, out_f16, N, H, gn_eps, (hipStream_t)stream);
+}
+
+int eend_dwconv_step_f16(const void* x_f16, float* cache, const float* w, const float* bn_weight, const float* bn_bias,
+                         const float* bn_mean, const float* bn_var, float eps, void* out_f16, int B, int D, int k,
+                         void* stream) {
+    if (!x_f16 || !cache || !w || !bn_weight || !bn_bias || !bn_mean || !bn_var || !out_f16) return EEND_EINVAL;
+    return eend_launch_dwconv_step(x_f16, cache, w, bn_weight, bn_bias, bn_mean, bn_var, eps, out_f16, B, D, k,
+                                   (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,102 @@
+// Frame-by-frame (streaming) state kernels of LS-EEND.  One frame of one stream is far too
+// little work for the matrix pipe: these are latency-bound VALU kernels whose job is to keep
+// the recurrent state resident in HBM/L2 in the layout the reference's driver owns
+// (LS-EEND/streaming_infer_dia.py:37-49) and to touch it exactly once per frame.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// MultiScaleRetention.recurrent_forward (LS-EEND/nnet/modules/retention.py:126-144) with
+// decay == 1, fused with the per-head LayerNorm (:222, eps, no affine) and the swish gate (:224).
+//   scale_t = scale_{t-1} + 1
+//   kv_t[a][b] = kv_{t-1}[a][b] * sqrt(scale_{t-1} / scale_t) + v[a] k[b] / sqrt(scale_t)
+//   o[a] = sum_b q[b] kv_t[a][b]
+// qkvg f16 [N][4*D] rows = [q | k (already * dk^-0.5) | v | g]; kv f32 [N][H][64 (a: value dim)][64 (b: key dim)]
+// updated in place; scale_in/scale_out f32 [H] (first frame: scale_in = 0, kv = 0).
+// One wave per (n, h): lane a owns row kv[a][:].
+__global__ __launch_bounds__(256)
+void ret_step_kernel(const _Float16* __restrict__ qkvg, float* __restrict__ kv, const float* __restrict__ scale_in,
+                     float* __restrict__ scale_out, _Float16* __restrict__ out, int N, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);       // n*H + h
+    if (idx >= N * H) return;
+    const int n = idx / H, h = idx - n * H;
+    const int D = H * 64;
+    const _Float16* row = qkvg + (size_t)n * 4 * D;
+    const float ps = scale_in[h];
+    const float ns = ps + 1.0f;
+    const float keep = __builtin_sqrtf(ps) / __builtin_sqrtf(ns);
+    const float add = 1.0f / __builtin_sqrtf(ns);
+    const float va = (float)row[2 * D + h * 64 + lane] * add;
+    float* st = kv + ((size_t)idx * 64 + lane) * 64;
+    float o = 0.f;
+#pragma unroll
+    for (int b = 0; b < 64; b += 4) {
+        float4 s = *(const float4*)(st + b);
+        const f16x4 kk = *(const f16x4*)(row + D + h * 64 + b);
+        const f16x4 qq = *(const f16x4*)(row + h * 64 + b);
+        s.x = __builtin_fmaf(s.x, keep, va * (float)kk[0]);
+        s.y = __builtin_fmaf(s.y, keep, va * (float)kk[1]);
+        s.z = __builtin_fmaf(s.z, keep, va * (float)kk[2]);
+        s.w = __builtin_fmaf(s.w, keep, va * (float)kk[3]);
+        *(float4*)(st + b) = s;
+        o += (float)qq[0] * s.x + (float)qq[1] * s.y + (float)qq[2] * s.z + (float)qq[3] * s.w;
+    }
+    float sum = o;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) sum = wave_xor_add(sum, m);
+    const float mean = sum * (1.0f / 64.0f);
+    float var = (o - mean) * (o - mean);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) var = wave_xor_add(var, m);
+    const float y = (o - mean) / __builtin_sqrtf(var * (1.0f / 64.0f) + eps);
+    const float g = (float)row[3 * D + h * 64 + lane];
+    out[(size_t)n * D + h * 64 + lane] = to_f16_sat(g / (1.0f + __expf(-g)) * y);
+    if (n == 0 && lane == 0) scale_out[h] = ns;
+}
+
+// ConformerConvModule.forward_one_step, depthwise part (conformer/convolution.py:157-163):
+// window = [cache (k-1 frames) | x_t]; y = sum_j w[c][j] window[c][j]; BatchNorm(eval); Swish;
+// new cache = window[:, 1:].  x f16 [B][D]; cache f32 [B][D][k-1] (the driver's layout), in place.
+__global__ __launch_bounds__(256)
+void dwconv_step_kernel(const _Float16* __restrict__ x, float* __restrict__ cache, const float* __restrict__ w,
+                        const float* __restrict__ bw, const float* __restrict__ bb, const float* __restrict__ bm,
+                        const float* __restrict__ bv, float eps, _Float16* __restrict__ out, int B, int D, int k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // b*D + c
+    if (i >= B * D) return;
+    const int c = i % D;
+    float* cc = cache + (size_t)i * (k - 1);
+    const float* wc = w + (size_t)c * k;
+    const float xn = (float)x[i];
+    float y = wc[k - 1] * xn;
+    float prev = xn;
+    for (int j = k - 2; j >= 0; --j) {           // walk backwards so the shift can be done in place
+        const float cur = cc[j];
+        y = __builtin_fmaf(wc[j], cur, y);
+        cc[j] = prev;                            // new_cache[j] = window[j+1]
+        prev = cur;
+    }
+    const float sc = bw[c] / __builtin_sqrtf(bv[c] + eps);
+    y = (y - bm[c]) * sc + bb[c];
+    out[i] = to_f16_sat(y / (1.0f + __expf(-y)));
+}
+
+}  // namespace
+
+int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N,
+                         int H, float eps, hipStream_t stream) {
+    if (N <= 0 || H <= 0) return EEND_EINVAL;
+    hipLaunchKernelGGL(ret_step_kernel, dim3((N * H + 3) / 4), dim3(256), 0, stream, (const _Float16*)qkvg, kv, scale_in,
+                       scale_out, (_Float16*)out16, N, H, eps);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const float* bn_w, const float* bn_b,
+                            const float* bn_mean, const float* bn_var, float eps, void* out16, int B, int D, int k,
+                            hipStream_t stream) {
+    if (B <= 0 || D <= 0 || k < 2) return EEND_EINVAL;
+    hipLaunchKernelGGL(dwconv_step_kernel, dim3((B * D + 255) / 256), dim3(256), 0, stream, (const _Float16*)x16, cache, w,
+                       bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, B, D, k);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}

@@ -198,3 +198,22 @@ def head_l2dot(emb32, attr32, attr_out, logits, B, T, Tp, C, D):
     _chk(emb32, F32, "emb32"); _chk(attr32, F32, "attr32"); _chk(attr_out, F32, "attr_out"); _chk(logits, F32, "logits")
     _lib.check(L.eend_head_l2dot_f32(_p(emb32), _p(attr32), _p(attr_out), _p(logits), B, T, Tp, C, D, _stream()),
                "eend_head_l2dot_f32")
+
+
+def retention_step(qkvg16, kv_state, scale_in, scale_out, out16, N, H, gn_eps=1e-6):
+    L = _lib.load()
+    _chk(qkvg16, F16, "qkvg16"); _chk(kv_state, F32, "kv_state"); _chk(scale_in, F32, "scale_in")
+    _chk(scale_out, F32, "scale_out"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_retention_step_f16(_p(qkvg16), _p(kv_state), _p(scale_in), _p(scale_out), _p(out16), N, H, gn_eps,
+                                         _stream()), "eend_retention_step_f16")
+
+
+def dwconv_step(x16, cache, w, bn, out16, eps=1e-5):
+    """x16/out16 f16 (B, D); cache f32 (B, D, k-1) shifted in place; w f32 (D, k)."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(cache, F32, "cache"); _chk(w, F32, "w"); _chk(out16, F16, "out16")
+    for t in bn:
+        _chk(t, F32, "bn")
+    B, D = x16.shape
+    _lib.check(L.eend_dwconv_step_f16(_p(x16), _p(cache), _p(w), _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), eps,
+                                      _p(out16), B, D, w.shape[1], _stream()), "eend_dwconv_step_f16")

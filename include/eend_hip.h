@@ -136,6 +136,20 @@ int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_
                              const float* bn_mean, const float* bn_var, float eps, void* out_f16, int nseq,
                              int Tp, int D, int k, void* stream);
 
+/* One frame of MultiScaleRetention.recurrent_forward (retention.py:126-144, decay 1) + per-head
+ * LayerNorm + swish gate, state updated in place.  qkvg f16 [N][4*H*64] = [q | k*dk^-0.5 | v | g];
+ * kv_state f32 [N][H][64][64] in the reference's incremental_state["prev_key_value"] layout;
+ * scale_in / scale_out f32 [H] (incremental_state["scale"]; zero state + scale 0 before frame 0). */
+int eend_retention_step_f16(const void* qkvg, float* kv_state, const float* scale_in, float* scale_out,
+                            void* out_f16, int N, int H, float gn_eps, void* stream);
+
+/* One frame of the causal depthwise conv + BatchNorm(eval) + Swish of ConformerConvModule.
+ * forward_one_step (conformer/convolution.py:157-163); cache f32 [B][D][k-1] (the driver's
+ * conv_caches layout, streaming_infer_dia.py:42-45) shifted in place.  x,out f16 [B][D]. */
+int eend_dwconv_step_f16(const void* x_f16, float* cache, const float* w, const float* bn_weight,
+                         const float* bn_bias, const float* bn_mean, const float* bn_var, float eps,
+                         void* out_f16, int B, int D, int k, void* stream);
+
 /* Unmasked MHA core over the C (<= 12) attractor slots of each frame (_sa_block2,
  * merge_tfm_encoder.py:388-394; LS-EEND/nnet/modules/merge_retnet_layer.py:301-306).
  * qkv f16 [B*C*Tp][768] (row = (b*C + c)*Tp + t) -> O f16 [B*C*Tp][256].  H = 4, dh = 64. */
