@@ -22,7 +22,7 @@ int eend_abi_version(void) { return 1; }
 int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                          const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,
                          int Fpad, int apply_bn, void* stream) {
-    if (!x || !out_f16 || (Tp % 64) != 0 || (Fpad % 64) != 0) return EEND_EINVAL;
+    if (!x || !out_f16 || Tp < T || (Fpad % 64) != 0) return EEND_EINVAL;
     if (apply_bn && (!bn_weight || !bn_bias || !bn_mean || !bn_var)) return EEND_EINVAL;
     return eend_launch_bn_cast_pad(x, bn_weight, bn_bias, bn_mean, bn_var, eps, out_f16, B, T, Tp, Fin, Fpad,
                                    apply_bn, (hipStream_t)stream);

@@ -11,6 +11,7 @@ The torch.nn modules below are parameter containers only (no forward); the arith
 in libeend_hip.so through ops.py.
 """
 import math
+import weakref
 from typing import Sequence
 
 import torch
@@ -20,6 +21,8 @@ from torch import Tensor
 from . import ops
 from .fs_model import PositionalEncoding, _f16, _f32
 from .lib import EendHipError
+from . import ls_stream
+from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
 
 
 # --------------------------------------------------------------------------- parameter containers
@@ -168,6 +171,10 @@ class EmbeddingEncoderModule(nn.Module):
                                         conv_expansion_factor, dropout, dropout, dropout, conv_kernel_size,
                                         half_step_residual, recurrent_chunk_size)
 
+    def forward_one_step(self, x_t: Tensor, t: int, ret_states: list, conv_caches: list) -> Tensor:
+        """x_t (B,1,in) -> (B,1,D); states updated in place (reference LS model :291-293)."""
+        return ls_stream.enc_step(self._owner(), x_t, t, ret_states, conv_caches)
+
 
 class TransformerEncoderFusionLayer(nn.Module):
     """Parameters of the LS decoder layer (reference modules/merge_retnet_layer.py:71-110)."""
@@ -200,6 +207,10 @@ class MaskedTransformerDecoderModel(nn.Module):
         self.convert = nn.Linear(n_units * 2, n_units)
         self.layers = nn.ModuleList([TransformerEncoderFusionLayer(n_units, n_heads, recurrent_chunk_size, dim_feedforward,
                                                                    dropout, batch_first=True) for _ in range(n_layers)])
+
+    def forward_one_step(self, emb_t: Tensor, t: int, max_nspks: int, ret_states: list) -> Tensor:
+        """emb_t (B,1,D) -> (B,1,C,D); retention states updated in place (reference LS model :235-243)."""
+        return ls_stream.dec_step(self._owner(), emb_t, t, max_nspks, ret_states)
 
 
 def _ret_pack(msr: MultiScaleRetention):
@@ -256,7 +267,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         self.cnn = nn.Conv1d(n_units, n_units, kernel_size=2 * conv_delay + 1, padding=conv_delay)
         self._in_size, self._n_heads = in_size, n_heads
         self._prep = self._prep_key = None
-        self._ws, self._pc = {}, {}
+        self._ws, self._pc, self._step_scratch = {}, {}, {}
+        # back-references for the one-step API (bypass nn.Module registration: no module cycle)
+        object.__setattr__(self.enc, "_owner", weakref.ref(self))
+        object.__setattr__(self.dec, "_owner", weakref.ref(self))
 
     # ------------------------------------------------------------------ weight preparation
     def _fingerprint(self):

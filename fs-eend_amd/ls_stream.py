@@ -1,0 +1,164 @@
+"""Frame-by-frame LS-EEND on MI355X: the one-step API the reference's streaming driver calls
+(LS-EEND/streaming_infer_dia.py:52-97):
+
+    model.enc.forward_one_step(x_t, t, ret_states, conv_caches) -> (B,1,D)      (LS model :291-293)
+    StreamingConv1d(...)(emb_t.transpose(1,2)) -> (B,D,1) | None                 (LS model :151-186)
+    model.dec.forward_one_step(emb_t, t, max_nspks, ret_states) -> (B,1,C,D)     (LS model :235-243)
+
+State is O(1) per stream and stays in HBM in the driver's own containers: each
+``ret_states[i]`` dict holds ``prev_key_value`` (N,H,64,64) f32 and ``scale`` (H,) f32 exactly as
+the reference's incremental_state does (retention.py:141-142), each ``conv_caches[i]`` is the
+driver's (B,D,k-1) f32 tensor, shifted in place.
+"""
+from collections import deque
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import EendHipError
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _ret_state(state: dict, N: int, H: int, dev):
+    """Fetch (or lazily create, like the reference's `"prev_key_value" in state` branch) the state."""
+    if "prev_key_value" not in state:
+        state["prev_key_value"] = torch.zeros(N, H, 64, 64, dtype=F32, device=dev)
+        state["scale"] = torch.zeros(H, dtype=F32, device=dev)       # scale_0 = 0 -> first frame gets scale 1
+        state["_scale_next"] = torch.empty(H, dtype=F32, device=dev)
+    kv = state["prev_key_value"]
+    if kv.shape != (N, H, 64, 64) or kv.dtype != F32 or not kv.is_contiguous():
+        raise EendHipError("retention state has an unexpected shape/dtype")
+    if "_scale_next" not in state:
+        state["_scale_next"] = torch.empty(H, dtype=F32, device=dev)
+    return kv, state["scale"].to(F32).contiguous(), state["_scale_next"]
+
+
+def _ret_step(x16, wqkvg, bqkvg, state, N, H, gn_eps, scratch):
+    qkvg, o16 = scratch["qkvg"][:N], scratch["o16"][:N]
+    ops.linear(x16, wqkvg, bqkvg, qkvg)
+    kv, s_in, s_out = _ret_state(state, N, H, x16.device)
+    ops.retention_step(qkvg, kv, s_in, s_out, o16, N, H, gn_eps)
+    state["scale"], state["_scale_next"] = s_out, s_in                # ping-pong
+    return o16
+
+
+def _scratch(owner, key, N, D, F):
+    sc = owner._step_scratch.get(key)
+    if sc is None or sc["N"] < N or sc["F"] < F:
+        dev = owner.cnn.weight.device
+        e = lambda *s, dt=F16: torch.empty(*s, dtype=dt, device=dev)
+        sc = dict(N=N, F=F, xin16=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F16, device=dev),
+                  h32=e(N, D, dt=F32), h16=e(N, D), x16=e(N, D), qkvg=e(N, 4 * D), o16=e(N, D), glu16=e(N, D),
+                  dw16=e(N, D), ff16=e(N * F), qkv16=e(N, 3 * D))
+        owner._step_scratch[key] = sc
+    return sc
+
+
+@torch.no_grad()
+def enc_step(owner, x_t, t, ret_states, conv_caches):
+    """ConformerEncoder.forward_one_step (conformer/encoder.py:223-228)."""
+    P = owner._prepare()
+    dev = owner.cnn.weight.device
+    D, H = owner.n_units, owner._n_heads
+    B = x_t.shape[0]
+    x = x_t.to(device=dev, dtype=F32).reshape(B, 1, -1).contiguous()
+    F = P["blocks"][0]["w1a"].shape[0] if P["blocks"] else 0
+    sc = _scratch(owner, "enc", B, D, F)
+    xin16, h32, h16, x16 = sc["xin16"][:B], sc["h32"][:B], sc["h16"][:B], sc["x16"][:B]
+    ops.bn_cast_pad(x, None, xin16, 1, 1, False)
+    ops.linear_res_ln(xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], h32, h16, P["in.eps"])
+    nb = len(P["blocks"])
+    for i, Bk in enumerate(P["blocks"]):
+        if i == 0:
+            ops.layernorm_f16(h32, Bk["lna"][0], Bk["lna"][1], x16, Bk["lna"][2])
+        Fi = Bk["w1a"].shape[0]
+        ff = sc["ff16"][:B * Fi].view(B, Fi)
+        ops.linear(x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
+        ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1], h32, x16, Bk["lnb"][2])
+        o16 = _ret_step(x16, Bk["wqkvg"], Bk["bqkvg"], ret_states[i], B, H, Bk["gn_eps"], sc)
+        ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], h32, 1.0, Bk["lnc"][0], Bk["lnc"][1], h32, x16, Bk["lnc"][2])
+        glu, dw = sc["glu16"][:B], sc["dw16"][:B]
+        ops.linear_glu(x16, Bk["pw1"], Bk["pb1"], glu)
+        cache = conv_caches[i]
+        if cache.dtype != F32 or not cache.is_contiguous() or cache.device != dev:
+            raise EendHipError("conv cache must be a contiguous f32 GPU tensor (B, D, k-1)")
+        ops.dwconv_step(glu, cache, Bk["dw"], Bk["bn"], dw, Bk["bn_eps"])      # cache shifted in place
+        ops.linear_res_scale_ln16(dw, Bk["pw2"], Bk["pb2"], h32, 1.0, Bk["lnd"][0], Bk["lnd"][1], h32, x16, Bk["lnd"][2])
+        ops.linear(x16, Bk["w1b"], Bk["b1b"], ff, act=ops.ACT_SWISH)
+        ops.linear_res_ln(ff, Bk["w2b"], Bk["b2b"], h32, Bk["lne"][0], Bk["lne"][1], h32, h16, Bk["lne"][2], alpha=Bk["fb"])
+        if i + 1 < nb:
+            nx = P["blocks"][i + 1]["lna"]
+            ops.layernorm_f16(h32, nx[0], nx[1], x16, nx[2])
+    return h32.view(B, 1, D).clone()
+
+
+@torch.no_grad()
+def dec_step(owner, emb_t, t, max_nspks, ret_states):
+    """MaskedTransformerDecoderModel.forward_one_step (LS model :235-243)."""
+    P = owner._prepare()
+    dev = owner.cnn.weight.device
+    D, H, C = owner.n_units, owner._n_heads, max_nspks
+    B = emb_t.shape[0]
+    N = B * C
+    F = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
+    sc = _scratch(owner, "dec", N, D, F)
+    e16 = emb_t.to(device=dev, dtype=F32).reshape(B, D).to(F16).contiguous()
+    a32, a16 = sc["h32"][:N], sc["h16"][:N]
+    ops.convert_fanout(e16, P["convert.w1"], owner._convert_const(C), a32, a16, B, 1, C)
+    for i, Ld in enumerate(P["dec.layers"]):
+        Fi = Ld["w1"].shape[0]
+        ff = sc["ff16"][:N * Fi].view(N, Fi)
+        o16 = _ret_step(a16, Ld["wqkvg"], Ld["bqkvg"], ret_states[i], N, H, Ld["gn_eps"], sc)
+        ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], a32, Ld["g11"], Ld["be11"], a32, a16, Ld["eps11"])
+        qkv = sc["qkv16"][:N]
+        ops.linear(a16, Ld["in2_w"], Ld["in2_b"], qkv)
+        ops.spk_attn(qkv, o16, B, C, 1, H)
+        ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], a32, Ld["g21"], Ld["be21"], a32, a16, Ld["eps21"])
+        ops.linear(a16, Ld["w1"], Ld["b1"], ff, relu=True)
+        ops.linear_res_ln(ff, Ld["w2"], Ld["b2"], a32, Ld["g22"], Ld["be22"], a32, a16, Ld["eps22"])
+    return a32.view(B, 1, C, D).clone()
+
+
+class StreamingConv1d(nn.Module):
+    """Ring-buffered look-ahead conv (reference LS model :151-186): emits from the (k//2+1)-th push,
+    zero left padding.  ``.conv`` holds the parameters (the driver copies model.cnn into it),
+    ``.buffer`` / ``.t`` are reset by the driver exactly like the reference's."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=19):
+        super().__init__()
+        if out_channels != 256 or in_channels % 64:
+            raise NotImplementedError("HIP path is specialised for 256 output channels")
+        self.kernel_size = kernel_size
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, padding=0)
+        self.buffer = deque(maxlen=kernel_size)
+        self.center = kernel_size // 2
+        self.t = 0
+        self._w = self._w_key = None
+
+    def _weights(self):
+        key = (self.conv.weight.data_ptr(), self.conv.weight._version, self.conv.bias._version)
+        if self._w is None or key != self._w_key:
+            w = self.conv.weight.detach()
+            if not w.is_cuda:
+                raise EendHipError("StreamingConv1d parameters must live on the GPU: no CPU fallback")
+            self._w = (w.permute(0, 2, 1).reshape(w.shape[0], -1).to(F16).contiguous(),
+                       self.conv.bias.detach().to(F32).contiguous())
+            self._w_key = key
+        return self._w
+
+    @torch.no_grad()
+    def forward(self, x_t):
+        """x_t (B, C, 1) -> (B, C_out, 1) or None while the look-ahead is not filled."""
+        self.t += 1
+        self.buffer.append(x_t)
+        left = self.kernel_size - len(self.buffer)
+        frames = [torch.zeros_like(x_t)] * left + list(self.buffer)
+        win = torch.cat(frames, dim=2)                                   # (B, C, k)
+        B = win.shape[0]
+        wr, bias = self._weights()
+        win16 = win.permute(0, 2, 1).reshape(B, -1).to(F16).contiguous()  # [b][tap*C + c]
+        out = torch.empty(B, wr.shape[0], dtype=F32, device=win16.device)
+        ops.linear_res_scale(win16, wr, bias, None, 1.0, out, None)
+        return out.unsqueeze(-1) if self.t >= self.center + 1 else None
