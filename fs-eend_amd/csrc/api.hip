@@ -173,6 +173,12 @@ int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, fl
     return eend_launch_head(emb, attr, attr_out, logits, B, T, Tp, C, D, (hipStream_t)stream);
 }
 
+int eend_attn_decode_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap, int t,
+                         float scale, void* stream) {
+    if (!qkv || !K_cache || !V_cache || !out_f16) return EEND_EINVAL;
+    return eend_launch_attn_decode(qkv, K_cache, V_cache, out_f16, N, H, cap, t, scale, (hipStream_t)stream);
+}
+
 int eend_retention_step_f16(const void* qkvg, float* kv_state, const float* scale_in, float* scale_out,
                             void* out_f16, int N, int H, float gn_eps, void* stream) {
     if (!qkvg || !kv_state || !scale_in || !scale_out || !out_f16) return EEND_EINVAL;

@@ -96,3 +96,5 @@ int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, flo
 int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const float* bn_w, const float* bn_b,
                             const float* bn_mean, const float* bn_var, float eps, void* out16, int B, int D, int k,
                             hipStream_t stream);
+int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t,
+                            float scale, hipStream_t stream);

@@ -82,7 +82,86 @@ void dwconv_step_kernel(const _Float16* __restrict__ x, float* __restrict__ cach
     out[i] = to_f16_sat(y / (1.0f + __expf(-y)));
 }
 
+// FS-EEND incremental self-attention (FS-EEND/nnet/modules/streaming_tfm.py:15-37): one new token
+// per sequence attends over its growing key/value history.  The reference caches the layer inputs
+// and re-projects all t keys every frame; caching the projected K/V is the same arithmetic at
+// O(t) instead of O(t * D^2) per frame.  qkv f16 [N][3*D] (packed in-proj of the new token);
+// caches f16 [N][H][cap][64]; `t` = tokens already cached.  One wave per (n, h): appends the new
+// k/v row, then an online softmax over 64-key chunks (lane = key for the scores, lane = d for PV).
+__global__ __launch_bounds__(256)
+void attn_decode_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ Kc, _Float16* __restrict__ Vc,
+                        _Float16* __restrict__ out, int N, int H, int cap, int t, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= N * H) return;
+    const int n = idx / H, h = idx - n * H;
+    const int D = H * 64;
+    const _Float16* row = qkv + (size_t)n * 3 * D + h * 64;
+    _Float16* Kh = Kc + (size_t)idx * cap * 64;
+    _Float16* Vh = Vc + (size_t)idx * cap * 64;
+    const _Float16 kn = row[D + lane], vn = row[2 * D + lane];
+    Kh[(size_t)t * 64 + lane] = kn;
+    Vh[(size_t)t * 64 + lane] = vn;
+    float qf[64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f16x8 q8 = *(const f16x8*)(row + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[i * 8 + e] = (float)q8[e] * scale;
+    }
+    // the new token's own score and value come from registers (its cache rows are not read back)
+    float s_new = qf[0] * 0.f;
+    {
+        float part = (float)row[lane] * scale * (float)kn;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) part = wave_xor_add(part, m);
+        s_new = part;
+    }
+    float m_run = s_new, l_run = 1.0f, o = (float)vn;        // softmax state seeded with the new token
+    for (int c0 = 0; c0 < t; c0 += 64) {
+        const int key = c0 + lane;
+        float s = -INFINITY;
+        if (key < t) {
+            const _Float16* kr = Kh + (size_t)key * 64;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f16x8 k8 = *(const f16x8*)(kr + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[i * 8 + e], (float)k8[e], acc);
+            }
+            s = acc;
+        }
+        float cm = s;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) cm = wave_xor_max(cm, m);
+        const float m_new = __builtin_fmaxf(m_run, cm);
+        const float alpha = __expf(m_run - m_new);
+        const float p = __expf(s - m_new);                    // 0 for key >= t
+        float ps = p;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) ps = wave_xor_add(ps, m);
+        l_run = l_run * alpha + ps;
+        o *= alpha;
+        const int nk = (t - c0) < 64 ? (t - c0) : 64;
+        for (int j = 0; j < nk; ++j) {
+            const float pj = __shfl(p, j, 64);
+            o = __builtin_fmaf(pj, (float)Vh[(size_t)(c0 + j) * 64 + lane], o);
+        }
+        m_run = m_new;
+    }
+    out[(size_t)n * D + h * 64 + lane] = to_f16_sat(o / l_run);
+}
+
 }  // namespace
+
+int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t,
+                            float scale, hipStream_t stream) {
+    if (N <= 0 || H <= 0 || cap <= 0 || t < 0 || t >= cap) return EEND_EINVAL;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3((N * H + 3) / 4), dim3(256), 0, stream, (const _Float16*)qkv, (_Float16*)Kc,
+                       (_Float16*)Vc, (_Float16*)out16, N, H, cap, t, scale);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
 
 int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N,
                          int H, float eps, hipStream_t stream) {

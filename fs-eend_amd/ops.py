@@ -217,3 +217,11 @@ def dwconv_step(x16, cache, w, bn, out16, eps=1e-5):
     B, D = x16.shape
     _lib.check(L.eend_dwconv_step_f16(_p(x16), _p(cache), _p(w), _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), eps,
                                       _p(out16), B, D, w.shape[1], _stream()), "eend_dwconv_step_f16")
+
+
+def attn_decode(qkv16, k_cache, v_cache, out16, N, H, cap, t):
+    """Append the new token's k/v (row t) to the caches (N,H,cap,64) f16 and attend over t+1 tokens."""
+    L = _lib.load()
+    _chk(qkv16, F16, "qkv16"); _chk(k_cache, F16, "k_cache"); _chk(v_cache, F16, "v_cache"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_attn_decode_f16(_p(qkv16), _p(k_cache), _p(v_cache), _p(out16), N, H, cap, t,
+                                      1.0 / math.sqrt(64.0), _stream()), "eend_attn_decode_f16")

@@ -136,6 +136,14 @@ int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_
                              const float* bn_mean, const float* bn_var, float eps, void* out_f16, int nseq,
                              int Tp, int D, int k, void* stream);
 
+/* Incremental self-attention of FS-EEND streaming (FS-EEND/nnet/modules/streaming_tfm.py:15-37,
+ * used by StreamingTransformerEncoderLayer :61-66 and StreamingAttractorDecoderLayer :197-201): the
+ * packed in-proj of ONE new token per sequence (qkv f16 [N][3*H*64]) is appended to the projected
+ * K/V caches (f16 [N][H][cap][64], `t` tokens already present, t < cap) and attends over all t+1
+ * tokens.  out f16 [N][H*64]. */
+int eend_attn_decode_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap,
+                         int t, float scale, void* stream);
+
 /* One frame of MultiScaleRetention.recurrent_forward (retention.py:126-144, decay 1) + per-head
  * LayerNorm + swish gate, state updated in place.  qkvg f16 [N][4*H*64] = [q | k*dk^-0.5 | v | g];
  * kv_state f32 [N][H][64][64] in the reference's incremental_state["prev_key_value"] layout;
