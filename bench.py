@@ -131,6 +131,77 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
                        f"; {time.perf_counter() - t_start:.1f} s of CPU work")
 
 
+def extras(dev):
+    """Side measurements (not the headline metric): LS-EEND chunked batch throughput (BASELINE config 3)
+    and frame-by-frame streaming latency / real-time factor of both flavours (config 5 mechanism)."""
+    from fs_eend_amd.fs_model import OnlineTransformerDADiarization
+    from fs_eend_amd.fs_stream import StreamingTransformerEDADiarization, copy_params_from_masked_to_streaming
+    from fs_eend_amd.ls_model import OnlineConformerRetentionDADiarization, StreamingConv1d
+    res = {}
+    LS_CFG = dict(n_units=256, n_heads=4, enc_n_layers=4, dec_n_layers=2, dropout=0.1, max_seqlen=1000,
+                  recurrent_chunk_size=500, feed_forward_expansion_factor=4, dec_dim_feedforward=2048,
+                  conv_expansion_factor=2, conv_kernel_size=16, half_step_residual=True, conv_delay=9)
+    torch.manual_seed(0)
+    ls = OnlineConformerRetentionDADiarization(n_speakers=None, in_size=345, **LS_CFG).eval().to(dev)
+    g = torch.Generator().manual_seed(1)
+    B, T, C = 16, 2000, 10
+    src = [(torch.randn(T, 345, generator=g) * 2 - 3).to(dev) for _ in range(B)]
+    for _ in range(2):
+        ls.test(src, [T] * B, C)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        ls.test(src, [T] * B, C)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    res["ls_eend_batch"] = dict(workload=f"LS-EEND model.test, {B} x T={T} (4 chunks of 500), max_nspks={C}, eager launches",
+                                frames_per_s=B * T / dt, ms_per_step=dt * 1e3, rtf=dt / (B * T * 0.1))
+
+    # LS-EEND streaming, 8 speakers + 2 slots, O(1) state (LS-EEND/streaming_infer_dia.py:52-97)
+    scnn = StreamingConv1d(256, 256, kernel_size=19).to(dev).eval()
+    scnn.conv.load_state_dict(ls.cnn.state_dict())
+    rs = [dict() for _ in range(4)]
+    cc = [torch.zeros(1, 256, 15, device=dev) for _ in range(4)]
+    ds = [dict() for _ in range(2)]
+    x = src[0]
+    nfr, warm = 260, 60
+    torch.cuda.synchronize()
+    for t in range(nfr):
+        if t == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        e = ls.enc.forward_one_step(x[t:t + 1].unsqueeze(0), t, rs, cc)
+        e = scnn(e.transpose(1, 2))
+        if e is not None:
+            e = e.transpose(1, 2)
+            e = e / torch.norm(e, dim=-1, keepdim=True)
+            a = ls.dec.forward_one_step(e, t, C, ds)
+            a = a / torch.norm(a, dim=-1, keepdim=True)
+            y = torch.matmul(e.unsqueeze(-2), a.transpose(-1, -2)).squeeze(-2)
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / (nfr - warm)
+    state_bytes = sum(s["prev_key_value"].numel() * 4 for s in rs + ds) + sum(c.numel() * 4 for c in cc) + 19 * 256 * 4
+    res["ls_eend_streaming"] = dict(workload=f"1 stream, max_nspks={C}, frame-by-frame one-step API, eager launches",
+                                    ms_per_frame=per * 1e3, rtf=per / 0.1, state_bytes=state_bytes)
+
+    torch.manual_seed(0)
+    fm = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **FS_CFG).eval().to(dev)
+    sm = StreamingTransformerEDADiarization(in_size=345, **FS_CFG).eval().to(dev)
+    copy_params_from_masked_to_streaming(fm, sm)
+    torch.cuda.synchronize()
+    for t in range(nfr):
+        if t == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        sm.test(x[t].view(1, 1, -1), 6)
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / (nfr - warm)
+    res["fs_eend_streaming"] = dict(workload=f"1 stream, max_nspks=6, K/V-cache decode attention, frames {warm}..{nfr}",
+                                    ms_per_frame=per * 1e3, rtf=per / 0.1)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +213,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the LS-EEND / streaming side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,13 +281,9 @@ def main():
         run()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    frames_per_step = world * B * T
-    value = frames_per_step * args.steps / dt
+    from fs_eend_amd.shard import job_throughput
+    value = job_throughput(B * T * args.steps, dt, dev)         # sum of frames / max of time over ranks (RCCL)
+    dt = world * B * T * args.steps / value
 
     out = {
         "metric": "audio frames/sec (T=500 chunks)", "value": value, "unit": "frames/s", "n_gpus": world,
@@ -258,6 +326,9 @@ def main():
                 "frac": fl / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                 "hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9, "hbm_frac": byt / (a["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "traffic": None, "avg_launch_ms": a["avg_ms"]}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["extras"] = extras(dev)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, C)

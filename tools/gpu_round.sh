@@ -23,7 +23,7 @@ fi
 if [[ "$WHAT" == all || "$WHAT" == *prof* ]]; then
   rm -rf gpurun_out/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o fs -- \
-      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --graph 0 ${BENCH_ARGS:-}) > gpurun_out/prof_bench.log 2>&1
+      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --graph 0 ${BENCH_ARGS:-}) > gpurun_out/prof_bench.log 2>&1
   echo "prof rc=$?"; tail -2 gpurun_out/prof_bench.log
   db=$(find gpurun_out/prof -name "*.db" | head -1)
   [ -n "$db" ] && python tools/rocpd_stats.py "$db" gpurun_out/kernel_stats.csv && head -25 gpurun_out/kernel_stats.csv | cut -c1-200
