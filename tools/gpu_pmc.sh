@@ -1,0 +1,20 @@
+#!/bin/bash
+# PMC passes on the GPU box (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE; kernel-trace only).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out/pmc
+export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+ROOT=$PWD
+run_pass() {  # name, counters...
+  name=$1; shift
+  rm -rf /tmp/pmc_$name
+  (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- \
+      python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-breakdown --graph 0 ${BENCH_ARGS:-}) > gpurun_out/pmc/$name.log 2>&1
+  echo "$name rc=$?"
+  f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python tools/pmc_summary.py "$f" gpurun_out/pmc/$name.csv
+}
+run_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES
+run_pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU
+run_pass fetch FETCH_SIZE TCC_HIT_sum TCC_MISS_sum
+run_pass write WRITE_SIZE
+head -40 gpurun_out/pmc/sq.csv | cut -c1-220
