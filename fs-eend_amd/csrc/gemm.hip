@@ -16,8 +16,17 @@
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
+
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N).  Register arrays
+// indexed through it have constant indices at IR-generation time (a `#pragma unroll` loop
+// variable is only constant after unrolling, too late for SROA -> the array lands in scratch).
+template <class F, int... I>
+DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1 };
 
@@ -33,7 +42,7 @@ template <> struct OutCvt<__bf16> {
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
+template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
 __global__ __launch_bounds__(WGM * WGN * 64)
 void gemm_f16_kernel(const GemmParams p) {
     constexpr int NT = WGM * WGN * 64;
@@ -64,16 +73,18 @@ void gemm_f16_kernel(const GemmParams p) {
     const _Float16* __restrict__ W = (const _Float16*)p.W;
 
     // ---- per-thread staging coordinates --------------------------------------------------
-    uint4 xr[XCH], wr[WCH];
+    constexpr int NSET = PF > 0 ? PF : 1;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vector: trivially SROA'd
+    u32x4 xr[NSET][XCH], wr[NSET][WCH];     // PF > 0: all PF == nk k-tiles in flight (straight-line code)
     const _Float16* xsrc[XCH];
     int xseq_t[XCH];            // conv: frame index t inside its slab
     int xilen[XCH];             // conv: valid length of that sequence
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
+    static_for<XCH>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
         const int q = tid + i * NT;
         int m = m0 + (q >> 3);
         m = m < p.M ? m : p.M - 1;
-        if (ALOAD == ALOAD_CONV) {
+        if constexpr (ALOAD == ALOAD_CONV) {
             const int seq = m / p.Tp;
             xseq_t[i] = m - seq * p.Tp;
             xilen[i] = p.ilens[seq];
@@ -81,50 +92,53 @@ void gemm_f16_kernel(const GemmParams p) {
         } else {
             xsrc[i] = A + (size_t)m * p.lda + (q & 7) * 8;
         }
-    }
+    });
     const _Float16* wsrc[WCH];
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
+    static_for<WCH>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
         const int q = tid + i * NT;
         wsrc[i] = W + (size_t)(n0 + (q >> 3)) * p.ldw + (q & 7) * 8;
-    }
+    });
 
-    // (macros, not lambdas: by-reference closures over the staging arrays end up in scratch)
-#define GEMM_GLOAD(kt_)                                                                          \
-    do {                                                                                         \
-        const int kt__ = (kt_);                                                                  \
-        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                        \
-            if (ALOAD == ALOAD_CONV) {                                                           \
-                /* implicit GEMM for Conv1d: k-tile kt covers input channels cin0..cin0+63 of   \
-                   tap `tap`; source frame t + tap - pad, zero outside [0, ilen) (reference:    \
-                   truncate to ilen, zero re-pad, then the conv's own zero padding). */         \
-                const int kpt = p.conv_cin >> 6;                                                 \
-                const int tap = kt__ / kpt;                                                      \
-                const int cin0 = (kt__ - tap * kpt) << 6;                                        \
-                const int ts = xseq_t[i] + tap - p.conv_pad;                                     \
-                if (ts >= 0 && ts < xilen[i])                                                    \
-                    xr[i] = *(const uint4*)(xsrc[i] + (size_t)ts * p.lda + cin0);                \
-                else                                                                             \
-                    xr[i] = make_uint4(0, 0, 0, 0);                                              \
-            } else {                                                                             \
-                xr[i] = *(const uint4*)(xsrc[i] + kt__ * 64);                                    \
-            }                                                                                    \
-        }                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < WCH; ++i) wr[i] = *(const uint4*)(wsrc[i] + kt__ * 64); \
-    } while (0)
-#define GEMM_LSTORE(buf_)                                                                        \
-    do {                                                                                         \
-        char* xb__ = smem + (buf_) * TILE_BYTES;                                                 \
-        char* wb__ = xb__ + BM * 128;                                                            \
-        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                        \
-            const int q = tid + i * NT;                                                          \
-            *(uint4*)(xb__ + swz128(q >> 3, q & 7)) = xr[i];                                     \
-        }                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                        \
-            const int q = tid + i * NT;                                                          \
-            *(uint4*)(wb__ + swz128(q >> 3, q & 7)) = wr[i];                                     \
-        }                                                                                        \
-    } while (0)
+    // staging helpers: SET / i are compile-time constants (see static_for)
+    auto gload = [&](auto SET, int kt) __attribute__((always_inline)) {
+        static_for<XCH>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (ALOAD == ALOAD_CONV) {
+                // implicit GEMM for Conv1d: k-tile kt covers input channels cin0..cin0+63 of tap `tap`;
+                // source frame t + tap - pad, zero outside [0, ilen) (reference: truncate to ilen,
+                // zero re-pad, then the conv's own zero padding).
+                const int kpt = p.conv_cin >> 6;
+                const int tap = kt / kpt;
+                const int cin0 = (kt - tap * kpt) << 6;
+                const int ts = xseq_t[i] + tap - p.conv_pad;
+                if (ts >= 0 && ts < xilen[i])
+                    xr[decltype(SET)::value][i] = *(const u32x4*)(xsrc[i] + (size_t)ts * p.lda + cin0);
+                else
+                    xr[decltype(SET)::value][i] = u32x4{0u, 0u, 0u, 0u};
+            } else {
+                xr[decltype(SET)::value][i] = *(const u32x4*)(xsrc[i] + kt * 64);
+            }
+        });
+        static_for<WCH>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            wr[decltype(SET)::value][i] = *(const u32x4*)(wsrc[i] + kt * 64);
+        });
+    };
+    auto lstore = [&](auto SET, int buf) __attribute__((always_inline)) {
+        char* xb = smem + buf * TILE_BYTES;
+        char* wb = xb + BM * 128;
+        static_for<XCH>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int q = tid + i * NT;
+            *(u32x4*)(xb + swz128(q >> 3, q & 7)) = xr[decltype(SET)::value][i];
+        });
+        static_for<WCH>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int q = tid + i * NT;
+            *(u32x4*)(wb + swz128(q >> 3, q & 7)) = wr[decltype(SET)::value][i];
+        });
+    };
 
     f32x4 acc[FR][FL];
 #pragma unroll
@@ -136,10 +150,6 @@ void gemm_f16_kernel(const GemmParams p) {
     const int r_tile_row0 = SWAP ? wn * WN : wm * WM;     // inside W tile if SWAP else X tile
     const int l_tile_row0 = SWAP ? wm * WM : wn * WN;
     const int frow = lane & 15, fkg = lane >> 4;
-
-    GEMM_GLOAD(0);
-    GEMM_LSTORE(0);
-    __syncthreads();
 
 #define GEMM_COMPUTE(buf_)                                                                       \
     do {                                                                                         \
@@ -159,16 +169,37 @@ void gemm_f16_kernel(const GemmParams p) {
         }                                                                                        \
     } while (0)
 
-    // k-tile kt+1 is in flight (registers) while k-tile kt feeds the matrix pipe; the last
-    // k-tile is peeled so the steady-state body has no conditionals.
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        const int buf = kt & 1;
-        GEMM_GLOAD(kt + 1);
-        GEMM_COMPUTE(buf);
-        GEMM_LSTORE(buf ^ 1);
+    if constexpr (PF > 0) {
+        // nk == PF (K = 64*PF, e.g. K = 256 -> PF = 4): straight-line code, every k-tile's loads are
+        // issued up front -- one L2 round trip for the whole K extent instead of one per k-tile
+        // (PMC: the looped form spent 65 % of its wave cycles in s_waitcnt at K = 256).  The kernel is
+        // LDS-limited to 2 blocks/CU, so the extra staging registers cost no occupancy.  Tile kt goes
+        // to LDS buffer kt&1 right before use; a wave passes barrier(kt) only after every wave has
+        // finished compute(kt-1), so buffer (kt+1)&1 is free for the next store.
+        static_assert(PF == 0 || PF == 4, "straight-line variant is written out for 4 k-tiles");
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+        gload(C0{}, 0); gload(C1{}, 1); gload(C2{}, 2); gload(C3{}, 3);
+        lstore(C0{}, 0); __syncthreads(); GEMM_COMPUTE(0);
+        lstore(C1{}, 1); __syncthreads(); GEMM_COMPUTE(1);
+        lstore(C2{}, 0); __syncthreads(); GEMM_COMPUTE(0);
+        lstore(C3{}, 1); __syncthreads(); GEMM_COMPUTE(1);
+    } else {
+        // generic K: k-tile kt+1 is in flight (registers) while k-tile kt feeds the matrix pipe; the
+        // last k-tile is peeled so the steady-state body has no conditionals.
+        using Z = std::integral_constant<int, 0>;
+        gload(Z{}, 0);
+        lstore(Z{}, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            const int buf = kt & 1;
+            gload(Z{}, kt + 1);
+            GEMM_COMPUTE(buf);
+            lstore(Z{}, buf ^ 1);
+            __syncthreads();
+        }
+        GEMM_COMPUTE((nk - 1) & 1);
     }
-    GEMM_COMPUTE((nk - 1) & 1);
     __syncthreads();
 
     // ---- epilogues -----------------------------------------------------------------------
@@ -295,7 +326,7 @@ void gemm_f16_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < FL; ++j) { mean[j] = 0.f; scale[j] = 1.f; }
         } else {
-            auto block_rowsum = [&](float (&part)[FL]) {
+            auto block_rowsum = [&](float (&part)[FL]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < FL; ++j) {
                     part[j] = wave_xor_add(part[j], 16);
@@ -395,13 +426,11 @@ void gemm_f16_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
-int launch(const GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
-    if (p.N % BN != 0 || p.K % 64 != 0 || (p.lda & 7) || (p.ldw & 7)) return EEND_EINVAL;
+template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
+int launch_pf(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
-    auto kern = gemm_f16_kernel<BM, BN, WGM, WGN, SWAP, ALOAD, EPI>;
+    auto kern = gemm_f16_kernel<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, PF>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return EEND_ELAUNCH;
@@ -410,6 +439,18 @@ int launch(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WGM * WGN * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+// K == 256 (4 k-tiles) takes the straight-line full-K variant when the tile's staging registers
+// fit (128x128: 8 uint4 per k-tile -> 128 VGPRs); everything else the looped variant.
+template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
+    if (p.N % BN != 0 || p.K % 64 != 0 || (p.lda & 7) || (p.ldw & 7)) return EEND_EINVAL;
+    if constexpr (BM + BN <= 256 && ALOAD == ALOAD_PLAIN) {
+        if (p.K == 256) return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 4>(p, stream);
+    }
+    return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 0>(p, stream);
 }
 
 }  // namespace
