@@ -2,6 +2,7 @@
 // The exported surface is exactly include/eend_hip.h.
 #include "../../include/eend_hip.h"
 #include "kernels.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -11,6 +12,8 @@ GemmParams base_params(const void* A, int lda, const void* W, int ldw, const flo
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldo = N; p.Tp = 64; p.H = 4; p.dh = 64; p.C = 1;
     p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0;
+    const char* d = getenv("EEND_GEMM_DBG");          // perf-study ablations only; unset in normal use
+    p.dbg = d ? atoi(d) : 0;
     return p;
 }
 }  // namespace

@@ -117,12 +117,12 @@ void gemm_f16_kernel(const GemmParams p) {
                 else
                     xr[decltype(SET)::value][i] = u32x4{0u, 0u, 0u, 0u};
             } else {
-                xr[decltype(SET)::value][i] = *(const u32x4*)(xsrc[i] + kt * 64);
+                xr[decltype(SET)::value][i] = *(const u32x4*)(xsrc[i] + ((p.dbg & 2) ? 0 : kt) * 64);
             }
         });
         static_for<WCH>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            wr[decltype(SET)::value][i] = *(const u32x4*)(wsrc[i] + kt * 64);
+            wr[decltype(SET)::value][i] = *(const u32x4*)(wsrc[i] + ((p.dbg & 2) ? 0 : kt) * 64);
         });
     };
     auto lstore = [&](auto SET, int buf) __attribute__((always_inline)) {
@@ -163,9 +163,11 @@ void gemm_f16_kernel(const GemmParams p) {
                 rf[i] = *(const f16x8*)(rb__ + swz128(r_tile_row0 + i * 16 + frow, ks * 4 + fkg)); \
             _Pragma("unroll") for (int j = 0; j < FL; ++j)                                       \
                 lf[j] = *(const f16x8*)(lb__ + swz128(l_tile_row0 + j * 16 + frow, ks * 4 + fkg)); \
+            if (!(p.dbg & 4)) {                                                                  \
             _Pragma("unroll") for (int i = 0; i < FR; ++i)                                       \
                 _Pragma("unroll") for (int j = 0; j < FL; ++j)                                   \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf[i], lf[j], acc[i][j], 0, 0, 0); \
+            } else { _Pragma("unroll") for (int i = 0; i < FR; ++i) acc[i][0][0] += (float)rf[i][0] + (float)lf[i % FL][0]; } \
         }                                                                                        \
     } while (0)
 
@@ -207,17 +209,27 @@ void gemm_f16_kernel(const GemmParams p) {
     const int R0 = (SWAP ? n0 + wn * WN : m0 + wm * WM) + fkg * 4;
     const int L0 = (SWAP ? m0 + wm * WM : n0 + wn * WN) + frow;
 
-    if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16) {
-        static_assert(SWAP, "plain epilogue expects SWAP");
-        _Float16* __restrict__ out = (_Float16*)p.out16;
+    if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16 ||
+                  EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16 || EPI == EPI_VT_HEADS || EPI == EPI_KTVT_HEADS_F16) {
+        // 2-byte outputs go through LDS (free after the main loop) so that global stores are full
+        // 256-byte row segments, 16 B per lane.  (Measured: the direct form -- 8 B per lane, 32-byte
+        // pieces scattered over 16 rows per instruction -- cost as much as the rest of the kernel.)
+        // Staged tile = [L index][R index]: SWAP -> rows are tokens, columns features (row-major
+        // outputs, Q/K head rows); !SWAP -> rows are features, columns tokens (the transposed
+        // K^T / V^T head layout falls out of the same code).
+        constexpr bool IS_BF16 = (EPI == EPI_QK_HEADS || EPI == EPI_VT_HEADS);
+        using OT = typename std::conditional<IS_BF16, __bf16, _Float16>::type;
+        constexpr int BL = SWAP ? BM : BN, BR = SWAP ? BN : BM;
+        constexpr int SROW = BR + 8;                                   // +16 B pad: bank spread
+        static_assert(BL * SROW * 2 <= 2 * TILE_BYTES, "staging tile must fit in the pipeline LDS");
+        OT* stage = (OT*)smem;
 #pragma unroll
         for (int i = 0; i < FR; ++i) {
-            const int n = R0 + i * 16;
-            const float4 b = p.bias ? *(const float4*)(p.bias + n) : make_float4(0, 0, 0, 0);
+            float4 b = make_float4(0, 0, 0, 0);
+            if (SWAP && p.bias) b = *(const float4*)(p.bias + R0 + i * 16);
 #pragma unroll
             for (int j = 0; j < FL; ++j) {
-                const int m = L0 + j * 16;
-                if (m >= p.M) continue;
+                if (!SWAP) { const float bb = p.bias ? p.bias[L0 + j * 16] : 0.f; b = make_float4(bb, bb, bb, bb); }
                 float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
                 if (EPI == EPI_PLAIN_RELU_F16) {
                     v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
@@ -227,8 +239,40 @@ void gemm_f16_kernel(const GemmParams p) {
                     v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
                     v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
                 }
-                *(f16x4*)(out + (size_t)m * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
+                const int lrow = l_tile_row0 + j * 16 + frow, rcol = r_tile_row0 + i * 16 + fkg * 4;
+                *(decltype(OutCvt<OT>::cvt(0, 0, 0, 0))*)(stage + lrow * SROW + rcol) = OutCvt<OT>::cvt(v0, v1, v2, v3);
             }
+        }
+        __syncthreads();
+        const int Lbase = SWAP ? m0 : n0, Rbase = SWAP ? n0 : m0;
+        constexpr int CPR = BR / 8;                                    // 16-B chunks per staged row
+        const int D = p.H * p.dh;
+#pragma unroll
+        for (int it = 0; it < BL * CPR / NT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / CPR, ch = idx % CPR;
+            const uint4 v = *(const uint4*)(stage + row * SROW + ch * 8);
+            const int li = Lbase + row, ri = Rbase + ch * 8;
+            OT* dst;
+            if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16) {
+                if (li >= p.M) continue;
+                dst = (OT*)p.out16 + (size_t)li * p.ldo + ri;
+            } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16) {
+                // li = token, ri = feature in [0, 2D): Q then K, [which][seq][H][Tp][dh]
+                if (li >= p.M) continue;
+                const int which = ri / D, nn = ri - which * D;
+                const int h = nn / p.dh, dd = nn - h * p.dh;
+                const int seq = li / p.Tp, t = li - seq * p.Tp;
+                dst = (OT*)(which ? p.out16b : p.out16) + (((size_t)seq * p.H + h) * p.Tp + t) * p.dh + dd;
+            } else {
+                // li = feature (V, or K then V), ri = first of 8 consecutive tokens: [seq][H][dh][Tp]
+                if (ri >= p.M) continue;
+                const int which = li / D, nn = li - which * D;
+                const int h = nn / p.dh, dd = nn - h * p.dh;
+                const int seq = ri / p.Tp, t = ri - seq * p.Tp;
+                dst = (OT*)(which ? p.out16b : p.out16) + (((size_t)seq * p.H + h) * p.dh + dd) * p.Tp + t;
+            }
+            if (!(p.dbg & 1)) *(uint4*)dst = v;
         }
     } else if constexpr (EPI == EPI_GLU_F16) {
         // W rows interleaved (2n = value_n, 2n+1 = gate_n): a lane's 4 consecutive rows are two
@@ -250,51 +294,6 @@ void gemm_f16_kernel(const GemmParams p) {
                 o[0] = to_f16_sat(a0 / (1.0f + __expf(-g0)));
                 o[1] = to_f16_sat(a1 / (1.0f + __expf(-g1)));
                 *(f16x2*)(out + (size_t)m * p.ldo + (r >> 1)) = o;
-            }
-        }
-    } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16) {
-        // n in [0, 2D): Q then K of the packed in-proj; bf16 [which][seq][H][Tp][dh]
-        static_assert(SWAP, "QK epilogue expects SWAP");
-        const int D = p.H * p.dh;
-#pragma unroll
-        for (int i = 0; i < FR; ++i) {
-            const int n = R0 + i * 16;
-            const float4 b = *(const float4*)(p.bias + n);
-            const int which = n / D;
-            const int nn = n - which * D;
-            const int h = nn / p.dh, d = nn - h * p.dh;
-            using OT = typename std::conditional<EPI == EPI_QK_HEADS, __bf16, _Float16>::type;
-            OT* __restrict__ dst = (OT*)(which ? p.out16b : p.out16);
-#pragma unroll
-            for (int j = 0; j < FL; ++j) {
-                const int m = L0 + j * 16;
-                if (m >= p.M) continue;
-                const int seq = m / p.Tp, t = m - seq * p.Tp;
-                *(decltype(OutCvt<OT>::cvt(0, 0, 0, 0))*)(dst + (((size_t)seq * p.H + h) * p.Tp + t) * p.dh + d) =
-                    OutCvt<OT>::cvt(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
-            }
-        }
-    } else if constexpr (EPI == EPI_VT_HEADS || EPI == EPI_KTVT_HEADS_F16) {
-        // transposed head layout [seq][H][dh][Tp]: V of the packed in-proj (bf16, n in [0, D)) or
-        // K then V of the retention projections (f16, n in [0, 2D): K^T -> out16, V^T -> out16b)
-        static_assert(!SWAP, "Vt epilogue expects !SWAP");
-        using OT = typename std::conditional<EPI == EPI_VT_HEADS, __bf16, _Float16>::type;
-        const int D = p.H * p.dh;
-#pragma unroll
-        for (int j = 0; j < FL; ++j) {
-            const int n = L0 + j * 16;
-            const float b = p.bias[n];
-            const int which = n / D;
-            const int nn = n - which * D;
-            OT* __restrict__ dst = (OT*)(which ? p.out16b : p.out16);
-            const int h = nn / p.dh, d = nn - h * p.dh;
-#pragma unroll
-            for (int i = 0; i < FR; ++i) {
-                const int m = R0 + i * 16;         // 4 consecutive frames m..m+3 (same slab: Tp % 4 == 0)
-                if (m >= p.M) continue;
-                const int seq = m / p.Tp, t = m - seq * p.Tp;
-                *(decltype(OutCvt<OT>::cvt(0, 0, 0, 0))*)(dst + (((size_t)seq * p.H + h) * p.dh + d) * p.Tp + t) =
-                    OutCvt<OT>::cvt(acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b);
             }
         }
     } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE || EPI == EPI_RES_SCALE_LN16) {

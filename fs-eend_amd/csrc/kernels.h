@@ -42,6 +42,7 @@ struct GemmParams {
     int C;              // speaker slots (EPI_CONVERT)
     int conv_cin;       // ALOAD_CONV: input channels (multiple of 64)
     int conv_pad;       // ALOAD_CONV: left padding (taps before the centre)
+    int dbg;            // ablation flags (EEND_GEMM_DBG env, perf studies only): 1 skip stores, 2 reload k-tile 0, 4 skip MFMA
 };
 
 struct AttnParams {
