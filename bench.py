@@ -33,6 +33,9 @@ def flops_per_launch(name, shape, T):
     if name == "attn_causal":          # 2*D*T*(T+1) causal-useful flops per sequence, D = H*64
         nseq, H = shape
         return nseq * 2.0 * (H * 64) * T * (T + 1)
+    if name == "ffn_fused":
+        M, F, K = shape
+        return 4.0 * M * F * K
     if name in ("linear", "linear_res_ln", "linear_res_scale", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
         M, N, K = shape
         return 2.0 * M * N * K
@@ -55,6 +58,8 @@ class OpTimer:
                 shape = (a[4], a[5])
             elif name in ("linear", "linear_res_ln", "linear_res_scale"):
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
+            elif name == "ffn_fused":
+                shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "inproj_heads":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "convert_fanout":
@@ -68,7 +73,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
                   "convert_fanout", "attn_causal", "spk_attn", "head_l2dot"):
             self.orig[n] = getattr(self.ops, n)
             setattr(self.ops, n, self._wrap(n, self.orig[n]))

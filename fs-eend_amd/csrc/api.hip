@@ -31,6 +31,15 @@ int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn
                                    apply_bn, (hipStream_t)stream);
 }
 
+int eend_gather_bn_cast_pad_f16(const void* const* x_ptrs, const int* lens, float pad_value, const float* bn_weight,
+                                const float* bn_bias, const float* bn_mean, const float* bn_var, float eps,
+                                void* out_f16, int B, int T, int Tp, int Fin, int Fpad, int apply_bn, void* stream) {
+    if (!x_ptrs || !lens || !out_f16 || Tp < T || (Fpad % 64) != 0) return EEND_EINVAL;
+    if (apply_bn && (!bn_weight || !bn_bias || !bn_mean || !bn_var)) return EEND_EINVAL;
+    return eend_launch_gather_bn_cast_pad((const float* const*)x_ptrs, lens, pad_value, bn_weight, bn_bias, bn_mean,
+                                          bn_var, eps, out_f16, B, T, Tp, Fin, Fpad, apply_bn, (hipStream_t)stream);
+}
+
 int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
                     int M, int N, int K, int act, void* stream) {
     if (!A || !W || !out_f16 || (ldo & 3) || act < 0 || act > 2) return EEND_EINVAL;
@@ -78,6 +87,17 @@ int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ld
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_SCALE_LN16, (hipStream_t)stream);
+}
+
+int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2,
+                       const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                       float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
+                       void* stream) {
+    FfnParams p;
+    p.X = X; p.ldx = ldx; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = alpha; p.gamma = gamma;
+    p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
+    return eend_launch_ffn_fused(p, act, residual_stream_unnormalised ? FFN_EPI_RES_SCALE_LN16 : FFN_EPI_RES_LN,
+                                 (hipStream_t)stream);
 }
 
 int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,

@@ -15,6 +15,7 @@
 // into the producer's epilogue instead of being a kernel of its own.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -29,6 +30,17 @@ template <int N, class F>
 DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1 };
+
+// Perf-study ablations (tools/gemm_ablate.py): compiled in only with -DEEND_GEMM_ABLATE.
+#ifdef EEND_GEMM_ABLATE
+#define EEND_DBG_KT(kt) ((p.dbg & 2) ? 0 : (kt))
+#define EEND_DBG_NO_MFMA (p.dbg & 4)
+#define EEND_DBG_NO_STORE (p.dbg & 1)
+#else
+#define EEND_DBG_KT(kt) (kt)
+#define EEND_DBG_NO_MFMA 0
+#define EEND_DBG_NO_STORE 0
+#endif
 
 template <class OT> struct OutCvt;
 template <> struct OutCvt<_Float16> {
@@ -117,12 +129,12 @@ void gemm_f16_kernel(const GemmParams p) {
                 else
                     xr[decltype(SET)::value][i] = u32x4{0u, 0u, 0u, 0u};
             } else {
-                xr[decltype(SET)::value][i] = *(const u32x4*)(xsrc[i] + ((p.dbg & 2) ? 0 : kt) * 64);
+                xr[decltype(SET)::value][i] = *(const u32x4*)(xsrc[i] + EEND_DBG_KT(kt) * 64);
             }
         });
         static_for<WCH>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            wr[decltype(SET)::value][i] = *(const u32x4*)(wsrc[i] + ((p.dbg & 2) ? 0 : kt) * 64);
+            wr[decltype(SET)::value][i] = *(const u32x4*)(wsrc[i] + EEND_DBG_KT(kt) * 64);
         });
     };
     auto lstore = [&](auto SET, int buf) __attribute__((always_inline)) {
@@ -163,7 +175,7 @@ void gemm_f16_kernel(const GemmParams p) {
                 rf[i] = *(const f16x8*)(rb__ + swz128(r_tile_row0 + i * 16 + frow, ks * 4 + fkg)); \
             _Pragma("unroll") for (int j = 0; j < FL; ++j)                                       \
                 lf[j] = *(const f16x8*)(lb__ + swz128(l_tile_row0 + j * 16 + frow, ks * 4 + fkg)); \
-            if (!(p.dbg & 4)) {                                                                  \
+            if (!EEND_DBG_NO_MFMA) {                                                               \
             _Pragma("unroll") for (int i = 0; i < FR; ++i)                                       \
                 _Pragma("unroll") for (int j = 0; j < FL; ++j)                                   \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf[i], lf[j], acc[i][j], 0, 0, 0); \
@@ -178,14 +190,23 @@ void gemm_f16_kernel(const GemmParams p) {
         // LDS-limited to 2 blocks/CU, so the extra staging registers cost no occupancy.  Tile kt goes
         // to LDS buffer kt&1 right before use; a wave passes barrier(kt) only after every wave has
         // finished compute(kt-1), so buffer (kt+1)&1 is free for the next store.
-        static_assert(PF == 0 || PF == 4, "straight-line variant is written out for 4 k-tiles");
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
-        using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
-        gload(C0{}, 0); gload(C1{}, 1); gload(C2{}, 2); gload(C3{}, 3);
-        lstore(C0{}, 0); __syncthreads(); GEMM_COMPUTE(0);
-        lstore(C1{}, 1); __syncthreads(); GEMM_COMPUTE(1);
-        lstore(C2{}, 0); __syncthreads(); GEMM_COMPUTE(0);
-        lstore(C3{}, 1); __syncthreads(); GEMM_COMPUTE(1);
+        if constexpr (PF == 4) {
+            using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+            gload(C0{}, 0); gload(C1{}, 1); gload(C2{}, 2); gload(C3{}, 3);
+            lstore(C0{}, 0); __syncthreads(); GEMM_COMPUTE(0);
+            lstore(C1{}, 1); __syncthreads(); GEMM_COMPUTE(1);
+            lstore(C2{}, 0); __syncthreads(); GEMM_COMPUTE(0);
+            lstore(C3{}, 1); __syncthreads(); GEMM_COMPUTE(1);
+        } else {
+            // PF == 2: two k-tiles in flight (64 staging registers: no AGPR round trips), 4 k-tiles
+            static_assert(PF == 2, "straight-line variants: PF = 2 or 4, K = 256");
+            gload(C0{}, 0); gload(C1{}, 1);
+            lstore(C0{}, 0); __syncthreads(); gload(C0{}, 2); GEMM_COMPUTE(0);
+            lstore(C1{}, 1); __syncthreads(); gload(C1{}, 3); GEMM_COMPUTE(1);
+            lstore(C0{}, 0); __syncthreads(); GEMM_COMPUTE(0);
+            lstore(C1{}, 1); __syncthreads(); GEMM_COMPUTE(1);
+        }
     } else {
         // generic K: k-tile kt+1 is in flight (registers) while k-tile kt feeds the matrix pipe; the
         // last k-tile is peeled so the steady-state body has no conditionals.
@@ -272,7 +293,7 @@ void gemm_f16_kernel(const GemmParams p) {
                 const int seq = ri / p.Tp, t = ri - seq * p.Tp;
                 dst = (OT*)(which ? p.out16b : p.out16) + (((size_t)seq * p.H + h) * p.dh + dd) * p.Tp + t;
             }
-            if (!(p.dbg & 1)) *(uint4*)dst = v;
+            if (!EEND_DBG_NO_STORE) *(uint4*)dst = v;
         }
     } else if constexpr (EPI == EPI_GLU_F16) {
         // W rows interleaved (2n = value_n, 2n+1 = gate_n): a lane's 4 consecutive rows are two
@@ -447,7 +468,11 @@ int launch(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
     if (p.N % BN != 0 || p.K % 64 != 0 || (p.lda & 7) || (p.ldw & 7)) return EEND_EINVAL;
     if constexpr (BM + BN <= 256 && ALOAD == ALOAD_PLAIN) {
-        if (p.K == 256) return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 4>(p, stream);
+        if (p.K == 256) {
+            static const int pf = getenv("EEND_GEMM_PF") ? atoi(getenv("EEND_GEMM_PF")) : 2;
+            if (pf == 4) return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 4>(p, stream);
+            if (pf == 2) return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 2>(p, stream);
+        }
     }
     return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 0>(p, stream);
 }

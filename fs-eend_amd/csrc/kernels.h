@@ -99,3 +99,27 @@ int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const
                             hipStream_t stream);
 int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t,
                             float scale, hipStream_t stream);
+int eend_launch_gather_bn_cast_pad(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w,
+                                   const float* bn_b, const float* bn_mean, const float* bn_var, float eps, void* out16,
+                                   int B, int T, int Tp, int Fin, int Fpad, int apply_bn, hipStream_t stream);
+
+enum FfnEpilogue {
+    FFN_EPI_RES_LN = 0,          // out32 = out16 = LN((h W2^T + b2) * alpha + res)
+    FFN_EPI_RES_SCALE_LN16 = 1,  // out32 = (h W2^T + b2) * alpha + res ; out16 = LN(out32)
+};
+
+struct FfnParams {
+    const void* X;      // f16 [M][ldx], K = 256
+    const void* W1;     // f16 [F][256]
+    const float* b1;    // [F]
+    const void* W2;     // f16 [256][F]
+    const float* b2;    // [256]
+    const float* res;   // f32 [M][256] or null
+    const float* gamma; // LN affine [256]
+    const float* beta;
+    float* out32;       // f32 [M][256]
+    void* out16;        // f16 [M][256]
+    float alpha, eps;
+    int M, F, ldx;
+};
+int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);

@@ -31,6 +31,35 @@ void bn_cast_pad_kernel(const float* __restrict__ x, const float* __restrict__ w
     }
 }
 
+// Same as bn_cast_pad_kernel, but reads every utterance through a device pointer table
+// (x_ptrs[b] -> f32 [len[b]][Fin]) and supplies the reference's pad value for t >= len[b]
+// (-1 for FS-EEND, model :165; 0 for LS-EEND, model :280): pad_sequence + BatchNorm + cast +
+// slab padding in one launch instead of B small device-to-device copies.
+__global__ __launch_bounds__(256)
+void gather_bn_cast_pad_kernel(const float* const* __restrict__ x_ptrs, const int* __restrict__ lens, float pad_value,
+                               const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, _Float16* __restrict__ out, int B, int T, int Tp,
+                               int Fin, int Fpad, int apply_bn) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * Tp) return;
+    const int bb = (int)(row / Tp), t = (int)(row - (long)bb * Tp);
+    _Float16* o = out + row * Fpad;
+    if (t >= T) {
+        for (int k = lane; k < Fpad; k += 64) o[k] = (_Float16)0.f;
+        return;
+    }
+    const float* xi = (t < lens[bb]) ? x_ptrs[bb] + (long)t * Fin : nullptr;
+    for (int k = lane; k < Fpad; k += 64) {
+        float v = 0.f;
+        if (k < Fin) {
+            v = xi ? xi[k] : pad_value;
+            if (apply_bn) v = (v - mean[k]) / __builtin_sqrtf(var[k] + eps) * w[k] + b[k];
+        }
+        o[k] = to_f16_sat(v);
+    }
+}
+
 // attractors /= ||attractors||_2 (FS model :43/:76, no eps) and
 // logits[b,t,c] = <emb[b,t,:], attractors[b,t,c,:]> (FS model :60/:79), one wave per (b,t,c).
 // attr slab rows are ((b*C + c)*Tp + t); outputs are dense (B,T,C,D) / (B,T,C).
@@ -168,6 +197,16 @@ int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b
     const long rows = (long)B * Tp;
     hipLaunchKernelGGL(bn_cast_pad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, bn_w,
                        bn_b, bn_mean, bn_var, eps, (_Float16*)out16, B, T, Tp, Fin, Fpad, apply_bn);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_gather_bn_cast_pad(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w,
+                                   const float* bn_b, const float* bn_mean, const float* bn_var, float eps, void* out16,
+                                   int B, int T, int Tp, int Fin, int Fpad, int apply_bn, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || Tp < T || Fin <= 0 || Fpad < Fin) return EEND_EINVAL;
+    const long rows = (long)B * Tp;
+    hipLaunchKernelGGL(gather_bn_cast_pad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x_ptrs, lens,
+                       pad_value, bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, B, T, Tp, Fin, Fpad, apply_bn);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

@@ -25,6 +25,8 @@ from .lib import EendHipError
 
 _D_SUPPORTED = 256
 _H_SUPPORTED = 4
+# A/B switch for perf studies: EEND_FFN_FUSED=0 runs linear1 / linear2 as two GEMM launches
+FUSED_FFN = __import__("os").environ.get("EEND_FFN_FUSED", "1") != "0"
 
 
 class PositionalEncoding(nn.Module):
@@ -133,7 +135,7 @@ class _Workspace:
         self.vt = e(Mx * D, dt=bf16)
         self.o16 = e(Mx, D, dt=f16)
         self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
-        self.emb32, self.emb16 = e(Me, D, dt=f32), e(Me, D, dt=f16)
+        self.emb16 = e(Me, D, dt=f16)
         self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
         self.qkv16 = e(Md, 3 * D, dt=f16)
 
@@ -244,9 +246,8 @@ class OnlineTransformerDADiarization(nn.Module):
         P = self._prepare()
         dev = self.cnn.weight.device
         D, H = self.enc.n_units, self.enc.n_heads
-        x = nn.utils.rnn.pad_sequence([s.to(device=dev, dtype=torch.float32) for s in src],
-                                      padding_value=-1.0, batch_first=True).contiguous()   # model :165
-        B, T, _ = x.shape
+        srcs = [s.to(device=dev, dtype=torch.float32).contiguous() for s in src]
+        B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
         Tp = ops.frames_pad(T)
         ws = self._workspace(dev, B, Tp, C)
         il_key = tuple(min(int(l), T) for l in ilens)
@@ -259,7 +260,8 @@ class OnlineTransformerDADiarization(nn.Module):
         kv_e = Tp if self.enc.has_mask else T
 
         # ---- embedding encoder (model :162-188)
-        ops.bn_cast_pad(x, P["bn"], ws.xin16, T, Tp, True, P["bn.eps"])
+        # pad_sequence(-1) (model :165) + BatchNorm + cast + slab padding: one gather launch
+        ops.gather_bn_cast_pad(srcs, P["bn"], ws.xin16, T, Tp, -1.0, True, P["bn.eps"])
         ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"],
                           ws.h32, ws.h16, P["enc.in.eps"])
         q, k, vt = ws.q[:Me * D], ws.k[:Me * D], ws.vt[:Me * D]
@@ -270,11 +272,16 @@ class OnlineTransformerDADiarization(nn.Module):
             ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
             ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e)
             ops.linear_res_ln(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], ws.h32, ws.h16, L["eps1"])
-            ops.linear(ws.h16, L["w1"], L["b1"], ff, relu=True)
-            ops.linear_res_ln(ff, L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16, L["eps2"])
+            if FUSED_FFN:      # linear1 + ReLU + linear2 + residual + norm2 in one launch (hidden stays on chip)
+                ops.ffn_fused(ws.h16, L["w1"], L["b1"], L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16,
+                              ops.ACT_RELU, 1.0, L["eps2"])
+            else:
+                ops.linear(ws.h16, L["w1"], L["b1"], ff, relu=True)
+                ops.linear_res_ln(ff, L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16, L["eps2"])
 
         # ---- truncate to ilen / zero re-pad, look-ahead conv, L2 norm (model :38-41)
-        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, ws.emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+        emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)       # returned to the caller (views, no copies)
+        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
 
         # ---- attractor decoder (model :112-118, merge_tfm_encoder.py:356-376)
         ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
@@ -289,14 +296,18 @@ class OnlineTransformerDADiarization(nn.Module):
             ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
             ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
             ops.linear_res_ln(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], ws.a32, ws.a16, L["eps21"])
-            ops.linear(ws.a16, L["w1"], L["b1"], ff, relu=True)
-            ops.linear_res_ln(ff, L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16, L["eps22"])
+            if FUSED_FFN:
+                ops.ffn_fused(ws.a16, L["w1"], L["b1"], L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16,
+                              ops.ACT_RELU, 1.0, L["eps22"])
+            else:
+                ops.linear(ws.a16, L["w1"], L["b1"], ff, relu=True)
+                ops.linear_res_ln(ff, L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16, L["eps22"])
 
         # ---- attractor L2 norm + embedding . attractor head (model :43,:60)
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
-        ops.head_l2dot(ws.emb32, ws.a32, attr, logits, B, T, Tp, C, D)
-        emb = ws.emb32.view(B, Tp, D)
+        ops.head_l2dot(emb32, ws.a32, attr, logits, B, T, Tp, C, D)
+        emb = emb32.view(B, Tp, D)
         return logits, emb, attr, T, Tp
 
     @torch.no_grad()
@@ -304,7 +315,7 @@ class OnlineTransformerDADiarization(nn.Module):
         """reference model :67-84 -> (logits [ (T_i,C) ], emb [ (T_i,D) ], attractors [ (T_i,C,D) ])."""
         logits, emb, attr, T, Tp = self._run(src, ilens, max_nspks)
         output = [logits[b, :l] for b, l in enumerate(ilens)]
-        embs = [emb[b, :l].clone() for b, l in enumerate(ilens)]
+        embs = [emb[b, :l] for b, l in enumerate(ilens)]
         attractors = [attr[b, :l] for b, l in enumerate(ilens)]
         return output, embs, attractors
 
@@ -330,6 +341,6 @@ class OnlineTransformerDADiarization(nn.Module):
         label_map = label_map / (tn @ tn.transpose(-1, -2) + 1e-6)
         emb_consis_loss = nn.functional.mse_loss(attn_map, label_map)
         output = [logits[b, :l, :n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
-        embs = [emb[b, :l].clone() for b, l in enumerate(ilens)]
+        embs = [emb[b, :l] for b, l in enumerate(ilens)]
         attractors = [attr[b, :l, 1:n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
         return output, emb_consis_loss, embs, attractors

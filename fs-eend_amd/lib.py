@@ -14,11 +14,13 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 PROTOTYPES = {
     "eend_abi_version": [],
     "eend_bn_cast_pad_f16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "eend_gather_bn_cast_pad_f16": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "eend_linear_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_inproj_heads_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_linear_glu_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_linear_res_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_linear_res_scale_ln16_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from .fs_model import PositionalEncoding, _f16, _f32
+from .fs_model import FUSED_FFN, PositionalEncoding, _f16, _f32
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -234,7 +234,7 @@ class _Workspace:
         self.o16 = e(Mx, D, dt=f16)
         self.glu16, self.dw16 = e(Me, D, dt=f16), e(Me, D, dt=f16)
         self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
-        self.emb32, self.emb16 = e(Me, D, dt=f32), e(Me, D, dt=f16)
+        self.emb16 = e(Me, D, dt=f16)
         self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
         self.qkv16 = e(Md, 3 * D, dt=f16)
         nseq = max(B, B * C)
@@ -367,9 +367,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         P = self._prepare()
         dev = self.cnn.weight.device
         D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
-        x = nn.utils.rnn.pad_sequence([s.to(device=dev, dtype=torch.float32) for s in src],
-                                      padding_value=0.0, batch_first=True).contiguous()    # LS model :280
-        B, T, _ = x.shape
+        srcs = [s.to(device=dev, dtype=torch.float32).contiguous() for s in src]
+        B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
         Tpad = math.ceil(T / L) * L                        # reference pads to a chunk multiple (:281-283)
         Tp = ops.frames_pad(Tpad)
         nc = (Tp + L - 1) // L
@@ -381,7 +380,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         Me, Md = B * Tp, B * C * Tp
 
         # ---- Conformer-retention encoder (conformer/encoder.py:194-201, :76-113)
-        ops.bn_cast_pad(x, None, ws.xin16, T, Tp, False)
+        ops.gather_bn_cast_pad(srcs, None, ws.xin16, T, Tp, 0.0, False)        # pad_sequence(0) (LS model :280) + cast
         ops.linear_res_ln(ws.xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], ws.h32, ws.h16, P["in.eps"])
         q, k, kt, vt = ws.q[:Me * D], ws.k[:Me * D], ws.kt[:Me * D], ws.vt[:Me * D]
         g, o16 = ws.g[:Me], ws.o16[:Me]
@@ -392,9 +391,13 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             F = Bk["w1a"].shape[0]
             ff = ws.ff16[:Me * F].view(Me, F)
             # x += fa * FFN(LN_a x)                      -> x16 = LN_b(x)
-            ops.linear(ws.x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
-            ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], ws.h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1],
-                                      ws.h32, ws.x16, Bk["lnb"][2])
+            if FUSED_FFN:
+                ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
+                              ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
+            else:
+                ops.linear(ws.x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
+                ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], ws.h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1],
+                                          ws.h32, ws.x16, Bk["lnb"][2])
             # x += Retention(LN_b x)                     -> x16 = LN_c(x)
             ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
             ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"])
@@ -406,15 +409,20 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
                                       ws.h32, ws.x16, Bk["lnd"][2])
             # x = LN_e(x + fb * FFN(LN_d x))
-            ops.linear(ws.x16, Bk["w1b"], Bk["b1b"], ff, act=ops.ACT_SWISH)
-            ops.linear_res_ln(ff, Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1], ws.h32, ws.h16,
-                              Bk["lne"][2], alpha=Bk["fb"])
+            if FUSED_FFN:
+                ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
+                              ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
+            else:
+                ops.linear(ws.x16, Bk["w1b"], Bk["b1b"], ff, act=ops.ACT_SWISH)
+                ops.linear_res_ln(ff, Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1], ws.h32, ws.h16,
+                                  Bk["lne"][2], alpha=Bk["fb"])
             if i + 1 < nb:
                 nx = P["blocks"][i + 1]["lna"]
                 ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
 
         # ---- truncate / zero re-pad, look-ahead conv, L2 (LS model :80-87)
-        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, ws.emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+        emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)
+        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
 
         # ---- attractor decoder (LS model :215-220; merge_retnet_layer.py:233-253)
         ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
@@ -429,19 +437,23 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
             ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
             ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], ws.a32, ws.a16, Ld["eps21"])
-            ops.linear(ws.a16, Ld["w1"], Ld["b1"], ff, relu=True)
-            ops.linear_res_ln(ff, Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16, Ld["eps22"])
+            if FUSED_FFN:
+                ops.ffn_fused(ws.a16, Ld["w1"], Ld["b1"], Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16,
+                              ops.ACT_RELU, 1.0, Ld["eps22"])
+            else:
+                ops.linear(ws.a16, Ld["w1"], Ld["b1"], ff, relu=True)
+                ops.linear_res_ln(ff, Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16, Ld["eps22"])
 
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
-        ops.head_l2dot(ws.emb32, ws.a32, attr, logits, B, T, Tp, C, D)
-        return logits, ws.emb32.view(B, Tp, D), attr, T, Tp
+        ops.head_l2dot(emb32, ws.a32, attr, logits, B, T, Tp, C, D)
+        return logits, emb32.view(B, Tp, D), attr, T, Tp
 
     @torch.no_grad()
     def test(self, src, ilens, max_nspks=6):
         """reference LS model :125-147."""
         logits, emb, attr, T, Tp = self._run(src, ilens, max_nspks)
-        return ([logits[b, :l] for b, l in enumerate(ilens)], [emb[b, :l].clone() for b, l in enumerate(ilens)],
+        return ([logits[b, :l] for b, l in enumerate(ilens)], [emb[b, :l] for b, l in enumerate(ilens)],
                 [attr[b, :l] for b, l in enumerate(ilens)])
 
     def forward(self, src, tgt, ilens):

@@ -225,3 +225,46 @@ def attn_decode(qkv16, k_cache, v_cache, out16, N, H, cap, t):
     _chk(qkv16, F16, "qkv16"); _chk(k_cache, F16, "k_cache"); _chk(v_cache, F16, "v_cache"); _chk(out16, F16, "out16")
     _lib.check(L.eend_attn_decode_f16(_p(qkv16), _p(k_cache), _p(v_cache), _p(out16), N, H, cap, t,
                                       1.0 / math.sqrt(64.0), _stream()), "eend_attn_decode_f16")
+
+
+_PTR_TABLES = {}
+
+
+def gather_bn_cast_pad(src, bn, out16, T, Tp, pad_value, apply_bn=True, eps=1e-5):
+    """src: list of B f32 GPU tensors (T_i, Fin) -> out16 f16 (B*Tp, Fpad) in one launch (pointer table)."""
+    L = _lib.load()
+    _chk(out16, F16, "out16")
+    for s_ in src:
+        _chk(s_, F32, "src[i]")
+    B, Fin, Fpad = len(src), src[0].shape[1], out16.shape[-1]
+    key = tuple((s_.data_ptr(), s_.shape[0]) for s_ in src)
+    tab = _PTR_TABLES.get(key)
+    if tab is None:                                            # tiny H2D upload, cached per (pointers, lengths)
+        if len(_PTR_TABLES) > 64:
+            _PTR_TABLES.clear()
+        dev = out16.device
+        tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
+               torch.tensor([min(k[1], T) for k in key], dtype=torch.int32, device=dev))
+        _PTR_TABLES[key] = tab
+    w = b = m = v = None
+    if apply_bn:
+        w, b, m, v = bn
+    _lib.check(L.eend_gather_bn_cast_pad_f16(_p(tab[0]), _p(tab[1]), float(pad_value), _p(w), _p(b), _p(m), _p(v), eps,
+                                             _p(out16), B, T, Tp, Fin, Fpad, 1 if apply_bn else 0, _stream()),
+               "eend_gather_bn_cast_pad_f16")
+    return out16
+
+
+def ffn_fused(x16, w1, b1, w2, b2, res, gamma, beta, out32, out16, act=ACT_RELU, alpha=1.0, eps=1e-5,
+              residual_unnormalised=False):
+    """out = LN((act(x16 @ w1.T + b1) @ w2.T + b2) * alpha + res); hidden activations stay on chip."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(w1, F16, "w1"); _chk(w2, F16, "w2"); _chk(b1, F32, "b1"); _chk(b2, F32, "b2")
+    _chk(res, F32, "res"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = x16.shape
+    Fh = w1.shape[0]
+    if K != 256 or w1.shape[1] != 256 or w2.shape != (256, Fh):
+        raise _lib.EendHipError("ffn_fused: expected d_model 256")
+    _lib.check(L.eend_ffn_fused_f16(_p(x16), x16.stride(0), _p(w1), _p(b1), _p(w2), _p(b2), _p(res), float(alpha),
+                                    _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, Fh, act,
+                                    1 if residual_unnormalised else 0, _stream()), "eend_ffn_fused_f16")

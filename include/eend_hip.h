@@ -41,6 +41,14 @@ int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn
                          const float* bn_mean, const float* bn_var, float eps, void* out_f16,
                          int B, int T, int Tp, int Fin, int Fpad, int apply_bn, void* stream);
 
+/* The same, reading the B utterances through a device table of pointers (x_ptrs[b] -> f32
+ * [lens[b]][Fin]) and using `pad_value` for frames lens[b] <= t < T: pad_sequence (FS model :165 pads
+ * with -1, LS model :280 with 0) + BatchNorm + cast + slab padding in ONE launch. */
+int eend_gather_bn_cast_pad_f16(const void* const* x_ptrs, const int* lens, float pad_value,
+                                const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                                const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,
+                                int Fpad, int apply_bn, void* stream);
+
 /* out = act(A W^T + bias), f16 in / f16 out, f32 accumulate; act: 0 none, 1 ReLU, 2 Swish.
  * torch.nn.Linear call sites: FFN linear1+ReLU of nn.TransformerEncoderLayer (FS model :147) and of
  * the fusion layer (FS-EEND/nnet/modules/merge_tfm_encoder.py:397-399), packed in-proj of the speaker
@@ -109,6 +117,18 @@ int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, floa
  * dh = 64.  Q,K bf16 [nseq][H][Tp][64], Vt bf16 [nseq][H][64][Tp] -> O f16 [nseq*Tp][ldo]. */
 int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, int nseq, int H,
                           int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream);
+
+/* Whole position-wise feed-forward block in one launch, hidden activations never leave the CU:
+ *   y = (act(X W1^T + b1) W2^T + b2) * alpha + res ;  out_f16 = LayerNorm(y) * gamma + beta ;
+ *   out_f32 = LayerNorm(y)... (residual_stream_unnormalised = 0) or y (= 1).
+ * act: 1 ReLU (nn.TransformerEncoderLayer linear1/linear2 + norm2, FS model :147; _ff_block + norm22,
+ * FS merge_tfm_encoder.py:374,397-399, LS merge_retnet_layer.py:252,309-311), 2 Swish (Conformer
+ * FeedForwardModule + half-step residual, LS conformer/feed_forward.py:47-57, encoder.py:76-110).
+ * X f16 [M][ldx] (256 features), W1 f16 [F][256], W2 f16 [256][F], F % 64 == 0. */
+int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2,
+                       const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                       float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
+                       void* stream);
 
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,

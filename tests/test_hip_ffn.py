@@ -1,0 +1,61 @@
+"""GPU: fused FFN kernel (linear1 + act + linear2 + residual + LayerNorm, hidden stays on chip)
+against plain torch fp32 on the same f16-quantised operands, and against the two-launch path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F16, F32 = torch.float16, torch.float32
+
+
+def rnd(shape, dev, seed, dtype=F32, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+@pytest.mark.parametrize("M,Fh,act,alpha,unnorm", [(128, 2048, 1, 1.0, False), (300, 1024, 2, 0.5, True),
+                                                   (1, 256, 1, 1.0, False), (1000, 2048, 1, 1.0, False),
+                                                   (77, 1024, 2, 0.5, False)])
+def test_ffn_fused(hip_lib, dev, M, Fh, act, alpha, unnorm):
+    from fs_eend_amd import ops
+    x = rnd((M, 256), dev, 1, F16)
+    w1, b1 = rnd((Fh, 256), dev, 2, F16, 0.08), rnd((Fh,), dev, 3) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 4, F16, 0.04), rnd((256,), dev, 5) * 0.3
+    res = rnd((M, 256), dev, 6)
+    g, be = rnd((256,), dev, 7) * 0.2 + 1, rnd((256,), dev, 8) * 0.1
+    o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+    ops.ffn_fused(x, w1, b1, w2, b2, res, g, be, o32, o16, act, alpha, 1e-5, residual_unnormalised=unnorm)
+    h = x.float() @ w1.float().t() + b1
+    h = h.relu() if act == 1 else h * torch.sigmoid(h)
+    h = h.to(F16).float()                                  # the hidden activations are f16 MFMA operands
+    y = (h @ w2.float().t() + b2) * alpha + res
+    ln = torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5)
+    assert torch.isfinite(o32).all() and torch.isfinite(o16).all()
+    e32 = (o32 - (y if unnorm else ln)).abs().max().item()
+    e16 = (o16.float() - ln).abs().max().item()
+    assert e32 < 2e-3 and e16 < 5e-3, (e32, e16)
+    # same arithmetic as the two-launch path (bit-for-bit: same k order, same f16 hidden rounding)
+    ff = torch.empty((M, Fh), dtype=F16, device=dev)
+    p32, p16 = torch.empty_like(o32), torch.empty_like(o16)
+    ops.linear(x, w1, b1, ff, act=act)
+    if unnorm:
+        ops.linear_res_scale_ln16(ff, w2, b2, res, alpha, g, be, p32, p16, 1e-5)
+    else:
+        ops.linear_res_ln(ff, w2, b2, res, g, be, p32, p16, 1e-5, alpha=alpha)
+    assert (o32 - p32).abs().max().item() < 1e-5
+    assert (o16.float() - p16.float()).abs().max().item() < 2e-3
+
+
+def test_ffn_fused_inplace_residual(hip_lib, dev):
+    from fs_eend_amd import ops
+    M, Fh = 260, 2048
+    x = rnd((M, 256), dev, 11, F16)
+    w1, b1 = rnd((Fh, 256), dev, 12, F16, 0.08), rnd((Fh,), dev, 13) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 14, F16, 0.04), rnd((256,), dev, 15) * 0.3
+    res = rnd((M, 256), dev, 16)
+    g, be = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    want32, want16 = torch.empty_like(res), torch.empty((M, 256), dtype=F16, device=dev)
+    ops.ffn_fused(x, w1, b1, w2, b2, res, g, be, want32, want16)
+    x2 = x.clone()
+    ops.ffn_fused(x2, w1, b1, w2, b2, res, g, be, res, x2)      # out32 aliases res, out16 aliases x (as the model calls it)
+    assert torch.equal(res, want32) and torch.equal(x2, want16)
