@@ -1,0 +1,207 @@
+// Causal MHA for chunks that fit on chip (Tp <= 512, i.e. the T = 500 chunks FS-EEND is
+// trained and benchmarked on): ONE workgroup per (sequence, head) keeps the head's whole K
+// ([Tp][64]) and V^T ([64][Tp]) in LDS (2 x 64 KB), loaded from HBM exactly once, and its 8 waves
+// then run the flash loop with NO further barriers.
+//
+// Why (PMC + timing of the tiled kernel, attn.hip): at T = 500 there are at most 8 key tiles per
+// query tile, so that kernel is a chain of load -> LDS -> barrier round trips (51 % of wave cycles
+// parked, MFMA pipe 12 % busy), and the 4 query-tile workgroups of a head each re-read its K/V.
+// Here the per-tile synchronisation disappears and K/V traffic drops 2.5x.
+//
+// Causal load balance: the Tp/32 query blocks are dealt to the 8 waves in pairs (w, nq-1-w): a
+// late block needs many key tiles, its early partner few -- every wave does ~the same work.
+//
+// Same arithmetic as attn.hip (transposed formulation, S^T = K Q^T and O^T = V^T P^T on
+// v_mfma_f32_32x32x16_bf16, key rows fed with index bits 2<->3 swapped, online softmax in the
+// log2 domain, index-predicate mask j - i <= mask_delay && j < kv_len); results are bit-identical
+// to it.  O is staged through a per-wave 4 KB LDS tile so that global stores are full 128-byte
+// rows (16 B per lane).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TMAX = 512;
+constexpr int KB = 64;
+constexpr int TILE = KB * 128;                       // one [64][64] bf16 tile
+constexpr int NW = 8;                                // waves per workgroup
+constexpr int OSTG = 32 * 128;                       // per-wave O staging: 32 rows x 128 B (chunk-swizzled)
+
+DEV int swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512)
+void attn_causal_full_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntiles = p.Tp / KB;                    // <= 8
+    char* Ks = smem;                                 // [ntiles][64 keys][128 B]
+    char* Vs = smem + ntiles * TILE;                 // [ntiles][64 d][128 B] (64 keys of that tile)
+    char* Os = smem + 2 * ntiles * TILE;             // [8 waves][32][128 B]; Tp = 512 -> 160 KB in total
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, seq = blockIdx.y;
+    const int lq = lane & 31, hi = lane >> 5;
+    const size_t sh = (size_t)seq * p.H + h;
+    const __bf16* __restrict__ Qg = (const __bf16*)p.Q + sh * p.Tp * 64;
+    const __bf16* __restrict__ Kg = (const __bf16*)p.K + sh * p.Tp * 64;
+    const __bf16* __restrict__ Vg = (const __bf16*)p.Vt + sh * 64 * p.Tp;
+
+    // ---- load the head's whole K and V^T once: Tp*8 16-byte chunks each, all in flight
+    {
+        const int nch = p.Tp * 8;                    // chunks per operand (<= 4096 -> <= 8 per thread)
+        u32x4 kr[8], vr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + i * 512;
+            if (c < nch) {
+                kr[i] = *(const u32x4*)(Kg + (size_t)c * 8);                               // row = c>>3, chunk = c&7
+                const int d = c / (p.Tp >> 3), kc = c - d * (p.Tp >> 3);                   // V^T row d, 8-key chunk kc
+                vr[i] = *(const u32x4*)(Vg + (size_t)d * p.Tp + kc * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + i * 512;
+            if (c < nch) {
+                const int row = c >> 3;
+                *(u32x4*)(Ks + (row >> 6) * TILE + swz128(row & 63, c & 7)) = kr[i];
+                const int d = c / (p.Tp >> 3), kc = c - d * (p.Tp >> 3);
+                *(u32x4*)(Vs + (kc >> 3) * TILE + swz128(d, kc & 7)) = vr[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nq = p.Tp / 32;                        // query blocks of 32 rows
+    const int krow = swap23(lq);
+    char* Ow = Os + wave * OSTG;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qb = pass == 0 ? wave : nq - 1 - wave;
+        if (qb < 0 || qb >= nq) continue;
+        if (pass == 1 && qb <= wave) continue;       // already done (or the pair coincides)
+        if (pass == 0 && wave > nq - 1 - wave) continue;
+        const int qw0 = qb * 32;
+        const int q = qw0 + lq;
+
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)q * 64 + ks * 16 + hi * 8);
+
+        f32x16 oT[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; }
+        float m_run = -INFINITY, l_run = 0.f;
+
+        int last_key = qw0 + 31 + p.mask_delay;
+        last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
+        const int jend = last_key < 0 ? 0 : last_key / KB + 1;
+
+        for (int j = 0; j < jend; ++j) {
+            const int key0 = j * KB;
+            const char* kb_ = Ks + j * TILE;
+            const char* vb_ = Vs + j * TILE;
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                }
+            }
+            const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
+            if (key0 + KB - 1 > wlim) {
+                const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
+                        if (key > lim) s[kb][i] = -INFINITY;
+                    }
+            }
+            float tmax = s[0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[1][i]);
+            tmax = wave_xor_max(tmax, 32);
+            const float m_new = __builtin_fmaxf(m_run, tmax * p.scale_log2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], p.scale_log2, -m_use));
+                    s[kb][i] = pv;
+                    lsum += pv;
+                }
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][kk * 8 + jj];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(db * 32 + lq, kb * 4 + kk * 2 + hi));
+                        oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                    }
+                }
+        }
+
+        // ---- O[q][d] = O^T / l: stage the wave's 32 x 64 f16 tile, then 128-byte rows to HBM
+        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 o;
+                o[0] = to_f16_sat(oT[db][g * 4 + 0] * inv);
+                o[1] = to_f16_sat(oT[db][g * 4 + 1] * inv);
+                o[2] = to_f16_sat(oT[db][g * 4 + 2] * inv);
+                o[3] = to_f16_sat(oT[db][g * 4 + 3] * inv);
+                *(f16x4*)(Ow + lq * 128 + (((db * 4 + g) ^ (lq & 7)) << 4) + hi * 8) = o;
+            }
+        // wave-local hand-off through LDS: a wave's DS operations complete in order, and the
+        // compiler's s_waitcnt lgkmcnt covers the read-after-write within the wave
+        __builtin_amdgcn_wave_barrier();
+        _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * p.Tp + qw0) * p.ldo + h * 64;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;           // 8 rows x 8 chunks per instruction
+            const uint4 v = *(const uint4*)(Ow + row * 128 + ((ch ^ (row & 7)) << 4));
+            *(uint4*)(Og + (size_t)row * p.ldo + ch * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream) {
+    if (p.Tp <= 0 || p.Tp > TMAX || (p.Tp % 64) != 0 || (p.ldo & 7)) return EEND_EINVAL;
+    const int smem = 2 * (p.Tp / KB) * TILE + NW * OSTG;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)attn_causal_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * (TMAX / KB) * TILE + NW * OSTG) != hipSuccess)
+            return EEND_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_causal_full_kernel, dim3(p.H, p.nseq), dim3(512), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}

@@ -171,7 +171,8 @@ def attn_ref(q, k, v, delay, kv_len):
 
 @pytest.mark.parametrize("nseq,Tp,delay,kv_len,scale", [(1, 64, 0, 64, 1.0), (2, 128, 0, 128, 1.0), (1, 192, 0, 192, 3.0),
                                                         (2, 512, 0, 512, 1.0), (1, 256, 2, 256, 1.0),
-                                                        (1, 128, 128, 100, 1.0), (1, 512, 0, 512, 6.0)])
+                                                        (1, 128, 128, 100, 1.0), (1, 512, 0, 512, 6.0),
+                                                        (1, 1024, 0, 1024, 1.0), (2, 640, 3, 600, 1.0), (3, 384, 0, 384, 1.0)])
 def test_attn_causal(hip_lib, dev, nseq, Tp, delay, kv_len, scale):
     from fs_eend_amd import ops
     H = 4
