@@ -59,3 +59,23 @@ def test_ffn_fused_inplace_residual(hip_lib, dev):
     x2 = x.clone()
     ops.ffn_fused(x2, w1, b1, w2, b2, res, g, be, res, x2)      # out32 aliases res, out16 aliases x (as the model calls it)
     assert torch.equal(res, want32) and torch.equal(x2, want16)
+
+
+@pytest.mark.parametrize("M,unnorm,alpha", [(128, False, 1.0), (300, True, 1.0), (1, False, 1.0), (70000, False, 1.0)])
+def test_proj256_ln_matches_generic_gemm(hip_lib, dev, M, unnorm, alpha):
+    """K = 256 out-proj + residual + LN goes to the X-resident 128-row kernel (ffn.hip PROJ mode):
+    check against torch fp32."""
+    from fs_eend_amd import ops
+    a, w, b = rnd((M, 256), dev, 21, F16), rnd((256, 256), dev, 22, F16, 0.1), rnd((256,), dev, 23)
+    r = rnd((M, 256), dev, 24)
+    g, be = rnd((256,), dev, 25) * 0.2 + 1, rnd((256,), dev, 26) * 0.1
+    o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+    if unnorm:
+        ops.linear_res_scale_ln16(a, w, b, r, alpha, g, be, o32, o16, 1e-5)
+    else:
+        ops.linear_res_ln(a, w, b, r, g, be, o32, o16, 1e-5, alpha=alpha)
+    y = (a.float() @ w.float().t() + b) * alpha + r
+    ln = torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5)
+    assert (o32 - (y if unnorm else ln)).abs().max().item() < 3e-4
+    assert (o16.float() - ln).abs().max().item() < 4e-3
