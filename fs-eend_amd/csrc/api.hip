@@ -16,18 +16,6 @@ GemmParams base_params(const void* A, int lda, const void* W, int ldw, const flo
     p.dbg = d ? atoi(d) : 0;
     return p;
 }
-bool proj256_enabled() {            // EEND_PROJ256=0: A/B switch back to the generic 64x256-tile GEMM
-    static const bool on = !(getenv("EEND_PROJ256") && atoi(getenv("EEND_PROJ256")) == 0);
-    return on;
-}
-FfnParams proj_params(const void* A, int lda, const void* W, const float* bias, const float* res, float alpha,
-                      const float* gamma, const float* beta, float eps, float* out32, void* out16, int M) {
-    FfnParams f;
-    memset(&f, 0, sizeof(f));
-    f.X = A; f.ldx = lda; f.W2 = W; f.b2 = bias; f.res = res; f.alpha = alpha; f.gamma = gamma; f.beta = beta;
-    f.eps = eps; f.out32 = out32; f.out16 = out16; f.M = M; f.F = 256;
-    return f;
-}
 }  // namespace
 
 extern "C" {
@@ -87,10 +75,6 @@ int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const
                            float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
                            void* out_f16, int M, int K, void* stream) {
     if (!A || !W || (!out_f32 && !out_f16) || ((gamma == nullptr) != (beta == nullptr))) return EEND_EINVAL;
-    if (K == 256 && ldw == 256 && bias && gamma && out_f32 && out_f16 && proj256_enabled()) {
-        FfnParams f = proj_params(A, lda, W, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M);
-        return eend_launch_proj256_ln(f, FFN_EPI_RES_LN, (hipStream_t)stream);       // X-resident 128-row blocks
-    }
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_LN, (hipStream_t)stream);
@@ -100,10 +84,6 @@ int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ld
                                    const float* res, float alpha, const float* gamma, const float* beta, float eps,
                                    float* out_f32, void* out_f16, int M, int K, void* stream) {
     if (!A || !W || !out_f32 || !out_f16 || !gamma || !beta) return EEND_EINVAL;
-    if (K == 256 && ldw == 256 && bias && proj256_enabled()) {
-        FfnParams f = proj_params(A, lda, W, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M);
-        return eend_launch_proj256_ln(f, FFN_EPI_RES_SCALE_LN16, (hipStream_t)stream);
-    }
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_SCALE_LN16, (hipStream_t)stream);

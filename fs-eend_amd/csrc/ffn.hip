@@ -40,10 +40,7 @@ constexpr int HS_BYTES = BM * 128;              // 16384
 constexpr int W2_BYTES = KD * 128;              // 32768
 constexpr int SMEM_BYTES = XS_BYTES + W1_BYTES + HS_BYTES + W2_BYTES;   // 147456
 
-// PROJ = true: the same block structure without GEMM1 -- y = epilogue(X W2^T + b2) for a
-// 256 x 256 projection (attention / retention out-proj + residual + LayerNorm): the B operand of
-// GEMM2 is the resident X tile itself, W2 = the projection weight streamed in four 64-wide K chunks.
-template <int ACT, int EPI, bool PROJ>
+template <int ACT, int EPI>
 __global__ __launch_bounds__(NT)
 void ffn_fused_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,12 +73,10 @@ void ffn_fused_kernel(const FfnParams p) {
     // ---- weight chunk staging: 4 + 4 16-byte pieces per thread
     u32x4 w1r[4], w2r[4];
     auto wload = [&](int f0) __attribute__((always_inline)) {
-        if constexpr (!PROJ) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = tid + i * NT;               // W1 chunk: 64 rows x 32 k-chunks
-                w1r[i] = *(const u32x4*)(W1 + (size_t)(f0 + (q >> 5)) * KD + (q & 31) * 8);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * NT;                   // W1 chunk: 64 rows x 32 k-chunks
+            w1r[i] = *(const u32x4*)(W1 + (size_t)(f0 + (q >> 5)) * KD + (q & 31) * 8);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -90,13 +85,11 @@ void ffn_fused_kernel(const FfnParams p) {
         }
     };
     auto wstore = [&]() __attribute__((always_inline)) {
-        if constexpr (!PROJ) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = tid + i * NT;
-                const int row = q >> 5, c32 = q & 31;
-                *(u32x4*)(W1s + (c32 >> 3) * (FC * 128) + swz128(row, c32 & 7)) = w1r[i];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * NT;
+            const int row = q >> 5, c32 = q & 31;
+            *(u32x4*)(W1s + (c32 >> 3) * (FC * 128) + swz128(row, c32 & 7)) = w1r[i];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -116,57 +109,52 @@ void ffn_fused_kernel(const FfnParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto chunk = [&](int f0) __attribute__((always_inline)) {
-        const char* Bs = Hs;
-        if constexpr (PROJ) {
-            Bs = Xs + (f0 / FC) * (BM * 128);            // k-tile f0/64 of the resident X tile
-        } else {
         // ---- GEMM1: h[f][m] = sum_k W1c[f][k] X[m][k]   (A = W1 rows, B = X rows)
-            f32x4 h[2][2];
+        f32x4 h[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) h[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) h[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    f16x8 a[2], b[2];
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[2], b[2];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        a[i] = *(const f16x8*)(W1s + kt * (FC * 128) + swz128(g1f + i * 16 + frow, ks * 4 + fkg));
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *(const f16x8*)(W1s + kt * (FC * 128) + swz128(g1f + i * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[j] = *(const f16x8*)(Xs + kt * (BM * 128) + swz128(g1m + j * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        b[j] = *(const f16x8*)(Xs + kt * (BM * 128) + swz128(g1m + j * 16 + frow, ks * 4 + fkg));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], h[i][j], 0, 0, 0);
-                }
-            // bias + activation, f16, into Hs[m][f] (lane: 4 consecutive f of token m)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int fl = g1f + i * 16 + fkg * 4;          // hidden index inside the chunk
-                const float4 bb = *(const float4*)(p.b1 + f0 + fl);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float v0 = h[i][j][0] + bb.x, v1 = h[i][j][1] + bb.y, v2 = h[i][j][2] + bb.z, v3 = h[i][j][3] + bb.w;
-                    if (ACT == 1) {
-                        v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
-                        v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
-                    } else if (ACT == 2) {
-                        v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
-                        v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
-                    }
-                    f16x4 o;
-                    o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
-                    const int row = g1m + j * 16 + frow;
-                    // element offset fl inside the 64-wide row: 16-B chunk fl>>3, 8-B half (fl>>2)&1
-                    *(f16x4*)(Hs + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
-                }
+                        h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], h[i][j], 0, 0, 0);
             }
-            __syncthreads();
+        // bias + activation, f16, into Hs[m][f] (lane: 4 consecutive f of token m)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int fl = g1f + i * 16 + fkg * 4;          // hidden index inside the chunk
+            const float4 bb = *(const float4*)(p.b1 + f0 + fl);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v0 = h[i][j][0] + bb.x, v1 = h[i][j][1] + bb.y, v2 = h[i][j][2] + bb.z, v3 = h[i][j][3] + bb.w;
+                if (ACT == 1) {
+                    v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
+                    v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
+                } else if (ACT == 2) {
+                    v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
+                    v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
+                }
+                f16x4 o;
+                o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
+                const int row = g1m + j * 16 + frow;
+                // element offset fl inside the 64-wide row: 16-B chunk fl>>3, 8-B half (fl>>2)&1
+                *(f16x4*)(Hs + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
+            }
         }
+        __syncthreads();
         // ---- GEMM2: acc[n][m] += sum_f W2c[n][f] H[m][f]   (A = W2 rows, B = H rows)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -174,7 +162,7 @@ void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = *(const f16x8*)(W2s + swz128(g2n + i * 16 + frow, ks * 4 + fkg));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *(const f16x8*)(Bs + swz128(g2m + j * 16 + frow, ks * 4 + fkg));
+            for (int j = 0; j < 4; ++j) b[j] = *(const f16x8*)(Hs + swz128(g2m + j * 16 + frow, ks * 4 + fkg));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -286,10 +274,10 @@ void ffn_fused_kernel(const FfnParams p) {
     }
 }
 
-template <int ACT, int EPI, bool PROJ = false>
+template <int ACT, int EPI>
 int launch(const FfnParams& p, hipStream_t stream) {
     static bool attr_done = false;
-    auto kern = ffn_fused_kernel<ACT, EPI, PROJ>;
+    auto kern = ffn_fused_kernel<ACT, EPI>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess)
             return EEND_ELAUNCH;
@@ -300,14 +288,6 @@ int launch(const FfnParams& p, hipStream_t stream) {
 }
 
 }  // namespace
-
-int eend_launch_proj256_ln(const FfnParams& p, int epi, hipStream_t stream) {
-    if (p.M <= 0 || p.F != KD || (p.ldx & 7) || !p.X || !p.W2 || !p.b2 || !p.gamma || !p.beta || !p.out32 || !p.out16)
-        return EEND_EINVAL;
-    if (epi == FFN_EPI_RES_LN) return launch<0, FFN_EPI_RES_LN, true>(p, stream);
-    if (epi == FFN_EPI_RES_SCALE_LN16) return launch<0, FFN_EPI_RES_SCALE_LN16, true>(p, stream);
-    return EEND_EINVAL;
-}
 
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.X || !p.W1 || !p.W2 || !p.b1 || !p.b2 || !p.gamma ||

@@ -124,4 +124,3 @@ struct FfnParams {
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);
-int eend_launch_proj256_ln(const FfnParams& p, int epi, hipStream_t stream);
