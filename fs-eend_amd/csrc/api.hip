@@ -16,6 +16,10 @@ GemmParams base_params(const void* A, int lda, const void* W, int ldw, const flo
     p.dbg = d ? atoi(d) : 0;
     return p;
 }
+bool proj_xres_enabled() {          // EEND_PROJ_XRES=0: A/B switch back to the generic 128x128-tile GEMM
+    static const bool on = !(getenv("EEND_PROJ_XRES") && atoi(getenv("EEND_PROJ_XRES")) == 0);
+    return on;
+}
 }  // namespace
 
 extern "C" {
@@ -43,6 +47,13 @@ int eend_gather_bn_cast_pad_f16(const void* const* x_ptrs, const int* lens, floa
 int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
                     int M, int N, int K, int act, void* stream) {
     if (!A || !W || !out_f16 || (ldo & 3) || act < 0 || act > 2) return EEND_EINVAL;
+    if (act == 0 && K == 256 && ldw == 256 && bias && (N % 256) == 0 && N <= 1024 && (ldo & 7) == 0 && proj_xres_enabled()) {
+        ProjParams q;                                     // X-resident projection kernel (proj.hip)
+        memset(&q, 0, sizeof(q));
+        q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = M; q.N = N; q.Tp = 64; q.H = 4;
+        for (int g = 0; g < N / 256; ++g) { q.kind[g] = PROJ_ROWMAJOR; q.out[g] = (char*)out_f16 + (size_t)g * 256 * 2; q.ld[g] = ldo; }
+        return eend_launch_proj_xres(q, (hipStream_t)stream);
+    }
     GemmParams p = base_params(A, lda, W, ldw, bias, M, N, K);
     p.out16 = out_f16; p.ldo = ldo;
     const int epi = act == 1 ? EPI_PLAIN_RELU_F16 : act == 2 ? EPI_PLAIN_SWISH_F16 : EPI_PLAIN_F16;
@@ -62,6 +73,15 @@ int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const
     if (!A || !W || !bias || !Q_bf16 || !K_bf16 || !Vt_bf16) return EEND_EINVAL;
     if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || dh != 64 || H <= 0 || ((H * dh) % 128) != 0) return EEND_EINVAL;
     const int D = H * dh;
+    if (K == 256 && ldw == 256 && H == 4 && proj_xres_enabled()) {
+        ProjParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = nseq * Tp; q.N = 768; q.Tp = Tp; q.H = H;
+        q.kind[0] = PROJ_HEADS; q.out[0] = Q_bf16; q.kind[1] = PROJ_HEADS; q.out[1] = K_bf16;
+        q.kind[2] = PROJ_HEADS_T; q.out[2] = Vt_bf16;
+        q.is_bf16[0] = q.is_bf16[1] = q.is_bf16[2] = 1;
+        return eend_launch_proj_xres(q, (hipStream_t)stream);
+    }
     GemmParams p = base_params(A, lda, W, ldw, bias, nseq * Tp, 2 * D, K);
     p.Tp = Tp; p.H = H; p.dh = dh; p.out16 = Q_bf16; p.out16b = K_bf16;
     int rc = eend_launch_gemm(p, EPI_QK_HEADS, (hipStream_t)stream);
@@ -105,6 +125,16 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;
     if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || dh != 64 || H <= 0 || ((H * dh) % 128) != 0) return EEND_EINVAL;
     const int D = H * dh, M = nseq * Tp;
+    if (Kdim == 256 && ldw == 256 && H == 4 && proj_xres_enabled()) {
+        ProjParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = A; q.ldx = lda; q.W = Wqkvg; q.bias = bias; q.M = M; q.N = 1024; q.Tp = Tp; q.H = H;
+        q.kind[0] = PROJ_HEADS; q.out[0] = Q;
+        q.kind[1] = PROJ_HEADS_BOTH; q.out[1] = K; q.out2[1] = Kt;
+        q.kind[2] = PROJ_HEADS_T; q.out[2] = Vt;
+        q.kind[3] = PROJ_ROWMAJOR; q.out[3] = G; q.ld[3] = D;
+        return eend_launch_proj_xres(q, (hipStream_t)stream);
+    }
     const char* W = (const char*)Wqkvg;
     const size_t rowb = (size_t)ldw * 2;
     GemmParams qk = base_params(A, lda, W, ldw, bias, M, 2 * D, Kdim);                      // rows [0, 2D): q, k

@@ -124,3 +124,17 @@ struct FfnParams {
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);
+
+enum ProjKind { PROJ_ROWMAJOR = 0, PROJ_HEADS = 1, PROJ_HEADS_T = 2, PROJ_HEADS_BOTH = 3 };
+struct ProjParams {       // proj.hip: up to four 256-feature output groups
+    const void* X;        // f16 [M][ldx], 256 features
+    const void* W;        // f16 [N][256]
+    const float* bias;    // [N]
+    int M, N, ldx, Tp, H;
+    int kind[4];          // ProjKind per group
+    int is_bf16[4];       // output element type per group (else f16)
+    void* out[4];         // ROWMAJOR: [M][ld] (+ column offset applied by the caller); HEADS: [seq][H][Tp][64]; HEADS_T: [seq][H][64][Tp]
+    void* out2[4];        // HEADS_BOTH: the transposed copy
+    int ld[4];
+};
+int eend_launch_proj_xres(const ProjParams& p, hipStream_t stream);
