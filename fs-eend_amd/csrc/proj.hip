@@ -29,7 +29,7 @@ constexpr int WS_BYTES = 4 * FC * 128;            // 32 KB
 constexpr int SROW_MN = FC + 8;                   // staged [m][n] row stride (elements)
 constexpr int SROW_NM = BM + 8;                   // staged [n][m] row stride (elements)
 constexpr int ST_BYTES = BM * SROW_MN * 2;        // 18432 (>= FC * SROW_NM * 2 = 17408)
-constexpr int SMEM_BYTES = XS_BYTES + WS_BYTES + 2 * ST_BYTES;
+constexpr int SMEM_BYTES = XS_BYTES + 2 * WS_BYTES + ST_BYTES;     // 146 KB: weight chunk double-buffered
 
 DEV unsigned pack2(float a, float b, bool bf) {
     if (bf) {
@@ -41,18 +41,14 @@ DEV unsigned pack2(float a, float b, bool bf) {
     h2 v; v[0] = to_f16_sat(a); v[1] = to_f16_sat(b);
     return __builtin_bit_cast(unsigned, v);
 }
-DEV unsigned short cvt1(float a, bool bf) {
-    if (bf) return __builtin_bit_cast(unsigned short, (__bf16)a);
-    return __builtin_bit_cast(unsigned short, to_f16_sat(a));
-}
 
 __global__ __launch_bounds__(NT)
 void proj_xres_kernel(const ProjParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
-    char* Ws = smem + XS_BYTES;
-    unsigned short* St = (unsigned short*)(Ws + WS_BYTES);        // [m][n] staging
-    unsigned short* St2 = St + ST_BYTES / 2;                      // [n][m] staging (transposed outputs)
+    char* Ws0 = smem + XS_BYTES;
+    unsigned short* St = (unsigned short*)(Ws0 + 2 * WS_BYTES);   // [m][n] staging ...
+    unsigned short* St2 = St;                                     // ... or [n][m] (transposed outputs): one per pass
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,7 +76,8 @@ void proj_xres_kernel(const ProjParams p) {
             wr[i] = *(const u32x4*)(W + (size_t)(n0 + (q >> 5)) * KD + (q & 31) * 8);
         }
     };
-    auto wstore = [&]() __attribute__((always_inline)) {
+    auto wstore = [&](int buf) __attribute__((always_inline)) {
+        char* Ws = Ws0 + buf * WS_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + i * NT;
@@ -91,19 +88,18 @@ void proj_xres_kernel(const ProjParams p) {
 
     const int gm = (wave >> 1) * 32, gn = (wave & 1) * 32;     // wave tile: 32 tokens x 32 features
 
-    auto chunk = [&](int c) __attribute__((always_inline)) {
+    // One pass = GEMM of chunk c in one orientation + staging.  `tr` (block-uniform): transposed pass.
+    auto chunk = [&](int c, bool tr) __attribute__((always_inline)) {
         const int n0 = c * FC;
         const int grp = n0 >> 8;                               // 256-feature group
-        const int kind = p.kind[grp];
         const bool bf = p.is_bf16[grp] != 0;
-        const bool want_mn = kind != PROJ_HEADS_T;             // row-major / head rows need [m][n]
-        const bool want_nm = kind == PROJ_HEADS_T || kind == PROJ_HEADS_BOTH;
+        const char* Ws = Ws0 + (c & 1) * WS_BYTES;
         f32x4 h[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) h[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kind != PROJ_HEADS_T) {
+        if (!tr) {
             // A = W rows (features), B = X rows (tokens): lane owns 4 consecutive features of a token
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -127,14 +123,8 @@ void proj_xres_kernel(const ProjParams p) {
                 for (int j = 0; j < 2; ++j) {
                     const int ml = gm + j * 16 + frow;
                     const float v0 = h[i][j][0] + bb.x, v1 = h[i][j][1] + bb.y, v2 = h[i][j][2] + bb.z, v3 = h[i][j][3] + bb.w;
-                    if (want_mn) {
-                        uint2 o; o.x = pack2(v0, v1, bf); o.y = pack2(v2, v3, bf);
-                        *(uint2*)(St + ml * SROW_MN + nl) = o;
-                    }
-                    if (want_nm) {                                 // K of the retention path: also K^T
-                        St2[(nl + 0) * SROW_NM + ml] = cvt1(v0, bf); St2[(nl + 1) * SROW_NM + ml] = cvt1(v1, bf);
-                        St2[(nl + 2) * SROW_NM + ml] = cvt1(v2, bf); St2[(nl + 3) * SROW_NM + ml] = cvt1(v3, bf);
-                    }
+                    uint2 o; o.x = pack2(v0, v1, bf); o.y = pack2(v2, v3, bf);
+                    *(uint2*)(St + ml * SROW_MN + nl) = o;
                 }
             }
         } else {
@@ -167,13 +157,13 @@ void proj_xres_kernel(const ProjParams p) {
         }
     };
 
-    auto store_out = [&](int c) __attribute__((always_inline)) {
+    auto store_out = [&](int c, bool tr) __attribute__((always_inline)) {
         const int n0 = c * FC;
         const int grp = n0 >> 8;
         const int kind = p.kind[grp];
         const int nn = n0 & 255;                                   // feature inside the 256-group
         const int head = nn >> 6;                                  // FC == dh == 64: chunk == one head
-        if (kind != PROJ_HEADS_T) {
+        if (!tr) {
             // [m][n] staging: 128 rows x 8 chunks of 16 B
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -192,7 +182,7 @@ void proj_xres_kernel(const ProjParams p) {
                 *(uint4*)dst = v;
             }
         }
-        if (kind == PROJ_HEADS_T || kind == PROJ_HEADS_BOTH) {
+        if (tr) {
             // [n][m] staging: 64 rows (d) x 16 chunks of 8 tokens
             unsigned short* base = (unsigned short*)(kind == PROJ_HEADS_T ? p.out[grp] : p.out2[grp]);
 #pragma unroll
@@ -208,20 +198,29 @@ void proj_xres_kernel(const ProjParams p) {
         }
     };
 
+    // Weight chunks are double-buffered in LDS and prefetched into registers one iteration ahead of
+    // their LDS store, i.e. two chunks ahead of their use: the loads have a whole chunk to land.
     wload(0);
-    wstore();
+    wstore(0);
+    if (nchunks > 1) wload(FC);
     __syncthreads();
-    for (int c = 0; c < nchunks - 1; ++c) {
-        wload((c + 1) * FC);
-        chunk(c);
-        __syncthreads();                 // staging complete; everyone is done with Ws of chunk c
-        wstore();
-        store_out(c);
-        __syncthreads();                 // next weights visible; staging free
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) wstore((c + 1) & 1);        // chunk c+1 (loaded during chunk c-1) -> other buffer
+        if (c + 2 < nchunks) wload((c + 2) * FC);
+        const int kind = p.kind[(c * FC) >> 8];
+        if (kind != PROJ_HEADS_T) {
+            chunk(c, false);
+            __syncthreads();
+            store_out(c, false);
+            __syncthreads();
+        }
+        if (kind == PROJ_HEADS_T || kind == PROJ_HEADS_BOTH) {   // BOTH (retention K): second pass, swapped operands
+            chunk(c, true);
+            __syncthreads();
+            store_out(c, true);
+            __syncthreads();
+        }
     }
-    chunk(nchunks - 1);
-    __syncthreads();
-    store_out(nchunks - 1);
 }
 
 }  // namespace
