@@ -42,6 +42,25 @@ def flops_per_launch(name, shape, T):
     return 0.0
 
 
+def pmc_traffic(kernel, shape):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
+    default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tags = {("ffn_fused", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0>", "786432"),
+            ("ffn_fused", (32768, 2048, 256)): ("ffn_fused_kernel<1, 0>", "131072"),
+            ("attn_causal", (64, 4)): ("attn_causal_full_kernel", "131072"),
+            ("attn_causal", (384, 4)): ("attn_causal_full_kernel", "786432"),
+            ("linear_res_ln", (196608, 256, 256)): ("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4", "786432")}
+    tag = tags.get((kernel, tuple(shape)))
+    if tag is None or not os.path.exists(path):
+        return None
+    for k, v in json.load(open(path))["kernels"].items():
+        if tag[0] in k and k.endswith("grid=" + tag[1]):
+            return v["hbm_bytes"]
+    return None
+
+
 class OpTimer:
     """Brackets every C-ABI call with HIP events on the launch stream (instrumented steps only)."""
 
@@ -319,7 +338,8 @@ def main():
         out["roofline"] = {"kernel": f"{dom['kernel']} {dom['shape']}", "bound": "mfma",
                            "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
-                           "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+                           "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
+                           "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
         if att:
             a = att[0]
@@ -330,7 +350,7 @@ def main():
                 "achieved": fl / (a["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": fl / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                 "hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9, "hbm_frac": byt / (a["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": None, "avg_launch_ms": a["avg_ms"]}
+                "traffic": pmc_traffic("attn_causal", a["shape"]), "avg_launch_ms": a["avg_ms"]}
 
     if rank == 0 and world == 1 and not args.no_extras:
         out["extras"] = extras(dev)

@@ -15,6 +15,7 @@ run_pass() {  # name, counters...
 }
 run_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES
 run_pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU
-run_pass fetch FETCH_SIZE TCC_HIT_sum TCC_MISS_sum
+run_pass fetch FETCH_SIZE
+run_pass tcc TCC_HIT_sum TCC_MISS_sum
 run_pass write WRITE_SIZE
 head -40 gpurun_out/pmc/sq.csv | cut -c1-220
