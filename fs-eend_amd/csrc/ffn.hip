@@ -84,13 +84,15 @@ void ffn_fused_kernel(const FfnParams p) {
             w2r[i] = *(const u32x4*)(W2 + (size_t)(q >> 3) * p.F + f0 + (q & 7) * 8);
         }
     };
-    auto wstore = [&]() __attribute__((always_inline)) {
+    auto wstore1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + i * NT;
             const int row = q >> 5, c32 = q & 31;
             *(u32x4*)(W1s + (c32 >> 3) * (FC * 128) + swz128(row, c32 & 7)) = w1r[i];
         }
+    };
+    auto wstore2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + i * NT;
@@ -108,7 +110,7 @@ void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto chunk = [&](int f0) __attribute__((always_inline)) {
+    auto chunk = [&](int f0, bool store_next_w1) __attribute__((always_inline)) {
         // ---- GEMM1: h[f][m] = sum_k W1c[f][k] X[m][k]   (A = W1 rows, B = X rows)
         f32x4 h[2][2];
 #pragma unroll
@@ -154,7 +156,8 @@ void ffn_fused_kernel(const FfnParams p) {
                 *(f16x4*)(Hs + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
             }
         }
-        __syncthreads();
+        __syncthreads();             // barrier A: Hs visible; every wave is done with W1s of this chunk
+        if (store_next_w1) wstore1();   // next chunk's W1 slice (prefetched in registers) -> W1s, consumed after barrier B
         // ---- GEMM2: acc[n][m] += sum_f W2c[n][f] H[m][f]   (A = W2 rows, B = H rows)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -171,17 +174,20 @@ void ffn_fused_kernel(const FfnParams p) {
         }
     };
 
+    // Two barriers per 64-wide chunk: A (inside chunk(): Hs complete, W1s free -> store next W1 slice)
+    // and B (GEMM2 done by every wave: Hs and W2s free -> store next W2 slice; it becomes visible at the
+    // next barrier A, before the next GEMM2 reads it; the W1 slice stored after A is visible after B).
     wload(0);
-    wstore();
+    wstore1();
+    wstore2();
     __syncthreads();
     for (int c = 0; c < nF - 1; ++c) {
         wload((c + 1) * FC);                 // next chunk's weights in flight during this chunk
-        chunk(c * FC);
-        __syncthreads();                     // every wave is done with W1s / W2s / Hs of chunk c
-        wstore();
-        __syncthreads();
+        chunk(c * FC, true);
+        __syncthreads();                     // barrier B
+        wstore2();
     }
-    chunk((nF - 1) * FC);
+    chunk((nF - 1) * FC, false);
     __syncthreads();
 
     // ---- epilogue: y = (acc + b2) * alpha + res ; LayerNorm over the 256 features of each token
