@@ -159,6 +159,9 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tp + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
     int rc = eend_launch_ret_state_scan(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
+    // chunk sizes that fit on chip (500 in every shipped config) take the chunk-resident kernel
+    static const bool use_full = !(getenv("EEND_RET_FULL") && atoi(getenv("EEND_RET_FULL")) == 0);
+    if (use_full && L <= 512 && (L & 3) == 0 && (ldo & 7) == 0) return eend_launch_ret_chunk_full(p, (hipStream_t)stream);
     return eend_launch_ret_chunk(p, (hipStream_t)stream);
 }
 

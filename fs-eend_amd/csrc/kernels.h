@@ -138,3 +138,4 @@ struct ProjParams {       // proj.hip: up to four 256-feature output groups
     int ld[4];
 };
 int eend_launch_proj_xres(const ProjParams& p, hipStream_t stream);
+int eend_launch_ret_chunk_full(const RetParams& p, hipStream_t stream);

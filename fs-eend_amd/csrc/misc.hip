@@ -147,8 +147,48 @@ void layernorm_f16_kernel(const float* __restrict__ x, const float* __restrict__
 
 // Causal depthwise Conv1d(k taps, left context k-1, no bias) -> BatchNorm1d(eval) -> Swish
 // (LS-EEND/nnet/conformer/convolution.py:65-68,143-147).  x,out f16 [nseq][Tp][D]; w f32 [D][k].
-// One thread per channel, a 64-frame strip per block: reads are 2*D-byte coalesced rows, the k-tap
-// window re-reads hit L1/L2.
+// One thread per channel, a 64-frame strip per block.  The k-tap window slides through registers:
+// every input element is read exactly once (2*D-byte coalesced rows, 8 frames per load batch so
+// 8 independent loads are in flight), k FMAs per output.  K is a template parameter for the
+// shipped kernel sizes; other sizes take the generic (re-reading) kernel below.
+template <int K>
+__global__ __launch_bounds__(256)
+void dwconv_bn_swish_win_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bw,
+                                const float* __restrict__ bb, const float* __restrict__ bm, const float* __restrict__ bv,
+                                float eps, _Float16* __restrict__ out, int Tp, int D) {
+    const int seq = blockIdx.y, t0 = blockIdx.x * 64;
+    const int c = blockIdx.z * 256 + threadIdx.x;
+    if (c >= D) return;
+    const float sc = bw[c] / __builtin_sqrtf(bv[c] + eps);
+    const float sh = bb[c] - bm[c] * sc;
+    const _Float16* xs = x + (size_t)seq * Tp * D + c;
+    _Float16* os = out + (size_t)seq * Tp * D + c;
+    float wk[K], win[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wk[j] = w[(size_t)c * K + j];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        const int ts = t0 - (K - 1) + j;
+        win[j] = ts >= 0 ? (float)xs[(size_t)ts * D] : 0.f;
+    }
+    for (int tb = t0; tb < t0 + 64 && tb < Tp; tb += 8) {
+        float xn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xn[u] = (tb + u < Tp) ? (float)xs[(size_t)(tb + u) * D] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            win[K - 1] = xn[u];
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) y = __builtin_fmaf(wk[j], win[j], y);
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) win[j] = win[j + 1];
+            y = y * sc + sh;
+            if (tb + u < Tp) os[(size_t)(tb + u) * D] = to_f16_sat(y / (1.0f + __expf(-y)));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256)
 void dwconv_bn_swish_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bw,
                             const float* __restrict__ bb, const float* __restrict__ bm, const float* __restrict__ bv,
@@ -185,8 +225,19 @@ int eend_launch_dwconv_bn_swish(const void* x16, const float* w, const float* bn
                                 const float* bn_mean, const float* bn_var, float eps, void* out16, int nseq,
                                 int Tp, int D, int k, hipStream_t stream) {
     if (nseq <= 0 || nseq > 65535 || Tp <= 0 || D <= 0 || k <= 0) return EEND_EINVAL;
-    hipLaunchKernelGGL(dwconv_bn_swish_kernel, dim3((Tp + 63) / 64, nseq), dim3(256), 0, stream, (const _Float16*)x16, w,
-                       bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D, k);
+    const dim3 grid((Tp + 63) / 64, nseq, (D + 255) / 256);
+#define DW_CASE(KK)                                                                                                    \
+    case KK:                                                                                                           \
+        hipLaunchKernelGGL(dwconv_bn_swish_win_kernel<KK>, grid, dim3(256), 0, stream, (const _Float16*)x16, w, bn_w,   \
+                           bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D);                                       \
+        break;
+    switch (k) {
+        DW_CASE(16) DW_CASE(7) DW_CASE(15) DW_CASE(31) DW_CASE(32)
+        default:
+            hipLaunchKernelGGL(dwconv_bn_swish_kernel, dim3((Tp + 63) / 64, nseq), dim3(256), 0, stream, (const _Float16*)x16,
+                               w, bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D, k);
+    }
+#undef DW_CASE
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

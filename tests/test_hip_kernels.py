@@ -304,7 +304,7 @@ def test_layernorm_f16(hip_lib, dev):
     close(out, torch.nn.functional.layer_norm(x, (256,), g, be, 1e-5), 3e-3, 2e-3, "layernorm")
 
 
-@pytest.mark.parametrize("k", [16, 7, 31])
+@pytest.mark.parametrize("k", [16, 7, 31, 5])
 def test_dwconv_bn_swish(hip_lib, dev, k):
     from fs_eend_amd import ops
     nseq, Tp, D = 2, 128, 256
@@ -342,7 +342,8 @@ def _ret_reference(q, k, v, g, L, T):
 
 
 @pytest.mark.parametrize("nseq,Tp,L,T,qs", [(2, 128, 64, 128, 1.0), (1, 512, 500, 500, 1.0), (2, 64, 10, 60, 1.0),
-                                            (1, 256, 100, 200, 1.0), (1, 192, 32, 192, 3.0), (1, 1024, 500, 1000, 0.3)])
+                                            (1, 256, 100, 200, 1.0), (1, 192, 32, 192, 3.0), (1, 1024, 500, 1000, 0.3),
+                                            (2, 2048, 500, 2000, 1.0), (1, 128, 6, 126, 1.0), (1, 1088, 544, 1088, 1.0)])
 def test_retention_chunk(hip_lib, dev, nseq, Tp, L, T, qs):
     from fs_eend_amd import ops
     H = 4
