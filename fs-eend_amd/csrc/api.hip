@@ -151,11 +151,11 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
 }
 
 int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
-                             void* O_f16, void* St_ws, float* cscale_ws, float* sexp_ws, int nseq, int H, int Tp,
-                             int L, int ldo, int ldg, float gn_eps, void* stream) {
-    if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !St_ws || !cscale_ws || !sexp_ws || L <= 0) return EEND_EINVAL;
+                             void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq, int H,
+                             int Tp, int L, int ldo, int ldg, float gn_eps, void* stream) {
+    if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !St_ws || !kv_ws || !cscale_ws || !sexp_ws || L <= 0) return EEND_EINVAL;
     RetParams p;
-    p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws;
+    p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws; p.kv_ws = kv_ws; p.kv_ws = kv_ws;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tp + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
     int rc = eend_launch_ret_state_scan(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;

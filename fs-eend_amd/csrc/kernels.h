@@ -73,6 +73,7 @@ struct RetParams {
     void* St;         // f16 [nseq][H][nc][2][64 hd][64 kd]: state before each chunk, hi/lo, prescaled
     float* cscale;    // [nseq][H][nc] reference cross_scale of that state
     float* sexp;      // [nseq][H][nc] 2^e undoing the prescale
+    float* kv_ws;     // [nseq][H][nc][64][64] f32 per-chunk K^T V (workspace)
     int nseq, H, Tp, L, nc, ldo, ldg;
     float gn_eps;
 };

@@ -47,76 +47,117 @@ DEV uint4 mask_frames(uint4 v, int j0, int lo, int hi) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Phase 1 (chunk-parallel): KV_c = K_c^T V_c, one workgroup per (chunk, head, sequence), 4 waves each
+// owning a 32x32 tile of the 64x64 result, fp32, written to the KV workspace.  The frame loop is
+// unrolled 4x so 8 independent 16-byte loads are in flight per lane.
 __global__ __launch_bounds__(256)
-void ret_state_scan_kernel(const RetParams p) {
-    __shared__ float red_max[4];
-    __shared__ float part[2][64];
+void ret_kv_chunk_kernel(const RetParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ti = wave >> 1, tj = wave & 1;            // 32x32 tile (kd block, hd block) of the 64x64 state
-    const int h = blockIdx.x, seq = blockIdx.y;
+    const int ti = wave >> 1, tj = wave & 1;
+    const int c = blockIdx.x, h = blockIdx.y, seq = blockIdx.z;
     const int lq = lane & 31, hi = lane >> 5;
     const size_t sh = (size_t)seq * p.H + h;
     const _Float16* __restrict__ Kt = (const _Float16*)p.Kt + sh * 64 * p.Tp + (size_t)(ti * 32 + lq) * p.Tp;
     const _Float16* __restrict__ Vt = (const _Float16*)p.Vt + sh * 64 * p.Tp + (size_t)(tj * 32 + lq) * p.Tp;
-    _Float16* __restrict__ St = (_Float16*)p.St + sh * p.nc * 2 * 4096;
-    const float inv_sqrtL = 1.0f / __builtin_sqrtf((float)p.L);
-
+    const int f0 = c * p.L;
+    int f1 = f0 + p.L;
+    f1 = f1 < p.Tp ? f1 : p.Tp;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    for (int c = 0; c < p.nc; ++c) {
-        // ---- emit the state before chunk c
-        float mx = 0.f, cs = 0.f;
+    const int jbeg = f0 & ~15;
+    for (int j0 = jbeg; j0 < f1; j0 += 64) {
+        uint4 a[4], b[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const float a = __builtin_fabsf(acc[i]); mx = __builtin_fmaxf(mx, a); cs += a; }
-        cs = wave_xor_add(cs, 32);                       // column (hd) sum over this wave's 32 kd rows
+        for (int u = 0; u < 4; ++u) {
+            int jj = j0 + u * 16 + hi * 8;
+            jj = jj + 8 <= p.Tp ? jj : p.Tp - 8;                       // stay in the row; masked below
+            a[u] = *(const uint4*)(Kt + jj);
+            b[u] = *(const uint4*)(Vt + jj);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int js = j0 + u * 16;
+            if (js >= f1) break;
+            uint4 am = a[u];
+            if (js < f0 || js + 16 > f1) am = mask_frames(am, js + hi * 8, f0, f1);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, am), __builtin_bit_cast(f16x8, b[u]), acc, 0, 0, 0);
+        }
+    }
+    // C layout: col = hd (tj*32 + lq), rows kd = ti*32 + 8*g + 4*hi + r  ->  KV[kd][hd] fp32
+    float* __restrict__ KV = p.kv_ws + (sh * p.nc + c) * 4096;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) KV[(ti * 32 + 8 * g + 4 * hi + r) * 64 + tj * 32 + lq] = acc[g * 4 + r];
+}
+
+// Phase 2: per (sequence, head) exclusive prefix sum of the chunk KVs; emits for every chunk the state
+// *before* it as a power-of-two-prescaled hi/lo f16 pair ([hd][kd], the A operand of the cross term)
+// plus the reference's cross_scale = max(1, max_hd sum_kd |S| / sqrt(L)) (retention.py:176-180).
+// 256 threads: thread t owns state elements (kd = t>>2 (+0), hd = (t&3)*16 .. +15).
+__global__ __launch_bounds__(256)
+void ret_state_scan_kernel(const RetParams p) {
+    __shared__ float colsum[4][64];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, seq = blockIdx.y;
+    const size_t sh = (size_t)seq * p.H + h;
+    const int kd = tid >> 2, hd0 = (tid & 3) * 16;
+    const float inv_sqrtL = 1.0f / __builtin_sqrtf((float)p.L);
+    float st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f;
+    _Float16* __restrict__ St = (_Float16*)p.St + sh * p.nc * 2 * 4096;
+    for (int c = 0; c < p.nc; ++c) {
+        // |S| column sums over kd and the global max
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = __builtin_fmaxf(mx, __builtin_fabsf(st[i]));
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) mx = wave_xor_max(mx, m);
+        // lanes of a wave: kd = wave*16 + (lane>>2), hd group = lane&3  -> sum over the 16 kd of the wave
+        float cs[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = __builtin_fabsf(st[i]);
+            v = wave_xor_add(v, 4); v = wave_xor_add(v, 8); v = wave_xor_add(v, 16); v = wave_xor_add(v, 32);
+            cs[i] = v;
+        }
         __syncthreads();
-        if (lane == 0) red_max[wave] = mx;
-        if (hi == 0) part[ti][tj * 32 + lq] = cs;
+        if (lane < 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) colsum[wave][lane * 16 + i] = cs[i];
+        }
+        if (lane == 0) red[wave] = mx;
         __syncthreads();
-        const float M = __builtin_fmaxf(__builtin_fmaxf(red_max[0], red_max[1]), __builtin_fmaxf(red_max[2], red_max[3]));
-        float colmax = part[0][lane] + part[1][lane];     // lane <-> hd 0..63
+        const float M = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+        float colmax = colsum[0][lane] + colsum[1][lane] + colsum[2][lane] + colsum[3][lane];
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) colmax = wave_xor_max(colmax, m);
         int e = 0;
         if (M > 0.f) e = ilogbf(M) - 9;                   // M * 2^-e in [512, 1024)
-        const float down = ldexpf(1.0f, -e), up = ldexpf(1.0f, e);
+        const float down = ldexpf(1.0f, -e);
         _Float16* hi_m = St + (size_t)c * 2 * 4096;
         _Float16* lo_m = hi_m + 4096;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f16x4 vh, vl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[g * 4 + r] * down;
-                const _Float16 hh = (_Float16)v;
-                vh[r] = hh;
-                vl[r] = (_Float16)(v - (float)hh);
-            }
-            const int hd = tj * 32 + lq, kd = ti * 32 + 8 * g + 4 * hi;     // C layout: col = hd, rows = kd
-            *(f16x4*)(hi_m + hd * 64 + kd) = vh;
-            *(f16x4*)(lo_m + hd * 64 + kd) = vl;
+        for (int i = 0; i < 16; ++i) {                    // St[hd][kd]
+            const float v = st[i] * down;
+            const _Float16 hh = (_Float16)v;
+            hi_m[(hd0 + i) * 64 + kd] = hh;
+            lo_m[(hd0 + i) * 64 + kd] = (_Float16)(v - (float)hh);
         }
         if (tid == 0) {
             p.cscale[sh * p.nc + c] = __builtin_fmaxf(1.0f, colmax * inv_sqrtL);
-            p.sexp[sh * p.nc + c] = up;
+            p.sexp[sh * p.nc + c] = ldexpf(1.0f, e);
         }
         if (c == p.nc - 1) break;
-        // ---- S += K_c^T V_c over the frames of chunk c
-        const int f0 = c * p.L;
-        int f1 = f0 + p.L;
-        f1 = f1 < p.Tp ? f1 : p.Tp;
-        for (int j0 = f0 & ~15; j0 < f1; j0 += 16) {
-            const int jj = j0 + hi * 8;
-            uint4 a = *(const uint4*)(Kt + jj);
-            const uint4 b = *(const uint4*)(Vt + jj);
-            if (j0 < f0 || j0 + 16 > f1) a = mask_frames(a, jj, f0, f1);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
-                                                         acc, 0, 0, 0);
+        const float* __restrict__ KV = p.kv_ws + (sh * p.nc + c) * 4096 + kd * 64 + hd0;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const float4 v = *(const float4*)(KV + i);
+            st[i] += v.x; st[i + 1] += v.y; st[i + 2] += v.z; st[i + 3] += v.w;
         }
     }
 }
@@ -310,8 +351,13 @@ void ret_chunk_kernel(const RetParams p) {
 }  // namespace
 
 int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream) {
-    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc != (p.Tp + p.L - 1) / p.L)
+    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc != (p.Tp + p.L - 1) / p.L ||
+        !p.kv_ws)
         return EEND_EINVAL;
+    if (p.nc > 1) {
+        hipLaunchKernelGGL(ret_kv_chunk_kernel, dim3(p.nc - 1, p.H, p.nseq), dim3(256), 0, stream, p);   // last chunk's KV is never used
+        if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
+    }
     hipLaunchKernelGGL(ret_state_scan_kernel, dim3(p.H, p.nseq), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

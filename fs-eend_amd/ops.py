@@ -109,6 +109,9 @@ def retention_proj(a16, wqkvg16, bias, q, k, kt, vt, g, nseq, Tp, H):
                "eend_retention_proj_f16")
 
 
+_KV_WS = {}
+
+
 def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp, chunk, gn_eps=1e-6):
     L = _lib.load()
     for t, n in ((q, "q"), (k, "k"), (kt, "kt"), (vt, "vt"), (g, "g"), (o16, "o16"), (st_ws, "st_ws")):
@@ -117,9 +120,14 @@ def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp
     nc = (Tp + chunk - 1) // chunk
     if st_ws.numel() < nseq * H * nc * 2 * 4096 or cscale_ws.numel() < nseq * H * nc or sexp_ws.numel() < nseq * H * nc:
         raise _lib.EendHipError("retention_chunk: workspace too small")
-    _lib.check(L.eend_retention_chunk_f16(_p(q), _p(k), _p(kt), _p(vt), _p(g), _p(o16), _p(st_ws), _p(cscale_ws),
-                                          _p(sexp_ws), nseq, H, Tp, chunk, o16.stride(0), g.stride(0), gn_eps,
-                                          _stream()), "eend_retention_chunk_f16")
+    need = nseq * H * nc * 4096
+    kv_ws = _KV_WS.get(str(q.device))
+    if kv_ws is None or kv_ws.numel() < need:                  # f32 per-chunk K^T V workspace, grown on demand
+        kv_ws = torch.empty(need, dtype=F32, device=q.device)
+        _KV_WS[str(q.device)] = kv_ws
+    _lib.check(L.eend_retention_chunk_f16(_p(q), _p(k), _p(kt), _p(vt), _p(g), _p(o16), _p(st_ws), _p(kv_ws),
+                                          _p(cscale_ws), _p(sexp_ws), nseq, H, Tp, chunk, o16.stride(0), g.stride(0),
+                                          gn_eps, _stream()), "eend_retention_chunk_f16")
 
 
 def layernorm_f16(x32, gamma, beta, out16, eps=1e-5):

@@ -140,10 +140,11 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
 /* Chunk-recurrent retention with decay 1 (retention.py:146-194 + RetNetRelPos :30-47), the per-head
  * LayerNorm (eps gn_eps, no affine, :222) and the swish gate (:224) in one pass:
  * O = swish(G) * LN_head(retention(Q,K,V)).  L = recurrent_chunk_size; workspaces: St_ws f16
- * [nseq][H][nc][2][64][64], cscale_ws / sexp_ws f32 [nseq][H][nc], nc = ceil(Tp / L). */
+ * [nseq][H][nc][2][64][64], kv_ws f32 [nseq][H][nc][64][64], cscale_ws / sexp_ws f32 [nseq][H][nc],
+ * nc = ceil(Tp / L).  Three launches: chunk-parallel K_c^T V_c, per-(seq,head) prefix scan, core. */
 int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
-                             void* O_f16, void* St_ws, float* cscale_ws, float* sexp_ws, int nseq, int H,
-                             int Tp, int L, int ldo, int ldg, float gn_eps, void* stream);
+                             void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq,
+                             int H, int Tp, int L, int ldo, int ldg, float gn_eps, void* stream);
 
 /* Stand-alone LayerNorm f32 [M][D] -> f16 (D <= 1024): second of two back-to-back LayerNorms
  * (conformer/encoder.py:110 then feed_forward.py:48; encoder.py:196 then feed_forward.py:48). */
