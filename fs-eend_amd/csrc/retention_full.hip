@@ -45,23 +45,48 @@ void ret_chunk_full_kernel(const RetParams p) {
     const _Float16* __restrict__ Kg = (const _Float16*)p.K + (sh * p.Tp + f0) * 64;
     const _Float16* __restrict__ Vg = (const _Float16*)p.Vt + sh * 64 * p.Tp;
 
-    // ---- chunk K (16-B loads) and V^T (8-B loads: f0 is only 8-byte aligned), clamped to valid frames
+    // ---- chunk K (16-B loads) and V^T (8-B loads: f0 is only 8-byte aligned), clamped to valid frames.
+    // Fixed trip counts (<= 512 frames): every load of the phase is in flight before the first LDS store.
     {
-        const int nrow = ntl * KB;                      // padded local frames
-        for (int cidx = tid; cidx < nrow * 8; cidx += 512) {
+        const int nrow = ntl * KB;                      // padded local frames (multiple of 64)
+        u32x4 kr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cidx = tid + i * 512;
             const int row = cidx >> 3, ch = cidx & 7;
-            const int r = row < n ? row : n - 1;        // rows >= n are never unmasked; keep them finite
-            const u32x4 v = *(const u32x4*)(Kg + (size_t)r * 64 + ch * 8);
-            *(u32x4*)(Ks + (row >> 6) * TILE + swz128(row & 63, ch)) = v;
+            if (row < nrow) {
+                const int r = row < n ? row : n - 1;    // rows >= n are never unmasked; keep them finite
+                kr[i] = *(const u32x4*)(Kg + (size_t)r * 64 + ch * 8);
+            }
         }
-        const int nc8 = nrow >> 2;                      // 4-frame (8-byte) pieces per V^T row
-        for (int cidx = tid; cidx < 64 * nc8; cidx += 512) {
+        u32x2 vr[16];
+        const int sh8 = __builtin_ctz(nrow >> 2) ;      // nrow/4 pieces per V^T row; nrow is 64 * {1..8}
+        const int nc8 = nrow >> 2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cidx = tid + i * 512;
             const int d = cidx / nc8, pc = cidx - d * nc8;
-            int fr = f0 + pc * 4;
-            fr = fr + 4 <= p.Tp ? fr : p.Tp - 4;        // stay inside the row (clamped frames are masked)
-            const u32x2 v = *(const u32x2*)(Vg + (size_t)d * p.Tp + fr);
-            const int key = pc * 4;                     // local key of the first of the 4 frames
-            *(u32x2*)(Vs + (key >> 6) * TILE + swz128(d, (key & 63) >> 3) + ((key >> 2) & 1) * 8) = v;
+            if (d < 64) {
+                int fr = f0 + pc * 4;
+                fr = fr + 4 <= p.Tp ? fr : p.Tp - 4;    // stay inside the row (clamped frames are masked)
+                vr[i] = *(const u32x2*)(Vg + (size_t)d * p.Tp + fr);
+            }
+        }
+        (void)sh8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cidx = tid + i * 512;
+            const int row = cidx >> 3, ch = cidx & 7;
+            if (row < nrow) *(u32x4*)(Ks + (row >> 6) * TILE + swz128(row & 63, ch)) = kr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cidx = tid + i * 512;
+            const int d = cidx / nc8, pc = cidx - d * nc8;
+            if (d < 64) {
+                const int key = pc * 4;                 // local key of the first of the 4 frames
+                *(u32x2*)(Vs + (key >> 6) * TILE + swz128(d, (key & 63) >> 3) + ((key >> 2) & 1) * 8) = vr[i];
+            }
         }
     }
     __syncthreads();
