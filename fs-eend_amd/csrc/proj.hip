@@ -88,6 +88,21 @@ void proj_xres_kernel(const ProjParams p) {
 
     const int gm = (wave >> 1) * 32, gn = (wave & 1) * 32;     // wave tile: 32 tokens x 32 features
 
+    // The wave's X fragments (32 tokens x 256 features) are the same for every weight chunk: read
+    // them from LDS once and keep them in registers (16 fragments, 64 VGPRs) -- halves the LDS reads
+    // of a chunk.  A- and B-operand fragments of v_mfma_f32_16x16x32_f16 have the same lane layout,
+    // so the same registers serve both operand orders.
+    wload(0);
+    __syncthreads();
+    f16x8 xf[4][2][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                xf[kt][ks][j] = *(const f16x8*)(Xs + kt * (BM * 128) + swz128(gm + j * 16 + frow, ks * 4 + fkg));
+
     // One pass = GEMM of chunk c in one orientation + staging.  `tr` (block-uniform): transposed pass.
     auto chunk = [&](int c, bool tr) __attribute__((always_inline)) {
         const int n0 = c * FC;
@@ -105,15 +120,13 @@ void proj_xres_kernel(const ProjParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    f16x8 a[2], b[2];
+                    f16x8 a[2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) a[i] = *(const f16x8*)(Ws + kt * (FC * 128) + swz128(gn + i * 16 + frow, ks * 4 + fkg));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) b[j] = *(const f16x8*)(Xs + kt * (BM * 128) + swz128(gm + j * 16 + frow, ks * 4 + fkg));
-#pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], h[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xf[kt][ks][j], h[i][j], 0, 0, 0);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -133,15 +146,13 @@ void proj_xres_kernel(const ProjParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    f16x8 a[2], b[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) a[j] = *(const f16x8*)(Xs + kt * (BM * 128) + swz128(gm + j * 16 + frow, ks * 4 + fkg));
+                    f16x8 b[2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) b[i] = *(const f16x8*)(Ws + kt * (FC * 128) + swz128(gn + i * 16 + frow, ks * 4 + fkg));
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[i], h[i][j], 0, 0, 0);
+                        for (int i = 0; i < 2; ++i) h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[kt][ks][j], b[i], h[i][j], 0, 0, 0);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -200,8 +211,7 @@ void proj_xres_kernel(const ProjParams p) {
 
     // Weight chunks are double-buffered in LDS and prefetched into registers one iteration ahead of
     // their LDS store, i.e. two chunks ahead of their use: the loads have a whole chunk to land.
-    wload(0);
-    wstore(0);
+    wstore(0);                               // chunk 0 was requested before the X fragments were read
     if (nchunks > 1) wload(FC);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
