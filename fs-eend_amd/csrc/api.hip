@@ -115,7 +115,10 @@ int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, 
                        void* stream) {
     FfnParams p;
     p.X = X; p.ldx = ldx; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = alpha; p.gamma = gamma;
-    p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
+    p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F; p.dbg = 0;
+#ifdef EEND_FFN_ABLATE
+    if (const char* d = getenv("EEND_FFN_DBG")) p.dbg = atoi(d);
+#endif
     return eend_launch_ffn_fused(p, act, residual_stream_unnormalised ? FFN_EPI_RES_SCALE_LN16 : FFN_EPI_RES_LN,
                                  (hipStream_t)stream);
 }

@@ -25,10 +25,17 @@
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
+#include <utility>
+#include <cstdlib>
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int BM = 128;
 constexpr int KD = 256;            // model dim (K of GEMM1, N of GEMM2)
@@ -40,9 +47,167 @@ constexpr int HS_BYTES = BM * 128;              // 16384
 constexpr int W2_BYTES = KD * 128;              // 32768
 constexpr int SMEM_BYTES = XS_BYTES + W1_BYTES + HS_BYTES + W2_BYTES;   // 147456
 
+// SEEDED: the accumulators already hold res / alpha + b2 (v2 kernel).  STAGED: the two output tiles go
+// through LDS so that every global store instruction writes whole rows (64 lanes x 16 B contiguous)
+// instead of 16 token-row segments of 64 B (fp32) / 32 B (f16): measured, the segment stores drained at
+// 2.7 TB/s and were the largest fixed cost of the kernel.
+template <int EPI, bool SEEDED = false, bool STAGED = false>
+__device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4][4], char* smem, int wave, int frow, int fkg,
+                                             int m0, int g2m, int g2n) {
+    // ---- epilogue: y = (acc + b2) * alpha + res ; LayerNorm over the 256 features of each token
+    // acc[i][j][r]: n = g2n + i*16 + fkg*4 + r ; m = m0 + g2m + j*16 + frow
+    float* red = (float*)(smem + (STAGED ? 131072 : 0));     // [4 n-waves][128 rows]; clear of the staging tiles
+    const int wn = wave & 3;
+    const int N0 = g2n + fkg * 4;
+    const int M0 = m0 + g2m + frow;
+    if constexpr (SEEDED) {                                  // accumulators were seeded with res / alpha + b2
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= p.alpha;
+    }
+    float4 b4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b4[i] = *(const float4*)(p.b2 + N0 + i * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (SEEDED) break;
+        const int m = M0 + j * 16;
+        const bool ok = m < p.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 r = make_float4(0, 0, 0, 0);
+            if (p.res && ok) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);
+            acc[i][j][0] = (acc[i][j][0] + b4[i].x) * p.alpha + r.x;
+            acc[i][j][1] = (acc[i][j][1] + b4[i].y) * p.alpha + r.y;
+            acc[i][j][2] = (acc[i][j][2] + b4[i].z) * p.alpha + r.z;
+            acc[i][j][3] = (acc[i][j][3] + b4[i].w) * p.alpha + r.w;
+        }
+    }
+    auto block_rowsum = [&](float (&part)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            part[j] = wave_xor_add(part[j], 16);
+            part[j] = wave_xor_add(part[j], 32);
+        }
+        __syncthreads();
+        if (fkg == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wn * BM + g2m + j * 16 + frow] = part[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = g2m + j * 16 + frow;
+            part[j] = red[row] + red[BM + row] + red[2 * BM + row] + red[3 * BM + row];
+        }
+    };
+    float part[4], mean[4], rstd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        part[j] = s;
+    }
+    block_rowsum(part);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mean[j] = part[j] * (1.0f / KD);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
+        part[j] = s;
+    }
+    block_rowsum(part);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rstd[j] = 1.0f / __builtin_sqrtf(part[j] * (1.0f / KD) + p.eps);
+
+    float* __restrict__ o32 = p.out32;
+    _Float16* __restrict__ o16 = (_Float16*)p.out16;
+    if constexpr (STAGED) {
+        const int lane = frow + fkg * 16;
+        f16x4 h16[4][4];
+        // fp32 tile -> LDS [128 rows][1 KB], 16-B chunk c of row r at chunk c ^ (r & 7)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = N0 + i * 16;
+            const float4 g = *(const float4*)(p.gamma + n), be = *(const float4*)(p.beta + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = g2m + j * 16 + frow;
+                f32x4 v;
+                v[0] = (acc[i][j][0] - mean[j]) * rstd[j] * g.x + be.x;
+                v[1] = (acc[i][j][1] - mean[j]) * rstd[j] * g.y + be.y;
+                v[2] = (acc[i][j][2] - mean[j]) * rstd[j] * g.z + be.z;
+                v[3] = (acc[i][j][3] - mean[j]) * rstd[j] * g.w + be.w;
+                h16[i][j][0] = to_f16_sat(v[0]); h16[i][j][1] = to_f16_sat(v[1]);
+                h16[i][j][2] = to_f16_sat(v[2]); h16[i][j][3] = to_f16_sat(v[3]);
+                *(f32x4*)(smem + row * 1024 + (((n >> 2) ^ (row & 7)) << 4)) =
+                    EPI == FFN_EPI_RES_SCALE_LN16 ? acc[i][j] : v;       // LS: the residual stream stays un-normalised
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = k * 8 + wave;
+            const f32x4 v = *(const f32x4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+            if (m0 + row < p.M) *(f32x4*)(o32 + (size_t)(m0 + row) * KD + lane * 4) = v;
+        }
+        __syncthreads();
+        // f16 tile -> LDS [128 rows][512 B], 16-B chunk c of row r at chunk c ^ ((r >> 1) & 7)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = N0 + i * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = g2m + j * 16 + frow;
+                *(f16x4*)(smem + row * 512 + (((n >> 3) ^ ((row >> 1) & 7)) << 4) + ((n >> 2) & 1) * 8) = h16[i][j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = (k * 8 + wave) * 2 + (lane >> 5), c = lane & 31;
+            const u32x4 v = *(const u32x4*)(smem + row * 512 + ((c ^ ((row >> 1) & 7)) << 4));
+            if (m0 + row < p.M) *(u32x4*)(o16 + (size_t)(m0 + row) * KD + c * 8) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = N0 + i * 16;
+        const float4 g = *(const float4*)(p.gamma + n), be = *(const float4*)(p.beta + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = M0 + j * 16;
+            if (m >= p.M) continue;
+#ifdef EEND_FFN_ABLATE
+            if ((p.dbg & 1) && acc[i][j][0] != 12345.0f) continue;
+#endif
+            const float v0 = (acc[i][j][0] - mean[j]) * rstd[j] * g.x + be.x;
+            const float v1 = (acc[i][j][1] - mean[j]) * rstd[j] * g.y + be.y;
+            const float v2 = (acc[i][j][2] - mean[j]) * rstd[j] * g.z + be.z;
+            const float v3 = (acc[i][j][3] - mean[j]) * rstd[j] * g.w + be.w;
+            if (EPI == FFN_EPI_RES_SCALE_LN16)               // residual stream stays un-normalised
+                *(float4*)(o32 + (size_t)m * KD + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            else
+                *(float4*)(o32 + (size_t)m * KD + n) = make_float4(v0, v1, v2, v3);
+            f16x4 o;
+            o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
+            *(f16x4*)(o16 + (size_t)m * KD + n) = o;
+        }
+    }
+}
+
 template <int ACT, int EPI>
 __global__ __launch_bounds__(NT)
-void ffn_fused_kernel(const FfnParams p) {
+void ffn_fused_v1_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
     char* W1s = smem + XS_BYTES;
@@ -190,106 +355,330 @@ void ffn_fused_kernel(const FfnParams p) {
     chunk((nF - 1) * FC, false);
     __syncthreads();
 
-    // ---- epilogue: y = (acc + b2) * alpha + res ; LayerNorm over the 256 features of each token
-    // acc[i][j][r]: n = g2n + i*16 + fkg*4 + r ; m = m0 + g2m + j*16 + frow
-    float* red = (float*)smem;                               // [4 n-waves][128 rows]
-    const int wn = wave & 3;
-    const int N0 = g2n + fkg * 4;
-    const int M0 = m0 + g2m + frow;
-    float4 b4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b4[i] = *(const float4*)(p.b2 + N0 + i * 16);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = M0 + j * 16;
-        const bool ok = m < p.M;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 r = make_float4(0, 0, 0, 0);
-            if (p.res && ok) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);
-            acc[i][j][0] = (acc[i][j][0] + b4[i].x) * p.alpha + r.x;
-            acc[i][j][1] = (acc[i][j][1] + b4[i].y) * p.alpha + r.y;
-            acc[i][j][2] = (acc[i][j][2] + b4[i].z) * p.alpha + r.z;
-            acc[i][j][3] = (acc[i][j][3] + b4[i].w) * p.alpha + r.w;
-        }
-    }
-    auto block_rowsum = [&](float (&part)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            part[j] = wave_xor_add(part[j], 16);
-            part[j] = wave_xor_add(part[j], 32);
-        }
-        __syncthreads();
-        if (fkg == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) red[wn * BM + g2m + j * 16 + frow] = part[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = g2m + j * 16 + frow;
-            part[j] = red[row] + red[BM + row] + red[2 * BM + row] + red[3 * BM + row];
-        }
-    };
-    float part[4], mean[4], rstd[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        part[j] = s;
-    }
-    block_rowsum(part);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mean[j] = part[j] * (1.0f / KD);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
-        part[j] = s;
-    }
-    block_rowsum(part);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rstd[j] = 1.0f / __builtin_sqrtf(part[j] * (1.0f / KD) + p.eps);
+    ffn_epilogue<EPI>(p, acc, smem, wave, frow, fkg, m0, g2m, g2n);
+}
 
-    float* __restrict__ o32 = p.out32;
-    _Float16* __restrict__ o16 = (_Float16*)p.out16;
+
+// ---------------------------------------------------------------------------------------------
+// v2: one barrier per hidden chunk.
+//   * the wave's X fragments (32 tokens x 256) live in registers for the whole block (64 VGPRs), so
+//     the 64 KB X tile is only a prologue staging area and GEMM1 reads just the W1 fragments;
+//   * W1s, W2s and Hs are double-buffered (2 x 32 + 2 x 32 + 2 x 16 KB = 160 KB): between two
+//     barriers a wave runs GEMM1 of chunk c+1 and GEMM2 of chunk c -- two independent MFMA chains,
+//     so LDS latency of one hides behind the other;
+//   * weight slices arrive by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+//     The DMA destination is lane-linear (wave base + lane*16), so the swz128 image is produced by
+//     permuting the per-lane SOURCE address (8 rows x 128 B per instruction; every global row is
+//     still read as one full 128-B line).  The barrier's vmcnt(0) is the completion wait; b1 is
+//     fetched one chunk ahead so no ordinary load result is consumed while a DMA is in flight.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const char glb_char;
+
+constexpr int V2_W1 = 0;                       // 2 x 32 KB
+constexpr int V2_W2 = 2 * W1_BYTES;            // 2 x 32 KB (prologue: X staging, 64 KB)
+constexpr int V2_HS = V2_W2 + 2 * W2_BYTES;    // 2 x 16 KB
+constexpr int V2_SMEM = V2_HS + 2 * HS_BYTES;  // 163840
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(NT)
+void ffn_fused_kernel(const FfnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nF = p.F / FC;
+    const int ntiles = (p.M + BM - 1) / BM;
+    // Persistent over row tiles (grid = #CUs, 1 block/CU): the output stores of a tile are never waited
+    // for, so they drain under the next tile's loads instead of being an exposed phase of every block.
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * BM;
+    if (tile != (int)blockIdx.x) {
+        // every wave is done reading the LN scratch at the start of LDS before the weight DMA lands there
+        // (raw barrier: __syncthreads() would also wait for the previous tile's global stores)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), vmcnt/expcnt untouched
+        __builtin_amdgcn_s_barrier();
+    }
+    // The thread index is laundered per tile so that everything derived from it (LDS addresses, DMA
+    // offsets, epilogue columns) is recomputed here instead of being hoisted out of the tile loop and
+    // kept live -- or spilled -- across the register-tight chunk loop.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fkg = lane >> 4;
+
+    const _Float16* __restrict__ X = (const _Float16*)p.X;
+    const _Float16* __restrict__ W1 = (const _Float16*)p.W1;
+    const _Float16* __restrict__ W2 = (const _Float16*)p.W2;
+
+    // DMA one 64-hidden-unit slice of W1 ([64][256] -> 4 k-tiles of [64][128 B]) / W2 ([256][64]).
+    // (buffer_load ... lds rather than global_load_lds: the latter is a FLAT encoding and, while one is
+    // pending, hipcc degrades every LDS wait to lgkmcnt(0), which would serialise the fragment pipeline.)
+    const int drow = lane >> 3, dslot = lane & 7;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.F * KD * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.F * KD * 2, 0x00020000);
+    int vo1[4], vo2[4];                                      // per-lane byte offsets of the 4 pieces this wave moves
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = N0 + i * 16;
-        const float4 g = *(const float4*)(p.gamma + n), be = *(const float4*)(p.beta + n);
+        const int piece = wave * 4 + i;                      // 32 pieces of 8 rows x 128 B
+        const int kt = piece >> 3, row1 = (piece & 7) * 8 + drow;
+        vo1[i] = (row1 * KD + kt * 64 + (dslot ^ ((row1 >> 1) & 7)) * 8) * 2;
+        const int row2 = piece * 8 + drow;
+        vo2[i] = (row2 * p.F + (dslot ^ ((row2 >> 1) & 7)) * 8) * 2;
+    }
+    auto dma_w1 = [&](int f0, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = M0 + j * 16;
-            if (m >= p.M) continue;
-            const float v0 = (acc[i][j][0] - mean[j]) * rstd[j] * g.x + be.x;
-            const float v1 = (acc[i][j][1] - mean[j]) * rstd[j] * g.y + be.y;
-            const float v2 = (acc[i][j][2] - mean[j]) * rstd[j] * g.z + be.z;
-            const float v3 = (acc[i][j][3] - mean[j]) * rstd[j] * g.w + be.w;
-            if (EPI == FFN_EPI_RES_SCALE_LN16)               // residual stream stays un-normalised
-                *(float4*)(o32 + (size_t)m * KD + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            else
-                *(float4*)(o32 + (size_t)m * KD + n) = make_float4(v0, v1, v2, v3);
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_char*)(smem + V2_W1 + buf * W1_BYTES + (wave * 4 + i) * 1024), 16, vo1[i],
+                                                     f0 * KD * 2, 0, 0);
+    };
+    auto dma_w2 = [&](int f0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_char*)(smem + V2_W2 + buf * W2_BYTES + (wave * 4 + i) * 1024), 16, vo2[i],
+                                                     f0 * 2, 0, 0);
+    };
+
+    const int g1m = (wave >> 1) * 32, g1f = (wave & 1) * 32;   // GEMM1 wave tile: 32 tokens x 32 hidden
+    const int g2m = (wave >> 2) * 64, g2n = (wave & 3) * 64;   // GEMM2 wave tile: 64 tokens x 64 outputs
+    const int bofs = g1f + fkg * 4;                            // this lane's b1 offsets inside a chunk: bofs, bofs+16
+
+    // ---- prologue: W1 slices 0/1 by DMA; X tile -> staging (W2 region) -> fragments
+    dma_w1(0, 0);
+    if (nF > 1) dma_w1(FC, 1);
+    char* Xst = smem + V2_W2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 5, c32 = q & 31;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        const u32x4 v = *(const u32x4*)(X + (size_t)m * p.ldx + c32 * 8);
+        *(u32x4*)(Xst + (c32 >> 3) * (BM * 128) + swz128(row, c32 & 7)) = v;
+    }
+    float4 bcur[2];
+    bcur[0] = *(const float4*)(p.b1 + bofs);
+    bcur[1] = *(const float4*)(p.b1 + bofs + 16);
+    __syncthreads();
+    f16x8 xf[4][2][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                xf[kt][ks][j] = *(const f16x8*)(Xst + kt * (BM * 128) + swz128(g1m + j * 16 + frow, ks * 4 + fkg));
+    __syncthreads();
+
+    // GEMM2 accumulators [n frag][m frag], seeded with res / alpha + b2: the residual is fetched here,
+    // together with the X tile, instead of as a second exposed HBM phase in the epilogue.
+    f32x4 acc[4][4];
+    {
+        const float ralpha = 1.0f / p.alpha;
+        const int N0 = g2n + fkg * 4, M0 = m0 + g2m + frow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 b4 = *(const float4*)(p.b2 + N0 + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = M0 + j * 16;
+                float4 r = make_float4(0, 0, 0, 0);
+#ifdef EEND_FFN_ABLATE
+                if (p.dbg & 2) {} else
+#endif
+                if (p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);
+                acc[i][j] = f32x4{r.x * ralpha + b4.x, r.y * ralpha + b4.y, r.z * ralpha + b4.z, r.w * ralpha + b4.w};
+            }
+        }
+    }
+
+    // GEMM1 of one chunk: h[f][m] = sum_k W1c[f][k] X[m][k] ; bias + activation ; f16 -> Hs[m][f]
+    auto gemm1 = [&](const char* W1s, char* Hs, const float4 (&bb)[2]) __attribute__((always_inline)) {
+        f32x4 h[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) h[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *(const f16x8*)(W1s + kt * (FC * 128) + swz128(g1f + i * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xf[kt][ks][j], h[i][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int fl = g1f + i * 16 + fkg * 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v0 = h[i][j][0] + bb[i].x, v1 = h[i][j][1] + bb[i].y, v2 = h[i][j][2] + bb[i].z, v3 = h[i][j][3] + bb[i].w;
+                if (ACT == 1) {
+                    v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
+                    v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
+                } else if (ACT == 2) {
+                    v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
+                    v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
+                }
+                f16x4 o;
+                o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
+                const int row = g1m + j * 16 + frow;
+                *(f16x4*)(Hs + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
+            }
+        }
+    };
+    // GEMM2 of one chunk: acc[n][m] += sum_f W2c[n][f] H[m][f]
+    auto gemm2 = [&](const char* W2s, const char* Hs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const f16x8*)(W2s + swz128(g2n + i * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const f16x8*)(Hs + swz128(g2m + j * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // chunk 0's hidden units; W2 slice 0 arrives meanwhile
+    dma_w2(0, 0);
+    gemm1(smem + V2_W1, smem + V2_HS, bcur);
+    if (nF > 1) {
+        bcur[0] = *(const float4*)(p.b1 + FC + bofs);
+        bcur[1] = *(const float4*)(p.b1 + FC + bofs + 16);
+    }
+    __syncthreads();
+
+    // iteration c: DMA W1(c+2), W2(c+1) | GEMM1(c+1) -> Hs[(c+1)&1] | GEMM2(c) | barrier
+    // The 64 MFMAs of an iteration are issued as 16 items of 4 (one GEMM1 k-step or one GEMM2 W2
+    // fragment x 4 token fragments) in a fixed interleaved order; the LDS fragments of item t+2 are
+    // requested right behind the MFMAs of item t, and the bias/activation/Hs-store of the new hidden
+    // chunk rides on the last GEMM2 items.  sched_barrier pins that order.
+    constexpr int KIND[16] = {1, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2, 2, 2, 2, 2};     // 1 = GEMM1 k-step, 2 = GEMM2 item
+    constexpr int ARG[16]  = {0, 1, 0, 2, 3, 1, 4, 5, 2, 6, 7, 3, 4, 5, 6, 7};
+    for (int c = 0; c < nF - 1; ++c) {
+        const int cb = c & 1, nb = cb ^ 1;
+        float4 bnext[2] = {bcur[0], bcur[1]};
+        if (c + 2 < nF) {
+            dma_w1((c + 2) * FC, cb);
+            // b1 of chunk c+2, requested a whole iteration before the barrier's vmcnt(0) has to cover it
+            bnext[0] = *(const float4*)(p.b1 + (c + 2) * FC + bofs);
+            bnext[1] = *(const float4*)(p.b1 + (c + 2) * FC + bofs + 16);
+        }
+        dma_w2((c + 1) * FC, nb);
+        const char* W1n = smem + V2_W1 + nb * W1_BYTES;
+        char* Hn = smem + V2_HS + nb * HS_BYTES;
+        const char* W2c = smem + V2_W2 + cb * W2_BYTES;
+        const char* Hc = smem + V2_HS + cb * HS_BYTES;
+
+        f16x8 wa[3][2], w2a[3], hb[2][4];
+        f32x4 h[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)                          // accumulators start at the bias
+#pragma unroll
+            for (int j = 0; j < 2; ++j) h[i][j] = f32x4{bcur[i].x, bcur[i].y, bcur[i].z, bcur[i].w};
+
+        auto ld_g1 = [&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wa[k % 3][i] = *(const f16x8*)(W1n + (k >> 1) * (FC * 128) + swz128(g1f + i * 16 + frow, (k & 1) * 4 + fkg));
+        };
+        auto ld_w2 = [&](auto S) __attribute__((always_inline)) {
+            constexpr int sidx = decltype(S)::value;
+            w2a[sidx % 3] = *(const f16x8*)(W2c + swz128(g2n + (sidx & 3) * 16 + frow, (sidx >> 2) * 4 + fkg));
+        };
+        auto ld_hb = [&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hb[ks][j] = *(const f16x8*)(Hc + swz128(g2m + j * 16 + frow, ks * 4 + fkg));
+        };
+        auto ld_item = [&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            if constexpr (t < 16) {
+                if constexpr (KIND[t] == 1) ld_g1(std::integral_constant<int, ARG[t]>{});
+                else ld_w2(std::integral_constant<int, ARG[t]>{});
+            }
+        };
+        auto act_part = [&](auto Q) __attribute__((always_inline)) {
+            constexpr int i = decltype(Q)::value >> 1, j = decltype(Q)::value & 1;
+            const int fl = g1f + i * 16 + fkg * 4;
+            float v0 = h[i][j][0], v1 = h[i][j][1], v2 = h[i][j][2], v3 = h[i][j][3];
+            if (ACT == 1) {
+                v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
+                v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
+            } else if (ACT == 2) {
+                v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
+                v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
+            }
             f16x4 o;
             o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
-            *(f16x4*)(o16 + (size_t)m * KD + n) = o;
-        }
+            const int row = g1m + j * 16 + frow;
+            *(f16x4*)(Hn + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
+        };
+
+        // fragments of items 0, 1 and of GEMM2 ks = 0
+        ld_item(std::integral_constant<int, 0>{});
+        ld_item(std::integral_constant<int, 1>{});
+        ld_hb(std::integral_constant<int, 0>{});
+        static_for<16>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            constexpr int a = ARG[t];
+            if constexpr (KIND[t] == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[a % 3][i], xf[a >> 1][a & 1][j], h[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[a & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2a[a % 3], hb[a >> 2][j], acc[a & 3][j], 0, 0, 0);
+            }
+            ld_item(std::integral_constant<int, t + 2>{});
+            if constexpr (t == 8) ld_hb(std::integral_constant<int, 1>{});
+            if constexpr (t == 12) { act_part(std::integral_constant<int, 0>{}); act_part(std::integral_constant<int, 1>{}); }
+            if constexpr (t == 13) { act_part(std::integral_constant<int, 2>{}); act_part(std::integral_constant<int, 3>{}); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        bcur[0] = bnext[0]; bcur[1] = bnext[1];
+        __syncthreads();
+    }
+    {
+        const int cb = (nF - 1) & 1;
+        gemm2(smem + V2_W2 + cb * W2_BYTES, smem + V2_HS + cb * HS_BYTES);
+    }
+    __syncthreads();
+
+    ffn_epilogue<EPI, true, true>(p, acc, smem, wave, frow, fkg, m0, g2m, g2n);
     }
 }
 
 template <int ACT, int EPI>
 int launch(const FfnParams& p, hipStream_t stream) {
     static bool attr_done = false;
-    auto kern = ffn_fused_kernel<ACT, EPI>;
+    static const bool v1 = [] { const char* e = getenv("EEND_FFN_V1"); return e && e[0] == '1'; }();
+    auto kern = v1 ? ffn_fused_v1_kernel<ACT, EPI> : ffn_fused_kernel<ACT, EPI>;
+    const int smem_bytes = v1 ? SMEM_BYTES : V2_SMEM;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
             return EEND_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(NT), SMEM_BYTES, stream, p);
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int ntiles = (p.M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3(v1 || ntiles < ncu ? ntiles : ncu), dim3(NT), smem_bytes, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

@@ -122,6 +122,7 @@ struct FfnParams {
     void* out16;        // f16 [M][256]
     float alpha, eps;
     int M, F, ldx;
+    int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);

@@ -34,7 +34,9 @@ def test_ffn_fused(hip_lib, dev, M, Fh, act, alpha, unnorm):
     e32 = (o32 - (y if unnorm else ln)).abs().max().item()
     e16 = (o16.float() - ln).abs().max().item()
     assert e32 < 2e-3 and e16 < 5e-3, (e32, e16)
-    # same arithmetic as the two-launch path (bit-for-bit: same k order, same f16 hidden rounding)
+    # same arithmetic as the two-launch path up to the position of the bias in the fp32 sum (the fused
+    # kernel seeds the accumulator with b1, the GEMM epilogue adds it last): a hidden unit can round to
+    # the neighbouring f16, which moves an output by <= ulp_f16(h) * |w2| ~ 1e-4
     ff = torch.empty((M, Fh), dtype=F16, device=dev)
     p32, p16 = torch.empty_like(o32), torch.empty_like(o16)
     ops.linear(x, w1, b1, ff, act=act)
@@ -42,7 +44,7 @@ def test_ffn_fused(hip_lib, dev, M, Fh, act, alpha, unnorm):
         ops.linear_res_scale_ln16(ff, w2, b2, res, alpha, g, be, p32, p16, 1e-5)
     else:
         ops.linear_res_ln(ff, w2, b2, res, g, be, p32, p16, 1e-5, alpha=alpha)
-    assert (o32 - p32).abs().max().item() < 1e-5
+    assert (o32 - p32).abs().max().item() < 5e-4
     assert (o16.float() - p16.float()).abs().max().item() < 2e-3
 
 

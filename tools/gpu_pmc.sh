@@ -13,9 +13,11 @@ run_pass() {  # name, counters...
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py "$f" gpurun_out/pmc/$name.csv
 }
-run_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES
-run_pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU
-run_pass fetch FETCH_SIZE
-run_pass tcc TCC_HIT_sum TCC_MISS_sum
-run_pass write WRITE_SIZE
+PASSES=${PMC_PASSES:-sq,sq2,fetch,tcc,write}
+want() { [[ ",$PASSES," == *",$1,"* ]]; }
+want sq && run_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES
+want sq2 && run_pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU
+want fetch && run_pass fetch FETCH_SIZE
+want tcc && run_pass tcc TCC_HIT_sum TCC_MISS_sum
+want write && run_pass write WRITE_SIZE
 head -40 gpurun_out/pmc/sq.csv | cut -c1-220
