@@ -36,6 +36,9 @@ def flops_per_launch(name, shape, T):
     if name == "ffn_fused":
         M, F, K = shape
         return 4.0 * M * F * K
+    if name == "attnout_ffn_fused":    # out-projection (K x K) + the two FFN GEMMs
+        M, F, K = shape
+        return 4.0 * M * F * K + 2.0 * M * K * K
     if name in ("linear", "linear_res_ln", "linear_res_scale", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
         M, N, K = shape
         return 2.0 * M * N * K
@@ -47,8 +50,8 @@ def pmc_traffic(kernel, shape):
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    tags = {("ffn_fused", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0>", "786432"),
-            ("ffn_fused", (32768, 2048, 256)): ("ffn_fused_kernel<1, 0>", "131072"),
+    tags = {("attnout_ffn_fused", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #hi", "131072"),
+            ("attnout_ffn_fused", (32768, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #lo", "131072"),
             ("attn_causal", (64, 4)): ("attn_causal_full_kernel", "131072"),
             ("attn_causal", (384, 4)): ("attn_causal_full_kernel", "786432"),
             ("linear_res_ln", (196608, 256, 256)): ("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4", "786432")}
@@ -79,6 +82,8 @@ class OpTimer:
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "ffn_fused":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
+            elif name == "attnout_ffn_fused":
+                shape = (a[0].shape[0], a[7].shape[0], a[0].shape[1])
             elif name == "inproj_heads":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "convert_fanout":
@@ -92,7 +97,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
                   "convert_fanout", "attn_causal", "spk_attn", "head_l2dot"):
             self.orig[n] = getattr(self.ops, n)
             setattr(self.ops, n, self._wrap(n, self.orig[n]))

@@ -379,7 +379,12 @@ constexpr int V2_W2 = 2 * W1_BYTES;            // 2 x 32 KB (prologue: X staging
 constexpr int V2_HS = V2_W2 + 2 * W2_BYTES;    // 2 x 16 KB
 constexpr int V2_SMEM = V2_HS + 2 * HS_BYTES;  // 163840
 
-template <int ACT, int EPI>
+// PRE: the block first computes its X tile itself, X = LayerNorm1(A Wo^T + bo + res) (attention
+// out-projection + residual + norm1 of the layer), so that the normalised activations between the two
+// sub-layers never travel through HBM: Wo (128 KB) sits in the still-unused weight buffers, the A
+// fragments come straight from global memory, and the result lands in the same accumulator layout that
+// seeds GEMM2 (fp32 residual) and, as f16, in the X staging tile.
+template <int ACT, int EPI, bool PRE>
 __global__ __launch_bounds__(NT)
 void ffn_fused_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -440,18 +445,130 @@ void ffn_fused_kernel(const FfnParams p) {
     const int g2m = (wave >> 2) * 64, g2n = (wave & 3) * 64;   // GEMM2 wave tile: 64 tokens x 64 outputs
     const int bofs = g1f + fkg * 4;                            // this lane's b1 offsets inside a chunk: bofs, bofs+16
 
-    // ---- prologue: W1 slices 0/1 by DMA; X tile -> staging (W2 region) -> fragments
-    dma_w1(0, 0);
-    if (nF > 1) dma_w1(FC, 1);
     char* Xst = smem + V2_W2;
+    f32x4 acc[4][4];                                         // GEMM2 accumulators [n frag][m frag]
+    if constexpr (!PRE) {
+        // ---- prologue: W1 slices 0/1 by DMA; X tile -> staging (W2 region) -> fragments
+        dma_w1(0, 0);
+        if (nF > 1) dma_w1(FC, 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = tid + i * NT;
-        const int row = q >> 5, c32 = q & 31;
-        int m = m0 + row;
-        m = m < p.M ? m : p.M - 1;
-        const u32x4 v = *(const u32x4*)(X + (size_t)m * p.ldx + c32 * 8);
-        *(u32x4*)(Xst + (c32 >> 3) * (BM * 128) + swz128(row, c32 & 7)) = v;
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + i * NT;
+            const int row = q >> 5, c32 = q & 31;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            const u32x4 v = *(const u32x4*)(X + (size_t)m * p.ldx + c32 * 8);
+            *(u32x4*)(Xst + (c32 >> 3) * (BM * 128) + swz128(row, c32 & 7)) = v;
+        }
+    } else {
+        // ---- fused producer: y = A Wo^T + bo + res ; x = LayerNorm1(y)
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wo, 0, KD * KD * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                       // Wo -> LDS [4 k-tiles][256 n][128 B], 128 pieces of 1 KB
+            const int piece = wave * 16 + i;
+            const int kt = piece >> 5, row = (piece & 31) * 8 + drow;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_char*)(smem + piece * 1024), 16,
+                                                     (row * KD + kt * 64 + (dslot ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+        }
+        const _Float16* __restrict__ A = (const _Float16*)p.A;
+        const int N0 = g2n + fkg * 4, M0 = m0 + g2m + frow;
+        f16x8 af[8][4];                                      // [k-step][token frag], straight from global
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = M0 + j * 16;
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) af[ks][j] = *(const f16x8*)(A + (size_t)m * p.lda + ks * 32 + fkg * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                        // accumulators start at bo + res
+            const float4 b4 = *(const float4*)(p.bo + N0 + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = M0 + j * 16;
+                float4 r = make_float4(0, 0, 0, 0);
+                if (p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);
+                acc[i][j] = f32x4{r.x + b4.x, r.y + b4.y, r.z + b4.z, r.w + b4.w};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            f16x8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *(const f16x8*)(smem + (ks >> 1) * (KD * 128) + swz128(g2n + i * 16 + frow, (ks & 1) * 4 + fkg));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], af[ks][j], acc[i][j], 0, 0, 0);
+        }
+        // LayerNorm1 over the 256 features of each token (4 n-waves share a row)
+        float* red = (float*)(smem + 131072);
+        const int wn = wave & 3;
+        auto block_rowsum = [&](float (&part)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[j] = wave_xor_add(part[j], 16);
+                part[j] = wave_xor_add(part[j], 32);
+            }
+            __syncthreads();
+            if (fkg == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[wn * BM + g2m + j * 16 + frow] = part[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = g2m + j * 16 + frow;
+                part[j] = red[row] + red[BM + row] + red[2 * BM + row] + red[3 * BM + row];
+            }
+        };
+        float part[4], mean[4], rstd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            part[j] = sum;
+        }
+        block_rowsum(part);
+        // every wave is past its Wo reads: W1 slices 0/1 can land in the first 64 KB now (the X staging
+        // barrier below, with its vmcnt(0), is the completion wait -- as in the plain kernel)
+        dma_w1(0, 0);
+        if (nF > 1) dma_w1(FC, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mean[j] = part[j] * (1.0f / KD);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; sum += d * d; }
+            part[j] = sum;
+        }
+        block_rowsum(part);                                  // (its barriers also retire every wave's Wo reads)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rstd[j] = 1.0f / __builtin_sqrtf(part[j] * (1.0f / KD) + p.eps1);
+        const float ralpha = 1.0f / p.alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = N0 + i * 16;
+            const float4 g = *(const float4*)(p.g1 + n), be = *(const float4*)(p.be1 + n), b4 = *(const float4*)(p.b2 + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = g2m + j * 16 + frow;
+                const float v0 = (acc[i][j][0] - mean[j]) * rstd[j] * g.x + be.x;
+                const float v1 = (acc[i][j][1] - mean[j]) * rstd[j] * g.y + be.y;
+                const float v2 = (acc[i][j][2] - mean[j]) * rstd[j] * g.z + be.z;
+                const float v3 = (acc[i][j][3] - mean[j]) * rstd[j] * g.w + be.w;
+                f16x4 o;
+                o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
+                *(f16x4*)(Xst + (n >> 6) * (BM * 128) + swz128(row, (n & 63) >> 3) + ((n >> 2) & 1) * 8) = o;
+                acc[i][j] = f32x4{v0 * ralpha + b4.x, v1 * ralpha + b4.y, v2 * ralpha + b4.z, v3 * ralpha + b4.w};   // GEMM2 seed
+            }
+        }
     }
     float4 bcur[2];
     bcur[0] = *(const float4*)(p.b1 + bofs);
@@ -467,10 +584,9 @@ void ffn_fused_kernel(const FfnParams p) {
                 xf[kt][ks][j] = *(const f16x8*)(Xst + kt * (BM * 128) + swz128(g1m + j * 16 + frow, ks * 4 + fkg));
     __syncthreads();
 
-    // GEMM2 accumulators [n frag][m frag], seeded with res / alpha + b2: the residual is fetched here,
-    // together with the X tile, instead of as a second exposed HBM phase in the epilogue.
-    f32x4 acc[4][4];
-    {
+    if constexpr (!PRE) {
+        // GEMM2 accumulators seeded with res / alpha + b2: the residual is fetched here, together with the
+        // X tile, instead of as a second exposed HBM phase in the epilogue.
         const float ralpha = 1.0f / p.alpha;
         const int N0 = g2n + fkg * 4, M0 = m0 + g2m + frow;
 #pragma unroll
@@ -661,12 +777,12 @@ void ffn_fused_kernel(const FfnParams p) {
     }
 }
 
-template <int ACT, int EPI>
+template <int ACT, int EPI, bool PRE>
 int launch(const FfnParams& p, hipStream_t stream) {
     static bool attr_done = false;
     static const bool v1 = [] { const char* e = getenv("EEND_FFN_V1"); return e && e[0] == '1'; }();
-    auto kern = v1 ? ffn_fused_v1_kernel<ACT, EPI> : ffn_fused_kernel<ACT, EPI>;
-    const int smem_bytes = v1 ? SMEM_BYTES : V2_SMEM;
+    auto kern = (v1 && !PRE) ? ffn_fused_v1_kernel<ACT, EPI> : ffn_fused_kernel<ACT, EPI, PRE>;
+    const int smem_bytes = (v1 && !PRE) ? SMEM_BYTES : V2_SMEM;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
             return EEND_ELAUNCH;
@@ -678,22 +794,27 @@ int launch(const FfnParams& p, hipStream_t stream) {
         return n;
     }();
     const int ntiles = (p.M + BM - 1) / BM;
-    hipLaunchKernelGGL(kern, dim3(v1 || ntiles < ncu ? ntiles : ncu), dim3(NT), smem_bytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3((v1 && !PRE) || ntiles < ncu ? ntiles : ncu), dim3(NT), smem_bytes, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
 }  // namespace
 
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream) {
-    if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.X || !p.W1 || !p.W2 || !p.b1 || !p.b2 || !p.gamma ||
+    if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.W1 || !p.W2 || !p.b1 || !p.b2 || !p.gamma ||
         !p.beta || !p.out32 || !p.out16)
         return EEND_EINVAL;
+    if (p.A) {                                               // fused attention out-projection + norm1 producer
+        if (!p.Wo || !p.bo || !p.g1 || !p.be1 || (p.lda & 7) || epi != FFN_EPI_RES_LN || act != 1) return EEND_EINVAL;
+        return launch<1, FFN_EPI_RES_LN, true>(p, stream);
+    }
+    if (!p.X) return EEND_EINVAL;
     if (epi == FFN_EPI_RES_LN) {
-        if (act == 1) return launch<1, FFN_EPI_RES_LN>(p, stream);
-        if (act == 2) return launch<2, FFN_EPI_RES_LN>(p, stream);
+        if (act == 1) return launch<1, FFN_EPI_RES_LN, false>(p, stream);
+        if (act == 2) return launch<2, FFN_EPI_RES_LN, false>(p, stream);
     } else if (epi == FFN_EPI_RES_SCALE_LN16) {
-        if (act == 1) return launch<1, FFN_EPI_RES_SCALE_LN16>(p, stream);
-        if (act == 2) return launch<2, FFN_EPI_RES_SCALE_LN16>(p, stream);
+        if (act == 1) return launch<1, FFN_EPI_RES_SCALE_LN16, false>(p, stream);
+        if (act == 2) return launch<2, FFN_EPI_RES_SCALE_LN16, false>(p, stream);
     }
     return EEND_EINVAL;
 }

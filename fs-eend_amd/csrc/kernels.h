@@ -122,6 +122,14 @@ struct FfnParams {
     void* out16;        // f16 [M][256]
     float alpha, eps;
     int M, F, ldx;
+    // optional fused producer (null A = off): X = LayerNorm1(A Wo^T + bo + res), which also becomes the residual
+    const void* A;      // f16 [M][lda] (attention output)
+    const void* Wo;     // f16 [256][256]
+    const float* bo;    // [256]
+    const float* g1;    // LayerNorm1 affine
+    const float* be1;
+    float eps1;
+    int lda;
     int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);

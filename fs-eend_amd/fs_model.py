@@ -27,6 +27,8 @@ _D_SUPPORTED = 256
 _H_SUPPORTED = 4
 # A/B switch for perf studies: EEND_FFN_FUSED=0 runs linear1 / linear2 as two GEMM launches
 FUSED_FFN = __import__("os").environ.get("EEND_FFN_FUSED", "1") != "0"
+# EEND_ATTNOUT_FUSED=0 keeps the attention out-projection + norm1 as its own launch in front of the FFN
+FUSED_ATTNOUT = __import__("os").environ.get("EEND_ATTNOUT_FUSED", "1") != "0"
 
 
 class PositionalEncoding(nn.Module):
@@ -271,6 +273,10 @@ class OnlineTransformerDADiarization(nn.Module):
             ff = ws.ff16[:Me * F].view(Me, F)
             ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
             ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e)
+            if FUSED_FFN and FUSED_ATTNOUT:   # out_proj + norm1 + FFN + norm2 in one launch (x never leaves the CU)
+                ops.attnout_ffn_fused(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
+                                      L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], ws.h32, ws.h16)
+                continue
             ops.linear_res_ln(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], ws.h32, ws.h16, L["eps1"])
             if FUSED_FFN:      # linear1 + ReLU + linear2 + residual + norm2 in one launch (hidden stays on chip)
                 ops.ffn_fused(ws.h16, L["w1"], L["b1"], L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16,
@@ -295,6 +301,10 @@ class OnlineTransformerDADiarization(nn.Module):
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
             ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
             ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            if FUSED_FFN and FUSED_ATTNOUT:
+                ops.attnout_ffn_fused(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
+                                      L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32, ws.a16)
+                continue
             ops.linear_res_ln(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], ws.a32, ws.a16, L["eps21"])
             if FUSED_FFN:
                 ops.ffn_fused(ws.a16, L["w1"], L["b1"], L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16,

@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from .fs_model import FUSED_FFN, PositionalEncoding, _f16, _f32
+from .fs_model import FUSED_ATTNOUT, FUSED_FFN, PositionalEncoding, _f16, _f32
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -436,6 +436,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
             ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
             ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            if FUSED_FFN and FUSED_ATTNOUT:
+                ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
+                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
+                continue
             ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], ws.a32, ws.a16, Ld["eps21"])
             if FUSED_FFN:
                 ops.ffn_fused(ws.a16, Ld["w1"], Ld["b1"], Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16,

@@ -130,6 +130,19 @@ int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, 
                        float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
                        void* stream);
 
+/* Attention out-projection + residual + norm1 AND the position-wise feed-forward block + residual +
+ * norm2 of one post-LN layer in ONE launch (ReLU FFN):
+ *   x = LayerNorm1(A Wo^T + bo + res) * g1 + be1 ;  out = LayerNorm2(relu(x W1^T + b1) W2^T + b2 + x) * g2 + be2
+ * i.e. nn.TransformerEncoderLayer's out_proj/dropout1/norm1 + linear1/linear2/norm2 (FS model :147) and
+ * the second half of the fusion layers (out_proj of self_attn2 + norm21, _ff_block + norm22: FS
+ * merge_tfm_encoder.py:371-376,397-399; LS merge_retnet_layer.py:248-253,309-311).  x never leaves the CU.
+ * A f16 [M][lda] (attention output), Wo f16 [256][256], res f32 [M][256] (stream before the attention
+ * sub-layer; may alias out_f32), out_f32 f32 [M][256], out_f16 f16 [M][256] (may alias A). */
+int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const float* bo, const float* res,
+                               const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
+                               const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
+                               float* out_f32, void* out_f16, int M, int F, void* stream);
+
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
  * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */

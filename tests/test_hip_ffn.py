@@ -81,3 +81,37 @@ def test_proj256_ln_matches_generic_gemm(hip_lib, dev, M, unnorm, alpha):
     ln = torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5)
     assert (o32 - (y if unnorm else ln)).abs().max().item() < 3e-4
     assert (o16.float() - ln).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("M,Fh", [(128, 2048), (1000, 2048), (77, 1024), (40000, 2048)])
+def test_attnout_ffn_fused(hip_lib, dev, M, Fh):
+    """out-proj + residual + norm1 + FFN + residual + norm2 in one launch == linear_res_ln followed by
+    ffn_fused (same MFMA k order and the same f16 rounding of x), and both match torch fp32."""
+    from fs_eend_amd import ops
+    a = rnd((M, 256), dev, 21, F16)
+    wo, bo = rnd((256, 256), dev, 22, F16, 0.06), rnd((256,), dev, 23) * 0.2
+    w1, b1 = rnd((Fh, 256), dev, 24, F16, 0.08), rnd((Fh,), dev, 25) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 26, F16, 0.04), rnd((256,), dev, 27) * 0.3
+    res = rnd((M, 256), dev, 28)
+    g1, be1 = rnd((256,), dev, 29) * 0.2 + 1, rnd((256,), dev, 30) * 0.1
+    g2, be2 = rnd((256,), dev, 31) * 0.2 + 1, rnd((256,), dev, 32) * 0.1
+    o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+    ops.attnout_ffn_fused(a, wo, bo, res, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, o32, o16)
+    # torch fp32 on the same f16-quantised operands
+    x = torch.nn.functional.layer_norm(a.float() @ wo.float().t() + bo + res, (256,), g1, be1, 1e-5)
+    h = (x.to(F16).float() @ w1.float().t() + b1).relu().to(F16).float()
+    want = torch.nn.functional.layer_norm(h @ w2.float().t() + b2 + x, (256,), g2, be2, 1e-5)
+    assert torch.isfinite(o32).all() and torch.isfinite(o16).all()
+    assert (o32 - want).abs().max().item() < 3e-3
+    assert (o16.float() - want).abs().max().item() < 6e-3
+    # two-launch path
+    x32, x16 = torch.empty_like(o32), torch.empty_like(o16)
+    p32, p16 = torch.empty_like(o32), torch.empty_like(o16)
+    ops.linear_res_ln(a, wo, bo, res, g1, be1, x32, x16, 1e-5)
+    ops.ffn_fused(x16, w1, b1, w2, b2, x32, g2, be2, p32, p16)
+    assert (o32 - p32).abs().max().item() < 3e-3          # f16 roundings of x / h may flip: fp32 sum order differs
+    # in place, as the model calls it: out32 aliases res, out16 aliases a
+    res2, a2 = res.clone(), a.clone()
+    ops.attnout_ffn_fused(a2, wo, bo, res2, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, res2, a2)
+    assert torch.equal(res2, o32) and torch.equal(a2, o16)
