@@ -36,6 +36,8 @@ def flops_per_launch(name, shape, T):
     if name == "ffn_fused":
         M, F, K = shape
         return 4.0 * M * F * K
+    if name == "spk_qkv_attn":         # the in-projection GEMM (the C x C attention itself is VALU work)
+        return 2.0 * shape[0] * 768 * 256
     if name == "attnout_ffn_fused":    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
@@ -86,6 +88,8 @@ class OpTimer:
                 shape = (a[0].shape[0], a[7].shape[0], a[0].shape[1])
             elif name == "inproj_heads":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
+            elif name == "spk_qkv_attn":
+                shape = (a[0].shape[0],)
             elif name == "convert_fanout":
                 shape = (a[0].shape[0], 256, 256)
             elif name == "conv1d_l2norm":
@@ -98,7 +102,7 @@ class OpTimer:
 
     def __enter__(self):
         for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
-                  "convert_fanout", "attn_causal", "spk_attn", "head_l2dot"):
+                  "convert_fanout", "attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot"):
             self.orig[n] = getattr(self.ops, n)
             setattr(self.ops, n, self._wrap(n, self.orig[n]))
         return self

@@ -233,6 +233,14 @@ int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_
     return eend_launch_attn_causal(p, (hipStream_t)stream);
 }
 
+int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
+                          int B, int C, int Tp, int H, float scale, void* stream) {
+    if (H != 4) return EEND_EINVAL;
+    SpkFusedParams p;
+    p.X = x_f16; p.ldx = ldx; p.W = W_in; p.bias = b_in; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.scale = scale;
+    return eend_launch_spk_qkv_attn(p, (hipStream_t)stream);
+}
+
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale, void* stream) {
     if (!qkv || !O_f16) return EEND_EINVAL;
     SpkAttnParams p;

@@ -63,6 +63,16 @@ struct SpkAttnParams {
     float scale;      // 1/sqrt(dh)
 };
 
+struct SpkFusedParams {
+    const void* X;      // f16 [B*C*Tp][ldx], row = (b*C + c)*Tp + t
+    const void* W;      // f16 [768][256] in_proj_weight (q rows, k rows, v rows)
+    const float* bias;  // [768]
+    void* O;            // f16 [B*C*Tp][256]
+    int B, C, Tp, ldx;
+    float scale;        // 1/sqrt(dh)
+};
+int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream);
+
 struct RetParams {
     const void* Q;    // f16 [nseq][H][Tp][64]
     const void* K;    // f16 [nseq][H][Tp][64]   (already scaled by dk^-0.5)

@@ -29,6 +29,8 @@ _H_SUPPORTED = 4
 FUSED_FFN = __import__("os").environ.get("EEND_FFN_FUSED", "1") != "0"
 # EEND_ATTNOUT_FUSED=0 keeps the attention out-projection + norm1 as its own launch in front of the FFN
 FUSED_ATTNOUT = __import__("os").environ.get("EEND_ATTNOUT_FUSED", "1") != "0"
+# EEND_SPK_FUSED=0 runs the speaker-axis qkv projection and attention as two launches
+FUSED_SPK = __import__("os").environ.get("EEND_SPK_FUSED", "1") != "0"
 
 
 class PositionalEncoding(nn.Module):
@@ -299,8 +301,11 @@ class OnlineTransformerDADiarization(nn.Module):
             ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
             ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, Tp)
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
-            ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
-            ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
+                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)
+            else:
+                ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
+                ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
             if FUSED_FFN and FUSED_ATTNOUT:
                 ops.attnout_ffn_fused(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
                                       L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32, ws.a16)

@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from .fs_model import FUSED_ATTNOUT, FUSED_FFN, PositionalEncoding, _f16, _f32
+from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, PositionalEncoding, _f16, _f32
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -434,8 +434,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
             ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"])
             ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
-            ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
-            ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
+                ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
+            else:
+                ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
+                ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
             if FUSED_FFN and FUSED_ATTNOUT:
                 ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
                                       Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)

@@ -198,6 +198,15 @@ int eend_dwconv_step_f16(const void* x_f16, float* cache, const float* w, const 
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                       void* stream);
 
+/* In-projection + attention core of the speaker-axis self-attention in one launch (the [M][768] qkv
+ * tensor never reaches HBM): qkv = x W_in^T + b_in, then the unmasked MHA over the C (<= 12) slots of each
+ * frame as eend_spk_attn_f16 (nn.MultiheadAttention self_attn2 of the fusion layers, _sa_block2: FS
+ * merge_tfm_encoder.py:388-394; LS merge_retnet_layer.py:301-306).  x f16 [B*C*Tp][ldx] (256 features,
+ * row = (b*C + c)*Tp + t), W_in f16 [768][256] (in_proj_weight), b_in f32 [768] -> O f16 [B*C*Tp][256].
+ * H = 4, dh = 64. */
+int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
+                          int B, int C, int Tp, int H, float scale, void* stream);
+
 /* attractors / ||attractors||_2 and logits[b,t,c] = <emb[b,t], attractors[b,t,c]>
  * (FS model :43,:60 / :76,:79; LS model :89,:117).  emb f32 [B][Tp][D], attr f32 [B*C][Tp][D]
  * -> attr_out f32 [B][T][C][D], logits f32 [B][T][C]. */
