@@ -31,6 +31,13 @@ DEV int swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// LAZY (scale_log2 == 1: the caller folded 1/sqrt(dh) * log2(e) into the q projection): the softmax is
+// VALU-bound at dh = 64 (PMC: 19 VALU instructions per MFMA, VALU busy 44 % vs MFMA 18 %), so the loop
+// sheds VALU work per score: the running reference m_ref of a query row is only moved when a tile's
+// scores exceed it by more than 2^8 (exact result either way: numerator and denominator share m_ref),
+// and -m_ref is the C operand of the first QK^T MFMA, so the scores leave the matrix pipe already
+// re-referenced -- no per-score scale, subtract or rescale of O on the common path.
+template <bool LAZY>
 __global__ __launch_bounds__(512)
 void attn_causal_full_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,6 +107,78 @@ void attn_causal_full_kernel(const AttnParams p) {
         last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
         const int jend = last_key < 0 ? 0 : last_key / KB + 1;
 
+        if constexpr (LAZY) {
+            f32x16 mneg;                                 // -m_ref of this lane's query in every entry
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mneg[i] = 0.f;
+            for (int j = 0; j < jend; ++j) {
+                const int key0 = j * KB;
+                const char* kb_ = Ks + j * TILE;
+                const char* vb_ = Vs + j * TILE;
+                f32x16 s[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? mneg : s[kb], 0, 0, 0);
+                    }
+                }
+                const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
+                if (key0 + KB - 1 > wlim) {
+                    const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
+                            if (key > lim) s[kb][i] = -INFINITY;
+                        }
+                }
+                float tmax = s[0][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[0][i]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[1][i]);
+                tmax = wave_xor_max(tmax, 32);
+                // move the reference only when a row outgrows it by 2^8 (or, on the first tile, sits far below it)
+                const bool move = tmax > 8.0f || (j == 0 && tmax < -8.0f);
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    float d = j == 0 ? tmax : __builtin_fmaxf(tmax, 0.f);
+                    d = d == -INFINITY ? 0.f : d;
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        oT[0][i] *= alpha; oT[1][i] *= alpha;
+                        s[0][i] -= d; s[1][i] -= d;
+                        mneg[i] -= d;
+                    }
+                }
+                float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[0][i] = __builtin_amdgcn_exp2f(s[0][i]);
+                    s[1][i] = __builtin_amdgcn_exp2f(s[1][i]);
+                    lsum0 += s[0][i];
+                    lsum1 += s[1][i];
+                }
+                l_run += lsum0 + lsum1;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        bf16x8 pf;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][kk * 8 + jj];
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(db * 32 + lq, kb * 4 + kk * 2 + hi));
+                            oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                        }
+                    }
+            }
+        } else
         for (int j = 0; j < jend; ++j) {
             const int key0 = j * KB;
             const char* kb_ = Ks + j * TILE;
@@ -197,11 +276,17 @@ int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream) {
     const int smem = 2 * (p.Tp / KB) * TILE + NW * OSTG;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn_causal_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)attn_causal_full_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * (TMAX / KB) * TILE + NW * OSTG) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_causal_full_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * (TMAX / KB) * TILE + NW * OSTG) != hipSuccess)
             return EEND_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(attn_causal_full_kernel, dim3(p.H, p.nseq), dim3(512), smem, stream, p);
+    const float dev1 = p.scale_log2 - 1.0f;
+    if (dev1 < 1e-6f && dev1 > -1e-6f)       // scores arrive in the log2 domain (scale folded into the q projection)
+        hipLaunchKernelGGL(attn_causal_full_kernel<true>, dim3(p.H, p.nseq), dim3(512), smem, stream, p);
+    else
+        hipLaunchKernelGGL(attn_causal_full_kernel<false>, dim3(p.H, p.nseq), dim3(512), smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -124,6 +124,15 @@ def _f32(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+def _qscaled(t: Tensor) -> Tensor:
+    """Packed in-projection (3D x D weight or 3D bias) with the q rows pre-multiplied by
+    1/sqrt(dh) * log2(e) in fp32 (ops.QSCALE_LOG2): the attention kernel then needs no per-score scale."""
+    from . import ops
+    t = t.detach().to(torch.float32).clone()
+    t[: t.shape[0] // 3] *= ops.QSCALE_LOG2
+    return t
+
+
 class _Workspace:
     """Device buffers for one (B, Tp, C) problem shape (allocated once, reused)."""
 
@@ -193,7 +202,7 @@ class OnlineTransformerDADiarization(nn.Module):
         layers = []
         for l in enc.transformer_encoder.layers:
             layers.append(dict(
-                in_w=_f16(l.self_attn.in_proj_weight), in_b=_f32(l.self_attn.in_proj_bias),
+                in_w=_f16(_qscaled(l.self_attn.in_proj_weight)), in_b=_f32(_qscaled(l.self_attn.in_proj_bias)),
                 out_w=_f16(l.self_attn.out_proj.weight), out_b=_f32(l.self_attn.out_proj.bias),
                 w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
                 g1=_f32(l.norm1.weight), be1=_f32(l.norm1.bias), eps1=l.norm1.eps,
@@ -208,7 +217,7 @@ class OnlineTransformerDADiarization(nn.Module):
         dl = []
         for l in self.dec.attractor_decoder.layers:
             dl.append(dict(
-                in1_w=_f16(l.self_attn1.in_proj_weight), in1_b=_f32(l.self_attn1.in_proj_bias),
+                in1_w=_f16(_qscaled(l.self_attn1.in_proj_weight)), in1_b=_f32(_qscaled(l.self_attn1.in_proj_bias)),
                 out1_w=_f16(l.self_attn1.out_proj.weight), out1_b=_f32(l.self_attn1.out_proj.bias),
                 in2_w=_f16(l.self_attn2.in_proj_weight), in2_b=_f32(l.self_attn2.in_proj_bias),
                 out2_w=_f16(l.self_attn2.out_proj.weight), out2_b=_f32(l.self_attn2.out_proj.bias),
@@ -274,7 +283,7 @@ class OnlineTransformerDADiarization(nn.Module):
             F = L["w1"].shape[0]
             ff = ws.ff16[:Me * F].view(Me, F)
             ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
-            ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e)
+            ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
             if FUSED_FFN and FUSED_ATTNOUT:   # out_proj + norm1 + FFN + norm2 in one launch (x never leaves the CU)
                 ops.attnout_ffn_fused(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
                                       L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], ws.h32, ws.h16)
@@ -299,7 +308,7 @@ class OnlineTransformerDADiarization(nn.Module):
             F = L["w1"].shape[0]
             ff = ws.ff16[:Md * F].view(Md, F)
             ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
-            ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, Tp)
+            ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, Tp, scale=ops.LN2)
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
             if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
                 ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)

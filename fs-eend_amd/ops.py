@@ -187,11 +187,18 @@ def convert_fanout(e16, w1_16, pc, out32, out16, B, Tp, C):
                "eend_convert_fanout_f16")
 
 
-def attn_causal(q, k, vt, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
+LN2 = math.log(2.0)
+# Multiply the q rows of an in-projection (weight and bias) by QSCALE_LOG2 and call attn_causal with
+# scale=LN2: the scores then leave the QK^T MFMA already scaled and in the log2 domain, which is what the
+# whole-sequence attention kernel's cheap softmax path needs (attn_full.hip, LAZY).
+QSCALE_LOG2 = (1.0 / math.sqrt(64.0)) * math.log2(math.e)
+
+
+def attn_causal(q, k, vt, o16, nseq, H, Tp, mask_delay=0, kv_len=None, scale=1.0 / math.sqrt(64.0)):
     L = _lib.load()
     _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt"); _chk(o16, F16, "o16")
     _lib.check(L.eend_attn_causal_bf16(_p(q), _p(k), _p(vt), _p(o16), nseq, H, Tp, o16.stride(0), mask_delay,
-                                       Tp if kv_len is None else kv_len, 1.0 / math.sqrt(64.0), _stream()), "eend_attn_causal_bf16")
+                                       Tp if kv_len is None else kv_len, scale, _stream()), "eend_attn_causal_bf16")
 
 
 def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4):
