@@ -36,6 +36,9 @@ def flops_per_launch(name, shape, T):
     if name == "ffn_fused":
         M, F, K = shape
         return 4.0 * M * F * K
+    if name == "fusion_layer_tail":    # 2 out-projections + speaker in-projection + the two FFN GEMMs
+        M, F, K = shape
+        return 4.0 * M * F * K + 2.0 * M * K * K * 2 + 2.0 * M * 768 * K
     if name == "spk_qkv_attn":         # the in-projection GEMM (the C x C attention itself is VALU work)
         return 2.0 * shape[0] * 768 * 256
     if name == "attnout_ffn_fused":    # out-projection (K x K) + the two FFN GEMMs
@@ -52,7 +55,8 @@ def pmc_traffic(kernel, shape):
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    tags = {("attnout_ffn_fused", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #hi", "131072"),
+    tags = {("fusion_layer_tail", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0, 2>(FfnParams)", "131072"),
+            ("attnout_ffn_fused", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #hi", "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #lo", "131072"),
             ("attn_causal", (64, 4)): ("attn_causal_full_kernel", "131072"),
             ("attn_causal", (384, 4)): ("attn_causal_full_kernel", "786432"),
@@ -90,6 +94,8 @@ class OpTimer:
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "spk_qkv_attn":
                 shape = (a[0].shape[0],)
+            elif name == "fusion_layer_tail":
+                shape = (a[0].shape[0], a[15].shape[0], 256)
             elif name == "convert_fanout":
                 shape = (a[0].shape[0], 256, 256)
             elif name == "conv1d_l2norm":
@@ -101,7 +107,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
                   "convert_fanout", "attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot"):
             self.orig[n] = getattr(self.ops, n)
             setattr(self.ops, n, self._wrap(n, self.orig[n]))
@@ -354,12 +360,17 @@ def main():
             a = att[0]
             fl = flops_per_launch("attn_causal", tuple(a["shape"]), T)
             byt = a["shape"][0] * 4.0 * T * 256 * 2            # Q,K,V read + O written once, 2-byte elements
+            # arithmetic intensity of the standalone kernel: 2*D*T*(T+1) flop over 4*T*D*2 B = (T+1)/4 = 125 flop/B at
+            # T = 500, below the MI355X ridge (2500 TFLOP/s / 8 TB/s = 312 flop/B): the HBM roof is the binding one,
+            # it caps this kernel at 8 TB/s * 125 flop/B = 1.0 PFLOP/s = 40 % of the MFMA peak.
+            tf = fl / (a["avg_ms"] * 1e-3) / 1e12
+            gbs = byt / (a["avg_ms"] * 1e-3) / 1e9
             out["roofline_attention"] = {
-                "kernel": f"encoder attn_causal nseq={a['shape'][0]} H=4 T={T}", "bound": "mfma",
-                "achieved": fl / (a["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
-                "hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9, "hbm_frac": byt / (a["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": pmc_traffic("attn_causal", a["shape"]), "avg_launch_ms": a["avg_ms"]}
+                "kernel": f"encoder attn_causal nseq={a['shape'][0]} H=4 T={T}", "bound": "hbm",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "traffic": pmc_traffic("attn_causal", a["shape"]), "avg_launch_ms": a["avg_ms"],
+                "intensity_flop_per_byte": fl / byt, "ridge_flop_per_byte": PEAK_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS,
+                "mfma_TFLOPs": tf, "mfma_frac": tf / PEAK_MFMA_TFLOPS}
 
     if rank == 0 and world == 1 and not args.no_extras:
         out["extras"] = extras(dev)

@@ -137,6 +137,26 @@ int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const flo
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
+                               const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
+                               const void* Win2, const float* bin2,
+                               const void* Wo2, const float* bo2, const float* g21, const float* be21, float eps21,
+                               const void* W1, const float* b1, const void* W2, const float* b2,
+                               const float* g22, const float* be22, float eps22,
+                               int B, int C, int Tp, int F, void* stream) {
+    if (!A1 || !stream_f32 || !out_f16 || !Wo1 || !bo1 || !g11 || !be11 || !Win2 || !bin2 || !Wo2 || !bo2 || !g21 || !be21)
+        return EEND_EINVAL;
+    if (B <= 0 || C < 1 || C > 12 || Tp <= 0) return EEND_EINVAL;
+    FfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A1; p.lda = lda; p.Wo = Wo1; p.bo = bo1; p.g1 = g11; p.be1 = be11; p.eps1 = eps11;
+    p.Win2 = Win2; p.bin2 = bin2; p.Wo2 = Wo2; p.bo2 = bo2; p.g21 = g21; p.be21 = be21; p.eps21 = eps21; p.spk_scale = 0.125f;
+    p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.gamma = g22; p.beta = be22; p.eps = eps22; p.alpha = 1.0f;
+    p.res = stream_f32; p.out32 = stream_f32; p.out16 = out_f16;
+    p.B = B; p.C = C; p.Tp = Tp; p.M = B * C * Tp; p.F = F;
+    return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
 int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,
                             void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim, void* stream) {
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;

@@ -51,9 +51,14 @@ constexpr int SMEM_BYTES = XS_BYTES + W1_BYTES + HS_BYTES + W2_BYTES;   // 14745
 // through LDS so that every global store instruction writes whole rows (64 lanes x 16 B contiguous)
 // instead of 16 token-row segments of 64 B (fp32) / 32 B (f16): measured, the segment stores drained at
 // 2.7 TB/s and were the largest fixed cost of the kernel.
-template <int EPI, bool SEEDED = false, bool STAGED = false>
+struct RowsContiguous {              // tile row -> global row (or -1): plain 128-row tiles
+    int m0, M;
+    __device__ __forceinline__ long operator()(int r) const { return m0 + r < M ? (long)(m0 + r) : -1L; }
+};
+
+template <int EPI, bool SEEDED = false, bool STAGED = false, class RowMap = RowsContiguous>
 __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4][4], char* smem, int wave, int frow, int fkg,
-                                             int m0, int g2m, int g2n) {
+                                             int m0, int g2m, int g2n, const RowMap rowmap = RowMap{0, 0}) {
     // ---- epilogue: y = (acc + b2) * alpha + res ; LayerNorm over the 256 features of each token
     // acc[i][j][r]: n = g2n + i*16 + fkg*4 + r ; m = m0 + g2m + j*16 + frow
     float* red = (float*)(smem + (STAGED ? 131072 : 0));     // [4 n-waves][128 rows]; clear of the staging tiles
@@ -157,7 +162,8 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
         for (int k = 0; k < 16; ++k) {
             const int row = k * 8 + wave;
             const f32x4 v = *(const f32x4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
-            if (m0 + row < p.M) *(f32x4*)(o32 + (size_t)(m0 + row) * KD + lane * 4) = v;
+            const long gr = rowmap(row);
+            if (gr >= 0) *(f32x4*)(o32 + (size_t)gr * KD + lane * 4) = v;
         }
         __syncthreads();
         // f16 tile -> LDS [128 rows][512 B], 16-B chunk c of row r at chunk c ^ ((r >> 1) & 7)
@@ -175,7 +181,8 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
         for (int k = 0; k < 8; ++k) {
             const int row = (k * 8 + wave) * 2 + (lane >> 5), c = lane & 31;
             const u32x4 v = *(const u32x4*)(smem + row * 512 + ((c ^ ((row >> 1) & 7)) << 4));
-            if (m0 + row < p.M) *(u32x4*)(o16 + (size_t)(m0 + row) * KD + c * 8) = v;
+            const long gr = rowmap(row);
+            if (gr >= 0) *(u32x4*)(o16 + (size_t)gr * KD + c * 8) = v;
         }
         return;
     }
@@ -384,16 +391,55 @@ constexpr int V2_SMEM = V2_HS + 2 * HS_BYTES;  // 163840
 // sub-layers never travel through HBM: Wo (128 KB) sits in the still-unused weight buffers, the A
 // fragments come straight from global memory, and the result lands in the same accumulator layout that
 // seeds GEMM2 (fp32 residual) and, as f16, in the X staging tile.
-template <int ACT, int EPI, bool PRE>
+//
+// MODE 2 (LAYER) runs the whole row-local second half of a fusion (decoder) layer on one tile:
+//     x1 = LN11(A1 Wo1^T + bo1 + res)                        (time-axis attention out-projection, norm11)
+//     o  = MHA over the C slots of each frame of x1 Win2^T    (speaker-axis attention, as spk_fused.hip)
+//     x2 = LN21(o Wo2^T + bo2 + x1)                          (its out-projection, norm21)
+//     out = LN22(relu(x2 W1^T + b1) W2^T + b2 + x2)          (FFN, norm22)
+// A tile is "all C slots of G = 128/C consecutive frames" (rows gathered with stride Tp), which makes the
+// speaker mix tile-local.  x1 (fp32) is parked in the output stream buffer between the two
+// projection phases (each thread reads back exactly what it wrote); qkv, o, x2 and the hidden
+// activations never leave the CU.
+struct RowsGathered {                // tile row r = c * G + t' -> row (b*C + c)*Tp + t0 + t' of the (b,c)-major slab
+    int b, t0, G, C, Tp, rows;
+    __device__ __forceinline__ long operator()(int r) const {
+        if (r >= rows) return -1L;
+        const int c = r / G, t = t0 + r - c * G;
+        return t < Tp ? ((long)b * C + c) * Tp + t : -1L;
+    }
+};
+
+template <int ACT, int EPI, int MODE>
 __global__ __launch_bounds__(NT)
 void ffn_fused_kernel(const FfnParams p) {
+    constexpr bool PRE = MODE >= 1, LAYER = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nF = p.F / FC;
-    const int ntiles = (p.M + BM - 1) / BM;
+    const int lyG = LAYER ? BM / p.C : 1;                       // frames per tile
+    const int tiles_per_b = LAYER ? (p.Tp + lyG - 1) / lyG : 1;
+    const int ntiles = LAYER ? p.B * tiles_per_b : (p.M + BM - 1) / BM;
     // Persistent over row tiles (grid = #CUs, 1 block/CU): the output stores of a tile are never waited
     // for, so they drain under the next tile's loads instead of being an exposed phase of every block.
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m0 = tile * BM;
+    const int lyb = LAYER ? tile / tiles_per_b : 0, lyt0 = LAYER ? (tile - lyb * tiles_per_b) * lyG : 0;
+    const RowsGathered rows_g{lyb, lyt0, lyG, LAYER ? p.C : 1, p.Tp, lyG * (LAYER ? p.C : 1)};
+    const RowsContiguous rows_c{m0, p.M};
+    auto rowmap = [&](int r) __attribute__((always_inline)) -> long {
+        if constexpr (LAYER) return rows_g(r); else return rows_c(r);
+    };
+    auto rowclamp = [&](int r) __attribute__((always_inline)) -> long {      // always a valid row (for loads)
+        if constexpr (LAYER) {
+            r = r < rows_g.rows ? r : rows_g.rows - 1;
+            const int c = r / lyG;
+            int t = lyt0 + r - c * lyG;
+            t = t < p.Tp ? t : p.Tp - 1;
+            return ((long)lyb * p.C + c) * p.Tp + t;
+        } else {
+            return m0 + r < p.M ? (long)(m0 + r) : (long)p.M - 1;
+        }
+    };
     if (tile != (int)blockIdx.x) {
         // every wave is done reading the LN scratch at the start of LDS before the weight DMA lands there
         // (raw barrier: __syncthreads() would also wait for the previous tile's global stores)
@@ -405,9 +451,9 @@ void ffn_fused_kernel(const FfnParams p) {
     // kept live -- or spilled -- across the register-tight chunk loop.
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frow = lane & 15, fkg = lane >> 4;
+    int frow = lane & 15, fkg = lane >> 4;
 
     const _Float16* __restrict__ X = (const _Float16*)p.X;
     const _Float16* __restrict__ W1 = (const _Float16*)p.W1;
@@ -416,18 +462,21 @@ void ffn_fused_kernel(const FfnParams p) {
     // DMA one 64-hidden-unit slice of W1 ([64][256] -> 4 k-tiles of [64][128 B]) / W2 ([256][64]).
     // (buffer_load ... lds rather than global_load_lds: the latter is a FLAT encoding and, while one is
     // pending, hipcc degrades every LDS wait to lgkmcnt(0), which would serialise the fragment pipeline.)
-    const int drow = lane >> 3, dslot = lane & 7;
+    int drow = lane >> 3, dslot = lane & 7;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.F * KD * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.F * KD * 2, 0x00020000);
     int vo1[4], vo2[4];                                      // per-lane byte offsets of the 4 pieces this wave moves
+    auto dma_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;                      // 32 pieces of 8 rows x 128 B
-        const int kt = piece >> 3, row1 = (piece & 7) * 8 + drow;
-        vo1[i] = (row1 * KD + kt * 64 + (dslot ^ ((row1 >> 1) & 7)) * 8) * 2;
-        const int row2 = piece * 8 + drow;
-        vo2[i] = (row2 * p.F + (dslot ^ ((row2 >> 1) & 7)) * 8) * 2;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;                  // 32 pieces of 8 rows x 128 B
+            const int kt = piece >> 3, row1 = (piece & 7) * 8 + drow;
+            vo1[i] = (row1 * KD + kt * 64 + (dslot ^ ((row1 >> 1) & 7)) * 8) * 2;
+            const int row2 = piece * 8 + drow;
+            vo2[i] = (row2 * p.F + (dslot ^ ((row2 >> 1) & 7)) * 8) * 2;
+        }
+    };
+    dma_offsets();
     auto dma_w1 = [&](int f0, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -441,9 +490,19 @@ void ffn_fused_kernel(const FfnParams p) {
                                                      f0 * 2, 0, 0);
     };
 
+    // LAYER: slice ch = 3*head + {q,k,v} of the speaker attention's in_proj_weight, same LDS image as a W1 slice
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(LAYER ? p.Win2 : p.W1), 0, 3 * KD * KD * 2, 0x00020000);
+    auto dma_spk = [&](int ch, int buf) __attribute__((always_inline)) {
+        const int wrow = (ch % 3) * KD + (ch / 3) * FC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_char*)(smem + V2_W1 + buf * W1_BYTES + (wave * 4 + i) * 1024), 16, vo1[i],
+                                                     wrow * KD * 2, 0, 0);
+    };
+
     const int g1m = (wave >> 1) * 32, g1f = (wave & 1) * 32;   // GEMM1 wave tile: 32 tokens x 32 hidden
     const int g2m = (wave >> 2) * 64, g2n = (wave & 3) * 64;   // GEMM2 wave tile: 64 tokens x 64 outputs
-    const int bofs = g1f + fkg * 4;                            // this lane's b1 offsets inside a chunk: bofs, bofs+16
+    int bofs = g1f + fkg * 4;                                  // this lane's b1 offsets inside a chunk: bofs, bofs+16
 
     char* Xst = smem + V2_W2;
     f32x4 acc[4][4];                                         // GEMM2 accumulators [n frag][m frag]
@@ -461,49 +520,12 @@ void ffn_fused_kernel(const FfnParams p) {
             *(u32x4*)(Xst + (c32 >> 3) * (BM * 128) + swz128(row, c32 & 7)) = v;
         }
     } else {
-        // ---- fused producer: y = A Wo^T + bo + res ; x = LayerNorm1(y)
-        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wo, 0, KD * KD * 2, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {                       // Wo -> LDS [4 k-tiles][256 n][128 B], 128 pieces of 1 KB
-            const int piece = wave * 16 + i;
-            const int kt = piece >> 5, row = (piece & 31) * 8 + drow;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_char*)(smem + piece * 1024), 16,
-                                                     (row * KD + kt * 64 + (dslot ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
-        }
-        const _Float16* __restrict__ A = (const _Float16*)p.A;
-        const int N0 = g2n + fkg * 4, M0 = m0 + g2m + frow;
-        f16x8 af[8][4];                                      // [k-step][token frag], straight from global
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int m = M0 + j * 16;
-            m = m < p.M ? m : p.M - 1;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) af[ks][j] = *(const f16x8*)(A + (size_t)m * p.lda + ks * 32 + fkg * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                        // accumulators start at bo + res
-            const float4 b4 = *(const float4*)(p.bo + N0 + i * 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = M0 + j * 16;
-                float4 r = make_float4(0, 0, 0, 0);
-                if (p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);
-                acc[i][j] = f32x4{r.x + b4.x, r.y + b4.y, r.z + b4.z, r.w + b4.w};
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            f16x8 a[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *(const f16x8*)(smem + (ks >> 1) * (KD * 128) + swz128(g2n + i * 16 + frow, (ks & 1) * 4 + fkg));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], af[ks][j], acc[i][j], 0, 0, 0);
-        }
-        // LayerNorm1 over the 256 features of each token (4 n-waves share a row)
+        // ---- projection + residual + LayerNorm phase: x = LN(A Wo^T + bo + res)
+        //   SRC_LDS: the A operand is the f16 tile in the staging region (else fragments come from global p.A)
+        //   LAST:    x feeds the FFN (f16 -> staging tile, fp32 + b2 -> GEMM2 seed, W1 slices 0/1 requested);
+        //            otherwise x feeds the speaker attention (f16 -> staging tile, fp32 -> out32 stream,
+        //            attention weight slices 0/1 requested)
+        const int N0 = g2n + fkg * 4;
         float* red = (float*)(smem + 131072);
         const int wn = wave & 3;
         auto block_rowsum = [&](float (&part)[4]) __attribute__((always_inline)) {
@@ -524,51 +546,254 @@ void ffn_fused_kernel(const FfnParams p) {
                 part[j] = red[row] + red[BM + row] + red[2 * BM + row] + red[3 * BM + row];
             }
         };
-        float part[4], mean[4], rstd[4];
+        auto proj_ln_phase = [&](const void* Wo, const float* bo, const float* g, const float* be, const float eps,
+                                 const float* resp, auto SRC_LDS, auto LAST) __attribute__((always_inline)) {
+            constexpr bool src_lds = decltype(SRC_LDS)::value, last = decltype(LAST)::value;
+            f16x8 af[8][4];                                  // A fragments [k-step][token frag]
+            if constexpr (src_lds) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float sum = 0.f;
+                for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-            part[j] = sum;
-        }
-        block_rowsum(part);
-        // every wave is past its Wo reads: W1 slices 0/1 can land in the first 64 KB now (the X staging
-        // barrier below, with its vmcnt(0), is the completion wait -- as in the plain kernel)
-        dma_w1(0, 0);
-        if (nF > 1) dma_w1(FC, 1);
+                    for (int j = 0; j < 4; ++j)
+                        af[ks][j] = *(const f16x8*)(Xst + (ks >> 1) * (BM * 128) + swz128(g2m + j * 16 + frow, (ks & 1) * 4 + fkg));
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave holds its fragments: the tile may be overwritten
+            }
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)Wo, 0, KD * KD * 2, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mean[j] = part[j] * (1.0f / KD);
+            for (int i = 0; i < 16; ++i) {                   // Wo -> LDS [4 k-tiles][256 n][128 B], 128 pieces of 1 KB
+                const int piece = wave * 16 + i;
+                const int kt = piece >> 5, row = (piece & 31) * 8 + drow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_char*)(smem + piece * 1024), 16,
+                                                         (row * KD + kt * 64 + (dslot ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+            }
+            if constexpr (!src_lds) {
+                const _Float16* __restrict__ A = (const _Float16*)p.A;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float sum = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const long m = rowclamp(g2m + j * 16 + frow);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int ks = 0; ks < 8; ++ks) af[ks][j] = *(const f16x8*)(A + (size_t)m * p.lda + ks * 32 + fkg * 8);
+                }
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; sum += d * d; }
-            part[j] = sum;
-        }
-        block_rowsum(part);                                  // (its barriers also retire every wave's Wo reads)
+            for (int j = 0; j < 4; ++j) {                    // accumulators start at bo + res
+                const long m = rowmap(g2m + j * 16 + frow);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rstd[j] = 1.0f / __builtin_sqrtf(part[j] * (1.0f / KD) + p.eps1);
-        const float ralpha = 1.0f / p.alpha;
+                for (int i = 0; i < 4; ++i) {
+                    const float4 b4 = *(const float4*)(bo + N0 + i * 16);
+                    float4 r = make_float4(0, 0, 0, 0);
+                    if (resp && m >= 0) r = *(const float4*)(resp + (size_t)m * KD + N0 + i * 16);
+                    acc[i][j] = f32x4{r.x + b4.x, r.y + b4.y, r.z + b4.z, r.w + b4.w};
+                }
+            }
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = N0 + i * 16;
-            const float4 g = *(const float4*)(p.g1 + n), be = *(const float4*)(p.be1 + n), b4 = *(const float4*)(p.b2 + n);
+            for (int ks = 0; ks < 8; ++ks) {
+                f16x8 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *(const f16x8*)(smem + (ks >> 1) * (KD * 128) + swz128(g2n + i * 16 + frow, (ks & 1) * 4 + fkg));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], af[ks][j], acc[i][j], 0, 0, 0);
+            }
+            float part[4], mean[4], rstd[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int row = g2m + j * 16 + frow;
-                const float v0 = (acc[i][j][0] - mean[j]) * rstd[j] * g.x + be.x;
-                const float v1 = (acc[i][j][1] - mean[j]) * rstd[j] * g.y + be.y;
-                const float v2 = (acc[i][j][2] - mean[j]) * rstd[j] * g.z + be.z;
-                const float v3 = (acc[i][j][3] - mean[j]) * rstd[j] * g.w + be.w;
-                f16x4 o;
-                o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
-                *(f16x4*)(Xst + (n >> 6) * (BM * 128) + swz128(row, (n & 63) >> 3) + ((n >> 2) & 1) * 8) = o;
-                acc[i][j] = f32x4{v0 * ralpha + b4.x, v1 * ralpha + b4.y, v2 * ralpha + b4.z, v3 * ralpha + b4.w};   // GEMM2 seed
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+                part[j] = sum;
             }
+            block_rowsum(part);
+            // every wave is past its Wo reads: the next phase's first two weight slices can land in the first
+            // 64 KB now (the staging barrier below, with its vmcnt(0), is the completion wait)
+            if constexpr (last) {
+                dma_w1(0, 0);
+                if (nF > 1) dma_w1(FC, 1);
+            } else {
+                dma_spk(0, 0);
+                dma_spk(1, 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mean[j] = part[j] * (1.0f / KD);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; sum += d * d; }
+                part[j] = sum;
+            }
+            block_rowsum(part);                              // (its barriers also retire every wave's Wo reads)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rstd[j] = 1.0f / __builtin_sqrtf(part[j] * (1.0f / KD) + eps);
+            const float ralpha = 1.0f / p.alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = N0 + i * 16;
+                const float4 gg = *(const float4*)(g + n), bb = *(const float4*)(be + n), b4 = *(const float4*)(p.b2 + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = g2m + j * 16 + frow;
+                    const float v0 = (acc[i][j][0] - mean[j]) * rstd[j] * gg.x + bb.x;
+                    const float v1 = (acc[i][j][1] - mean[j]) * rstd[j] * gg.y + bb.y;
+                    const float v2 = (acc[i][j][2] - mean[j]) * rstd[j] * gg.z + bb.z;
+                    const float v3 = (acc[i][j][3] - mean[j]) * rstd[j] * gg.w + bb.w;
+                    f16x4 o;
+                    o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
+                    *(f16x4*)(Xst + (n >> 6) * (BM * 128) + swz128(row, (n & 63) >> 3) + ((n >> 2) & 1) * 8) = o;
+                    if constexpr (last) {
+                        acc[i][j] = f32x4{v0 * ralpha + b4.x, v1 * ralpha + b4.y, v2 * ralpha + b4.z, v3 * ralpha + b4.w};   // GEMM2 seed
+                    } else {
+                        const long m = rowmap(row);
+                        if (m >= 0) *(float4*)(p.out32 + (size_t)m * KD + n) = make_float4(v0, v1, v2, v3);
+                    }
+                }
+            }
+        };
+
+        if constexpr (!LAYER) {
+            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::false_type{}, std::true_type{});
+        } else {
+            // ---- x1 = LN11(A1 Wo1^T + bo1 + res): f16 -> staging tile, fp32 -> out32 stream
+            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::false_type{}, std::false_type{});
+            __syncthreads();
+            f16x8 xs[4][2][2];                               // x1 fragments of the wave's 32 tokens
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        xs[kt][ks][j] = *(const f16x8*)(Xst + kt * (BM * 128) + swz128(g1m + j * 16 + frow, ks * 4 + fkg));
+            __syncthreads();                                 // staging tile free: it becomes the q / k / v tiles
+
+            // ---- speaker-axis attention (see spk_fused.hip): 12 weight slices, after each head's v slice
+            // 4 threads per (slot, frame) run the C-slot softmax for 16 of the 64 head dims
+            const int item = tid >> 2, part = tid & 3;
+            const int cq = item / lyG, tq = item - cq * lyG;
+            f16x8 oreg[4][2];                                // this thread's 16 output dims of each head
+            for (int head = 0; head < 4; ++head) {
+                static_for<3>([&](auto SS) __attribute__((always_inline)) {
+                    constexpr int sidx = decltype(SS)::value;          // 0 q, 1 k, 2 v
+                    const int ch = head * 3 + sidx;
+                    const char* Ws = smem + V2_W1 + (ch & 1) * W1_BYTES;
+                    char* S = Xst + sidx * HS_BYTES;
+                    const int wrow = sidx * KD + head * FC;
+                    f32x4 h[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float4 bb = *(const float4*)(p.bin2 + wrow + g1f + i * 16 + fkg * 4);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) h[i][j] = f32x4{bb.x, bb.y, bb.z, bb.w};
+                    }
+                    f16x8 wa[3][2];
+                    auto ld = [&](auto K) __attribute__((always_inline)) {
+                        constexpr int k = decltype(K)::value;
+                        if constexpr (k < 8) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                wa[k % 3][i] = *(const f16x8*)(Ws + (k >> 1) * (FC * 128) + swz128(g1f + i * 16 + frow, (k & 1) * 4 + fkg));
+                        }
+                    };
+                    ld(std::integral_constant<int, 0>{});
+                    ld(std::integral_constant<int, 1>{});
+                    static_for<8>([&](auto K) __attribute__((always_inline)) {
+                        constexpr int k = decltype(K)::value;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[k % 3][i], xs[k >> 1][k & 1][j], h[i][j], 0, 0, 0);
+                        ld(std::integral_constant<int, k + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int fl = g1f + i * 16 + fkg * 4;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f16x4 o;
+                            o[0] = to_f16_sat(h[i][j][0]); o[1] = to_f16_sat(h[i][j][1]);
+                            o[2] = to_f16_sat(h[i][j][2]); o[3] = to_f16_sat(h[i][j][3]);
+                            *(f16x4*)(S + swz128(g1m + j * 16 + frow, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
+                        }
+                    }
+                    __syncthreads();          // tile visible; this slice's buffer is free; slice ch+1 has landed
+                    if (ch + 2 < 12) dma_spk(ch + 2, ch & 1);
+                });
+                // attention of this head: online softmax over the C slots of the frame (fp32)
+                {
+                    const char* Sq = Xst;
+                    const char* Sk = Sq + HS_BYTES;
+                    const char* Sv = Sk + HS_BYTES;
+                    float o[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+                    if (item < rows_g.rows) {
+                        const f16x8 q0 = *(const f16x8*)(Sq + swz128(item, 2 * part));
+                        const f16x8 q1 = *(const f16x8*)(Sq + swz128(item, 2 * part + 1));
+                        float mrun = -INFINITY, lrun = 0.f;
+                        for (int c2 = 0; c2 < p.C; ++c2) {
+                            const int row = c2 * lyG + tq;
+                            const f16x8 k0 = *(const f16x8*)(Sk + swz128(row, 2 * part));
+                            const f16x8 k1 = *(const f16x8*)(Sk + swz128(row, 2 * part + 1));
+                            float d = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)q0[e], (float)k0[e], d);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)q1[e], (float)k1[e], d);
+                            int tt;
+                            tt = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false);
+                            d += __builtin_bit_cast(float, tt);
+                            tt = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false);
+                            d += __builtin_bit_cast(float, tt);
+                            const float sc = d * p.spk_scale;
+                            const float mnew = __builtin_fmaxf(mrun, sc);
+                            const float al = __expf(mrun - mnew), pw = __expf(sc - mnew);
+                            lrun = lrun * al + pw;
+                            mrun = mnew;
+                            const f16x8 v0 = *(const f16x8*)(Sv + swz128(row, 2 * part));
+                            const f16x8 v1 = *(const f16x8*)(Sv + swz128(row, 2 * part + 1));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pw, (float)v0[e], o[e] * al);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[8 + e] = __builtin_fmaf(pw, (float)v1[e], o[8 + e] * al);
+                        }
+                        const float inv = 1.0f / lrun;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[e] *= inv;
+                    }
+                    static_for<4>([&](auto HH) __attribute__((always_inline)) {      // oreg[head] with a static index
+                        if (decltype(HH)::value == head) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { oreg[decltype(HH)::value][0][e] = to_f16_sat(o[e]); oreg[decltype(HH)::value][1][e] = to_f16_sat(o[8 + e]); }
+                        }
+                    });
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // q / k / v tiles are free again
+            }
+            // attention output tile (A operand of the second projection) -> staging region, k-tile = head
+#pragma unroll
+            for (int hd = 0; hd < 4; ++hd) {
+                *(f16x8*)(Xst + hd * (BM * 128) + swz128(item, 2 * part)) = oreg[hd][0];
+                *(f16x8*)(Xst + hd * (BM * 128) + swz128(item, 2 * part + 1)) = oreg[hd][1];
+            }
+            __syncthreads();
+            // ---- x2 = LN21(o Wo2^T + bo2 + x1): x1 is read back from the out32 stream (same thread, same addresses)
+            proj_ln_phase(p.Wo2, p.bo2, p.g21, p.be21, p.eps21, p.out32, std::true_type{}, std::true_type{});
         }
+    }
+    if constexpr (LAYER) {
+        // launder the thread index again: the lane-derived addresses of the phases above must not stay live
+        // (or be spilled and reloaded) inside the register-tight chunk loop below
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; frow = lane & 15; fkg = lane >> 4; drow = lane >> 3; dslot = lane & 7;
+        bofs = g1f + fkg * 4;
+        dma_offsets();
     }
     float4 bcur[2];
     bcur[0] = *(const float4*)(p.b1 + bofs);
@@ -773,15 +998,17 @@ void ffn_fused_kernel(const FfnParams p) {
     }
     __syncthreads();
 
-    ffn_epilogue<EPI, true, true>(p, acc, smem, wave, frow, fkg, m0, g2m, g2n);
+    if constexpr (LAYER) ffn_epilogue<EPI, true, true>(p, acc, smem, wave, frow, fkg, m0, g2m, g2n, rows_g);
+    else ffn_epilogue<EPI, true, true>(p, acc, smem, wave, frow, fkg, m0, g2m, g2n, rows_c);
     }
 }
 
-template <int ACT, int EPI, bool PRE>
+template <int ACT, int EPI, int MODE>
 int launch(const FfnParams& p, hipStream_t stream) {
+    constexpr bool PRE = MODE >= 1;
     static bool attr_done = false;
     static const bool v1 = [] { const char* e = getenv("EEND_FFN_V1"); return e && e[0] == '1'; }();
-    auto kern = (v1 && !PRE) ? ffn_fused_v1_kernel<ACT, EPI> : ffn_fused_kernel<ACT, EPI, PRE>;
+    auto kern = (v1 && !PRE) ? ffn_fused_v1_kernel<ACT, EPI> : ffn_fused_kernel<ACT, EPI, MODE>;
     const int smem_bytes = (v1 && !PRE) ? SMEM_BYTES : V2_SMEM;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
@@ -793,7 +1020,7 @@ int launch(const FfnParams& p, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const int ntiles = (p.M + BM - 1) / BM;
+    const int ntiles = MODE == 2 ? p.B * ((p.Tp + BM / p.C - 1) / (BM / p.C)) : (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3((v1 && !PRE) || ntiles < ncu ? ntiles : ncu), dim3(NT), smem_bytes, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
@@ -806,15 +1033,21 @@ int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stre
         return EEND_EINVAL;
     if (p.A) {                                               // fused attention out-projection + norm1 producer
         if (!p.Wo || !p.bo || !p.g1 || !p.be1 || (p.lda & 7) || epi != FFN_EPI_RES_LN || act != 1) return EEND_EINVAL;
-        return launch<1, FFN_EPI_RES_LN, true>(p, stream);
+        if (p.Win2) {                                        // whole second half of a fusion layer
+            if (!p.bin2 || !p.Wo2 || !p.bo2 || !p.g21 || !p.be21 || !p.res || p.res != p.out32 || p.B <= 0 || p.Tp <= 0 ||
+                p.C < 1 || p.C > 12 || (long)p.B * p.C * p.Tp != p.M)
+                return EEND_EINVAL;
+            return launch<1, FFN_EPI_RES_LN, 2>(p, stream);
+        }
+        return launch<1, FFN_EPI_RES_LN, 1>(p, stream);
     }
     if (!p.X) return EEND_EINVAL;
     if (epi == FFN_EPI_RES_LN) {
-        if (act == 1) return launch<1, FFN_EPI_RES_LN, false>(p, stream);
-        if (act == 2) return launch<2, FFN_EPI_RES_LN, false>(p, stream);
+        if (act == 1) return launch<1, FFN_EPI_RES_LN, 0>(p, stream);
+        if (act == 2) return launch<2, FFN_EPI_RES_LN, 0>(p, stream);
     } else if (epi == FFN_EPI_RES_SCALE_LN16) {
-        if (act == 1) return launch<1, FFN_EPI_RES_SCALE_LN16, false>(p, stream);
-        if (act == 2) return launch<2, FFN_EPI_RES_SCALE_LN16, false>(p, stream);
+        if (act == 1) return launch<1, FFN_EPI_RES_SCALE_LN16, 0>(p, stream);
+        if (act == 2) return launch<2, FFN_EPI_RES_SCALE_LN16, 0>(p, stream);
     }
     return EEND_EINVAL;
 }

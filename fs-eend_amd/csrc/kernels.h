@@ -140,6 +140,16 @@ struct FfnParams {
     const float* be1;
     float eps1;
     int lda;
+    // optional speaker-attention stage between two projection+LN producers (null Win2 = off; needs A):
+    // x1 = LN(A Wo^T + bo + res) [g1, be1]; o = MHA_slots(x1 Win2^T + bin2); X = LN(o Wo2^T + bo2 + x1) [g21, be21]
+    const void* Win2;   // f16 [768][256]
+    const float* bin2;  // [768]
+    const void* Wo2;    // f16 [256][256]
+    const float* bo2;
+    const float* g21;
+    const float* be21;
+    float eps21, spk_scale;
+    int B, C, Tp;       // M = B*C*Tp, row = (b*C + c)*Tp + t
     int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);

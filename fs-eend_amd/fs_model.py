@@ -31,6 +31,11 @@ FUSED_FFN = __import__("os").environ.get("EEND_FFN_FUSED", "1") != "0"
 FUSED_ATTNOUT = __import__("os").environ.get("EEND_ATTNOUT_FUSED", "1") != "0"
 # EEND_SPK_FUSED=0 runs the speaker-axis qkv projection and attention as two launches
 FUSED_SPK = __import__("os").environ.get("EEND_SPK_FUSED", "1") != "0"
+# EEND_TAIL_FUSED=1 runs out-proj+norm11 / speaker attention / out-proj+norm21+FFN as ONE launch
+# (eend_fusion_layer_tail_f16).  Off by default: measured 1.00 ms vs 0.875 ms for the three launches at
+# B=64, C=6, T=500 -- with one 160 KB block per CU every extra phase is exposed latency, and the gathered
+# 126-row tiles need a 7th round on 256 CUs.
+FUSED_TAIL = __import__("os").environ.get("EEND_TAIL_FUSED", "0") == "1"
 
 
 class PositionalEncoding(nn.Module):
@@ -309,6 +314,11 @@ class OnlineTransformerDADiarization(nn.Module):
             ff = ws.ff16[:Md * F].view(Md, F)
             ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
             ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, Tp, scale=ops.LN2)
+            if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
+                ops.fusion_layer_tail(o16, ws.a32, ws.a16, L["out1_w"], L["out1_b"], L["g11"], L["be11"], L["eps11"],
+                                      L["in2_w"], L["in2_b"], L["out2_w"], L["out2_b"], L["g21"], L["be21"], L["eps21"],
+                                      L["w1"], L["b1"], L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], B, C, Tp)
+                continue
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
             if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
                 ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)

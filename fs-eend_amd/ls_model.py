@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, PositionalEncoding, _f16, _f32
+from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, PositionalEncoding, _f16, _f32
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -433,6 +433,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ff = ws.ff16[:Md * F].view(Md, F)
             ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
             ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"])
+            if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
+                ops.fusion_layer_tail(o16, ws.a32, ws.a16, Ld["out1_w"], Ld["out1_b"], Ld["g11"], Ld["be11"], Ld["eps11"],
+                                      Ld["in2_w"], Ld["in2_b"], Ld["out2_w"], Ld["out2_b"], Ld["g21"], Ld["be21"], Ld["eps21"],
+                                      Ld["w1"], Ld["b1"], Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], B, C, Tp)
+                continue
             ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
             if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
                 ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)

@@ -297,6 +297,28 @@ def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, 
                "eend_attnout_ffn_fused_f16")
 
 
+def fusion_layer_tail(a16, stream32, out16, wo1, bo1, g11, be11, eps11, win2, bin2, wo2, bo2, g21, be21, eps21,
+                      w1, b1, w2, b2, g22, be22, eps22, B, C, Tp):
+    """Everything of a fusion (decoder) layer after the time-axis attention core, in one launch:
+    out-proj + norm11, speaker-axis MHA (in-proj, attention), its out-proj + norm21, FFN + norm22.
+    stream32 is updated in place, out16 receives the f16 copy."""
+    L = _lib.load()
+    for n, t in (("a16", a16), ("out16", out16), ("wo1", wo1), ("win2", win2), ("wo2", wo2), ("w1", w1), ("w2", w2)):
+        _chk(t, F16, n)
+    for n, t in (("stream32", stream32), ("bo1", bo1), ("g11", g11), ("be11", be11), ("bin2", bin2), ("bo2", bo2), ("g21", g21),
+                 ("be21", be21), ("b1", b1), ("b2", b2), ("g22", g22), ("be22", be22)):
+        _chk(t, F32, n)
+    M = B * C * Tp
+    Fh = w1.shape[0]
+    if a16.shape != (M, 256) or stream32.shape != (M, 256) or out16.shape != (M, 256) or win2.shape != (768, 256) or \
+            wo1.shape != (256, 256) or wo2.shape != (256, 256) or w1.shape[1] != 256 or w2.shape != (256, Fh):
+        raise _lib.EendHipError("fusion_layer_tail: shape mismatch")
+    _lib.check(L.eend_fusion_layer_tail_f16(_p(a16), a16.stride(0), _p(stream32), _p(out16), _p(wo1), _p(bo1), _p(g11), _p(be11), eps11,
+                                            _p(win2), _p(bin2), _p(wo2), _p(bo2), _p(g21), _p(be21), eps21,
+                                            _p(w1), _p(b1), _p(w2), _p(b2), _p(g22), _p(be22), eps22, B, C, Tp, Fh, _stream()),
+               "eend_fusion_layer_tail_f16")
+
+
 def ffn_fused(x16, w1, b1, w2, b2, res, gamma, beta, out32, out16, act=ACT_RELU, alpha=1.0, eps=1e-5,
               residual_unnormalised=False):
     """out = LN((act(x16 @ w1.T + b1) @ w2.T + b2) * alpha + res); hidden activations stay on chip."""

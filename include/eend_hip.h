@@ -143,6 +143,23 @@ int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const flo
                                const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
                                float* out_f32, void* out_f16, int M, int F, void* stream);
 
+/* The whole row-local tail of a fusion (attractor decoder) layer in ONE launch, after the time-axis
+ * attention / retention core (FS merge_tfm_encoder.py:364-376: out_proj of self_attn1 + norm11, _sa_block2 +
+ * norm21, _ff_block + norm22; LS merge_retnet_layer.py:240-253 likewise with the retention out_proj):
+ *   x1  = LayerNorm11(A1 Wo1^T + bo1 + stream)
+ *   o   = MHA over the C slots of each frame of (x1 Win2^T + bin2)              (H = 4, dh = 64)
+ *   x2  = LayerNorm21(o Wo2^T + bo2 + x1)
+ *   out = LayerNorm22(relu(x2 W1^T + b1) W2^T + b2 + x2)
+ * stream_f32 f32 [B*C*Tp][256] is read (layer input) and overwritten (layer output) in place, out_f16 gets
+ * the f16 copy; A1 f16 [B*C*Tp][lda] is the attention-core output.  Rows are (b*C + c)*Tp + t; 1 <= C <= 12. */
+int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
+                               const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
+                               const void* Win2, const float* bin2,
+                               const void* Wo2, const float* bo2, const float* g21, const float* be21, float eps21,
+                               const void* W1, const float* b1, const void* W2, const float* b2,
+                               const float* g22, const float* be22, float eps22,
+                               int B, int C, int Tp, int F, void* stream);
+
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
  * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */
