@@ -157,6 +157,11 @@ int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void*
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_emb_consistency_f32(const float* emb, const float* labels, const int* lens, float inv_count,
+                             float* partial_ws, float* out, int B, int T, int Tp, int D, int C, void* stream) {
+    return eend_launch_emb_consistency(emb, labels, lens, inv_count, partial_ws, out, B, T, Tp, D, C, (hipStream_t)stream);
+}
+
 int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,
                             void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim, void* stream) {
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;

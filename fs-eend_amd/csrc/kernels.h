@@ -73,6 +73,9 @@ struct SpkFusedParams {
 };
 int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream);
 
+int eend_launch_emb_consistency(const float* emb, const float* tgt, const int* lens, float inv_count, float* partial_ws, float* out,
+                                int B, int T, int Tp, int D, int C, hipStream_t stream);
+
 struct RetParams {
     const void* Q;    // f16 [nseq][H][Tp][64]
     const void* K;    // f16 [nseq][H][Tp][64]   (already scaled by dk^-0.5)

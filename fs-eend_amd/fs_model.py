@@ -364,16 +364,9 @@ class OnlineTransformerDADiarization(nn.Module):
         logits, emb, attr, T, Tp = self._run(src, ilens, C)
         dev = logits.device
         # embedding-consistency loss (model :46-57); (B,T,T) cosine maps, training-time diagnostic
-        e = emb[:, :max(int(l) for l in ilens)]
-        attn_map = e @ e.transpose(-1, -2)
-        n = torch.linalg.vector_norm(e, dim=-1, keepdim=True)
-        attn_map = attn_map / (n @ n.transpose(-1, -2) + 1e-6)
         tgt_pad = [nn.functional.pad(t.to(dev, torch.float32), (0, C - t.shape[1])) for t in tgt]
-        tgt_pad = nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True)
-        label_map = tgt_pad @ tgt_pad.transpose(-1, -2)
-        tn = torch.linalg.vector_norm(tgt_pad, dim=-1, keepdim=True)
-        label_map = label_map / (tn @ tn.transpose(-1, -2) + 1e-6)
-        emb_consis_loss = nn.functional.mse_loss(attn_map, label_map)
+        tgt_pad = nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True).contiguous()
+        emb_consis_loss = ops.emb_consistency(emb, tgt_pad, tgt_pad.shape[1])
         output = [logits[b, :l, :n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
         embs = [emb[b, :l] for b, l in enumerate(ilens)]
         attractors = [attr[b, :l, 1:n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]

@@ -25,6 +25,7 @@ PROTOTYPES = {
     "eend_spk_qkv_attn_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_fusion_layer_tail_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f,
                                    _i, _i, _i, _i, _vp],
+    "eend_emb_consistency_f32": [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -477,18 +477,12 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         logits, emb, attr, T, Tp = self._run(src, ilens, C)
         dev = logits.device
         seq_len = max(int(l) for l in ilens)
-        len_mask = nn.utils.rnn.pad_sequence([torch.ones(int(l), device=dev) for l in ilens], batch_first=True)[..., None]
-        e = emb[:, :seq_len] * len_mask                                        # :100
-        attn_map = e @ e.transpose(-1, -2)
-        n = torch.linalg.vector_norm(e, dim=-1, keepdim=True)
-        attn_map = attn_map / (n @ n.transpose(-1, -2) + 1e-6)
         tgt_pad = [nn.functional.pad(t.to(dev, torch.float32), (0, C - t.shape[1])) for t in tgt]
-        tgt_pad = nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True)
-        label_map = tgt_pad @ tgt_pad.transpose(-1, -2)
-        tn = torch.linalg.vector_norm(tgt_pad, dim=-1, keepdim=True)
-        label_map = label_map / (tn @ tn.transpose(-1, -2) + 1e-6)
-        loss = nn.functional.mse_loss(attn_map, label_map, reduction="sum") / sum(int(l) * int(l) for l in ilens)
+        tgt_pad = nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True).contiguous()
+        lens = torch.tensor([int(l) for l in ilens], dtype=torch.int32, device=dev)
+        loss = ops.emb_consistency(emb, tgt_pad, seq_len, lens=lens,              # length-masked embeddings (:100), sum / sum(len^2) (:113)
+                                   inv_count=1.0 / sum(int(l) * int(l) for l in ilens))
         output = [logits[b, :l, :n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
-        embs = [e[b, :l].clone() for b, l in enumerate(ilens)]
+        embs = [emb[b, :l].clone() for b, l in enumerate(ilens)]
         attractors = [attr[b, :l, 1:n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
         return output, loss, embs, attractors

@@ -218,6 +218,25 @@ def spk_attn(qkv16, o16, B, C, Tp, H):
                "eend_spk_attn_f16")
 
 
+def emb_consistency(emb32, labels, T, lens=None, inv_count=0.0):
+    """MSE between the cosine-similarity maps of the embeddings and of the labels (FS model :46-57).
+    emb32 f32 (B, Tp, D) (frames >= T ignored), labels f32 (B, T, C) zero-padded -> 0-dim f32 tensor.
+    lens (int32 device tensor, B) zeroes the embeddings beyond each length and inv_count overrides the
+    1/(B*T*T) normalisation (LS model :92-113)."""
+    L = _lib.load()
+    _chk(emb32, F32, "emb32"); _chk(labels, F32, "labels"); _chk(lens, torch.int32, "lens")
+    B, Tp, D = emb32.shape
+    if labels.shape[0] != B or labels.shape[1] != T or Tp < T:
+        raise _lib.EendHipError("emb_consistency: shape mismatch")
+    nt = (T + 63) // 64
+    ws = torch.empty(B * nt * nt, dtype=F32, device=emb32.device)
+    out = torch.empty(1, dtype=F32, device=emb32.device)
+    _lib.check(L.eend_emb_consistency_f32(_p(emb32), _p(labels), _p(lens) if lens is not None else None, float(inv_count),
+                                          _p(ws), _p(out), B, T, Tp, D, labels.shape[2], _stream()),
+               "eend_emb_consistency_f32")
+    return out[0]
+
+
 def head_l2dot(emb32, attr32, attr_out, logits, B, T, Tp, C, D):
     L = _lib.load()
     _chk(emb32, F32, "emb32"); _chk(attr32, F32, "attr32"); _chk(attr_out, F32, "attr_out"); _chk(logits, F32, "logits")

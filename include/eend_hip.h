@@ -160,6 +160,15 @@ int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void*
                                const float* g22, const float* be22, float eps22,
                                int B, int C, int Tp, int F, void* stream);
 
+/* Embedding-consistency loss (FS model :46-57; LS model :92-113): mean over (b,i,j) of
+ * (cos(emb_i, emb_j) - cos(label_i, label_j))^2 with the reference's "+1e-6" denominators, without
+ * materialising the (B,T,T) maps.  emb f32 [B][Tp][D] (rows >= T ignored), labels f32 [B][T][C] zero-padded
+ * (C <= 16), partial_ws f32 [B * ceil(T/64)^2] scratch, out f32 [1].  lens (device int [B]) may be null; when
+ * given, embeddings of frames >= lens[b] count as zero (the LS model's length mask, :100).  inv_count > 0
+ * replaces the default 1/(B*T*T) normalisation (LS: 1/sum(len^2)).  Exact-fp32 MFMA; deterministic. */
+int eend_emb_consistency_f32(const float* emb, const float* labels, const int* lens, float inv_count,
+                             float* partial_ws, float* out, int B, int T, int Tp, int D, int C, void* stream);
+
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
  * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */

@@ -428,3 +428,33 @@ def test_spk_qkv_attn_fused(hip_lib, dev, B, C, Tp):
     s = torch.einsum("bcthd,bethd->bthce", q, k) * 0.125
     want = torch.einsum("bthce,bethd->bcthd", s.softmax(-1), v).reshape(M, 256)
     assert (o.float() - want).abs().max().item() < 3e-3
+
+
+@pytest.mark.parametrize("B,T,Tp,C,masked", [(2, 130, 192, 4, False), (3, 64, 64, 3, True), (1, 500, 512, 6, False), (2, 77, 128, 10, True)])
+def test_emb_consistency_loss(hip_lib, dev, B, T, Tp, C, masked):
+    """HIP embedding-consistency loss vs the reference formula in torch fp32 (FS model :46-57; LS :92-113)."""
+    from fs_eend_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    emb = torch.randn(B, Tp, 256, generator=g).to(dev)
+    emb = emb / emb.norm(dim=-1, keepdim=True)
+    lab = (torch.rand(B, T, C, generator=g) > 0.6).float().to(dev)
+    lens = [T - 7 * b for b in range(B)]
+    e = emb[:, :T].clone()
+    if masked:
+        for b, l in enumerate(lens):
+            e[b, l:] = 0
+            lab[b, l:] = 0
+    a = e @ e.transpose(-1, -2)
+    n = e.norm(dim=-1, keepdim=True)
+    a = a / (n @ n.transpose(-1, -2) + 1e-6)
+    lm = lab @ lab.transpose(-1, -2)
+    tn = lab.norm(dim=-1, keepdim=True)
+    lm = lm / (tn @ tn.transpose(-1, -2) + 1e-6)
+    if masked:
+        want = torch.nn.functional.mse_loss(a, lm, reduction="sum") / sum(l * l for l in lens)
+        got = ops.emb_consistency(emb, lab.contiguous(), T, lens=torch.tensor(lens, dtype=torch.int32, device=dev),
+                                  inv_count=1.0 / sum(l * l for l in lens))
+    else:
+        want = torch.nn.functional.mse_loss(a, lm)
+        got = ops.emb_consistency(emb, lab.contiguous(), T)
+    assert abs(got.item() - want.item()) < 1e-6 + 1e-5 * abs(want.item()), (got.item(), want.item())
