@@ -197,6 +197,26 @@ def extras(dev):
     res["ls_eend_batch"] = dict(workload=f"LS-EEND model.test, {B} x T={T} (4 chunks of 500), max_nspks={C}, eager launches",
                                 frames_per_s=B * T / dt, ms_per_step=dt * 1e3, rtf=dt / (B * T * 0.1))
 
+    # BASELINE config 5: one hour of 8 kHz audio (36 000 frames of 100 ms), 8 speakers (+2 slots), processed as
+    # 72 chunks of 500 with the retention state carried across chunks -- one model.test call
+    try:
+        torch.cuda.reset_peak_memory_stats(dev)
+        Tl = 36000
+        long_src = [(torch.randn(Tl, 345, generator=g) * 2 - 3).to(dev)]
+        ls.test(long_src, [Tl], C)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            ls.test(long_src, [Tl], C)
+        torch.cuda.synchronize()
+        dl = (time.perf_counter() - t0) / 2
+        res["ls_eend_longform"] = dict(workload=f"LS-EEND model.test, 1 x T={Tl} (1 h of audio, 72 chunks of 500, state carried), "
+                                                f"max_nspks={C}", seconds=dl, rtf=dl / (Tl * 0.1),
+                                       peak_hbm_bytes=int(torch.cuda.max_memory_allocated(dev)))
+        del long_src
+    except Exception as ex:                      # never let a side measurement take the headline number down
+        res["ls_eend_longform"] = dict(error=f"{type(ex).__name__}: {ex}")
+
     # LS-EEND streaming, 8 speakers + 2 slots, O(1) state (LS-EEND/streaming_infer_dia.py:52-97)
     scnn = StreamingConv1d(256, 256, kernel_size=19).to(dev).eval()
     scnn.conv.load_state_dict(ls.cnn.state_dict())

@@ -75,3 +75,20 @@ def test_ls_batch_independence_and_causality(hip_lib, dev):
     s2[0][t0:] = s2[0][t0:] * -0.5 + 1.0
     out2 = m.test(s2, [T], 4)
     assert torch.equal(out2[0][0][: t0 - 9], m.test(src[:1], [T], 4)[0][0][: t0 - 9])
+
+
+def test_ls_long_sequence_vs_oracle(hip_lib, dev):
+    """Many carried chunks (the long-form streaming mechanism, BASELINE config 5): T = 5000 = 10 chunks of 500
+    with the retention state scanned across all of them, against the fp32 oracle."""
+    meta, _ = FX.load_case("ls_T500_c3")
+    m = build_ls_mirror(meta)
+    T = 5000
+    src = FX.make_src([T], meta["in_size"], 9876)
+    with torch.no_grad():
+        want = R.ls_test(src, [T], m.state_dict(), max_nspks=4, **ls_kwargs(meta))
+    got = m.to(dev).test([s.to(dev) for s in src], [T], max_nspks=4)
+    err = max_abs(got[0][0], want[0][0])
+    tail = max_abs(got[0][0][-500:], want[0][0][-500:])
+    print(f"T=5000: max |logits - oracle| = {err:.2e} (last chunk {tail:.2e})")
+    assert torch.isfinite(got[0][0]).all()
+    assert err < LOGIT_TOL
