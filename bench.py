@@ -55,17 +55,17 @@ def pmc_traffic(kernel, shape):
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    tags = {("fusion_layer_tail", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0, 2>(FfnParams)", "131072"),
-            ("attnout_ffn_fused", (196608, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #hi", "131072"),
-            ("attnout_ffn_fused", (32768, 2048, 256)): ("ffn_fused_kernel<1, 0, true>(FfnParams) #lo", "131072"),
-            ("attn_causal", (64, 4)): ("attn_causal_full_kernel", "131072"),
-            ("attn_causal", (384, 4)): ("attn_causal_full_kernel", "786432"),
-            ("linear_res_ln", (196608, 256, 256)): ("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4", "786432")}
+    tags = {("fusion_layer_tail", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 2>(FfnParams)",), "131072"),
+            ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
+            ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
+            ("attn_causal", (64, 4)): (("attn_causal_full_kernel",), "131072"),
+            ("attn_causal", (384, 4)): (("attn_causal_full_kernel",), "786432"),
+            ("linear_res_ln", (196608, 256, 256)): (("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4",), "786432")}
     tag = tags.get((kernel, tuple(shape)))
     if tag is None or not os.path.exists(path):
         return None
     for k, v in json.load(open(path))["kernels"].items():
-        if tag[0] in k and k.endswith("grid=" + tag[1]):
+        if any(t in k for t in tag[0]) and k.endswith("grid=" + tag[1]):
             return v["hbm_bytes"]
     return None
 
