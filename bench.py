@@ -217,6 +217,51 @@ def extras(dev):
     except Exception as ex:                      # never let a side measurement take the headline number down
         res["ls_eend_longform"] = dict(error=f"{type(ex).__name__}: {ex}")
 
+    # output-side post-processing: threshold + median-11 + segments of a 1-hour activity map,
+    # and the DER counters of one evaluation batch, device kernels only (events), next to the reference's CPU path
+    try:
+        from fs_eend_amd import postproc
+        Tl, S = 36000, 8
+        xx = torch.randn(Tl + 40, S, generator=g)                # slowly varying tracks: realistic segment structure
+        xx = torch.nn.functional.avg_pool1d(xx.t().unsqueeze(0), 41, 1).squeeze(0).t() * 6
+        prob = torch.sigmoid(xx + 0.3 * torch.randn(Tl, S, generator=g)).to(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        act = postproc.activity(prob)
+        postproc.segments(act)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(20):
+            act = postproc.activity(prob)
+        ev1.record()
+        torch.cuda.synchronize()
+        t_act = ev0.elapsed_time(ev1) / 20 * 1e-3
+        t0 = time.perf_counter()
+        for _ in range(5):
+            postproc.make_rttm("rec", prob)
+        torch.cuda.synchronize()
+        t_rttm = (time.perf_counter() - t0) / 5
+        from scipy.signal import medfilt
+        pc = prob.cpu()
+        t0 = time.perf_counter()
+        medfilt(torch.where(pc > 0.5, 1, 0), (11, 1))
+        t_cpu = time.perf_counter() - t0
+        lg = [torch.randn(500, 6, generator=g).to(dev) for _ in range(64)]
+        lb = [(torch.rand(500, 6, generator=g) < 0.3).float().to(dev) for _ in range(64)]
+        postproc.der_counters(lg[0], lb[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in zip(lg, lb):
+            postproc.der_counters(a, b)
+        torch.cuda.synchronize()
+        t_der = time.perf_counter() - t0
+        res["postprocessing"] = dict(
+            workload=f"1-hour activity map T={Tl} x {S} speakers: threshold + median-11 (kernel), full make_rttm (kernels + host "
+                     f"formatting); DER counters of 64 x (500 x 6) (64 launches, no host sync)",
+            activity_kernel_us=t_act * 1e6, activity_GBps=(Tl * S * 5) / t_act / 1e9, make_rttm_ms=t_rttm * 1e3,
+            reference_cpu_threshold_medfilt_ms=t_cpu * 1e3, der_counters_64utt_ms=t_der * 1e3)
+    except Exception as ex:
+        res["postprocessing"] = dict(error=f"{type(ex).__name__}: {ex}")
+
     # LS-EEND streaming, 8 speakers + 2 slots, O(1) state (LS-EEND/streaming_infer_dia.py:52-97)
     scnn = StreamingConv1d(256, 256, kernel_size=19).to(dev).eval()
     scnn.conv.load_state_dict(ls.cnn.state_dict())

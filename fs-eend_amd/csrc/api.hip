@@ -162,6 +162,21 @@ int eend_emb_consistency_f32(const float* emb, const float* labels, const int* l
     return eend_launch_emb_consistency(emb, labels, lens, inv_count, partial_ws, out, B, T, Tp, D, C, (hipStream_t)stream);
 }
 
+int eend_activity_median_u8(const float* pred, int ld, int T, int S, float threshold, int median,
+                            unsigned char* act, void* stream) {
+    return eend_launch_activity_median(pred, ld, T, S, threshold, median, act, (hipStream_t)stream);
+}
+
+int eend_activity_segments_i32(const unsigned char* act, int T, int S, int* changes, int* counts, int cap,
+                               void* stream) {
+    return eend_launch_segments(act, T, S, changes, counts, cap, (hipStream_t)stream);
+}
+
+int eend_der_counters_u64(const float* pred, int ldp, const float* label, int ldl, int T, int C, int label_delay,
+                          unsigned long long* counters, void* stream) {
+    return eend_launch_der_counters(pred, ldp, label, ldl, T, C, label_delay, counters, (hipStream_t)stream);
+}
+
 int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,
                             void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim, void* stream) {
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;

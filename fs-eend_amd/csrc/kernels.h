@@ -76,6 +76,11 @@ int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream);
 int eend_launch_emb_consistency(const float* emb, const float* tgt, const int* lens, float inv_count, float* partial_ws, float* out,
                                 int B, int T, int Tp, int D, int C, hipStream_t stream);
 
+int eend_launch_activity_median(const float* pred, int ld, int T, int S, float thr, int k, unsigned char* out, hipStream_t stream);
+int eend_launch_segments(const unsigned char* act, int T, int S, int* changes, int* counts, int cap, hipStream_t stream);
+int eend_launch_der_counters(const float* pred, int ldp, const float* label, int ldl, int T, int C, int delay,
+                             unsigned long long* counters, hipStream_t stream);
+
 struct RetParams {
     const void* Q;    // f16 [nseq][H][Tp][64]
     const void* K;    // f16 [nseq][H][Tp][64]   (already scaled by dk^-0.5)

@@ -26,6 +26,9 @@ PROTOTYPES = {
     "eend_fusion_layer_tail_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f,
                                    _i, _i, _i, _i, _vp],
     "eend_emb_consistency_f32": [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "eend_activity_median_u8": [_vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "eend_activity_segments_i32": [_vp, _i, _i, _vp, _vp, _i, _vp],
+    "eend_der_counters_u64": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -169,6 +169,26 @@ int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void*
 int eend_emb_consistency_f32(const float* emb, const float* labels, const int* lens, float inv_count,
                              float* partial_ws, float* out, int B, int T, int Tp, int D, int C, void* stream);
 
+/* ---- output-side post-processing (FS-EEND/train/utils/make_rttm.py:10-28, train/utils/loss.py:198-236;
+ * the LS-EEND copies are identical).  Bit exact against the reference.  ---- */
+
+/* pred f32 [T][ld] (S <= ld columns used; probabilities) -> act u8 [T][S]: (pred > threshold), then the
+ * zero-padded median of `median` (odd) frames along time, i.e. scipy.signal.medfilt(x, (median, 1)). */
+int eend_activity_median_u8(const float* pred, int ld, int T, int S, float threshold, int median,
+                            unsigned char* act, void* stream);
+
+/* act u8 [T][S] -> per speaker the increasing frame indices (0..T) at which the zero-padded track changes:
+ * changes i32 [S][cap] (even entries = segment starts, odd = ends; entries beyond cap are dropped),
+ * counts i32 [S] (number found, may exceed cap). */
+int eend_activity_segments_i32(const unsigned char* act, int T, int S, int* changes, int* counts, int cap,
+                               void* stream);
+
+/* Frame-level DER counters of pre-activations pred f32 [T][ldp] against 0/1 labels f32 [T][ldl], C columns,
+ * label_delay as in the reference: counters u64 [8] = speech_scored, speech_miss, speech_falarm,
+ * speaker_scored, speaker_miss, speaker_falarm, speaker_error, #(label == decision).  Zeroed by the call. */
+int eend_der_counters_u64(const float* pred, int ldp, const float* label, int ldl, int T, int C, int label_delay,
+                          unsigned long long* counters, void* stream);
+
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
  * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */
