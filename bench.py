@@ -262,6 +262,25 @@ def extras(dev):
     except Exception as ex:
         res["postprocessing"] = dict(error=f"{type(ex).__name__}: {ex}")
 
+    # feature front-end: one hour of 8 kHz audio -> (36000, 345) log-mel features
+    try:
+        from fs_eend_amd import feature
+        wav = (torch.randn(3600 * 8000, generator=g) * 0.05).to(dev)
+        feature.extract_fbank_wave(wav, input_transform="logmel23_cummn")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ft = feature.extract_fbank_wave(wav, input_transform="logmel23_cummn")
+        torch.cuda.synchronize()
+        tf_ = (time.perf_counter() - t0) / 5
+        byt = wav.numel() * 4 + 2 * 360000 * 23 * 4 * 2 + ft.numel() * 4       # wave in, log-mel out/in (x2: normalise), features out
+        res["feature_frontend"] = dict(workload="1 h of 8 kHz audio: STFT(200/256/80) -> 23 log-mel -> cumulative-mean norm -> +-7 splice "
+                                                "-> /10 subsample, 3 launches", seconds=tf_, rtf=tf_ / 3600.0, out_shape=list(ft.shape),
+                                       algorithmic_GBps=byt / tf_ / 1e9)
+        del wav, ft
+    except Exception as ex:
+        res["feature_frontend"] = dict(error=f"{type(ex).__name__}: {ex}")
+
     # LS-EEND streaming, 8 speakers + 2 slots, O(1) state (LS-EEND/streaming_infer_dia.py:52-97)
     scnn = StreamingConv1d(256, 256, kernel_size=19).to(dev).eval()
     scnn.conv.load_state_dict(ls.cnn.state_dict())

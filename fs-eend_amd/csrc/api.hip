@@ -177,6 +177,19 @@ int eend_der_counters_u64(const float* pred, int ldp, const float* label, int ld
     return eend_launch_der_counters(pred, ldp, label, ldl, T, C, label_delay, counters, (hipStream_t)stream);
 }
 
+int eend_stft_logmel23_f32(const float* y, long len, long first, int n_frames, const float* dft, const float* melT,
+                           float* out, void* stream) {
+    return eend_launch_stft_logmel(y, len, first, n_frames, dft, melT, out, (hipStream_t)stream);
+}
+
+int eend_feature_meannorm_f32(const float* Y, float* out, int T, int F, int mode, void* stream) {
+    return eend_launch_colnorm(Y, out, T, F, mode, (hipStream_t)stream);
+}
+
+int eend_splice_subsample_f32(const float* Y, int T, int F, int ctx, int sub, float* out, void* stream) {
+    return eend_launch_splice_subsample(Y, T, F, ctx, sub, out, (hipStream_t)stream);
+}
+
 int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,
                             void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim, void* stream) {
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;

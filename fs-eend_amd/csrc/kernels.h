@@ -81,6 +81,11 @@ int eend_launch_segments(const unsigned char* act, int T, int S, int* changes, i
 int eend_launch_der_counters(const float* pred, int ldp, const float* label, int ldl, int T, int C, int delay,
                              unsigned long long* counters, hipStream_t stream);
 
+int eend_launch_stft_logmel(const float* y, long len, long first, int n_frames, const float* dft, const float* melT, float* out,
+                            hipStream_t stream);
+int eend_launch_colnorm(const float* Y, float* out, int T, int F, int mode, hipStream_t stream);
+int eend_launch_splice_subsample(const float* Y, int T, int F, int ctx, int sub, float* out, hipStream_t stream);
+
 struct RetParams {
     const void* Q;    // f16 [nseq][H][Tp][64]
     const void* K;    // f16 [nseq][H][Tp][64]   (already scaled by dk^-0.5)

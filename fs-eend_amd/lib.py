@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libeend_hip.so")
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_l = ctypes.c_long
 
 # name -> argtypes, exactly the prototypes of include/eend_hip.h
 PROTOTYPES = {
@@ -29,6 +30,9 @@ PROTOTYPES = {
     "eend_activity_median_u8": [_vp, _i, _i, _i, _f, _i, _vp, _vp],
     "eend_activity_segments_i32": [_vp, _i, _i, _vp, _vp, _i, _vp],
     "eend_der_counters_u64": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp],
+    "eend_stft_logmel23_f32": [_vp, _l, _l, _i, _vp, _vp, _vp, _vp],
+    "eend_feature_meannorm_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "eend_splice_subsample_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -189,6 +189,27 @@ int eend_activity_segments_i32(const unsigned char* act, int T, int S, int* chan
 int eend_der_counters_u64(const float* pred, int ldp, const float* label, int ldl, int T, int C, int label_delay,
                           unsigned long long* counters, void* stream);
 
+/* ---- feature front-end ({LS,FS}-EEND/datasets/feature.py: stft :166-191, transform :43-131, splice :141-163,
+ * subsample :133-138, extract_fbank :324-336); fp32 throughout.  ---- */
+
+/* STFT (Hann window of 200 samples zero-padded to n_fft = 256, hop 80) -> power -> 23 mel bands -> log10(max(.,1e-10)).
+ * Frame t uses samples y[first + 80 t + k], k = 0..199 (the non-zero window taps), zero outside [0, len):
+ * first = -100 reproduces librosa.stft(center=True, pad_mode="constant"); a host that pre-pads the signal
+ * itself (e.g. reflect) passes the padded buffer and first = 28.  dft f32 [200][288]: windowed DFT table,
+ * row k = w[k] * cos(2 pi (k+28) n / 256) in column n (n <= 128) and -w[k] * sin(..) in column 144 + n, zeros
+ * elsewhere; melT f32 [132][32]: mel filterbank transposed (rows = bins, 129 used), zero padded.
+ * out f32 [n_frames][23]. */
+int eend_stft_logmel23_f32(const float* y, long len, long first, int n_frames, const float* dft, const float* melT,
+                           float* out, void* stream);
+
+/* Column-mean normalisation of Y f32 [T][F] into out: mode 1 = subtract the mean over all frames
+ * (logmel23_mn), mode 2 = subtract the running mean of frames 0..t (logmel23_cummn).  fp64 running sums. */
+int eend_feature_meannorm_f32(const float* Y, float* out, int T, int F, int mode, void* stream);
+
+/* out f32 [ceil(T/sub)][F (2 ctx + 1)]: row j = frames j sub - ctx .. j sub + ctx of Y f32 [T][F] side by side,
+ * zero outside [0, T) (splice + subsample). */
+int eend_splice_subsample_f32(const float* Y, int T, int F, int ctx, int sub, float* out, void* stream);
+
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
  * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */
