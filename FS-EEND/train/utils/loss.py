@@ -1,5 +1,5 @@
-"""Drop-in import path for the frame-level DER report (`train/utils/loss.py`: calc_diarization_error,
-report_diarization_error).  The training losses of that module (PIT) are not part of this build."""
+"""Drop-in import path for `train/utils/loss.py`: the frame-level DER report and the permutation-invariant
+label assignment (values only -- the training losses are not differentiable in this build)."""
 import os
 import sys
 
@@ -7,3 +7,4 @@ _ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 from fs_eend_amd.postproc import calc_diarization_error, report_diarization_error  # noqa: E402,F401
+from fs_eend_amd.pit import batch_pit_n_speaker_loss, pad_labels, pad_preds, pit_loss_multispk  # noqa: E402,F401

@@ -262,6 +262,22 @@ def extras(dev):
     except Exception as ex:
         res["postprocessing"] = dict(error=f"{type(ex).__name__}: {ex}")
 
+    # PIT label assignment: training-batch sized, 64 utterances x 500 frames x 4 speakers
+    try:
+        from fs_eend_amd import pit
+        yl = [torch.randn(500, 4, generator=g).to(dev) for _ in range(64)]
+        tl = [(torch.rand(500, 4, generator=g) < 0.4).float().to(dev) for _ in range(64)]
+        pit.batch_pit_n_speaker_loss(yl, tl, [4] * 64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            pit.batch_pit_n_speaker_loss(yl, tl, [4] * 64)
+        torch.cuda.synchronize()
+        res["pit_assignment"] = dict(workload="batch_pit_n_speaker_loss, 64 x (500 x 4): cost matrices + assignment + permuted labels, "
+                                              "no host round trip for the assignment", ms=(time.perf_counter() - t0) / 10 * 1e3)
+    except Exception as ex:
+        res["pit_assignment"] = dict(error=f"{type(ex).__name__}: {ex}")
+
     # feature front-end: one hour of 8 kHz audio -> (36000, 345) log-mel features
     try:
         from fs_eend_amd import feature

@@ -190,6 +190,14 @@ int eend_splice_subsample_f32(const float* Y, int T, int F, int ctx, int sub, fl
     return eend_launch_splice_subsample(Y, T, F, ctx, sub, out, (hipStream_t)stream);
 }
 
+int eend_pit_cost_f64(const float* y, const float* labels, int B, int T, int C, double* cost, void* stream) {
+    return eend_launch_pit_cost(y, labels, B, T, C, cost, (hipStream_t)stream);
+}
+
+int eend_pit_assign_i32(const double* cost, const int* nspk, int B, int C, int* perm, double* loss, void* stream) {
+    return eend_launch_pit_assign(cost, nspk, B, C, perm, loss, (hipStream_t)stream);
+}
+
 int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, const float* bias, void* Q, void* K,
                             void* Kt, void* Vt, void* G, int nseq, int Tp, int H, int dh, int Kdim, void* stream) {
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;

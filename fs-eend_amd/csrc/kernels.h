@@ -86,6 +86,9 @@ int eend_launch_stft_logmel(const float* y, long len, long first, int n_frames, 
 int eend_launch_colnorm(const float* Y, float* out, int T, int F, int mode, hipStream_t stream);
 int eend_launch_splice_subsample(const float* Y, int T, int F, int ctx, int sub, float* out, hipStream_t stream);
 
+int eend_launch_pit_cost(const float* y, const float* lab, int B, int T, int C, double* cost, hipStream_t stream);
+int eend_launch_pit_assign(const double* cost, const int* nspk, int B, int C, int* perm, double* loss, hipStream_t stream);
+
 struct RetParams {
     const void* Q;    // f16 [nseq][H][Tp][64]
     const void* K;    // f16 [nseq][H][Tp][64]   (already scaled by dk^-0.5)

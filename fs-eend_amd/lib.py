@@ -33,6 +33,8 @@ PROTOTYPES = {
     "eend_stft_logmel23_f32": [_vp, _l, _l, _i, _vp, _vp, _vp, _vp],
     "eend_feature_meannorm_f32": [_vp, _vp, _i, _i, _i, _vp],
     "eend_splice_subsample_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "eend_pit_cost_f64": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "eend_pit_assign_i32": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -1,0 +1,84 @@
+"""Permutation-invariant label assignment on the device (csrc/pit.hip; no CPU fallback):
+
+    batch_pit_n_speaker_loss   FS-EEND/train/utils/loss.py:257-327 (LS-EEND train/utils/loss.py:276-348)
+    pit_loss_multispk          LS-EEND/train/utils/loss.py:350-379
+    pad_labels / pad_preds     LS-EEND/train/utils/loss.py:47-71
+
+Same names, arguments and return structure as the reference.  Values only: like the rest of this build the
+loss is not differentiable (training backward is not implemented).  Neither function leaves the GPU for the
+assignment (the reference's pit_loss_multispk copies every cost matrix to the host for scipy).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import lib as _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _assign(ys, ts, n_speakers_list):
+    L = _lib.load()
+    if not ys or not all(t.is_cuda for t in list(ys) + list(ts)):
+        raise _lib.EendHipError("pit: expected GPU tensors (the HIP path has no CPU fallback)")
+    y = nn.utils.rnn.pad_sequence([t.to(torch.float32) for t in ys], padding_value=-1, batch_first=True).contiguous()
+    lab = nn.utils.rnn.pad_sequence([t.to(torch.float32) for t in ts], padding_value=-1, batch_first=True).contiguous()
+    B, T, C = y.shape
+    if lab.shape != y.shape:
+        raise _lib.EendHipError("pit: logits and labels must have the same (padded) shape")
+    dev = y.device
+    cost = torch.empty(B, C, C, dtype=torch.float64, device=dev)
+    perm = torch.empty(B, C, dtype=torch.int32, device=dev)
+    loss = torch.empty(B, dtype=torch.float64, device=dev)
+    nspk = torch.tensor([int(n) for n in n_speakers_list], dtype=torch.int32, device=dev)
+    _lib.check(L.eend_pit_cost_f64(y.data_ptr(), lab.data_ptr(), B, T, C, cost.data_ptr(), _stream()), "eend_pit_cost_f64")
+    _lib.check(L.eend_pit_assign_i32(cost.data_ptr(), nspk.data_ptr(), B, C, perm.data_ptr(), loss.data_ptr(), _stream()),
+               "eend_pit_assign_i32")
+    return perm.long(), loss
+
+
+def batch_pit_n_speaker_loss(ys, ts, n_speakers_list):
+    """-> (mean BCE of the best permutation per utterance over the batch, permuted labels)."""
+    perm, loss = _assign(ys, ts, n_speakers_list)
+    n_frames = sum(t.shape[0] for t in ts)
+    min_loss = (loss.sum() / n_frames).to(torch.float32)
+    labels_perm = [t[:, perm[b]][:, :n] for b, (t, n) in enumerate(zip(ts, n_speakers_list))]
+    return min_loss, labels_perm
+
+
+def pit_loss_multispk(logits, target, n_speakers, detach_attractor_loss=False):
+    """target: (B, T, C) padded tensor (as the reference's trainer passes it) or a list of (T_i, C) tensors."""
+    if isinstance(target, torch.Tensor):
+        clip = [l.shape[0] for l in logits]
+        tl = [target[i, :clip[i]] for i in range(target.shape[0])]
+    else:
+        tl = list(target)
+    if detach_attractor_loss:
+        tl = [t.clone() for t in tl]
+        for t, n in zip(tl, n_speakers):
+            t[:, int(n):] = -1
+    perm, _ = _assign(logits, tl, [int(n) for n in n_speakers])
+    return [t[:, perm[b]][: logits[b].shape[0], : int(n)] for b, (t, n) in enumerate(zip(tl, n_speakers))]
+
+
+def pad_labels(ts, out_size):
+    for i, t in enumerate(ts):
+        if t.shape[1] < out_size:
+            ts[i] = F.pad(t, (0, out_size - t.shape[1], 0, 0), mode="constant", value=0.)
+        elif t.shape[1] > out_size:
+            raise ValueError
+    return ts
+
+
+def pad_preds(ys, out_size):
+    out = []
+    for y in ys:
+        if y.shape[1] < out_size:
+            out.append(torch.cat([y, torch.zeros((y.shape[0], out_size - y.shape[1]), dtype=y.dtype, device=y.device)], dim=1))
+        elif y.shape[1] > out_size:
+            raise ValueError
+        else:
+            out.append(y)
+    return out

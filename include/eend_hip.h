@@ -210,6 +210,19 @@ int eend_feature_meannorm_f32(const float* Y, float* out, int T, int F, int mode
  * zero outside [0, T) (splice + subsample). */
 int eend_splice_subsample_f32(const float* Y, int T, int F, int ctx, int sub, float* out, void* stream);
 
+/* ---- permutation-invariant label assignment (FS-EEND/train/utils/loss.py:257-327 batch_pit_n_speaker_loss;
+ * LS-EEND/train/utils/loss.py:350-379 pit_loss_multispk) ---- */
+
+/* cost f64 [B][C][C]: cost[b][i][j] = sum_t BCEwithLogits(y[b][t][i], labels[b][t][j]) over all T frames of
+ * the padded batch (the reference pads both logits and labels with -1, pad_sequence); y, labels f32 [B][T][C],
+ * C <= 16.  batch_pit's losses[b][i][s] is cost[b][i][(i+s) % C]; pit_loss_multispk's cost_mxs is cost itself. */
+int eend_pit_cost_f64(const float* y, const float* labels, int B, int T, int C, double* cost, void* stream);
+
+/* Optimal assignment on the leading nspk[b] x nspk[b] block of every cost matrix (shortest augmenting paths,
+ * fp64; the remaining slots keep their place): perm i32 [B][C] = label column assigned to prediction i,
+ * loss f64 [B] = mean over the C slots of the assigned costs (batch_pit's per-utterance minimum). */
+int eend_pit_assign_i32(const double* cost, const int* nspk, int B, int C, int* perm, double* loss, void* stream);
+
 /* q/k/v/g projections of MultiScaleRetention (LS-EEND/nnet/modules/retention.py:200-207) in the
  * layouts eend_retention_chunk_f16 consumes.  Wqkvg f16 [4*H*dh][ldw] = rows of q_proj, k_proj * dk^-0.5,
  * v_proj, g_proj (bias likewise); Q,K f16 [nseq][H][Tp][dh]; Kt,Vt f16 [nseq][H][dh][Tp]; G f16 [M][H*dh]. */

@@ -87,7 +87,7 @@ def test_dropin_import_paths():
     # output-side post-processing (train/utils/make_rttm.py, train/utils/loss.py DER report)
     for flavour in ("FS-EEND", "LS-EEND"):
         code = ("import sys; sys.path.insert(0, r'%s'); "
-                "from train.utils.make_rttm import make_rttm; from train.utils.loss import calc_diarization_error, report_diarization_error; "
+                "from train.utils.make_rttm import make_rttm; from train.utils.loss import calc_diarization_error, report_diarization_error, batch_pit_n_speaker_loss, pit_loss_multispk, pad_labels; "
                 "from datasets.feature import extract_fbank, splice, subsample; import fs_eend_amd.feature as FE; assert extract_fbank is FE.extract_fbank; "
                 "import fs_eend_amd.postproc as P; assert make_rttm is P.make_rttm and calc_diarization_error is P.calc_diarization_error; print('ok')")
         out = subprocess.run([sys.executable, "-c", code % os.path.join(ROOT, flavour)], capture_output=True, text=True, cwd="/tmp")
