@@ -400,6 +400,59 @@ void gemm_f16_kernel(const GemmParams p) {
         }
         float* __restrict__ o32 = (float*)p.out32;
         _Float16* __restrict__ o16 = (_Float16*)p.out16;
+        if constexpr (BM == 64 && BN == 256 && WGN == 4 && 2 * TILE_BYTES >= 2048 + BM * BN * 4) {
+            // Staged stores (as ffn.hip): the direct form writes 64-byte (fp32) / 32-byte (f16) pieces of 16 rows per
+            // instruction -- PMC WRITE_SIZE showed 1.5x the algorithmic bytes for this kernel.  Through LDS every
+            // store instruction writes one whole 1 KB row (fp32) or two 512 B rows (f16).
+            char* stg = smem + 2048;                          // clear of the row-statistics scratch
+            if constexpr (EPI == EPI_RES_SCALE) __syncthreads();   // (no statistics pass: nothing has fenced the main loop's LDS reads yet)
+            f16x4 h16[FR][FL];
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                const int n = R0 + i * 16, nl = n - n0;
+                float4 g = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
+                if ((EPI == EPI_RES_LN || EPI == EPI_RES_SCALE_LN16) && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
+#pragma unroll
+                for (int j = 0; j < FL; ++j) {
+                    const int row = j * 16 + frow;
+                    f32x4 v;
+                    v[0] = (acc[i][j][0] - mean[j]) * scale[j] * g.x + be.x;
+                    v[1] = (acc[i][j][1] - mean[j]) * scale[j] * g.y + be.y;
+                    v[2] = (acc[i][j][2] - mean[j]) * scale[j] * g.z + be.z;
+                    v[3] = (acc[i][j][3] - mean[j]) * scale[j] * g.w + be.w;
+                    h16[i][j] = OutCvt<_Float16>::cvt(v[0], v[1], v[2], v[3]);
+                    *(f32x4*)(stg + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = EPI == EPI_RES_SCALE_LN16 ? acc[i][j] : v;
+                }
+            }
+            __syncthreads();
+            if (o32) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int row = k * 4 + wave;
+                    const f32x4 v = *(const f32x4*)(stg + row * 1024 + ((lane ^ (row & 7)) << 4));
+                    if (m0 + row < p.M) *(f32x4*)(o32 + (size_t)(m0 + row) * p.ldo + n0 + lane * 4) = v;
+                }
+            }
+            if (o16) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    const int nl = R0 + i * 16 - n0;
+#pragma unroll
+                    for (int j = 0; j < FL; ++j) {
+                        const int row = j * 16 + frow;
+                        *(f16x4*)(stg + row * 512 + (((nl >> 3) ^ ((row >> 1) & 7)) << 4) + ((nl >> 2) & 1) * 8) = h16[i][j];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = (k * 4 + wave) * 2 + (lane >> 5), c = lane & 31;
+                    const u32x4 v = *(const u32x4*)(stg + row * 512 + ((c ^ ((row >> 1) & 7)) << 4));
+                    if (m0 + row < p.M) *(u32x4*)(o16 + (size_t)(m0 + row) * p.ldo + n0 + c * 8) = v;
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < FR; ++i) {
             const int n = R0 + i * 16;
