@@ -24,7 +24,7 @@ bool proj_xres_enabled() {          // EEND_PROJ_XRES=0: A/B switch back to the 
 
 extern "C" {
 
-int eend_abi_version(void) { return 1; }
+int eend_abi_version(void) { return 2; }
 
 int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                          const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,
@@ -230,16 +230,20 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
 
 int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
                              void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq, int H,
-                             int Tp, int L, int ldo, int ldg, float gn_eps, void* stream) {
+                             int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid, void* stream) {
     if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !St_ws || !kv_ws || !cscale_ws || !sexp_ws || L <= 0) return EEND_EINVAL;
     RetParams p;
     p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws; p.kv_ws = kv_ws; p.kv_ws = kv_ws;
-    p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tp + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
+    // chunk sizes that fit on chip (500 in every shipped config) take the chunk-resident kernel, one block per
+    // (chunk, head, sequence): there, chunks that start at or beyond T_valid (pure slab padding) are skipped
+    // altogether.  The tiled kernel's waves span chunk boundaries, so it always sees every chunk.
+    static const bool use_full_env = !(getenv("EEND_RET_FULL") && atoi(getenv("EEND_RET_FULL")) == 0);
+    const bool use_full = use_full_env && L <= 512 && (L & 3) == 0 && (ldo & 7) == 0;
+    const int Tv = (use_full && T_valid > 0 && T_valid < Tp) ? T_valid : Tp;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tv + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
     int rc = eend_launch_ret_state_scan(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    // chunk sizes that fit on chip (500 in every shipped config) take the chunk-resident kernel
-    static const bool use_full = !(getenv("EEND_RET_FULL") && atoi(getenv("EEND_RET_FULL")) == 0);
-    if (use_full && L <= 512 && (L & 3) == 0 && (ldo & 7) == 0) return eend_launch_ret_chunk_full(p, (hipStream_t)stream);
+    if (use_full) return eend_launch_ret_chunk_full(p, (hipStream_t)stream);
     return eend_launch_ret_chunk(p, (hipStream_t)stream);
 }
 

@@ -351,7 +351,7 @@ void ret_chunk_kernel(const RetParams p) {
 }  // namespace
 
 int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream) {
-    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc != (p.Tp + p.L - 1) / p.L ||
+    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc < 1 || p.nc > (p.Tp + p.L - 1) / p.L ||
         !p.kv_ws)
         return EEND_EINVAL;
     if (p.nc > 1) {
@@ -363,7 +363,7 @@ int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream) {
 }
 
 int eend_launch_ret_chunk(const RetParams& p, hipStream_t stream) {
-    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc != (p.Tp + p.L - 1) / p.L ||
+    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc < 1 || p.nc > (p.Tp + p.L - 1) / p.L ||
         (p.ldo & 3) || (p.ldg & 3))
         return EEND_EINVAL;
     hipLaunchKernelGGL(ret_chunk_kernel, dim3((p.Tp + QB - 1) / QB, p.H, p.nseq), dim3(256), 0, stream, p);

@@ -229,7 +229,7 @@ void ret_chunk_full_kernel(const RetParams p) {
 
 int eend_launch_ret_chunk_full(const RetParams& p, hipStream_t stream) {
     if (p.L <= 0 || p.L > LMAX || p.nseq <= 0 || p.nseq > 65535 || p.Tp <= 0 || (p.Tp % 64) != 0 || (p.ldo & 7) || (p.ldg & 3) ||
-        p.nc != (p.Tp + p.L - 1) / p.L || (p.L & 3))
+        p.nc < 1 || p.nc > (p.Tp + p.L - 1) / p.L || (p.L & 3))
         return EEND_EINVAL;
     const int ntl = ((p.L < p.Tp ? p.L : p.Tp) + KB - 1) / KB;
     const int smem = 2 * ntl * TILE + NW * OSTG;

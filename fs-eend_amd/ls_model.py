@@ -231,7 +231,7 @@ class _Workspace:
         self.h32, self.h16, self.x16 = e(Me, D, dt=f32), e(Me, D, dt=f16), e(Me, D, dt=f16)
         self.q, self.k, self.kt, self.vt = (e(Mx * D, dt=f16) for _ in range(4))
         self.g = e(Mx, D, dt=f16)
-        self.o16 = e(Mx, D, dt=f16)
+        self.o16 = torch.zeros(Mx, D, dtype=f16, device=dev)     # rows of skipped padding chunks are never written: keep them finite
         self.glu16, self.dw16 = e(Me, D, dt=f16), e(Me, D, dt=f16)
         self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
         self.emb16 = e(Me, D, dt=f16)
@@ -400,7 +400,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                                           ws.h32, ws.x16, Bk["lnb"][2])
             # x += Retention(LN_b x)                     -> x16 = LN_c(x)
             ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
-            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"])
+            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tpad)
             ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
                                       ws.h32, ws.x16, Bk["lnc"][2])
             # x += ConvModule(x): 1x1 + GLU, causal depthwise + BN + swish, 1x1   -> x16 = LN_d(x)
@@ -432,7 +432,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             F = Ld["w1"].shape[0]
             ff = ws.ff16[:Md * F].view(Md, F)
             ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
-            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"])
+            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tpad)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
                 ops.fusion_layer_tail(o16, ws.a32, ws.a16, Ld["out1_w"], Ld["out1_b"], Ld["g11"], Ld["be11"], Ld["eps11"],
                                       Ld["in2_w"], Ld["in2_b"], Ld["out2_w"], Ld["out2_b"], Ld["g21"], Ld["be21"], Ld["eps21"],

@@ -112,7 +112,7 @@ def retention_proj(a16, wqkvg16, bias, q, k, kt, vt, g, nseq, Tp, H):
 _KV_WS = {}
 
 
-def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp, chunk, gn_eps=1e-6):
+def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp, chunk, gn_eps=1e-6, t_valid=0):
     L = _lib.load()
     for t, n in ((q, "q"), (k, "k"), (kt, "kt"), (vt, "vt"), (g, "g"), (o16, "o16"), (st_ws, "st_ws")):
         _chk(t, F16, n)
@@ -127,7 +127,7 @@ def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp
         _KV_WS[str(q.device)] = kv_ws
     _lib.check(L.eend_retention_chunk_f16(_p(q), _p(k), _p(kt), _p(vt), _p(g), _p(o16), _p(st_ws), _p(kv_ws),
                                           _p(cscale_ws), _p(sexp_ws), nseq, H, Tp, chunk, o16.stride(0), g.stride(0),
-                                          gn_eps, _stream()), "eend_retention_chunk_f16")
+                                          gn_eps, int(t_valid), _stream()), "eend_retention_chunk_f16")
 
 
 def layernorm_f16(x32, gamma, beta, out16, eps=1e-5):

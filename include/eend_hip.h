@@ -234,10 +234,12 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
  * LayerNorm (eps gn_eps, no affine, :222) and the swish gate (:224) in one pass:
  * O = swish(G) * LN_head(retention(Q,K,V)).  L = recurrent_chunk_size; workspaces: St_ws f16
  * [nseq][H][nc][2][64][64], kv_ws f32 [nseq][H][nc][64][64], cscale_ws / sexp_ws f32 [nseq][H][nc],
- * nc = ceil(Tp / L).  Three launches: chunk-parallel K_c^T V_c, per-(seq,head) prefix scan, core. */
+ * nc = ceil(Tp / L).  Three launches: chunk-parallel K_c^T V_c, per-(seq,head) prefix scan, core.
+ * T_valid (0 = Tp): frames at or beyond it are slab padding (Tp rounds the chunk-padded length up to 64);
+ * chunks that start there are skipped and their rows of O are left untouched. */
 int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
                              void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq,
-                             int H, int Tp, int L, int ldo, int ldg, float gn_eps, void* stream);
+                             int H, int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid, void* stream);
 
 /* Stand-alone LayerNorm f32 [M][D] -> f16 (D <= 1024): second of two back-to-back LayerNorms
  * (conformer/encoder.py:110 then feed_forward.py:48; encoder.py:196 then feed_forward.py:48). */
