@@ -700,13 +700,26 @@ void ffn_fused_kernel(const FfnParams p) {
     for (int c = 0; c < nF - 1; ++c) {
         const int cb = c & 1, nb = cb ^ 1;
         float4 bnext[2] = {bcur[0], bcur[1]};
-        if (c + 2 < nF) {
-            dma_w1((c + 2) * FC, cb);
+        const bool more = c + 2 < nF;
+        if (more) {
             // b1 of chunk c+2, requested a whole iteration before the barrier's vmcnt(0) has to cover it
             bnext[0] = *(const float4*)(p.b1 + (c + 2) * FC + bofs);
             bnext[1] = *(const float4*)(p.b1 + (c + 2) * FC + bofs + 16);
         }
-        dma_w2((c + 1) * FC, nb);
+        // The 8 DMA pieces of this iteration (W2 slice c+1, W1 slice c+2) are issued one per early item instead
+        // of as a burst in front of the first MFMA: an LDS-DMA instruction occupies the issuing wave for
+        // ~60-180 cycles, which hides behind the matrix pipe once MFMAs are in flight.
+        auto dma_piece = [&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i < 4) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_char*)(smem + V2_W2 + nb * W2_BYTES + (wave * 4 + i) * 1024), 16, vo2[i],
+                                                         (c + 1) * FC * 2, 0, 0);
+            } else if constexpr (i < 8) {
+                if (more)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_char*)(smem + V2_W1 + cb * W1_BYTES + (wave * 4 + i - 4) * 1024), 16, vo1[i - 4],
+                                                             (c + 2) * FC * KD * 2, 0, 0);
+            }
+        };
         const char* W1n = smem + V2_W1 + nb * W1_BYTES;
         char* Hn = smem + V2_HS + nb * HS_BYTES;
         const char* W2c = smem + V2_W2 + cb * W2_BYTES;
@@ -777,6 +790,7 @@ void ffn_fused_kernel(const FfnParams p) {
                     acc[a & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2a[a % 3], hb[a >> 2][j], acc[a & 3][j], 0, 0, 0);
             }
             ld_item(std::integral_constant<int, t + 2>{});
+            if constexpr (t < 8) dma_piece(std::integral_constant<int, t>{});
             if constexpr (t == 8) ld_hb(std::integral_constant<int, 1>{});
             if constexpr (t == 12) { act_part(std::integral_constant<int, 0>{}); act_part(std::integral_constant<int, 1>{}); }
             if constexpr (t == 13) { act_part(std::integral_constant<int, 2>{}); act_part(std::integral_constant<int, 3>{}); }
