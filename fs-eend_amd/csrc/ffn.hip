@@ -697,6 +697,8 @@ void ffn_fused_kernel(const FfnParams p) {
     // chunk rides on the last GEMM2 items.  sched_barrier pins that order.
     constexpr int KIND[16] = {1, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2, 2, 2, 2, 2};     // 1 = GEMM1 k-step, 2 = GEMM2 item
     constexpr int ARG[16]  = {0, 1, 0, 2, 3, 1, 4, 5, 2, 6, 7, 3, 4, 5, 6, 7};
+    constexpr int HB1_T = 8, ACT_T0 = 12, ACT_T1 = 13;       // item after which the ks=1 H fragments / the activation parts are issued
+    // (a strictly alternating G1/G2 order with the activation after the last item measured the same, same-box A/B)
     for (int c = 0; c < nF - 1; ++c) {
         const int cb = c & 1, nb = cb ^ 1;
         float4 bnext[2] = {bcur[0], bcur[1]};
@@ -791,9 +793,9 @@ void ffn_fused_kernel(const FfnParams p) {
             }
             ld_item(std::integral_constant<int, t + 2>{});
             if constexpr (t < 8) dma_piece(std::integral_constant<int, t>{});
-            if constexpr (t == 8) ld_hb(std::integral_constant<int, 1>{});
-            if constexpr (t == 12) { act_part(std::integral_constant<int, 0>{}); act_part(std::integral_constant<int, 1>{}); }
-            if constexpr (t == 13) { act_part(std::integral_constant<int, 2>{}); act_part(std::integral_constant<int, 3>{}); }
+            if constexpr (t == HB1_T) ld_hb(std::integral_constant<int, 1>{});
+            if constexpr (t == ACT_T0) { act_part(std::integral_constant<int, 0>{}); act_part(std::integral_constant<int, 1>{}); }
+            if constexpr (t == ACT_T1) { act_part(std::integral_constant<int, 2>{}); act_part(std::integral_constant<int, 3>{}); }
             __builtin_amdgcn_sched_barrier(0);
         });
         bcur[0] = bnext[0]; bcur[1] = bnext[1];

@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libeend_hip.so")
+# EEND_HIP_LIB: load another build of the same library (same-box A/B perf studies, tools/ab_variants.sh)
+LIB_PATH = os.environ.get("EEND_HIP_LIB") or os.path.join(_HERE, "csrc", "libeend_hip.so")
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _l = ctypes.c_long
