@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   for spec in "$@"; do
     name=${spec%%=*}; flags=${spec#*=}
     objs=""
-    for f in gemm ffn proj attn attn_full spk_fused embloss postproc feature pit misc retention retention_full stream api; do
+    for f in $(python -c "import sys; sys.path.insert(0, '.'); import fs_eend_amd.build as b; print(' '.join(s[:-4] for s in b.SOURCES))"); do
       /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc $flags -c $CS/$f.hip -o $CS/variants/${name}_$f.o &
       objs="$objs $CS/variants/${name}_$f.o"
     done
