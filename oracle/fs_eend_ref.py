@@ -125,15 +125,26 @@ def encoder_layer(x: Tensor, sd: Dict[str, Tensor], pfx: str, n_heads: int,
 
 def encoder(src: Sequence[Tensor], sd: Dict[str, Tensor], n_heads: int, n_layers: int,
             has_mask: bool = True, mask_delay: int = 0, q=_id, dtype=torch.float32,
-            taps: Optional[dict] = None) -> Tensor:
-    """MaskedTransformerEncoderModel.forward (model :162-188), eval mode.
+            taps: Optional[dict] = None, bn_batch_stats: Optional[dict] = None) -> Tensor:
+    """MaskedTransformerEncoderModel.forward (model :162-188).
 
-    pad(-1) -> BatchNorm1d(running stats) -> Linear -> LN -> n_layers causal
-    post-norm Transformer layers.  Returns (B, Tmax, D).
+    pad(-1) -> BatchNorm1d -> Linear -> LN -> n_layers causal post-norm Transformer layers.
+    Returns (B, Tmax, D).  BatchNorm uses the running statistics (eval mode) unless
+    ``bn_batch_stats`` is a dict: then it is train mode -- statistics over all B*Tmax padded
+    frames (the -1 padding included, exactly as ``self.bn(src.transpose(1, 2))`` sees it),
+    biased variance for the normalisation; the dict receives ``mean``, ``var_biased`` and
+    ``count`` for the caller's running-statistics update.
     """
     x = torch.nn.utils.rnn.pad_sequence([s.to(dtype) for s in src], padding_value=-1.0,
                                         batch_first=True)                      # :165
-    x = (x - sd["enc.bn.running_mean"]) / torch.sqrt(sd["enc.bn.running_var"] + BN_EPS)
+    if bn_batch_stats is None:
+        x = (x - sd["enc.bn.running_mean"]) / torch.sqrt(sd["enc.bn.running_var"] + BN_EPS)
+    else:
+        flat = x.reshape(-1, x.shape[-1])
+        mu = flat.mean(dim=0)
+        var = ((flat - mu) ** 2).mean(dim=0)
+        bn_batch_stats.update(mean=mu.detach(), var_biased=var.detach(), count=flat.shape[0])
+        x = (x - mu) / torch.sqrt(var + BN_EPS)
     x = x * sd["enc.bn.weight"] + sd["enc.bn.bias"]                            # :166
     x = linear(x, sd["enc.encoder.weight"], sd["enc.encoder.bias"], q, "enc.in")   # :173
     x = layer_norm(x, sd["enc.encoder_norm.weight"], sd["enc.encoder_norm.bias"])  # :174
@@ -241,13 +252,15 @@ def emb_consistency_loss(emb: Tensor, tgt_pad: Tensor) -> Tensor:
 
 def fs_forward(src: Sequence[Tensor], tgt: Sequence[Tensor], ilens: Sequence[int],
                sd: Dict[str, Tensor], *, n_heads: int, enc_n_layers: int, dec_n_layers: int,
-               has_mask: bool = True, mask_delay: int = 0, q=_id, dtype=torch.float32):
-    """OnlineTransformerDADiarization.forward (model :32-65), eval-mode numerics
-    (dropout off, BN running stats)."""
+               has_mask: bool = True, mask_delay: int = 0, q=_id, dtype=torch.float32,
+               bn_batch_stats: Optional[dict] = None):
+    """OnlineTransformerDADiarization.forward (model :32-65), dropout off; BN running stats
+    (eval) or, with ``bn_batch_stats`` a dict, batch statistics (train mode, see encoder())."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     n_speakers = [t.shape[1] for t in tgt]
     C = max(n_speakers)
-    enc_out = encoder(src, sd, n_heads, enc_n_layers, has_mask, mask_delay, q, dtype)
+    enc_out = encoder(src, sd, n_heads, enc_n_layers, has_mask, mask_delay, q, dtype,
+                      bn_batch_stats=bn_batch_stats)
     emb = lookahead_conv_l2(enc_out, ilens, sd, q)
     attr = decoder(emb, C, sd, n_heads, dec_n_layers, mask_delay, q)
     attr = attr / torch.linalg.vector_norm(attr, dim=-1, keepdim=True)

@@ -1,0 +1,65 @@
+"""CPU: the training-step oracle (oracle/train_ref.py) against the golden vectors the reference itself produced
+(oracle/gen_golden_train.py: the reference's training_step, standard_loss, model, Adam, NoamScheduler)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as FX
+from oracle import train_ref as TR
+from tests.helpers import build_fs_mirror
+
+CASES = [c for c in FX.list_cases("fs_train_")]
+
+
+def _slice_index(numel, n=24):
+    a = np.arange(min(12, numel))
+    b = (np.arange(12) * 7919 + 13) % numel
+    return np.concatenate([a, b]).astype(np.int64)[:n]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_oracle_vs_reference(name):
+    meta, arr = FX.load_case(name)
+    if name == "fs_train_full":
+        torch.set_num_threads(max(torch.get_num_threads(), 4))
+    m = build_fs_mirror(meta)
+    assert [n for n, _ in m.named_parameters()] == meta["param_names"]
+    feats = FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])
+    labels = FX.make_labels(meta["lengths"], meta["nspk"], meta["lseed"])
+    tr = TR.TrainRef(m.state_dict(), meta["cfg"], meta["warm"], meta["clip"], meta["pit"])
+    assert tr.pnames == meta["param_names"]
+    for s in range(meta["steps"]):
+        out = tr.step(feats, labels)
+        want = arr[f"s{s}_loss"]
+        assert abs(out["loss"] - want[0]) < 2e-6 and abs(out["bce"] - want[1]) < 2e-6 and abs(out["emb"] - want[2]) < 2e-6
+        assert abs(out["lr"] - arr[f"s{s}_lr"][0]) <= 1e-12 + 1e-9 * arr[f"s{s}_lr"][0]
+        assert abs(out["gradnorm"] - arr[f"s{s}_gradnorm"][0]) < 2e-4 * arr[f"s{s}_gradnorm"][0]
+        if s == 0:
+            for i, k in enumerate(meta["param_names"]):
+                g = out["grads"][k]
+                if k in meta["nograd"]:
+                    assert g is None and TR.never_graded(k)
+                    continue
+                assert not TR.never_graded(k)
+                gn = float(g.double().norm())
+                assert abs(gn - arr["grad_norms"][i]) < 1e-4 * arr["grad_norms"][i] + 1e-9, k
+                idx = _slice_index(g.numel())
+                got = g.flatten()[torch.as_tensor(idx)].numpy()
+                assert np.abs(got - arr["grad_slices"][i][:len(idx)]).max() < 1e-4 * max(arr["grad_norms"][i], 1e-6), k
+        # parameters after the optimiser step
+        for i, k in enumerate(meta["param_names"]):
+            idx = _slice_index(tr.sd[k].numel())
+            got = tr.sd[k].flatten()[torch.as_tensor(idx)].numpy()
+            assert np.abs(got - arr[f"s{s}_param_slices"][i][:len(idx)]).max() < 2e-5, (k, s)
+        assert np.abs(tr.sd["enc.bn.running_mean"].numpy() - arr[f"s{s}_bn_mean"]).max() < 1e-5
+        assert np.abs(tr.sd["enc.bn.running_var"].numpy() - arr[f"s{s}_bn_var"]).max() < 1e-4
+
+
+def test_label_preparation_properties():
+    """silence column = 1 - max, none-speaker column = 0, speakers ordered by first activity (stable)."""
+    lab = [torch.tensor([[0, 1, 0], [1, 1, 0], [0, 0, 0], [0, 0, 1.]]), torch.tensor([[0.], [1.], [1.], [0.]])]
+    out = TR.prepare_labels(lab, [4, 4])
+    assert out[0].shape == (4, 5) and out[1].shape == (4, 3)
+    assert out[0][:, 1:4].tolist() == [[1, 0, 0], [1, 1, 0], [0, 0, 0], [0, 0, 1]]
+    assert out[0][:, 0].tolist() == [0, 0, 1, 0] and out[0][:, -1].tolist() == [0, 0, 0, 0]
+    assert out[1][:, 0].tolist() == [1, 0, 0, 1]
