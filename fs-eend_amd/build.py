@@ -7,7 +7,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "ffn.hip", "proj.hip", "attn.hip", "attn_full.hip", "spk_fused.hip", "embloss.hip", "postproc.hip", "feature.hip", "pit.hip", "misc.hip", "retention.hip", "retention_full.hip", "stream.hip", "api.hip"]
+SOURCES = ["gemm.hip", "ffn.hip", "proj.hip", "attn.hip", "attn_full.hip", "spk_fused.hip", "embloss.hip", "postproc.hip", "feature.hip", "pit.hip", "misc.hip", "retention.hip", "retention_full.hip", "stream.hip", "api.hip",
+           # training step: backward kernels, optimiser
+           "wgrad.hip", "attn_bwd.hip", "train_rows.hip", "embloss_bwd.hip", "optim.hip", "api_train.hip"]
 LIB = os.path.join(CSRC, "libeend_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"]
@@ -28,7 +30,10 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    missing = [s for s in srcs if not os.path.exists(s)]
+    if missing:
+        raise FileNotFoundError(f"HIP sources listed in build.SOURCES are missing: {missing}")
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "eend_hip.h"))
     objs = [s[:-4] + ".o" for s in srcs]

@@ -24,7 +24,7 @@ bool proj_xres_enabled() {          // EEND_PROJ_XRES=0: A/B switch back to the 
 
 extern "C" {
 
-int eend_abi_version(void) { return 2; }
+int eend_abi_version(void) { return 3; }
 
 int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                          const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,
@@ -294,7 +294,7 @@ int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_
     if (!Q || !K || !Vt || !O_f16 || nseq > 65535 || H > 65535) return EEND_EINVAL;
     AttnParams p;
     p.Q = Q; p.K = K; p.Vt = Vt; p.O = O_f16; p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo;
-    p.mask_delay = mask_delay; p.kv_len = kv_len; p.scale_log2 = scale * 1.4426950408889634f;
+    p.mask_delay = mask_delay; p.kv_len = kv_len; p.scale_log2 = scale * 1.4426950408889634f; p.Lse = nullptr;
     return eend_launch_attn_causal(p, (hipStream_t)stream);
 }
 

@@ -1,0 +1,276 @@
+// C-ABI shim of the training-step entry points (include/eend_hip.h, "TRAINING STEP"): argument validation,
+// workspace partitioning, launch sequencing.  No allocation, no synchronisation.
+#include "../../include/eend_hip.h"
+#include "kernels.h"
+#include <string.h>
+
+namespace {
+
+GemmParams gemm_base(const void* A, int lda, const void* W, int ldw, const float* bias, int M, int N, int K) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.ldo = N; p.Tp = 64; p.H = 4; p.dh = 64; p.C = 1;
+    p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0;
+    return p;
+}
+
+// split the token axis so that about 512 workgroups run, within the workspace
+int plan_wgrad(long M, int N, int K, long ws_floats, int* nsplit, long* m_per_split) {
+    const long tile_floats = (long)N * K;
+    if (tile_floats <= 0 || ws_floats < tile_floats) return EEND_EINVAL;
+    const int ntiles = (N / 128) * (K / 128);
+    long want = (512 + ntiles - 1) / ntiles;
+    const long cap = ws_floats / tile_floats;
+    if (want > cap) want = cap;
+    const long steps = (M + 63) / 64;
+    if (want > steps) want = steps;
+    if (want < 1) want = 1;
+    const long sps = (steps + want - 1) / want;          // 64-row steps per split
+    *m_per_split = sps * 64;
+    *nsplit = (int)((steps + sps - 1) / sps);
+    return EEND_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eend_linear_res_ln_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
+                                 float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
+                                 void* out_f16, void* xhat_f16, float* rstd, int M, int K, void* stream) {
+    if (!A || !W || !out_f32 || !out_f16 || !xhat_f16 || !rstd || !gamma || !beta) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, bias, M, 256, K);
+    p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
+    p.xhat16 = xhat_f16; p.rstat = rstd;
+    return eend_launch_gemm(p, EPI_RES_LN_TRAIN, (hipStream_t)stream);
+}
+
+int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bias, const int* ilens, float* out_f32,
+                                 void* out_f16, float* inv_norm, int nseq, int Tp, int cin, int ktaps, int pad,
+                                 void* stream) {
+    if (!X || !Wr || !ilens || !out_f32 || !out_f16 || !inv_norm) return EEND_EINVAL;
+    if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || cin <= 0 || (cin % 64) != 0 || ktaps <= 0 || pad < 0 || pad >= ktaps)
+        return EEND_EINVAL;
+    GemmParams p = gemm_base(X, cin, Wr, ktaps * cin, bias, nseq * Tp, 256, ktaps * cin);
+    p.Tp = Tp; p.ilens = ilens; p.conv_cin = cin; p.conv_pad = pad; p.out32 = out_f32; p.out16 = out_f16; p.rstat = inv_norm;
+    return eend_launch_gemm(p, EPI_L2NORM_TRAIN, (hipStream_t)stream);
+}
+
+int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const float* bias, void* Q, void* Qt,
+                                 void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream) {
+    if (!A || !W || !bias || !Q || !Qt || !K || !Kt || !V || !Vt) return EEND_EINVAL;
+    if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || H != 4) return EEND_EINVAL;
+    ProjParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = nseq * Tp; q.N = 768; q.Tp = Tp; q.H = H;
+    q.kind[0] = PROJ_HEADS_BOTH; q.out[0] = Q; q.out2[0] = Qt;
+    q.kind[1] = PROJ_HEADS_BOTH; q.out[1] = K; q.out2[1] = Kt;
+    q.kind[2] = PROJ_HEADS_BOTH; q.out[2] = V; q.out2[2] = Vt;
+    q.is_bf16[0] = q.is_bf16[1] = q.is_bf16[2] = 1;
+    return eend_launch_proj_xres(q, (hipStream_t)stream);
+}
+
+int eend_attn_causal_lse_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, float* lse, int nseq, int H,
+                              int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream) {
+    if (!Q || !K || !Vt || !O_f16 || !lse || nseq > 65535 || H > 65535) return EEND_EINVAL;
+    AttnParams p;
+    p.Q = Q; p.K = K; p.Vt = Vt; p.O = O_f16; p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo;
+    p.mask_delay = mask_delay; p.kv_len = kv_len; p.scale_log2 = scale * 1.4426950408889634f; p.Lse = lse;
+    return eend_launch_attn_causal(p, (hipStream_t)stream);
+}
+
+int eend_attn_causal_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
+                              const void* dO, int ldo, const void* O_f16, int ldout, const float* lse, void* dOt_ws,
+                              float* dh_ws, void* dQKV, int ldg, int nseq, int H, int Tp, int mask_delay, int kv_len,
+                              int q_len, float scale_log2, float sq, float sk, void* stream) {
+    if (!dO || !O_f16 || !dOt_ws || !dh_ws || H != 4 || ldo != 256 || ldout != 256) return EEND_EINVAL;
+    int rc = eend_launch_attn_rowdot(dO, O_f16, dh_ws, nseq, H, Tp, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_heads_transpose(dO, ldo, dOt_ws, nseq, H, Tp, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    AttnBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.Q = Q; p.Qt = Qt; p.K = K; p.Kt = Kt; p.V = V; p.dO = dO; p.dOt = dOt_ws; p.Lse = lse; p.Dh = dh_ws; p.dQKV = dQKV;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.ldg = ldg; p.mask_delay = mask_delay; p.kv_len = kv_len; p.q_len = q_len;
+    p.scale_log2 = scale_log2; p.sq = sq; p.sk = sk;
+    return eend_launch_attn_bwd(p, (hipStream_t)stream);
+}
+
+int eend_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_bf16, int ldo,
+                   int M, int N, int K, void* stream) {
+    if (!A || !W || !out_bf16 || (ldo & 7)) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, bias, M, N, K);
+    p.bf16 = 1; p.out16 = out_bf16; p.ldo = ldo;
+    return eend_launch_gemm(p, EPI_PLAIN_BF16, (hipStream_t)stream);
+}
+
+int eend_gemm_relu_bwd_bf16(const void* A, int lda, const void* W, int ldw, const void* act, int ldact,
+                            void* out_bf16, int ldo, int M, int N, int K, void* stream) {
+    if (!A || !W || !act || !out_bf16 || (ldo & 7) || (ldact & 7)) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, nullptr, M, N, K);
+    p.bf16 = 1; p.out16 = out_bf16; p.ldo = ldo; p.mask = act; p.ldmask = ldact;
+    return eend_launch_gemm(p, EPI_MASK_BF16, (hipStream_t)stream);
+}
+
+int eend_gemm_acc_bf16(const void* A, int lda, const void* W, int ldw, const float* res_f32, float alpha,
+                       float* out_f32, void* out_bf16, int M, int K, void* stream) {
+    if (!A || !W || (!out_f32 && !out_bf16)) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, nullptr, M, 256, K);
+    p.bf16 = 1; p.res = res_f32; p.alpha = alpha; p.out32 = out_f32; p.out16 = out_bf16;
+    return eend_launch_gemm(p, EPI_RES_SCALE, (hipStream_t)stream);
+}
+
+int eend_conv1d_dgrad_bf16(const void* dY, const void* Wd, const int* src_lens, const int* mask_lens, float* out_f32,
+                           int nseq, int Tp, int cout, int ktaps, int pad, void* stream) {
+    if (!dY || !Wd || !src_lens || !mask_lens || !out_f32) return EEND_EINVAL;
+    if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || cout != 256 || ktaps <= 0 || pad < 0 || pad >= ktaps) return EEND_EINVAL;
+    GemmParams p = gemm_base(dY, cout, Wd, ktaps * cout, nullptr, nseq * Tp, 256, ktaps * cout);
+    p.bf16 = 1; p.Tp = Tp; p.ilens = src_lens; p.mask_lens = mask_lens; p.conv_cin = cout; p.conv_pad = pad; p.out32 = out_f32;
+    return eend_launch_gemm(p, EPI_F32_ROWMASK, (hipStream_t)stream);
+}
+
+int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
+                    long ws_floats, float* out, int ld_out, int K_out, float scale, int accumulate, void* stream) {
+    if (!dY || !X || !ws || !out || M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return EEND_EINVAL;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.b_is_f16 = x_is_f16 ? 1 : 0;
+    int rc = plan_wgrad(M, N, K, ws_floats, &p.nsplit, &p.m_per_split);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad(p, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws, (long)N * K, p.nsplit, N, K, K_out, out, ld_out, scale, accumulate, (hipStream_t)stream);
+}
+
+int eend_conv1d_wgrad_bf16(const void* dY, const void* X_f16, const int* ilens, int nseq, int Tp, int cin, int ktaps,
+                           int pad, float* ws, long ws_floats, float* tmp, float* out, void* stream) {
+    if (!dY || !X_f16 || !ilens || !ws || !tmp || !out || nseq <= 0 || Tp <= 0 || cin != 256 || ktaps <= 0 || pad < 0 || pad >= ktaps)
+        return EEND_EINVAL;
+    const int N = 256, K = ktaps * cin;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = dY; p.B = X_f16; p.partial = ws; p.M = (long)nseq * Tp; p.N = N; p.K = K; p.lda = 256; p.ldb = cin; p.b_is_f16 = 1;
+    p.conv = 1; p.conv_cin = cin; p.conv_pad = pad; p.Tp = Tp; p.ilens = ilens;
+    int rc = plan_wgrad(p.M, N, K, ws_floats, &p.nsplit, &p.m_per_split);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad(p, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, (long)N * K, p.nsplit, N, K, K, tmp, K, 1.0f, 0, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_conv_wgrad_unpermute(tmp, out, N, cin, ktaps, (hipStream_t)stream);
+}
+
+int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws, long ws_floats, float* out,
+                    float scale, int accumulate, void* stream) {
+    if (!Y || !ws || !out || M <= 0 || N <= 0 || ws_floats < N) return EEND_EINVAL;
+    long ns = ws_floats / N;
+    if (ns > 256) ns = 256;
+    if (ns > M) ns = M;
+    int rc = eend_launch_colsum_partial(Y, ld, M, N, is_bf16, (int)ns, ws, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws, N, (int)ns, 1, N, N, out, N, scale, accumulate, (hipStream_t)stream);
+}
+
+int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rstd, const float* gamma, float* ds_f32,
+                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M, void* stream) {
+    if (!ws || !dgamma || !dbeta || ws_floats < 1024L * 512) return EEND_EINVAL;
+    int nb = 0;
+    int rc = eend_launch_ln_bwd(g, xhat_f16, rstd, gamma, ds_f32, ds_bf16, ws, &nb, M, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, 512, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws + 256, 512, nb, 1, 256, 256, dbeta, 256, 1.0f, 0, (hipStream_t)stream);
+}
+
+int eend_head_bce_f32(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
+                      float inv_frames, float* logits, float* da, float* de, float* ws, long ws_floats,
+                      float* loss_out, int B, int T, int Tp, int C, void* stream) {
+    const long nb = ((long)B * Tp + 3) / 4;
+    if (!ws || !loss_out || ws_floats < nb) return EEND_EINVAL;
+    int rc = eend_launch_head_bce(emb, attr, labels, ilens, ncols, inv_frames, logits, da, de, ws, B, T, Tp, C, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_scalar_sum(ws, nb, 1.0f, loss_out, (hipStream_t)stream);
+}
+
+int eend_l2norm_bwd_bf16(const float* y, const float* dy, const float* inv_norm, void* dx_bf16, int B, int T, int Tp,
+                         void* stream) {
+    return eend_launch_l2norm_bwd(y, dy, inv_norm, dx_bf16, B, T, Tp, (hipStream_t)stream);
+}
+
+int eend_convert_fanout_bwd_f32(const float* g0, void* gsum_bf16, float* ws, long ws_floats, float* dpc, int B, int Tp,
+                                int C, void* stream) {
+    if (!ws || !dpc || C < 1 || C > 12 || ws_floats < 256L * C * 256) return EEND_EINVAL;
+    int nb = 0;
+    int rc = eend_launch_slot_sum(g0, gsum_bf16, ws, &nb, B, Tp, C, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws, (long)C * 256, nb, C, 256, 256, dpc, 256, 1.0f, 0, (hipStream_t)stream);
+}
+
+int eend_convert_const_f32(int mode, const float* W, const float* bias, const float* pe, float* pc, const float* dpc,
+                           float* dW, float* dbias, int C, void* stream) {
+    return eend_launch_convert_const(mode, W, bias, pe, pc, dpc, dW, dbias, C, (hipStream_t)stream);
+}
+
+int eend_spk_attn_bwd_bf16(const void* qkv_f16, const void* dO_bf16, void* dqkv_bf16, int B, int C, int Tp, int H,
+                           float scale, void* stream) {
+    if (H != 4) return EEND_EINVAL;
+    return eend_launch_spk_attn_bwd(qkv_f16, dO_bf16, dqkv_bf16, B, C, Tp, scale, (hipStream_t)stream);
+}
+
+int eend_bn_train_stats_f32(const void* const* x_ptrs, const int* lens, float pad_value, float* ws, long ws_floats,
+                            float* mean, float* var, float* run_mean, float* run_var, float momentum, int B, int T,
+                            int F, void* stream) {
+    if (!ws || !mean || !var || B <= 0 || T <= 0 || F <= 0) return EEND_EINVAL;
+    long ns = ((long)B * T + 255) / 256;
+    if (ns > 512) ns = 512;
+    if (ws_floats < (ns + 1) * 2L * F) return EEND_EINVAL;
+    float* sums = ws + ns * 2L * F;
+    const float n = (float)((long)B * T);
+    for (int pass = 0; pass < 2; ++pass) {
+        int rc = eend_launch_bn_colstats((const float* const*)x_ptrs, lens, pad_value, pass ? mean : nullptr, ws, B, T, F, (int)ns,
+                                         (hipStream_t)stream);
+        if (rc != EEND_OK) return rc;
+        rc = eend_launch_wgrad_reduce(ws, 2L * F, (int)ns, 1, 2 * F, 2 * F, sums, 2 * F, 1.0f, 0, (hipStream_t)stream);
+        if (rc != EEND_OK) return rc;
+        rc = eend_launch_bn_finalize(pass, sums, n, mean, var, run_mean, run_var, momentum, F, (hipStream_t)stream);
+        if (rc != EEND_OK) return rc;
+    }
+    return EEND_OK;
+}
+
+int eend_bn_bwd_f32(const void* const* x_ptrs, const int* lens, float pad_value, const float* mean, const float* var,
+                    float eps, const void* dy_bf16, int ld, float* ws, long ws_floats, float* dgamma, float* dbeta,
+                    int B, int T, int Tp, int F, void* stream) {
+    if (!ws || !dgamma || !dbeta || B <= 0 || T <= 0 || F <= 0) return EEND_EINVAL;
+    long ns = ((long)B * T + 255) / 256;
+    if (ns > 512) ns = 512;
+    if (ws_floats < ns * 2L * F) return EEND_EINVAL;
+    int rc = eend_launch_bn_bwd((const float* const*)x_ptrs, lens, pad_value, mean, var, eps, dy_bf16, ld, ws, B, T, Tp, F, (int)ns,
+                                (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, 2L * F, (int)ns, 1, 2 * F, F, dgamma, F, 1.0f, 0, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws + F, 2L * F, (int)ns, 1, 2 * F, F, dbeta, F, 1.0f, 0, (hipStream_t)stream);
+}
+
+int eend_emb_consistency_bwd_f16(const void* emb_f16, const float* labels, const int* lens, float inv_count, float* de,
+                                 int B, int T, int Tp, int D, int C, void* stream) {
+    return eend_launch_emb_consistency_bwd(emb_f16, labels, lens, inv_count, de, B, T, Tp, D, C, (hipStream_t)stream);
+}
+
+int eend_grad_sumsq_f32(const float* g, long n, float* ws, long ws_floats, float* out, void* stream) {
+    if (!ws || ws_floats < 1024) return EEND_EINVAL;
+    return eend_launch_grad_sumsq(g, n, ws, out, (hipStream_t)stream);
+}
+
+int eend_adam_step_f32(float* p, const float* g, float* m, float* v, long n, const float* hp, const float* gsumsq,
+                       float beta1, float beta2, float eps, void* stream) {
+    return eend_launch_adam(p, g, m, v, n, hp, gsumsq, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+int eend_prep_weights(const eend_prep_entry* table, int n, void* stream) {
+    return eend_launch_prep_weights(table, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

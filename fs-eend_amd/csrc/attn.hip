@@ -164,6 +164,8 @@ void attn_causal_kernel(const AttnParams p) {
 
     // O[q][h*64 + d] = O^T[d][q] / l ; reg i of oT[db] <-> d = db*32 + 8*(i>>2) + 4*hi + (i&3)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (p.Lse && hi == 0 && q < p.Tp)                  // training: log2-domain log-sum-exp of the row
+        p.Lse[sh * p.Tp + q] = m_run + __builtin_amdgcn_logf(l_tot);
     if (q < p.Tp) {
         const float inv = 1.0f / l_tot;
         _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * p.Tp + q) * p.ldo + h * 64;

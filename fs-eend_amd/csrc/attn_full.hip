@@ -102,6 +102,7 @@ void attn_causal_full_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; }
         float m_run = -INFINITY, l_run = 0.f;
+        float m_ref_final = 0.f;                       // softmax reference the accumulated l / O are relative to
 
         int last_key = qw0 + 31 + p.mask_delay;
         last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
@@ -178,6 +179,7 @@ void attn_causal_full_kernel(const AttnParams p) {
                         }
                     }
             }
+            m_ref_final = -mneg[0];
         } else
         for (int j = 0; j < jend; ++j) {
             const int key0 = j * KB;
@@ -240,10 +242,14 @@ void attn_causal_full_kernel(const AttnParams p) {
                         oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
                     }
                 }
+            m_ref_final = m_run;
         }
 
         // ---- O[q][d] = O^T / l: stage the wave's 32 x 64 f16 tile, then 128-byte rows to HBM
-        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (p.Lse && hi == 0)                          // training: log2-domain log-sum-exp of the row, for the backward
+            p.Lse[sh * p.Tp + q] = m_ref_final + __builtin_amdgcn_logf(l_tot);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll

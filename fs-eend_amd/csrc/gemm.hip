@@ -54,7 +54,19 @@ template <> struct OutCvt<__bf16> {
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
+// Operand element type of a GEMM instantiation: f16 for the forward linears, bf16 for the gradient GEMMs of the
+// training step (gradients need bf16's exponent range; same MFMA rate, same fragment layout).
+template <class ET> struct Mfma16;
+template <> struct Mfma16<_Float16> {
+    using V = f16x8;
+    static DEV f32x4 run(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<__bf16> {
+    using V = bf16x8;
+    static DEV f32x4 run(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <class ET, int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
 __global__ __launch_bounds__(WGM * WGN * 64)
 void gemm_f16_kernel(const GemmParams p) {
     constexpr int NT = WGM * WGN * 64;
@@ -81,14 +93,14 @@ void gemm_f16_kernel(const GemmParams p) {
     const int n0 = (L % ntn) * BN;
     const int nk = p.K >> 6;
 
-    const _Float16* __restrict__ A = (const _Float16*)p.A;
-    const _Float16* __restrict__ W = (const _Float16*)p.W;
+    const ET* __restrict__ A = (const ET*)p.A;
+    const ET* __restrict__ W = (const ET*)p.W;
 
     // ---- per-thread staging coordinates --------------------------------------------------
     constexpr int NSET = PF > 0 ? PF : 1;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vector: trivially SROA'd
     u32x4 xr[NSET][XCH], wr[NSET][WCH];     // PF > 0: all PF == nk k-tiles in flight (straight-line code)
-    const _Float16* xsrc[XCH];
+    const ET* xsrc[XCH];
     int xseq_t[XCH];            // conv: frame index t inside its slab
     int xilen[XCH];             // conv: valid length of that sequence
     static_for<XCH>([&](auto I) __attribute__((always_inline)) {
@@ -105,7 +117,7 @@ void gemm_f16_kernel(const GemmParams p) {
             xsrc[i] = A + (size_t)m * p.lda + (q & 7) * 8;
         }
     });
-    const _Float16* wsrc[WCH];
+    const ET* wsrc[WCH];
     static_for<WCH>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const int q = tid + i * NT;
@@ -170,15 +182,15 @@ void gemm_f16_kernel(const GemmParams p) {
         const char* rb__ = SWAP ? wb__ : xb__;                                                   \
         const char* lb__ = SWAP ? xb__ : wb__;                                                   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                       \
-            f16x8 rf[FR], lf[FL];                                                                \
+            typename Mfma16<ET>::V rf[FR], lf[FL];                                               \
             _Pragma("unroll") for (int i = 0; i < FR; ++i)                                       \
-                rf[i] = *(const f16x8*)(rb__ + swz128(r_tile_row0 + i * 16 + frow, ks * 4 + fkg)); \
+                rf[i] = *(const typename Mfma16<ET>::V*)(rb__ + swz128(r_tile_row0 + i * 16 + frow, ks * 4 + fkg)); \
             _Pragma("unroll") for (int j = 0; j < FL; ++j)                                       \
-                lf[j] = *(const f16x8*)(lb__ + swz128(l_tile_row0 + j * 16 + frow, ks * 4 + fkg)); \
+                lf[j] = *(const typename Mfma16<ET>::V*)(lb__ + swz128(l_tile_row0 + j * 16 + frow, ks * 4 + fkg)); \
             if (!EEND_DBG_NO_MFMA) {                                                               \
             _Pragma("unroll") for (int i = 0; i < FR; ++i)                                       \
                 _Pragma("unroll") for (int j = 0; j < FL; ++j)                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf[i], lf[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = Mfma16<ET>::run(rf[i], lf[j], acc[i][j]);                        \
             } else { _Pragma("unroll") for (int i = 0; i < FR; ++i) acc[i][0][0] += (float)rf[i][0] + (float)lf[i % FL][0]; } \
         }                                                                                        \
     } while (0)
@@ -231,14 +243,15 @@ void gemm_f16_kernel(const GemmParams p) {
     const int L0 = (SWAP ? m0 + wm * WM : n0 + wn * WN) + frow;
 
     if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16 ||
-                  EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16 || EPI == EPI_VT_HEADS || EPI == EPI_KTVT_HEADS_F16) {
+                  EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16 || EPI == EPI_VT_HEADS || EPI == EPI_KTVT_HEADS_F16 ||
+                  EPI == EPI_PLAIN_BF16 || EPI == EPI_MASK_BF16) {
         // 2-byte outputs go through LDS (free after the main loop) so that global stores are full
         // 256-byte row segments, 16 B per lane.  (Measured: the direct form -- 8 B per lane, 32-byte
         // pieces scattered over 16 rows per instruction -- cost as much as the rest of the kernel.)
         // Staged tile = [L index][R index]: SWAP -> rows are tokens, columns features (row-major
         // outputs, Q/K head rows); !SWAP -> rows are features, columns tokens (the transposed
         // K^T / V^T head layout falls out of the same code).
-        constexpr bool IS_BF16 = (EPI == EPI_QK_HEADS || EPI == EPI_VT_HEADS);
+        constexpr bool IS_BF16 = (EPI == EPI_QK_HEADS || EPI == EPI_VT_HEADS || EPI == EPI_PLAIN_BF16 || EPI == EPI_MASK_BF16);
         using OT = typename std::conditional<IS_BF16, __bf16, _Float16>::type;
         constexpr int BL = SWAP ? BM : BN, BR = SWAP ? BN : BM;
         constexpr int SROW = BR + 8;                                   // +16 B pad: bank spread
@@ -272,12 +285,22 @@ void gemm_f16_kernel(const GemmParams p) {
         for (int it = 0; it < BL * CPR / NT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx / CPR, ch = idx % CPR;
-            const uint4 v = *(const uint4*)(stage + row * SROW + ch * 8);
+            uint4 v = *(const uint4*)(stage + row * SROW + ch * 8);
             const int li = Lbase + row, ri = Rbase + ch * 8;
             OT* dst;
-            if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16) {
+            if constexpr (EPI == EPI_PLAIN_F16 || EPI == EPI_PLAIN_RELU_F16 || EPI == EPI_PLAIN_SWISH_F16 ||
+                          EPI == EPI_PLAIN_BF16 || EPI == EPI_MASK_BF16) {
                 if (li >= p.M) continue;
                 dst = (OT*)p.out16 + (size_t)li * p.ldo + ri;
+                if constexpr (EPI == EPI_MASK_BF16) {
+                    // ReLU backward: keep the gradient where the saved forward activation (f16 or bf16, any
+                    // 2-byte float: zero <=> no magnitude bits) is non-zero
+                    const uint4 mk = *(const uint4*)((const unsigned short*)p.mask + (size_t)li * p.ldmask + ri);
+                    auto keep = [](unsigned g, unsigned m) {
+                        return g & (((m & 0x7FFFu) ? 0xFFFFu : 0u) | ((m & 0x7FFF0000u) ? 0xFFFF0000u : 0u));
+                    };
+                    v.x = keep(v.x, mk.x); v.y = keep(v.y, mk.y); v.z = keep(v.z, mk.z); v.w = keep(v.w, mk.w);
+                }
             } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_QK_HEADS_F16) {
                 // li = token, ri = feature in [0, 2D): Q then K, [which][seq][H][Tp][dh]
                 if (li >= p.M) continue;
@@ -317,9 +340,14 @@ void gemm_f16_kernel(const GemmParams p) {
                 *(f16x2*)(out + (size_t)m * p.ldo + (r >> 1)) = o;
             }
         }
-    } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE || EPI == EPI_RES_SCALE_LN16) {
+    } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE || EPI == EPI_RES_SCALE_LN16 ||
+                         EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN) {
         // The block owns complete rows (BN == N, WGM == 1): per-token statistics.
         static_assert(SWAP && WGM == 1, "row-stat epilogues expect SWAP and one wave row");
+        constexpr bool LNK = (EPI == EPI_RES_LN || EPI == EPI_RES_LN_TRAIN || EPI == EPI_RES_SCALE_LN16);   // LayerNorm
+        constexpr bool L2K = (EPI == EPI_L2NORM || EPI == EPI_L2NORM_TRAIN);                               // x / ||x||
+        constexpr bool TRAINK = (EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN);  // also save the row statistics
+        using O16 = decltype(OutCvt<ET>::cvt(0, 0, 0, 0));
         float* red = (float*)smem;                        // [WGN][BM] (main loop is done with LDS)
         float4 bias4[FR];
 #pragma unroll
@@ -333,8 +361,8 @@ void gemm_f16_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < FR; ++i) {
                 float4 r = make_float4(0, 0, 0, 0);
-                if (EPI != EPI_L2NORM && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
-                const float s = (EPI == EPI_L2NORM) ? 1.0f : p.alpha;
+                if (!L2K && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
+                const float s = L2K ? 1.0f : p.alpha;
                 acc[i][j][0] = (acc[i][j][0] + bias4[i].x) * s + r.x;
                 acc[i][j][1] = (acc[i][j][1] + bias4[i].y) * s + r.y;
                 acc[i][j][2] = (acc[i][j][2] + bias4[i].z) * s + r.z;
@@ -368,7 +396,7 @@ void gemm_f16_kernel(const GemmParams p) {
             };
             const float invN = 1.0f / (float)p.N;
             float part[FL];
-            if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_SCALE_LN16) {
+            if constexpr (LNK) {
 #pragma unroll
                 for (int j = 0; j < FL; ++j) {
                     float s = 0.f;
@@ -395,23 +423,31 @@ void gemm_f16_kernel(const GemmParams p) {
             block_rowsum(part);
 #pragma unroll
             for (int j = 0; j < FL; ++j)
-                scale[j] = (EPI == EPI_L2NORM) ? 1.0f / __builtin_sqrtf(part[j])
-                                               : 1.0f / __builtin_sqrtf(part[j] * invN + p.eps);
+                scale[j] = L2K ? 1.0f / __builtin_sqrtf(part[j]) : 1.0f / __builtin_sqrtf(part[j] * invN + p.eps);
         }
         float* __restrict__ o32 = (float*)p.out32;
-        _Float16* __restrict__ o16 = (_Float16*)p.out16;
+        ET* __restrict__ o16 = (ET*)p.out16;
+        if constexpr (TRAINK) {
+            // training forward: 1/sigma (LayerNorm) or 1/||x|| (L2 norm) of every row, for the backward kernels
+            if (p.rstat && wn == 0 && fkg == 0) {
+#pragma unroll
+                for (int j = 0; j < FL; ++j)
+                    if (L0 + j * 16 < p.M) p.rstat[L0 + j * 16] = scale[j];
+            }
+        }
         if constexpr (BM == 64 && BN == 256 && WGN == 4 && 2 * TILE_BYTES >= 2048 + BM * BN * 4) {
             // Staged stores (as ffn.hip): the direct form writes 64-byte (fp32) / 32-byte (f16) pieces of 16 rows per
             // instruction -- PMC WRITE_SIZE showed 1.5x the algorithmic bytes for this kernel.  Through LDS every
             // store instruction writes one whole 1 KB row (fp32) or two 512 B rows (f16).
             char* stg = smem + 2048;                          // clear of the row-statistics scratch
             if constexpr (EPI == EPI_RES_SCALE) __syncthreads();   // (no statistics pass: nothing has fenced the main loop's LDS reads yet)
-            f16x4 h16[FR][FL];
+            O16 h16[FR][FL];
+            O16 xh16[TRAINK && LNK ? FR : 1][TRAINK && LNK ? FL : 1];
 #pragma unroll
             for (int i = 0; i < FR; ++i) {
                 const int n = R0 + i * 16, nl = n - n0;
                 float4 g = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
-                if ((EPI == EPI_RES_LN || EPI == EPI_RES_SCALE_LN16) && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
+                if (LNK && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
 #pragma unroll
                 for (int j = 0; j < FL; ++j) {
                     const int row = j * 16 + frow;
@@ -420,7 +456,10 @@ void gemm_f16_kernel(const GemmParams p) {
                     v[1] = (acc[i][j][1] - mean[j]) * scale[j] * g.y + be.y;
                     v[2] = (acc[i][j][2] - mean[j]) * scale[j] * g.z + be.z;
                     v[3] = (acc[i][j][3] - mean[j]) * scale[j] * g.w + be.w;
-                    h16[i][j] = OutCvt<_Float16>::cvt(v[0], v[1], v[2], v[3]);
+                    h16[i][j] = OutCvt<ET>::cvt(v[0], v[1], v[2], v[3]);
+                    if constexpr (TRAINK && LNK)            // normalised, pre-affine row: what LayerNorm backward needs
+                        xh16[i][j] = OutCvt<ET>::cvt((acc[i][j][0] - mean[j]) * scale[j], (acc[i][j][1] - mean[j]) * scale[j],
+                                                     (acc[i][j][2] - mean[j]) * scale[j], (acc[i][j][3] - mean[j]) * scale[j]);
                     *(f32x4*)(stg + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = EPI == EPI_RES_SCALE_LN16 ? acc[i][j] : v;
                 }
             }
@@ -441,7 +480,7 @@ void gemm_f16_kernel(const GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < FL; ++j) {
                         const int row = j * 16 + frow;
-                        *(f16x4*)(stg + row * 512 + (((nl >> 3) ^ ((row >> 1) & 7)) << 4) + ((nl >> 2) & 1) * 8) = h16[i][j];
+                        *(O16*)(stg + row * 512 + (((nl >> 3) ^ ((row >> 1) & 7)) << 4) + ((nl >> 2) & 1) * 8) = h16[i][j];
                     }
                 }
                 __syncthreads();
@@ -452,12 +491,34 @@ void gemm_f16_kernel(const GemmParams p) {
                     if (m0 + row < p.M) *(u32x4*)(o16 + (size_t)(m0 + row) * p.ldo + n0 + c * 8) = v;
                 }
             }
+            if constexpr (TRAINK && LNK) {
+                if (p.xhat16) {                                     // third staged tile: x_hat (same 2-byte staging as out16)
+                    ET* __restrict__ xo = (ET*)p.xhat16;
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < FR; ++i) {
+                        const int nl = R0 + i * 16 - n0;
+#pragma unroll
+                        for (int j = 0; j < FL; ++j) {
+                            const int row = j * 16 + frow;
+                            *(O16*)(stg + row * 512 + (((nl >> 3) ^ ((row >> 1) & 7)) << 4) + ((nl >> 2) & 1) * 8) = xh16[i][j];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int row = (k * 4 + wave) * 2 + (lane >> 5), c = lane & 31;
+                        const u32x4 v = *(const u32x4*)(stg + row * 512 + ((c ^ ((row >> 1) & 7)) << 4));
+                        if (m0 + row < p.M) *(u32x4*)(xo + (size_t)(m0 + row) * p.ldo + n0 + c * 8) = v;
+                    }
+                }
+            }
         } else
 #pragma unroll
         for (int i = 0; i < FR; ++i) {
             const int n = R0 + i * 16;
             float4 g = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
-            if ((EPI == EPI_RES_LN || EPI == EPI_RES_SCALE_LN16) && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
+            if (LNK && p.gamma) { g = *(const float4*)(p.gamma + n); be = *(const float4*)(p.beta + n); }
 #pragma unroll
             for (int j = 0; j < FL; ++j) {
                 const int m = L0 + j * 16;
@@ -469,7 +530,26 @@ void gemm_f16_kernel(const GemmParams p) {
                 if (EPI == EPI_RES_SCALE_LN16) {           // residual stream stays un-normalised
                     if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 } else if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
-                if (o16) *(f16x4*)(o16 + (size_t)m * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
+                if (o16) *(O16*)(o16 + (size_t)m * p.ldo + n) = OutCvt<ET>::cvt(v0, v1, v2, v3);
+            }
+        }
+    } else if constexpr (EPI == EPI_F32_ROWMASK) {
+        // Conv1d data gradient (implicit GEMM over (tap, c_out)): f32 rows, zero for frames t >= mask_lens[seq]
+        // (the reference truncates the encoder output to ilen before the conv, FS model :38-39, so no gradient
+        // reaches frames beyond it).
+        static_assert(SWAP, "row-mask epilogue expects SWAP");
+        float* __restrict__ o32 = (float*)p.out32;
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+            const int m = L0 + j * 16;
+            if (m >= p.M) continue;
+            const int seq = m / p.Tp, t = m - seq * p.Tp;
+            const bool live = t < p.mask_lens[seq];
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                const int n = R0 + i * 16;
+                *(float4*)(o32 + (size_t)m * p.ldo + n) = live ? make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3])
+                                                             : make_float4(0, 0, 0, 0);
             }
         }
     } else if constexpr (EPI == EPI_CONVERT) {
@@ -499,11 +579,11 @@ void gemm_f16_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
+template <class ET, int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
 int launch_pf(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
-    auto kern = gemm_f16_kernel<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, PF>;
+    auto kern = gemm_f16_kernel<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, PF>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return EEND_ELAUNCH;
@@ -516,47 +596,70 @@ int launch_pf(const GemmParams& p, hipStream_t stream) {
 
 // K == 256 (4 k-tiles) takes the straight-line full-K variant when the tile's staging registers
 // fit (128x128: 8 uint4 per k-tile -> 128 VGPRs); everything else the looped variant.
-template <int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
+template <class ET, int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
     if (p.N % BN != 0 || p.K % 64 != 0 || (p.lda & 7) || (p.ldw & 7)) return EEND_EINVAL;
     if constexpr (BM + BN <= 256 && ALOAD == ALOAD_PLAIN) {
         if (p.K == 256) {
             static const int pf = getenv("EEND_GEMM_PF") ? atoi(getenv("EEND_GEMM_PF")) : 2;
-            if (pf == 4) return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 4>(p, stream);
-            if (pf == 2) return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 2>(p, stream);
+            if (pf == 4) return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 4>(p, stream);
+            if (pf == 2) return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 2>(p, stream);
         }
     }
-    return launch_pf<BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 0>(p, stream);
+    return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 0>(p, stream);
 }
 
 }  // namespace
 
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
+    using H = _Float16;
+    using B = __bf16;
+    if (p.bf16) {                      // gradient GEMMs of the training step: bf16 operands
+        switch (epi) {
+            case EPI_PLAIN_BF16:  return launch<B, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_BF16>(p, stream);
+            case EPI_MASK_BF16:
+                if (!p.mask || (p.ldmask & 7)) return EEND_EINVAL;
+                return launch<B, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_MASK_BF16>(p, stream);
+            case EPI_RES_SCALE:
+                if (p.N != 256) return EEND_EINVAL;
+                return launch<B, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
+            case EPI_F32_ROWMASK:
+                if (p.N != 256 || !p.ilens || !p.mask_lens || !p.out32) return EEND_EINVAL;
+                return launch<B, 64, 256, 1, 4, true, ALOAD_CONV, EPI_F32_ROWMASK>(p, stream);
+            default: return EEND_EINVAL;
+        }
+    }
     switch (epi) {
-        case EPI_PLAIN_F16:      return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_F16>(p, stream);
-        case EPI_PLAIN_RELU_F16: return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_RELU_F16>(p, stream);
-        case EPI_PLAIN_SWISH_F16:return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_SWISH_F16>(p, stream);
-        case EPI_GLU_F16:        return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_GLU_F16>(p, stream);
-        case EPI_QK_HEADS_F16:   return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS_F16>(p, stream);
-        case EPI_KTVT_HEADS_F16: return launch<128, 128, 2, 2, false, ALOAD_PLAIN, EPI_KTVT_HEADS_F16>(p, stream);
-        case EPI_QK_HEADS:       return launch<128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS>(p, stream);
-        case EPI_VT_HEADS:       return launch<128, 128, 2, 2, false, ALOAD_PLAIN, EPI_VT_HEADS>(p, stream);
+        case EPI_PLAIN_F16:      return launch<H, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_F16>(p, stream);
+        case EPI_PLAIN_RELU_F16: return launch<H, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_RELU_F16>(p, stream);
+        case EPI_PLAIN_SWISH_F16:return launch<H, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_PLAIN_SWISH_F16>(p, stream);
+        case EPI_GLU_F16:        return launch<H, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_GLU_F16>(p, stream);
+        case EPI_QK_HEADS_F16:   return launch<H, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS_F16>(p, stream);
+        case EPI_KTVT_HEADS_F16: return launch<H, 128, 128, 2, 2, false, ALOAD_PLAIN, EPI_KTVT_HEADS_F16>(p, stream);
+        case EPI_QK_HEADS:       return launch<H, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_QK_HEADS>(p, stream);
+        case EPI_VT_HEADS:       return launch<H, 128, 128, 2, 2, false, ALOAD_PLAIN, EPI_VT_HEADS>(p, stream);
         case EPI_RES_LN:
             if (p.N != 256) return EEND_EINVAL;
-            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN>(p, stream);
+            return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN>(p, stream);
+        case EPI_RES_LN_TRAIN:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN_TRAIN>(p, stream);
         case EPI_RES_SCALE_LN16:
             if (p.N != 256) return EEND_EINVAL;
-            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE_LN16>(p, stream);
+            return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE_LN16>(p, stream);
         case EPI_RES_SCALE:
             if (p.N != 256) return EEND_EINVAL;
-            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
+            return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
         case EPI_L2NORM:
             if (p.N != 256) return EEND_EINVAL;
-            return launch<64, 256, 1, 4, true, ALOAD_CONV, EPI_L2NORM>(p, stream);
+            return launch<H, 64, 256, 1, 4, true, ALOAD_CONV, EPI_L2NORM>(p, stream);
+        case EPI_L2NORM_TRAIN:
+            if (p.N != 256) return EEND_EINVAL;
+            return launch<H, 64, 256, 1, 4, true, ALOAD_CONV, EPI_L2NORM_TRAIN>(p, stream);
         case EPI_CONVERT:
             if (p.N != 256) return EEND_EINVAL;
-            return launch<64, 256, 1, 4, true, ALOAD_PLAIN, EPI_CONVERT>(p, stream);
+            return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_CONVERT>(p, stream);
         default: return EEND_EINVAL;
     }
 }

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/eend_hip.h"
 
 enum GemmEpilogue {
     EPI_PLAIN_F16 = 0,       // out16[m][n] = f16(acc + bias)
@@ -19,6 +20,12 @@ enum GemmEpilogue {
     EPI_GLU_F16 = 10,        // rows of W interleaved (value, gate): out16[m][n/2] = v * sigmoid(g)
     EPI_QK_HEADS_F16 = 11,   // as EPI_QK_HEADS, f16 outputs (retention)
     EPI_KTVT_HEADS_F16 = 12, // K^T -> out16, V^T -> out16b, f16 [seq][H][dh][Tp] (retention)
+    // ---- training step (gradient GEMMs run on bf16 operands: GemmParams::bf16 = 1)
+    EPI_PLAIN_BF16 = 13,     // out16[m][n] = bf16(acc + bias)
+    EPI_MASK_BF16 = 14,      // out16[m][n] = bf16(acc) where mask[m][n] != 0 else 0   (ReLU backward)
+    EPI_F32_ROWMASK = 15,    // out32[m][n] = acc for frames t < mask_lens[seq], else 0 (ALOAD_CONV: Conv1d data gradient)
+    EPI_RES_LN_TRAIN = 16,   // EPI_RES_LN that also saves x_hat (xhat16) and 1/sigma (rstat) of every row
+    EPI_L2NORM_TRAIN = 17,   // EPI_L2NORM that also saves 1/||x|| (rstat)
 };
 
 struct GemmParams {
@@ -43,6 +50,13 @@ struct GemmParams {
     int conv_cin;       // ALOAD_CONV: input channels (multiple of 64)
     int conv_pad;       // ALOAD_CONV: left padding (taps before the centre)
     int dbg;            // ablation flags (EEND_GEMM_DBG env, perf studies only): 1 skip stores, 2 reload k-tile 0, 4 skip MFMA
+    // training step
+    int bf16;           // operands (A, W) and 2-byte outputs are bf16 instead of f16
+    const void* mask;   // EPI_MASK_BF16: saved forward activation, 2-byte floats [M][ldmask]
+    int ldmask;
+    const int* mask_lens; // EPI_F32_ROWMASK: frames per sequence that receive a gradient
+    void* xhat16;       // EPI_RES_LN_TRAIN: normalised rows before the affine, [M][ldo]
+    float* rstat;       // EPI_*_TRAIN: 1/sigma or 1/||x|| per row, [M]
 };
 
 struct AttnParams {
@@ -54,6 +68,7 @@ struct AttnParams {
     int mask_delay;  // allowed(i,j) <=> j - i <= mask_delay && j < kv_len
     int kv_len;      // number of real key frames (<= Tp)
     float scale_log2;  // (1/sqrt(dh)) * log2(e)
+    float* Lse;        // optional (training): f32 [nseq][H][Tp], log2-domain log-sum-exp of every query row
 };
 
 struct SpkAttnParams {
@@ -185,3 +200,69 @@ struct ProjParams {       // proj.hip: up to four 256-feature output groups
 };
 int eend_launch_proj_xres(const ProjParams& p, hipStream_t stream);
 int eend_launch_ret_chunk_full(const RetParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------
+// training step (backward kernels, optimiser)
+// ---------------------------------------------------------------------------------------------------
+struct WgradParams {          // wgrad.hip: partial[s][n][k] = sum_{m in split s} A[m][n] * B[m][k]
+    const void* A;            // dY, bf16 [M][lda]
+    const void* B;            // X, f16 (b_is_f16) or bf16 [M][ldb]
+    float* partial;           // f32 [nsplit][N][K]
+    long M;
+    int N, K, lda, ldb;
+    int nsplit;
+    long m_per_split;         // multiple of 64
+    int b_is_f16;
+    // Conv1d weight gradient: B rows of k-tile (tap, c_in block) are read at frame t + tap - conv_pad (zero outside [0, ilen))
+    int conv, conv_cin, conv_pad, Tp;
+    const int* ilens;
+};
+int eend_launch_wgrad(const WgradParams& p, hipStream_t stream);
+int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit, int N, int K, int K_out, float* out,
+                             int ld_out, float scale, int accumulate, hipStream_t stream);
+int eend_launch_colsum_partial(const void* Y, int ld, long M, int N, int is_bf16, int nsplit, float* partial,
+                               hipStream_t stream);
+int eend_launch_conv_wgrad_unpermute(const float* tmp, float* g, int cout, int cin, int ktaps, hipStream_t stream);
+
+struct AttnBwdParams {        // attn_bwd.hip
+    const void *Q, *Qt;       // bf16 [nseq][H][Tp][64] / [nseq][H][64][Tp]  (Q as the forward kernel saw it)
+    const void *K, *Kt;       // bf16, same two layouts
+    const void* V;            // bf16 [nseq][H][Tp][64]
+    const void* dO;           // bf16 [nseq*Tp][ldo], head h at columns h*64
+    const void* dOt;          // bf16 [nseq][H][64][Tp]
+    const float* Lse;         // f32 [nseq][H][Tp] from the forward (log2 domain)
+    const float* Dh;          // f32 [nseq][H][Tp]: <dO_i, O_i> per head
+    void* dQKV;               // bf16 [nseq*Tp][ldg]: dQ at column h*64, dK at 256 + h*64, dV at 512 + h*64
+    int nseq, H, Tp, ldo, ldg;
+    int mask_delay, kv_len, q_len;
+    float scale_log2;         // as the forward
+    float sq, sk;             // output scales of dQ and dK
+};
+int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream);
+int eend_launch_heads_transpose(const void* in, int ld, void* out, int nseq, int H, int Tp, hipStream_t stream);
+
+int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, const float* gamma, float* ds32, void* ds16,
+                       float* partial, int* nblocks_out, long M, hipStream_t stream);
+int eend_launch_head_bce(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
+                         float inv_frames, float* logits, float* da, float* de, float* loss_partial, int B, int T, int Tp, int C,
+                         hipStream_t stream);
+int eend_launch_l2norm_bwd(const float* y, const float* dy, const float* inv_norm, void* dx16, int B, int T, int Tp, hipStream_t stream);
+int eend_launch_slot_sum(const float* g0, void* gsum16, float* partial, int* nblocks_out, int B, int Tp, int C, hipStream_t stream);
+int eend_launch_convert_const(int mode, const float* W, const float* bias, const float* pe, float* pc, const float* dpc, float* dW,
+                              float* dbias, int C, hipStream_t stream);
+int eend_launch_spk_attn_bwd(const void* qkv16, const void* dO16, void* dqkv16, int B, int C, int Tp, float scale, hipStream_t stream);
+int eend_launch_bn_colstats(const float* const* x_ptrs, const int* lens, float pad_value, const float* shift, float* partial,
+                            int B, int T, int F, int nsplit, hipStream_t stream);
+int eend_launch_bn_finalize(int pass, const float* sums, float n, float* mean, float* var, float* run_mean, float* run_var,
+                            float momentum, int F, hipStream_t stream);
+int eend_launch_bn_bwd(const float* const* x_ptrs, const int* lens, float pad_value, const float* mean, const float* var, float eps,
+                       const void* dy16, int ld, float* partial, int B, int T, int Tp, int F, int nsplit, hipStream_t stream);
+int eend_launch_attn_rowdot(const void* dO16, const void* O16, float* Dh, int nseq, int H, int Tp, hipStream_t stream);
+int eend_launch_emb_consistency_bwd(const void* emb16, const float* tgt, const int* lens, float inv_count, float* de,
+                                    int B, int T, int Tp, int D, int C, hipStream_t stream);
+typedef eend_prep_entry PrepEntry;
+int eend_launch_grad_sumsq(const float* g, long n, float* partial_ws, float* out, hipStream_t stream);
+int eend_launch_scalar_sum(const float* partial, long n, float scale, float* out, hipStream_t stream);
+int eend_launch_adam(float* p, const float* g, float* m, float* v, long n, const float* hp, const float* gsumsq, float b1, float b2,
+                     float eps, hipStream_t stream);
+int eend_launch_prep_weights(const PrepEntry* tab, int n_entries, hipStream_t stream);

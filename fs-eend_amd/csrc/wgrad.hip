@@ -1,0 +1,243 @@
+// Weight gradients of the training step:  dW[n][k] = sum_m dY[m][n] * X[m][k]   ("TN" GEMM: both operands are
+// stored token-major, the contraction runs over the token axis m).
+//
+// MFMA fragments want the contraction index contiguous per lane, the operands have it strided.  The transpose
+// happens once, in registers, on the way from HBM to LDS: a thread loads an 8-token x 8-feature block (8 coalesced
+// 16-byte loads), transposes it with 32 byte-permutes (transpose8x8_b16) and writes 8 feature rows of 8 tokens.
+// After that the LDS tiles are [feature][64 tokens] -- exactly the K-contiguous image of gemm.hip -- and the inner
+// loop is the same conflict-free ds_read_b128 + v_mfma_f32_16x16x32_bf16 stream.
+//
+// dY is bf16 (gradients need the exponent range).  X is a saved forward activation: f16 (converted to bf16 in the
+// staging registers) or bf16.  Accumulation is f32.  The token range is split over `nsplit` workgroups per output
+// tile; every workgroup writes its partial tile to a workspace and wgrad_reduce_kernel sums the partials in a fixed
+// order (deterministic: no atomics), optionally scales, and writes the f32 gradient with the destination's own row
+// stride (the flat gradient buffer of the optimiser).
+//
+// Conv1d weight gradient (FS model :30,:40): the same kernel with the X rows of k-tile (tap, c_in block) read at
+// frame t + tap - pad of the same sequence, zero outside [0, ilen) -- the implicit-GEMM loader of gemm.hip mirrored.
+#include "train_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 64;
+
+template <bool B_F16, bool CONV>
+__global__ __launch_bounds__(256)
+void wgrad_tn_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x (A^T [128][128 B] + B^T [128][128 B]) = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wn = wave & 1;                          // wave tile: 64 k-rows x 64 n-cols
+    const int ntk = p.K / TN_BK, ntn = p.N / TN_BN;
+    const int tile = blockIdx.x % (ntk * ntn), split = blockIdx.x / (ntk * ntn);
+    const int n0 = (tile / ntk) * TN_BN, k0 = (tile % ntk) * TN_BK;
+    const long m_begin = (long)split * p.m_per_split;
+    long m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int nsteps = m_end > m_begin ? (int)((m_end - m_begin + TN_BM - 1) / TN_BM) : 0;
+
+    // staging role: threads 0..127 transpose the dY tile, 128..255 the X tile; unit = (8 tokens mg, 8 features fc)
+    const bool isB = tid >= 128;
+    const int u = tid & 127, fc = u & 15, mg = u >> 4;
+    const unsigned short* src = isB ? (const unsigned short*)p.B + (CONV ? 0 : k0) + fc * 8
+                                    : (const unsigned short*)p.A + n0 + fc * 8;
+    const int ld = isB ? p.ldb : p.lda;
+    int conv_shift = 0, conv_c0 = 0;
+    if constexpr (CONV) {
+        const int tap = k0 / p.conv_cin;
+        conv_c0 = k0 - tap * p.conv_cin;
+        conv_shift = tap - p.conv_pad;
+    }
+
+    u32x4 reg[8];
+    auto gload = [&](int step) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const long m = m_begin + (long)step * TN_BM + mg * 8 + r;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (m < m_end) {
+                if (CONV && isB) {
+                    const int seq = (int)(m / p.Tp), t = (int)(m - (long)seq * p.Tp);
+                    const int ts = t + conv_shift;
+                    if (ts >= 0 && ts < p.ilens[seq])
+                        v = *(const u32x4*)(src + ((long)seq * p.Tp + ts) * ld + conv_c0);
+                } else {
+                    v = *(const u32x4*)(src + m * ld);
+                }
+            }
+            reg[r] = v;
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        u32x4 in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (B_F16 && isB) ? f16x8_to_bf16x8(reg[r]) : reg[r];
+        transpose8x8_b16(in, out);
+        char* base = smem + buf * (2 * TN_BN * 128) + (isB ? TN_BN * 128 : 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(u32x4*)(base + swzT(fc * 8 + e, mg)) = out[e];
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fkg = lane >> 4;
+
+    if (nsteps > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) gload(st + 1);
+        const char* at = smem + buf * (2 * TN_BN * 128);              // dY^T: [n][64 m]
+        const char* bt = at + TN_BN * 128;                           // X^T : [k][64 m]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 rf[4], lf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rf[i] = *(const bf16x8*)(bt + swzT(wk * 64 + i * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lf[j] = *(const bf16x8*)(at + swzT(wn * 64 + j * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[i], lf[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // acc[i][j][r]: k = k0 + wk*64 + i*16 + fkg*4 + r (4 consecutive k per lane), n = n0 + wn*64 + j*16 + frow
+    float* __restrict__ out = p.partial + (size_t)split * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wk * 64 + i * 16 + fkg * 4, n = n0 + wn * 64 + j * 16 + frow;
+            *(f32x4*)(out + (size_t)n * p.K + k) = acc[i][j];
+        }
+}
+
+// out[n][k] (row stride ld_out, k < K_out) = scale * sum_s partial[s][n][k]   (+ out if accumulate)
+__global__ __launch_bounds__(256)
+void wgrad_reduce_kernel(const float* __restrict__ partial, long split_stride, int nsplit, int N, int K, int K_out,
+                         float* __restrict__ out, int ld_out, float scale, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * K_out) return;
+    const int n = (int)(idx / K_out), k = (int)(idx - (long)n * K_out);
+    const float* src = partial + (size_t)n * K + k;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        s0 += src[(size_t)(s + 0) * split_stride];
+        s1 += src[(size_t)(s + 1) * split_stride];
+        s2 += src[(size_t)(s + 2) * split_stride];
+        s3 += src[(size_t)(s + 3) * split_stride];
+    }
+    for (; s < nsplit; ++s) s0 += src[(size_t)s * split_stride];
+    float v = ((s0 + s1) + (s2 + s3)) * scale;
+    float* o = out + (size_t)n * ld_out + k;
+    if (accumulate) v += *o;
+    *o = v;
+}
+
+// Column sums of a 2-byte-float matrix [M][N] (bias gradients): partial[s][n] = sum over the split's rows.
+// Thread = 2 adjacent columns, two row phases per block.
+template <bool IS_BF16>
+__global__ __launch_bounds__(256)
+void colsum_partial_kernel(const unsigned* __restrict__ Y, int ld /* in 2-byte elements */, long M, int N, long rows_per_split,
+                           float* __restrict__ partial) {
+    __shared__ float red[2][256];
+    const int cp = threadIdx.x & 127, ph = threadIdx.x >> 7;
+    const int col = blockIdx.x * 256 + cp * 2;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    long r1 = r0 + rows_per_split;
+    if (r1 > M) r1 = M;
+    float a0 = 0.f, a1 = 0.f;
+    if (col < N) {
+        for (long r = r0 + ph; r < r1; r += 2) {
+            const unsigned v = Y[(r * ld + col) >> 1];
+            if (IS_BF16) { a0 += bf16_lo(v); a1 += bf16_hi(v); }
+            else { a0 += f16_lo(v); a1 += f16_hi(v); }
+        }
+    }
+    red[ph][cp * 2] = a0;
+    red[ph][cp * 2 + 1] = a1;
+    __syncthreads();
+    if (ph == 0 && col < N) {
+        partial[(size_t)blockIdx.y * N + col] = red[0][cp * 2] + red[1][cp * 2];
+        partial[(size_t)blockIdx.y * N + col + 1] = red[0][cp * 2 + 1] + red[1][cp * 2 + 1];
+    }
+}
+
+// cnn.weight gradient back to the parameter's own layout: g[co][ci][tap] = tmp[co][tap*cin + ci]
+__global__ __launch_bounds__(256)
+void conv_wgrad_unpermute_kernel(const float* __restrict__ tmp, float* __restrict__ g, int cout, int cin, int ktaps) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)cout * cin * ktaps) return;
+    const int tap = (int)(idx % ktaps);
+    const long r = idx / ktaps;
+    const int ci = (int)(r % cin), co = (int)(r / cin);
+    g[idx] = tmp[((size_t)co * ktaps + tap) * cin + ci];
+}
+
+}  // namespace
+
+int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
+    if (!p.A || !p.B || !p.partial || p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
+    if ((p.N % TN_BN) || (p.K % TN_BK) || (p.lda & 7) || (p.ldb & 7) || p.nsplit <= 0 || p.m_per_split <= 0 ||
+        (p.m_per_split % TN_BM))
+        return EEND_EINVAL;
+    if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % TN_BK) || p.Tp <= 0)) return EEND_EINVAL;
+    const int smem = 2 * 2 * TN_BN * 128;
+    const dim3 grid((unsigned)((p.N / TN_BN) * (p.K / TN_BK) * p.nsplit));
+#define WG_LAUNCH(F16, CV)                                                                                              \
+    do {                                                                                                                \
+        static bool done = false;                                                                                       \
+        if (!done) {                                                                                                    \
+            if (hipFuncSetAttribute((const void*)wgrad_tn_kernel<F16, CV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                    smem) != hipSuccess)                                                                \
+                return EEND_ELAUNCH;                                                                                    \
+            done = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV>), grid, dim3(256), smem, stream, p);                               \
+    } while (0)
+    if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true); else WG_LAUNCH(false, true); }
+    else { if (p.b_is_f16) WG_LAUNCH(true, false); else WG_LAUNCH(false, false); }
+#undef WG_LAUNCH
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit, int N, int K, int K_out, float* out,
+                             int ld_out, float scale, int accumulate, hipStream_t stream) {
+    if (!partial || !out || nsplit <= 0 || N <= 0 || K <= 0 || K_out <= 0 || K_out > K || ld_out < K_out) return EEND_EINVAL;
+    const long n = (long)N * K_out;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, split_stride,
+                       nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_colsum_partial(const void* Y, int ld, long M, int N, int is_bf16, int nsplit, float* partial,
+                               hipStream_t stream) {
+    if (!Y || !partial || M <= 0 || N <= 0 || (N & 1) || (ld & 1) || nsplit <= 0) return EEND_EINVAL;
+    const long rps = (M + nsplit - 1) / nsplit;
+    const dim3 grid((N + 255) / 256, nsplit);
+    if (is_bf16)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, stream, (const unsigned*)Y, ld, M, N, rps, partial);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, stream, (const unsigned*)Y, ld, M, N, rps, partial);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_conv_wgrad_unpermute(const float* tmp, float* g, int cout, int cin, int ktaps, hipStream_t stream) {
+    if (!tmp || !g || cout <= 0 || cin <= 0 || ktaps <= 0) return EEND_EINVAL;
+    const long n = (long)cout * cin * ktaps;
+    hipLaunchKernelGGL(conv_wgrad_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tmp, g, cout, cin, ktaps);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}

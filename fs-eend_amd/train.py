@@ -1,0 +1,559 @@
+"""FS-EEND training step on MI355X: forward with saved activations, hand-written backward, Adam -- all HIP.
+
+Reference behaviour reproduced (paths relative to the reference root):
+  * FS-EEND/nnet/model/onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm.py:32-65   model.forward (train mode:
+    BatchNorm1d batch statistics over the -1-padded input, :165-166)
+  * FS-EEND/train/utils/loss.py:119-125   standard_loss (label_delay = 0)
+  * FS-EEND/train_dia.py:83-100,153       Adam(betas (0.9, 0.98), eps 1e-9) x NoamScheduler, gradient_clip_val
+  * torch autograd                         replaced by the backward kernels of csrc/{wgrad,attn_bwd,train_rows,
+                                           embloss_bwd}.hip and the bf16 gradient GEMMs of gemm.hip
+
+Design:
+  * parameters, gradients and the Adam moments are four FLAT f32 buffers (`FlatState`); every nn.Parameter of the
+    mirror model is a view into the parameter buffer, so checkpoints / state_dict keep working, the optimiser is one
+    elementwise launch, and data parallelism is ONE all-reduce of the gradient buffer (RCCL over xGMI);
+  * the 8 tensors the reference never back-propagates into keep an all-zero gradient slice (Adam's update for a
+    zero gradient with zero moments is exactly zero -- the reference's Adam skips them because .grad is None);
+  * MFMA operand copies of the weights (f16 forward layouts, bf16 transposed backward layouts) are rebuilt from the
+    updated f32 parameters by one table-driven launch per step;
+  * dropout: the reference's drop masks cannot be matched by any other implementation; the training step runs with
+    dropout = 0 and refuses anything else loudly.
+
+There is no autograd / eager fallback: everything below is a call into libeend_hip.so.
+"""
+import ctypes
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import lib as _lib
+from . import ops
+from .lib import EendHipError
+
+F16, BF16, F32, I32 = torch.float16, torch.bfloat16, torch.float32, torch.int32
+D = 256
+H = 4
+WS_FLOATS = 32 * 1024 * 1024          # f32 scratch for split-sum partials (128 MB)
+
+
+def _call(name: str, *args):
+    """One C-ABI call: tensors -> device pointers, current stream appended, return code checked."""
+    L = _lib.load()
+    a = []
+    for x in args:
+        if isinstance(x, Tensor):
+            if not x.is_cuda:
+                raise EendHipError(f"{name}: expected GPU tensors (the HIP path has no CPU fallback)")
+            a.append(x.data_ptr())
+        else:
+            a.append(x)
+    a.append(torch.cuda.current_stream().cuda_stream)
+    _lib.check(getattr(L, name)(*a), name)
+
+
+def never_graded(name: str) -> bool:
+    """Parameters of the FS model that are not on the forward path: the decoder's dead input projection
+    and the fusion layers' norm12."""
+    return name.startswith("dec.encoder.") or name.startswith("dec.encoder_norm.") or ".norm12." in name
+
+
+class FlatState:
+    """Flat f32 parameter / gradient / Adam-moment buffers; the model's parameters become views of `params`."""
+
+    def __init__(self, model: torch.nn.Module):
+        named = list(model.named_parameters())
+        dev = named[0][1].device
+        if dev.type != "cuda":
+            raise EendHipError("training needs the model on the GPU: the HIP path has no CPU fallback")
+        self.names = [n for n, _ in named]
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for n, p in named:
+            self.offsets[n] = off
+            off += (p.numel() + 3) // 4 * 4                      # 16-byte aligned slices
+        self.numel = off
+        self.params = torch.zeros(off, dtype=F32, device=dev)
+        self.grads = torch.zeros(off, dtype=F32, device=dev)
+        self.m = torch.zeros(off, dtype=F32, device=dev)
+        self.v = torch.zeros(off, dtype=F32, device=dev)
+        with torch.no_grad():
+            for n, p in named:
+                o = self.offsets[n]
+                view = self.params[o:o + p.numel()].view(p.shape)
+                view.copy_(p.detach().to(F32))
+                p.data = view
+        self.shapes = {n: tuple(p.shape) for n, p in named}
+
+    def p(self, name: str) -> Tensor:
+        o = self.offsets[name]
+        return self.params[o:o + math.prod(self.shapes[name])].view(self.shapes[name])
+
+    def g(self, name: str) -> Tensor:
+        o = self.offsets[name]
+        return self.grads[o:o + math.prod(self.shapes[name])].view(self.shapes[name])
+
+
+def noam_lr(opt_step: int, d_model: int, warmup: int, scale: float = 1.0, base_lr: float = 1.0) -> float:
+    """Learning rate of optimiser step `opt_step` (1-based): utlis/scheduler.py:3-28 stepped once per optimiser step
+    (oln_tfm_enc_dec.py:274); the scheduler's construction-time step makes step k run at last_epoch = k - 1 (>= 1)."""
+    e = max(1, opt_step - 1)
+    return base_lr * scale * d_model ** (-0.5) * min(e ** (-0.5), e * warmup ** (-1.5))
+
+
+class _Site:
+    """Saved tensors of one `linear + residual + LayerNorm` site: f16 output, normalised rows, 1/sigma."""
+
+    def __init__(self, dev, M):
+        self.out16 = torch.empty(M, D, dtype=F16, device=dev)
+        self.xhat = torch.empty(M, D, dtype=F16, device=dev)
+        self.rstd = torch.empty(M, dtype=F32, device=dev)
+
+
+class _AttnSave:
+    def __init__(self, dev, nseq, Tp):
+        n = nseq * Tp * D
+        self.q, self.qt, self.k, self.kt, self.v, self.vt = (torch.empty(n, dtype=BF16, device=dev) for _ in range(6))
+        self.lse = torch.empty(nseq * H * Tp, dtype=F32, device=dev)
+        self.ctx = torch.empty(nseq * Tp, D, dtype=F16, device=dev)
+
+
+class _Buffers:
+    """Device buffers of one (B, Tp, C) training shape."""
+
+    def __init__(self, dev, B, Tp, C, n_enc, n_dec, F_enc, F_dec, Fin, Fin_pad):
+        e = lambda *s, dt: torch.empty(*s, dtype=dt, device=dev)
+        Me, Md = B * Tp, B * C * Tp
+        Mx = max(Me, Md)
+        self.xin16 = torch.zeros(Me, Fin_pad, dtype=F16, device=dev)
+        self.bn_mean, self.bn_var = e(Fin, dt=F32), e(Fin, dt=F32)
+        self.h32 = e(Me, D, dt=F32)
+        self.site0 = _Site(dev, Me)
+        self.enc = [dict(att=_AttnSave(dev, B, Tp), s1=_Site(dev, Me), hid=e(Me, F_enc, dt=F16), s2=_Site(dev, Me))
+                    for _ in range(n_enc)]
+        self.emb32, self.emb16, self.inv_norm = e(Me, D, dt=F32), e(Me, D, dt=F16), e(Me, dt=F32)
+        self.a32, self.a16 = e(Md, D, dt=F32), e(Md, D, dt=F16)
+        self.dec = [dict(att=_AttnSave(dev, B * C, Tp), s11=_Site(dev, Md), qkv=e(Md, 3 * D, dt=F16), o2=e(Md, D, dt=F16),
+                         s21=_Site(dev, Md), hid=e(Md, F_dec, dt=F16), s22=_Site(dev, Md)) for _ in range(n_dec)]
+        # backward temporaries
+        self.g32 = e(Md, D, dt=F32)
+        self.ge32 = e(Me, D, dt=F32)
+        self.de32 = e(Me, D, dt=F32)
+        self.ds16 = e(Mx, D, dt=BF16)
+        self.dctx16 = e(Mx, D, dt=BF16)
+        self.dh16 = e(Mx * max(F_enc, F_dec), dt=BF16)
+        self.dqkv16 = e(Mx, 3 * D, dt=BF16)
+        self.dot_ws = e(Mx * D, dt=BF16)
+        self.dh_ws = e(max(B, B * C) * H * Tp, dt=F32)
+        self.gsum16 = e(Me, D, dt=BF16)
+        self.demb16 = e(Me, D, dt=BF16)
+        self.dy_in = e(Me, Fin_pad, dt=BF16)
+        self.conv_tmp = e(D * 19 * D, dt=F32)
+        self.dpc = e(C, D, dt=F32)
+        self.pc = e(C, D, dt=F32)
+        self.logits = e(B, Tp, C, dt=F32)
+        self.loss = torch.zeros(4, dtype=F32, device=dev)         # [bce, emb, -, -]
+
+
+class FsTrainStep:
+    """One training step of FS-EEND (`OnlineTransformerDADiarization` mirror) entirely in HIP."""
+
+    def __init__(self, model, warmup: int = 100000, lr: float = 1.0, schedule_scale: float = 1.0, grad_clip: float = 5.0,
+                 betas=(0.9, 0.98), eps: float = 1e-9, bn_momentum: float = 0.1, process_group=None):
+        from .fs_model import OnlineTransformerDADiarization
+        if not isinstance(model, OnlineTransformerDADiarization):
+            raise TypeError("FsTrainStep drives fs_eend_amd.fs_model.OnlineTransformerDADiarization")
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout) and mod.p != 0.0:
+                raise NotImplementedError("training kernels run with dropout = 0 (the reference's drop masks cannot be "
+                                          "reproduced); build the model with dropout=0.0")
+            if isinstance(mod, torch.nn.MultiheadAttention) and mod.dropout != 0.0:
+                raise NotImplementedError("training kernels run with dropout = 0; build the model with dropout=0.0")
+        if model.enc.mask_delay != model.dec.mask_delay:
+            raise NotImplementedError
+        self.model = model
+        self.warmup, self.base_lr, self.sched_scale, self.clip = warmup, lr, schedule_scale, grad_clip
+        self.b1, self.b2, self.eps, self.bn_momentum = betas[0], betas[1], eps, bn_momentum
+        self.opt_step = 0
+        self.group = process_group
+        self.flat = FlatState(model)
+        dev = self.flat.params.device
+        self.dev = dev
+        self.ws = torch.empty(WS_FLOATS, dtype=F32, device=dev)
+        self.hp = torch.zeros(4, dtype=F32, device=dev)
+        self.gsumsq = torch.zeros(1, dtype=F32, device=dev)
+        self._hp_host = torch.zeros(4, dtype=F32).pin_memory()
+        self._bufs: Dict[tuple, _Buffers] = {}
+        self._ptr_tables = {}
+        self._build_weight_table()
+        self.last = {}
+
+    # ------------------------------------------------------------------ weight operand copies
+    def _build_weight_table(self):
+        m, fl, dev = self.model, self.flat, self.dev
+        W: Dict[str, Tensor] = {}
+        entries: List[_lib.PrepEntry] = []
+
+        def add(key, pname, dims, strides, dtype, off=0, cpad=None, nscale=0, scale=1.0, alloc=None):
+            A, B_, C_ = dims
+            cpad = C_ if cpad is None else cpad
+            dt = {0: F16, 1: BF16, 2: F32}[dtype]
+            shape = alloc if alloc is not None else (A * B_, cpad)
+            t = torch.zeros(*shape, dtype=dt, device=dev)
+            W[key] = t
+            e = _lib.PrepEntry()
+            e.src = fl.params.data_ptr()
+            e.off = fl.offsets[pname] + off
+            e.dst = t.data_ptr()
+            e.A, e.B, e.C, e.Cpad = A, B_, C_, cpad
+            e.sa, e.sb, e.sc = strides
+            e.dtype, e.nscale, e.scale, e.reserved = dtype, nscale, float(scale), 0
+            entries.append(e)
+
+        def plain(key, pname, N, K, dtype=0, kpad=None, nscale=0, scale=1.0):        # [N][K] row-major copy
+            add(key, pname, (N, 1, K), (K, 0, 1), dtype, cpad=kpad, nscale=nscale, scale=scale)
+
+        def transposed(key, pname, N, K, ld=None, rows_alloc=None):                 # bf16 [K][N]: dst[k][n] = W[n][k]
+            ld = K if ld is None else ld
+            add(key, pname, (K, 1, N), (1, 0, ld), 1, alloc=(rows_alloc or K, N))
+
+        def vec(key, pname, n, nscale=0, scale=1.0):
+            add(key, pname, (n, 1, 1), (1, 0, 0), 2, nscale=nscale, scale=scale, alloc=(n,))
+
+        Fin = m.enc.in_size
+        self.Fin, self.Fin_pad = Fin, (Fin + 127) // 128 * 128
+        qs = ops.QSCALE_LOG2
+        plain("enc.in.w", "enc.encoder.weight", D, Fin, kpad=self.Fin_pad)
+        transposed("enc.in.wT", "enc.encoder.weight", D, Fin, rows_alloc=self.Fin_pad)
+        for i, l in enumerate(m.enc.transformer_encoder.layers):
+            p_ = f"enc.transformer_encoder.layers.{i}."
+            Fh = l.linear1.out_features
+            plain(f"e{i}.in_w", p_ + "self_attn.in_proj_weight", 3 * D, D, nscale=D, scale=qs)
+            vec(f"e{i}.in_b", p_ + "self_attn.in_proj_bias", 3 * D, nscale=D, scale=qs)
+            transposed(f"e{i}.in_wT", p_ + "self_attn.in_proj_weight", 3 * D, D)
+            plain(f"e{i}.out_w", p_ + "self_attn.out_proj.weight", D, D)
+            transposed(f"e{i}.out_wT", p_ + "self_attn.out_proj.weight", D, D)
+            plain(f"e{i}.w1", p_ + "linear1.weight", Fh, D)
+            transposed(f"e{i}.w1T", p_ + "linear1.weight", Fh, D)
+            plain(f"e{i}.w2", p_ + "linear2.weight", D, Fh)
+            transposed(f"e{i}.w2T", p_ + "linear2.weight", D, Fh)
+        k = m.cnn.kernel_size[0]
+        self.ktaps, self.cpad = k, m.cnn.padding[0]
+        # forward: [co][tap*256 + ci]; data gradient: [ci][tap'*256 + co] = W[co][ci][k-1-tap']
+        add("cnn.w", "cnn.weight", (D, k, D), (D * k, 1, k), 0, alloc=(D, k * D))
+        add("cnn.wd", "cnn.weight", (D, k, D), (k, -1, D * k), 1, off=k - 1, alloc=(D, k * D))
+        add("convert.w1", "dec.convert.weight", (D, 1, D), (2 * D, 0, 1), 0)
+        add("convert.w1T", "dec.convert.weight", (D, 1, D), (1, 0, 2 * D), 1)
+        for i, l in enumerate(m.dec.attractor_decoder.layers):
+            p_ = f"dec.attractor_decoder.layers.{i}."
+            Fh = l.linear1.out_features
+            plain(f"d{i}.in1_w", p_ + "self_attn1.in_proj_weight", 3 * D, D, nscale=D, scale=qs)
+            vec(f"d{i}.in1_b", p_ + "self_attn1.in_proj_bias", 3 * D, nscale=D, scale=qs)
+            transposed(f"d{i}.in1_wT", p_ + "self_attn1.in_proj_weight", 3 * D, D)
+            plain(f"d{i}.out1_w", p_ + "self_attn1.out_proj.weight", D, D)
+            transposed(f"d{i}.out1_wT", p_ + "self_attn1.out_proj.weight", D, D)
+            plain(f"d{i}.in2_w", p_ + "self_attn2.in_proj_weight", 3 * D, D)
+            transposed(f"d{i}.in2_wT", p_ + "self_attn2.in_proj_weight", 3 * D, D)
+            plain(f"d{i}.out2_w", p_ + "self_attn2.out_proj.weight", D, D)
+            transposed(f"d{i}.out2_wT", p_ + "self_attn2.out_proj.weight", D, D)
+            plain(f"d{i}.w1", p_ + "linear1.weight", Fh, D)
+            transposed(f"d{i}.w1T", p_ + "linear1.weight", Fh, D)
+            plain(f"d{i}.w2", p_ + "linear2.weight", D, Fh)
+            transposed(f"d{i}.w2T", p_ + "linear2.weight", D, Fh)
+        self.W = W
+        arr = (_lib.PrepEntry * len(entries))(*entries)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._table = raw.to(dev)
+        self._n_entries = len(entries)
+        self.pe = m.dec.pos_enc.pe[0].to(device=dev, dtype=F32).contiguous()       # (5000, 256) sinusoid rows
+
+    def prep_weights(self):
+        """f32 parameters -> MFMA operand copies (one launch)."""
+        _call("eend_prep_weights", self._table, self._n_entries)
+
+    # ------------------------------------------------------------------ helpers
+    def _buffers(self, B, Tp, C) -> _Buffers:
+        key = (B, Tp, C)
+        b = self._bufs.get(key)
+        if b is None:
+            if len(self._bufs) >= 2:
+                self._bufs.clear()
+            m = self.model
+            Fe = m.enc.transformer_encoder.layers[0].linear1.out_features if len(m.enc.transformer_encoder.layers) else D
+            Fd = m.dec.attractor_decoder.layers[0].linear1.out_features if len(m.dec.attractor_decoder.layers) else D
+            b = _Buffers(self.dev, B, Tp, C, len(m.enc.transformer_encoder.layers), len(m.dec.attractor_decoder.layers),
+                         Fe, Fd, self.Fin, self.Fin_pad)
+            self._bufs[key] = b
+        return b
+
+    def _table_for(self, srcs, T):
+        key = tuple((s.data_ptr(), s.shape[0]) for s in srcs)
+        tab = self._ptr_tables.get(key)
+        if tab is None:
+            if len(self._ptr_tables) > 64:
+                self._ptr_tables.clear()
+            tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=self.dev),
+                   torch.tensor([min(k[1], T) for k in key], dtype=I32, device=self.dev))
+            self._ptr_tables[key] = tab
+        return tab
+
+    def _P(self, name):          # f32 parameter view
+        return self.flat.p(name)
+
+    def _G(self, name):          # f32 gradient view
+        return self.flat.g(name)
+
+    def _linear_ln(self, a16, w, bias, res, ln, site: _Site, out32, M, K):
+        _call("eend_linear_res_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, res, 1.0, self._P(ln + ".weight"),
+              self._P(ln + ".bias"), 1e-5, out32, site.out16, site.xhat, site.rstd, M, K)
+
+    def _attn_fwd(self, x16, w, bias, sv: _AttnSave, nseq, Tp, mask_delay, kv_len):
+        _call("eend_inproj_heads_train_bf16", x16, x16.stride(0), w, bias, sv.q, sv.qt, sv.k, sv.kt, sv.v, sv.vt, nseq, Tp, H)
+        _call("eend_attn_causal_lse_bf16", sv.q, sv.k, sv.vt, sv.ctx, sv.lse, nseq, H, Tp, D, mask_delay, kv_len, ops.LN2)
+
+    # ------------------------------------------------------------------ forward (saves activations)
+    def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False):
+        """Train-mode model.forward + losses + the gradient w.r.t. the head inputs.  labels: prepared (T_i, nspk_i+2)
+        tensors (oln_tfm_enc_dec.py:53-75).  Returns the device scalars (bce, emb_loss)."""
+        m, W, dev = self.model, self.W, self.dev
+        srcs = [s.to(device=dev, dtype=F32).contiguous() for s in src]
+        B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
+        ncols = [int(l.shape[1]) for l in labels]
+        C = max(ncols)
+        Tp = ops.frames_pad(T)
+        bf = self._buffers(B, Tp, C)
+        Me, Md = B * Tp, B * C * Tp
+        il = [min(int(l), T) for l in ilens]
+        bf.il = torch.tensor(il, dtype=I32, device=dev)
+        bf.tl = torch.full((B,), T, dtype=I32, device=dev)
+        bf.nc = torch.tensor(ncols, dtype=I32, device=dev)
+        bf.shape = (B, T, Tp, C)
+        bf.srcs = srcs
+        n_frames = sum(int(l.shape[0]) for l in labels)
+        lab = torch.zeros(B, T, C, dtype=F32, device=dev)
+        for b_, l in enumerate(labels):
+            lab[b_, :l.shape[0], :l.shape[1]] = l.to(device=dev, dtype=F32)
+        bf.labels = lab
+        enc = m.enc
+        delay_e = enc.mask_delay if enc.has_mask else Tp
+        kv_e = T
+        bf.delay_e, bf.kv_e = delay_e, kv_e
+
+        # ---- BatchNorm1d, train mode: batch statistics over all B*T padded frames, running-stat update (model :165-166)
+        ptrs, lens = self._table_for(srcs, T)
+        bf.ptrs, bf.lens = ptrs, lens
+        _call("eend_bn_train_stats_f32", ptrs, lens, -1.0, self.ws, WS_FLOATS, bf.bn_mean, bf.bn_var, enc.bn.running_mean,
+              enc.bn.running_var, self.bn_momentum, B, T, self.Fin)
+        enc.bn.num_batches_tracked += 1
+        _call("eend_gather_bn_cast_pad_f16", ptrs, lens, -1.0, self._P("enc.bn.weight"), self._P("enc.bn.bias"), bf.bn_mean,
+              bf.bn_var, enc.bn.eps, bf.xin16, B, T, Tp, self.Fin, self.Fin_pad, 1)
+        self._linear_ln(bf.xin16, W["enc.in.w"], self._P("enc.encoder.bias"), None, "enc.encoder_norm", bf.site0, bf.h32, Me,
+                        self.Fin_pad)
+        x16 = bf.site0.out16
+        for i, sv in enumerate(bf.enc):
+            p_ = f"enc.transformer_encoder.layers.{i}."
+            self._attn_fwd(x16, W[f"e{i}.in_w"], W[f"e{i}.in_b"], sv["att"], B, Tp, delay_e, kv_e)
+            self._linear_ln(sv["att"].ctx, W[f"e{i}.out_w"], self._P(p_ + "self_attn.out_proj.bias"), bf.h32, p_ + "norm1", sv["s1"],
+                            bf.h32, Me, D)
+            ops.linear(sv["s1"].out16, W[f"e{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], relu=True)
+            self._linear_ln(sv["hid"], W[f"e{i}.w2"], self._P(p_ + "linear2.bias"), bf.h32, p_ + "norm2", sv["s2"], bf.h32, Me,
+                            sv["hid"].shape[1])
+            x16 = sv["s2"].out16
+        bf.enc_out16 = x16
+
+        # ---- truncate / look-ahead conv / L2 norm (model :38-41)
+        _call("eend_conv1d_l2norm_train_f16", x16, W["cnn.w"], self._P("cnn.bias"), bf.il, bf.emb32, bf.emb16, bf.inv_norm, B, Tp, D,
+              self.ktaps, self.cpad)
+
+        # ---- attractor decoder (model :112-118)
+        _call("eend_convert_const_f32", 0, self._P("dec.convert.weight"), self._P("dec.convert.bias"), self.pe, bf.pc, None, None,
+              None, C)
+        ops.convert_fanout(bf.emb16, W["convert.w1"], bf.pc, bf.a32, bf.a16, B, Tp, C)
+        x16 = bf.a16
+        dm = m.dec.mask_delay
+        for i, sv in enumerate(bf.dec):
+            p_ = f"dec.attractor_decoder.layers.{i}."
+            self._attn_fwd(x16, W[f"d{i}.in1_w"], W[f"d{i}.in1_b"], sv["att"], B * C, Tp, dm, T)
+            self._linear_ln(sv["att"].ctx, W[f"d{i}.out1_w"], self._P(p_ + "self_attn1.out_proj.bias"), bf.a32, p_ + "norm11",
+                            sv["s11"], bf.a32, Md, D)
+            ops.linear(sv["s11"].out16, W[f"d{i}.in2_w"], self._P(p_ + "self_attn2.in_proj_bias"), sv["qkv"])
+            ops.spk_attn(sv["qkv"], sv["o2"], B, C, Tp, H)
+            self._linear_ln(sv["o2"], W[f"d{i}.out2_w"], self._P(p_ + "self_attn2.out_proj.bias"), bf.a32, p_ + "norm21", sv["s21"],
+                            bf.a32, Md, D)
+            ops.linear(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], relu=True)
+            self._linear_ln(sv["hid"], W[f"d{i}.w2"], self._P(p_ + "linear2.bias"), bf.a32, p_ + "norm22", sv["s22"], bf.a32, Md,
+                            sv["hid"].shape[1])
+            x16 = sv["s22"].out16
+
+        # ---- head + BCE (+ PIT label choice) + emb-consistency loss, and their gradients w.r.t. attractors / embeddings
+        if pit:
+            lab = self._pit_labels(bf, lab, il, ncols)
+            bf.labels = lab
+        _call("eend_head_bce_f32", bf.emb32, bf.a32, lab, bf.il, bf.nc, 1.0 / float(n_frames), bf.logits, bf.g32, bf.de32, self.ws,
+              WS_FLOATS, bf.loss[0:1], B, T, Tp, C)
+        emb_loss = ops.emb_consistency(bf.emb32.view(B, Tp, D), lab, T)
+        bf.loss[1] = emb_loss
+        _call("eend_emb_consistency_bwd_f16", bf.emb16, lab, None, 0.0, bf.de32, B, T, Tp, D, C)
+        return bf
+
+    def _pit_labels(self, bf, lab, il, ncols):
+        """train/oln_tfm_enc_dec_spk_pit.py:78-87: re-order the speaker columns (1..ncols-2) of the labels by
+        batch_pit_n_speaker_loss on the same columns of the logits (device PIT kernels, pit.py)."""
+        from . import pit as P
+        B, T, Tp, C = bf.shape
+        logits = torch.empty(B, T, C, dtype=F32, device=self.dev)
+        attr = torch.empty(B, T, C, D, dtype=F32, device=self.dev)
+        ops.head_l2dot(bf.emb32, bf.a32, attr, logits, B, T, Tp, C, D)
+        n_spk = [n - 2 for n in ncols]
+        S = max(n_spk)
+        ys = [torch.nn.functional.pad(logits[b, :il[b], 1:1 + n_spk[b]], (0, S - n_spk[b])) for b in range(B)]
+        ts = [torch.nn.functional.pad(lab[b, :il[b], 1:1 + n_spk[b]], (0, S - n_spk[b])) for b in range(B)]
+        _, perm = P.batch_pit_n_speaker_loss(ys, ts, n_spk)
+        out = lab.clone()
+        for b in range(B):
+            out[b, :il[b], 1:1 + n_spk[b]] = perm[b]
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def _bias_grad(self, dy16, M, N, gname):
+        _call("eend_colsum_f32", dy16, dy16.stride(0), M, N, 1, self.ws, WS_FLOATS, self._G(gname), 1.0, 0)
+
+    def _wgrad(self, dy16, x, M, N, K, gname, x_is_f16=True, ld_out=None, k_out=None, goff=0):
+        g = self._G(gname).view(-1)[goff:]
+        _call("eend_wgrad_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS, g,
+              K if ld_out is None else ld_out, K if k_out is None else k_out, 1.0, 0)
+
+    def _ln_bwd(self, g32, site: _Site, ln, ds16, M):
+        _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
+              self._G(ln + ".weight"), self._G(ln + ".bias"), M)
+
+    def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm):
+        """backward of x -> LN(x + W2 relu(W1 x + b1) + b2); g32 in/out (gradient w.r.t. output -> w.r.t. x)."""
+        W = self.W
+        Fh = hid.shape[1]
+        dh = dh16[:M * Fh].view(M, Fh)
+        _call("eend_colsum_f32", ds16, D, M, D, 1, self.ws, WS_FLOATS, self._G(p_ + "linear2.bias"), 1.0, 0)
+        self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
+        _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D)
+        self._bias_grad(dh, M, Fh, p_ + "linear1.bias")
+        self._wgrad(dh, x_in16, M, Fh, D, p_ + "linear1.weight")
+        _call("eend_gemm_acc_bf16", dh, Fh, W[wkey + ".w1T"], Fh, g32, 1.0, g32, None, M, Fh)
+
+    def _attn_bwd(self, g32, ds16, dctx16, dqkv16, sv: _AttnSave, x_in16, nseq, Tp, M, w_outT, w_inT, p_out, p_in, bf, delay,
+                  kv_len, T):
+        """backward of x -> x + out_proj(causal_mha(in_proj x)) given ds16 = gradient w.r.t. that sum (bf16) and
+        g32 = the same in f32 (residual path); g32 += gradient through the attention branch."""
+        self._bias_grad(ds16, M, D, p_out + ".bias")
+        self._wgrad(ds16, sv.ctx, M, D, D, p_out + ".weight")
+        _call("eend_gemm_bf16", ds16, D, w_outT, D, None, dctx16, D, M, D, D)
+        _call("eend_attn_causal_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, dctx16, D, sv.ctx, D, sv.lse, bf.dot_ws, bf.dh_ws, dqkv16,
+              3 * D, nseq, H, Tp, delay, kv_len, T, 1.0, 0.125, ops.LN2)
+        self._bias_grad(dqkv16, M, 3 * D, p_in + "_bias")
+        self._wgrad(dqkv16, x_in16, M, 3 * D, D, p_in + "_weight")
+        _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
+
+    def backward(self, bf: _Buffers):
+        """Gradients of (bce + emb_loss) w.r.t. every parameter -> self.flat.grads."""
+        W = self.W
+        B, T, Tp, C = bf.shape
+        Me, Md = B * Tp, B * C * Tp
+        m = self.model
+        dm = m.dec.mask_delay
+        ds16, dctx16, dqkv16 = bf.ds16, bf.dctx16, bf.dqkv16
+
+        # ---- decoder layers, last to first; bf.g32 = gradient w.r.t. the layer output
+        g32 = bf.g32
+        for i in reversed(range(len(bf.dec))):
+            sv = bf.dec[i]
+            p_ = f"dec.attractor_decoder.layers.{i}."
+            x_in16 = bf.dec[i - 1]["s22"].out16 if i > 0 else bf.a16
+            dsd = ds16[:Md]
+            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md)
+            self._ffn_bwd(g32, dsd, bf.dh16, sv["hid"], sv["s21"].out16, Md, f"d{i}", p_, "norm22")
+            # speaker-axis attention block (merge_tfm_encoder.py:373, :388-394)
+            self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md)
+            self._bias_grad(dsd, Md, D, p_ + "self_attn2.out_proj.bias")
+            self._wgrad(dsd, sv["o2"], Md, D, D, p_ + "self_attn2.out_proj.weight")
+            _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
+            _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125)
+            self._bias_grad(dqkv16[:Md], Md, 3 * D, p_ + "self_attn2.in_proj_bias")
+            self._wgrad(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight")
+            _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
+            # time-axis attention block (:364, :379-385)
+            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md)
+            self._attn_bwd(g32, dsd, dctx16[:Md], dqkv16[:Md], sv["att"], x_in16, B * C, Tp, Md, W[f"d{i}.out1_wT"],
+                           W[f"d{i}.in1_wT"], p_ + "self_attn1.out_proj", p_ + "self_attn1.in_proj", bf, dm, T, T)
+
+        # ---- convert fan-out (model :113-114, factored): g32 = gradient w.r.t. attr0
+        _call("eend_convert_fanout_bwd_f32", g32, bf.gsum16, self.ws, WS_FLOATS, bf.dpc, B, Tp, C)
+        _call("eend_convert_const_f32", 1, None, None, self.pe, None, bf.dpc, self._G("dec.convert.weight"), self._G("dec.convert.bias"), C)
+        self._wgrad(bf.gsum16, bf.emb16, Me, D, D, "dec.convert.weight", ld_out=2 * D, k_out=D)
+        _call("eend_gemm_acc_bf16", bf.gsum16, D, W["convert.w1T"], D, bf.de32, 1.0, bf.de32, None, Me, D)
+
+        # ---- L2 norm + look-ahead conv (model :40-41); de32 = gradient w.r.t. the unit embeddings (head + emb loss + convert)
+        _call("eend_l2norm_bwd_bf16", bf.emb32, bf.de32, bf.inv_norm, bf.demb16, B, T, Tp)
+        self._bias_grad(bf.demb16, Me, D, "cnn.bias")
+        _call("eend_conv1d_wgrad_bf16", bf.demb16, bf.enc_out16, bf.il, B, Tp, D, self.ktaps, self.cpad, self.ws, WS_FLOATS, bf.conv_tmp,
+              self._G("cnn.weight"))
+        _call("eend_conv1d_dgrad_bf16", bf.demb16, W["cnn.wd"], bf.tl, bf.il, bf.ge32, B, Tp, D, self.ktaps, self.ktaps - 1 - self.cpad)
+
+        # ---- encoder layers, last to first
+        g32 = bf.ge32
+        dse = ds16[:Me]
+        for i in reversed(range(len(bf.enc))):
+            sv = bf.enc[i]
+            p_ = f"enc.transformer_encoder.layers.{i}."
+            x_in16 = bf.enc[i - 1]["s2"].out16 if i > 0 else bf.site0.out16
+            self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me)
+            self._ffn_bwd(g32, dse, bf.dh16, sv["hid"], sv["s1"].out16, Me, f"e{i}", p_, "norm2")
+            self._ln_bwd(g32, sv["s1"], p_ + "norm1", dse, Me)
+            self._attn_bwd(g32, dse, dctx16[:Me], dqkv16[:Me], sv["att"], x_in16, B, Tp, Me, W[f"e{i}.out_wT"], W[f"e{i}.in_wT"],
+                           p_ + "self_attn.out_proj", p_ + "self_attn.in_proj", bf, bf.delay_e, bf.kv_e, T)
+
+        # ---- input projection + LayerNorm + BatchNorm (model :166,:173-174)
+        self._ln_bwd(g32, bf.site0, "enc.encoder_norm", dse, Me)
+        self._bias_grad(dse, Me, D, "enc.encoder.bias")
+        _call("eend_wgrad_bf16", dse, D, bf.xin16, self.Fin_pad, 1, Me, D, self.Fin_pad, self.ws, WS_FLOATS, self._G("enc.encoder.weight"),
+              self.Fin, self.Fin, 1.0, 0)
+        _call("eend_gemm_bf16", dse, D, W["enc.in.wT"], D, None, bf.dy_in, self.Fin_pad, Me, self.Fin_pad, D)
+        _call("eend_bn_bwd_f32", bf.ptrs, bf.lens, -1.0, bf.bn_mean, bf.bn_var, m.enc.bn.eps, bf.dy_in, self.Fin_pad, self.ws, WS_FLOATS,
+              self._G("enc.bn.weight"), self._G("enc.bn.bias"), B, T, Tp, self.Fin)
+
+    # ------------------------------------------------------------------ optimiser
+    def all_reduce_grads(self):
+        """Data parallelism: ONE all-reduce (mean) of the flat gradient buffer over RCCL (torch.distributed 'nccl')."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        ws = dist.get_world_size(self.group)
+        if ws == 1:
+            return
+        dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.grads.mul_(1.0 / ws)
+
+    def optimizer_step(self):
+        self.opt_step += 1
+        lr = noam_lr(self.opt_step, D, self.warmup, self.sched_scale, self.base_lr)
+        t = self.opt_step
+        self._hp_host[0], self._hp_host[1], self._hp_host[2], self._hp_host[3] = lr, 1 - self.b1 ** t, 1 - self.b2 ** t, self.clip
+        self.hp.copy_(self._hp_host, non_blocking=True)
+        fl = self.flat
+        _call("eend_grad_sumsq_f32", fl.grads, fl.numel, self.ws, WS_FLOATS, self.gsumsq)
+        _call("eend_adam_step_f32", fl.params, fl.grads, fl.m, fl.v, fl.numel, self.hp, self.gsumsq, self.b1, self.b2, self.eps)
+        self.last_lr = lr
+        self.prep_weights()
+        self.model._prep = None            # the inference-path operand cache is stale now
+        return lr
+
+    def step(self, src, labels, ilens, pit: bool = False):
+        """forward + backward + (all-reduce) + Adam.  Returns dict(loss, bce, emb, lr, gradnorm) of device scalars /
+        floats; nothing here synchronises with the host."""
+        if self.opt_step == 0 and not getattr(self, "_prepped", False):
+            self.prep_weights()
+            self._prepped = True
+        bf = self.forward(src, labels, ilens, pit=pit)
+        self.backward(bf)
+        self.all_reduce_grads()
+        lr = self.optimizer_step()
+        return dict(bce=bf.loss[0], emb=bf.loss[1], loss=bf.loss[0] + bf.loss[1], lr=lr, gradnorm=self.gsumsq.sqrt())

@@ -1,0 +1,302 @@
+"""The training-harness surface of the reference, on the HIP training step.
+
+`SpeakerDiarization` mirrors FS-EEND/train/oln_tfm_enc_dec.py:18-313 (and, with ``pit=True``, the label permutation of
+train/oln_tfm_enc_dec_spk_pit.py:78-87): same constructor ``(hparams, model, datasets, opt, scheduler, collate_func)``
+and the same LightningModule-style methods (`training_step`, `validation_step`, `validation_epoch_end`, `test_step`,
+`test_epoch_end`, `predict_step`, `configure_optimizers`, `*_dataloader`).  pytorch_lightning is not a dependency:
+`Trainer` below is the minimal loop that drives these methods the way Lightning 1.8 does (FS-EEND/train_dia.py:145-160):
+one process per GPU, `strategy="ddp"` = one all-reduce of the flat gradient buffer per optimiser step over
+torch.distributed (backend "nccl" = RCCL over xGMI), `gradient_clip_val`, Noam stepped per optimiser step.
+
+`opt` / `scheduler` may be the objects the reference script builds (torch.optim.Adam and utlis/scheduler.NoamScheduler:
+only their hyper-parameters are read -- the update itself is eend_adam_step_f32 on the flat buffers) or plain dicts.
+"""
+import math
+from collections import defaultdict
+from typing import List, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import postproc
+from .lib import EendHipError
+
+
+def prepare_labels(labels: Sequence[Tensor], clip_lengths: Sequence[int]) -> List[Tensor]:
+    """train/oln_tfm_enc_dec.py:53-75 (identical in validation_step / test_step): pad the speaker columns, order each
+    utterance's speakers by first activity (never-active last), prepend the silence column, append the all-zero
+    "none speaker" column, cut to (ilen, nspk_i + 2).  Index work on the (B, T, S) label tensor, on its own device."""
+    n_spks = [l.shape[1] for l in labels]
+    max_spk = max(n_spks)
+    lab = [F.pad(l, (0, max_spk - l.shape[1])) for l in labels]
+    lab = torch.nn.utils.rnn.pad_sequence(lab, padding_value=0.0, batch_first=True)
+    B, T, _ = lab.shape
+    frame_index = torch.arange(1, T + 1, device=lab.device, dtype=lab.dtype)[None, :, None]
+    first = frame_index * lab
+    first = first.masked_fill(first == 0, float("inf")).min(dim=1)[0]
+    order = torch.argsort(first, dim=1)
+    lab = torch.gather(lab, 2, order[:, None, :].expand(B, T, max_spk))
+    silence = 1.0 - lab.max(dim=-1)[0]
+    lab = torch.cat([silence[..., None], lab, torch.zeros(B, T, 1, dtype=lab.dtype, device=lab.device)], dim=-1)
+    return [lab[b, :l, :n + 2] for b, (l, n) in enumerate(zip(clip_lengths, n_spks))]
+
+
+def _hyper(opt, scheduler, hparams):
+    """Optimiser hyper-parameters from whatever the caller built (FS-EEND/train_dia.py:77-100)."""
+    tr = (hparams or {}).get("training", {}) if isinstance(hparams, dict) else {}
+    h = dict(lr=float(tr.get("lr", 1.0)), betas=(0.9, 0.98), eps=1e-9, warmup=int(tr.get("warm_steps", 100000)),
+             scale=float(tr.get("schedule_scale", 1.0)), clip=float(tr.get("grad_clip", 5.0) or 0.0), noam=True)
+    if isinstance(opt, dict):
+        h.update({k: opt[k] for k in ("lr", "betas", "eps") if k in opt})
+    elif opt is not None and hasattr(opt, "param_groups"):
+        g = opt.param_groups[0]
+        h["lr"] = float(getattr(scheduler, "base_lrs", [g.get("initial_lr", g["lr"])])[0]) if scheduler is not None else float(g["lr"])
+        h["betas"], h["eps"] = tuple(g.get("betas", h["betas"])), float(g.get("eps", h["eps"]))
+    if isinstance(scheduler, dict):
+        h["warmup"], h["scale"] = int(scheduler.get("warmup_steps", h["warmup"])), float(scheduler.get("scale", h["scale"]))
+    elif scheduler is not None:
+        h["warmup"], h["scale"] = int(getattr(scheduler, "warmup_steps", h["warmup"])), float(getattr(scheduler, "scale", h["scale"]))
+    else:
+        h["noam"] = False
+    return h
+
+
+class SpeakerDiarization:
+    """LightningModule-shaped training / evaluation module for the FS-EEND mirror model."""
+
+    def __init__(self, hparams, model, datasets, opt, scheduler, collate_func, pit: bool = False):
+        self.hparams = dict(hparams)
+        self.datasets, self.model, self.opt, self.scheduler, self.collate_func = datasets, model, opt, scheduler, collate_func
+        self.max_spks = self.hparams["data"]["max_speakers"]
+        self.label_delay = self.hparams["data"].get("label_delay", 0)
+        if self.label_delay:
+            raise NotImplementedError("label_delay != 0 is not used by any shipped FS-EEND config")
+        self.pit = pit
+        self._step = None
+        self.logged = {}
+        self.global_rank, self.world_size = 0, 1
+
+    # ---- plumbing
+    def log(self, key, value, **kw):
+        self.logged[key] = value
+
+    def _engine(self):
+        if self._step is None:
+            from .train import FsTrainStep
+            h = _hyper(self.opt, self.scheduler, self.hparams)
+            self._step = FsTrainStep(self.model, warmup=h["warmup"] if h["noam"] else 1, lr=h["lr"], schedule_scale=h["scale"],
+                                     grad_clip=h["clip"], betas=h["betas"], eps=h["eps"])
+            self._noam = h["noam"]
+        return self._step
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+    def state_dict(self):
+        return {"model." + k: v for k, v in self.model.state_dict().items()}
+
+    def load_state_dict(self, sd, strict=True):
+        sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
+        with torch.no_grad():
+            own = self.model.state_dict()
+            missing = [k for k in own if k not in sd]
+            if strict and (missing or [k for k in sd if k not in own]):
+                raise KeyError(f"state_dict mismatch: missing {missing}")
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v)                    # in place: parameters may be views of the flat buffer
+        self.model._prep = None
+        if self._step is not None:
+            self._step.prep_weights()
+
+    # ---- LightningModule methods
+    def detect(self, x, labels, ilens):
+        return self.model(x, tgt=labels, ilens=ilens)
+
+    def training_step(self, batch, batch_index):
+        """forward (HIP) + losses; the gradients are produced by `backward()`, the update by `optimizer_step()`
+        (Lightning calls them in this order; `Trainer` below does the same)."""
+        feats, labels, _ = batch
+        eng = self._engine()
+        dev = eng.dev
+        clip_lengths = [x.shape[0] for x in feats]
+        labels = prepare_labels([l.to(dev, torch.float32) for l in labels], clip_lengths)
+        if not getattr(eng, "_prepped", False):
+            eng.prep_weights()
+            eng._prepped = True
+        self._bf = eng.forward(feats, labels, clip_lengths, pit=self.pit)
+        pit_loss, emb_loss = self._bf.loss[0], self._bf.loss[1]
+        tot_loss = pit_loss + emb_loss
+        self.log("train/lr", getattr(eng, "last_lr", 0.0), prog_bar=True)
+        self.log("train/pit_loss", pit_loss)
+        self.log("train/emb_loss", emb_loss)
+        self.log("train/tot_loss", tot_loss)
+        return tot_loss
+
+    def backward(self):
+        self._engine().backward(self._bf)
+
+    def optimizer_step(self):
+        eng = self._engine()
+        eng.all_reduce_grads()
+        return eng.optimizer_step()
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_index):
+        feats, labels, _ = batch
+        dev = next(self.model.parameters()).device
+        clip_lengths = [x.shape[0] for x in feats]
+        n_spks = [l.shape[1] for l in labels]
+        labels = prepare_labels([l.to(dev, torch.float32) for l in labels], clip_lengths)
+        was = self.model.training
+        self.model.eval()
+        preds, emb_loss, _, _ = self.detect([f.to(dev) for f in feats], labels, clip_lengths)
+        self.model.train(was)
+        preds_realspk = [p[:, 1:-1] for p in preds]
+        labels_realspk = [l[:, 1:-1] for l in labels]
+        stats = postproc.report_diarization_error(preds_realspk, labels_realspk, label_delay=self.label_delay)
+        self.log("val/emb_loss", emb_loss)
+        return stats
+
+    def _epoch_end(self, outputs, prefix):
+        holder = defaultdict(list)
+        for stats in outputs:
+            for k, v in stats.items():
+                holder[k] += v
+        avg = {k: sum(v) / len(v) for k, v in holder.items()}
+        avg["DER"] = avg["diarization_error"] / avg["speaker_scored"] if avg.get("speaker_scored") else float("nan")
+        for k, v in avg.items():
+            self.log(f"{prefix}/{k}", v, sync_dist=True)
+        self.log(f"{prefix}/obj_metric", avg["DER"], sync_dist=True)
+        return avg
+
+    def validation_epoch_end(self, val_step_outputs):
+        return self._epoch_end(val_step_outputs, "val")
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_index):
+        feats, labels, rec = batch
+        dev = next(self.model.parameters()).device
+        clip_lengths = [x.shape[0] for x in feats]
+        n_spks = [l.shape[1] for l in labels]
+        labels = prepare_labels([l.to(dev, torch.float32) for l in labels], clip_lengths)
+        preds, embs, attractors = self.model.test([f.to(dev) for f in feats], clip_lengths, self.max_spks + 2)
+        preds_realspk = [p[:, 1:nspk + 1] for p, nspk in zip(preds, n_spks)]
+        labels_realspk = [l[:, 1:-1] for l in labels]
+        return postproc.report_diarization_error(preds_realspk, labels_realspk, label_delay=self.label_delay)
+
+    def test_epoch_end(self, test_step_outputs):
+        avg = self._epoch_end(test_step_outputs, "test")
+        for k in ("speaker_miss", "speaker_falarm", "speaker_error"):
+            if avg.get("speaker_scored"):
+                self.log(f"test/{k}_rate", avg[k] / avg["speaker_scored"])
+        return avg
+
+    @torch.no_grad()
+    def predict_step(self, batch, batch_index):
+        feats, rec = batch
+        dev = next(self.model.parameters()).device
+        clip_lengths = [x.shape[0] for x in feats]
+        preds, _, _ = self.model.test([f.to(dev) for f in feats], clip_lengths, self.max_spks + 2)
+        return preds[0][:, 1:]
+
+    def configure_optimizers(self):
+        if self.scheduler is not None:
+            return {"optimizer": self.opt, "lr_scheduler": {"scheduler": self.scheduler, "interval": "step"}}
+        return {"optimizer": self.opt}
+
+    def _loader(self, split, batch_size, shuffle, sampler=None):
+        from torch.utils.data import DataLoader
+        tr = self.hparams.get("training", {})
+        return DataLoader(self.datasets[split], batch_size=batch_size, shuffle=shuffle if sampler is None else False,
+                          sampler=sampler, num_workers=tr.get("n_workers", 0), collate_fn=self.collate_func)
+
+    def train_dataloader(self, sampler=None):
+        tr = self.hparams["training"]
+        return self._loader("train", tr["batch_size"], tr.get("shuffle", True), sampler)
+
+    def val_dataloader(self):
+        return self._loader("val", self.hparams["training"]["batch_size"], False)
+
+    def test_dataloader(self):
+        return self._loader("val", 1, False)
+
+    def predict_dataloader(self):
+        return self._loader("val", 1, False)
+
+
+class Trainer:
+    """The slice of pytorch_lightning.Trainer the reference uses (FS-EEND/train_dia.py:145-160,185), one process per GPU."""
+
+    def __init__(self, max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=1, check_val_every_n_epoch=1,
+                 strategy=None, limit_train_batches=None, limit_val_batches=None, log_every_n_steps=100, callbacks=None,
+                 num_sanity_val_steps=0, **_ignored):
+        if accumulate_grad_batches not in (None, 1):
+            raise NotImplementedError("accumulate_grad_batches > 1 (no shipped config uses it)")
+        self.max_epochs, self.clip, self.val_every = max_epochs, gradient_clip_val, check_val_every_n_epoch
+        self.limit_train, self.limit_val, self.log_every = limit_train_batches, limit_val_batches, log_every_n_steps
+        self.strategy = strategy
+        self.global_step = 0
+        self.history = []
+
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        return dist if dist.is_available() and dist.is_initialized() else None
+
+    def fit(self, module: SpeakerDiarization):
+        dist = self._dist()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+        module.global_rank, module.world_size = rank, world
+        if self.clip is not None:
+            module.hparams.setdefault("training", {})["grad_clip"] = self.clip
+        eng = module._engine()
+        if dist and world > 1:                         # DDP start-up: every rank begins from rank 0's parameters / buffers
+            dist.broadcast(eng.flat.params, 0)
+            for b in module.model.buffers():
+                dist.broadcast(b, 0)
+            eng.prep_weights()
+        sampler = None
+        if world > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(module.datasets["train"], num_replicas=world, rank=rank,
+                                         shuffle=module.hparams["training"].get("shuffle", True))
+        for epoch in range(self.max_epochs):
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            module.model.train()
+            for bi, batch in enumerate(module.train_dataloader(sampler)):
+                if self.limit_train is not None and bi >= self.limit_train:
+                    break
+                loss = module.training_step(batch, bi)
+                module.backward()
+                lr = module.optimizer_step()
+                self.global_step += 1
+                if self.global_step % self.log_every == 0 or self.global_step == 1:
+                    self.history.append(dict(step=self.global_step, loss=float(loss), lr=lr))
+            if self.val_every and (epoch + 1) % self.val_every == 0 and "val" in module.datasets:
+                outs = []
+                for bi, batch in enumerate(module.val_dataloader()):
+                    if self.limit_val is not None and bi >= self.limit_val:
+                        break
+                    outs.append(module.validation_step(batch, bi))
+                if outs:
+                    module.validation_epoch_end(outs)
+        return self
+
+    def test(self, module: SpeakerDiarization):
+        outs = [module.test_step(b, i) for i, b in enumerate(module.test_dataloader())]
+        return module.test_epoch_end(outs) if outs else {}
+
+
+def average_checkpoints(state_dicts):
+    """FS-EEND/train_dia.py:176-180 / utlis/avg_ckpt.py:6-22: element-wise mean of the listed state dicts
+    (`test_state[name] += param / len(ckpts)`, integer buffers included, in the reference's accumulation order)."""
+    out = defaultdict(float)
+    n = len(state_dicts)
+    for sd in state_dicts:
+        for name, param in sd.items():
+            out[name] += param / n
+    return dict(out)

@@ -295,6 +295,144 @@ int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const fl
 int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
                         int Tp, int C, int D, void* stream);
 
+
+/* ======================================================================================================
+ * TRAINING STEP (BASELINE config 4).  The reference trains through torch autograd + torch.optim.Adam under
+ * PyTorch-Lightning (FS-EEND/train/oln_tfm_enc_dec.py:51-91 training_step, train/utils/loss.py:119-125
+ * standard_loss, FS-EEND/train_dia.py:77-100 optimiser, :145-156 Trainer); the entry points below are the
+ * hand-written backward of every forward op above, the loss, and the optimiser.  Gradient tensors that feed
+ * an MFMA are bf16 (exponent range), saved forward activations f16, accumulation and the residual-gradient
+ * stream f32.  `ws` arguments are caller-owned f32 scratch (`ws_floats` = its capacity in floats); parameter
+ * gradients are written in fixed summation order (no atomics), so a step is bit-reproducible.
+ * ====================================================================================================== */
+
+/* eend_linear_res_ln_f16 that also saves what LayerNorm backward needs: xhat_f16 [M][256] = the normalised
+ * row before the affine, rstd [M] = 1/sigma.  (torch.nn.LayerNorm inside nn.TransformerEncoderLayer, FS model
+ * :147,:174; merge_tfm_encoder.py:364,373-374.) */
+int eend_linear_res_ln_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
+                                 float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
+                                 void* out_f16, void* xhat_f16, float* rstd, int M, int K, void* stream);
+
+/* eend_conv1d_l2norm_f16 that also saves inv_norm [nseq*Tp] = 1/||conv output|| (FS model :40-41). */
+int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bias, const int* ilens, float* out_f32,
+                                 void* out_f16, float* inv_norm, int nseq, int Tp, int cin, int ktaps, int pad,
+                                 void* stream);
+
+/* Packed MHA in-projection for training: Q, K, V in BOTH head layouts (bf16 [nseq][H][Tp][64] and
+ * [nseq][H][64][Tp]) -- the forward attention reads Q, K, Vt, its backward Q, Qt, K, Kt, V.  K = 256. */
+int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const float* bias, void* Q, void* Qt,
+                                 void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream);
+
+/* eend_attn_causal_bf16 that also writes lse [nseq][H][Tp]: the log2-domain log-sum-exp of every query row. */
+int eend_attn_causal_lse_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, float* lse, int nseq, int H,
+                              int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream);
+
+/* Backward of the causal time-axis attention (torch autograd through nn.MultiheadAttention's core: FS model :147,
+ * merge_tfm_encoder.py:379-385).  dO bf16 [nseq*Tp][ldo] (gradient w.r.t. the concatenated head outputs), O f16
+ * the forward output; dQKV bf16 [nseq*Tp][ldg] receives dQ | dK | dV at columns 0 / 256 / 512 (+ h*64).
+ * dOt_ws (bf16, nseq*Tp*256) and dh_ws (f32, nseq*H*Tp) are scratch.  scale_log2 as given to the forward
+ * (its `scale` * log2 e); sq / sk: factors applied to dQ / dK (for the pre-scaled-q convention of
+ * eend_attn_causal_bf16: scale_log2 = 1, sq = 1/sqrt(dh), sk = ln 2). */
+int eend_attn_causal_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
+                              const void* dO, int ldo, const void* O_f16, int ldout, const float* lse, void* dOt_ws,
+                              float* dh_ws, void* dQKV, int ldg, int nseq, int H, int Tp, int mask_delay, int kv_len,
+                              int q_len, float scale_log2, float sq, float sk, void* stream);
+
+/* Gradient GEMMs, bf16 operands, f32 accumulate (autograd of every torch.nn.Linear on the path):
+ *   out = A W^T (+ bias)            -> bf16 [M][ldo]                 N % 128 == 0, K % 64 == 0 */
+int eend_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_bf16, int ldo,
+                   int M, int N, int K, void* stream);
+/*   out = (A W^T) where act != 0    (ReLU backward; act = the saved forward activation, any 2-byte float) */
+int eend_gemm_relu_bwd_bf16(const void* A, int lda, const void* W, int ldw, const void* act, int ldact,
+                            void* out_bf16, int ldo, int M, int N, int K, void* stream);
+/*   out_f32 = (A W^T) * alpha + res_f32 (N = 256; the residual-gradient stream), optional bf16 copy */
+int eend_gemm_acc_bf16(const void* A, int lda, const void* W, int ldw, const float* res_f32, float alpha,
+                       float* out_f32, void* out_bf16, int M, int K, void* stream);
+
+/* Conv1d(256,256,k) data gradient as an implicit GEMM over (tap, c_out) (autograd of FS model :40): dY bf16 slab,
+ * Wd bf16 [c_in][k*c_out] with Wd[ci][tap'*c_out + co] = W[co][ci][k-1-tap']; frames >= src_lens[seq] of dY count as
+ * zero; out_f32 rows t >= mask_lens[seq] are written as zero (the input was truncated to ilen, FS model :38-39). */
+int eend_conv1d_dgrad_bf16(const void* dY, const void* Wd, const int* src_lens, const int* mask_lens, float* out_f32,
+                           int nseq, int Tp, int cout, int ktaps, int pad, void* stream);
+
+/* Weight gradient out[n][k] (row stride ld_out, k < K_out) (+)= scale * sum_m dY[m][n] X[m][k]; dY bf16 [M][lda],
+ * X f16 (x_is_f16) or bf16 [M][ldb]; N, K % 128 == 0. */
+int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
+                    long ws_floats, float* out, int ld_out, int K_out, float scale, int accumulate, void* stream);
+/* Conv1d weight gradient into the parameter's own (c_out, c_in, k) layout; tmp: f32 [c_out][k*c_in] scratch. */
+int eend_conv1d_wgrad_bf16(const void* dY, const void* X_f16, const int* ilens, int nseq, int Tp, int cin, int ktaps,
+                           int pad, float* ws, long ws_floats, float* tmp, float* out, void* stream);
+/* out[n] (+)= scale * sum_m Y[m][n]   (bias gradients); Y bf16 or f16 [M][ld]. */
+int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws, long ws_floats, float* out,
+                    float scale, int accumulate, void* stream);
+
+/* LayerNorm backward (autograd of torch.nn.LayerNorm): g = gradient w.r.t. the output (f32 [M][256]); writes the
+ * gradient w.r.t. the input as f32 (ds_f32, may alias g) and bf16, and dgamma / dbeta [256]. */
+int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rstd, const float* gamma, float* ds_f32,
+                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M, void* stream);
+
+/* Head forward + standard_loss + their gradient in one pass (FS model :43,:60; train/utils/loss.py:119-125 with
+ * label_delay = 0): labels f32 [B][T][C] (prepared: silence / speakers / none columns, zero padded), ilens / ncols
+ * [B]; loss_out[0] = BCE loss; da f32 slab [(b*C+c)*Tp+t][256] = gradient w.r.t. the un-normalised attractors,
+ * de f32 [B*Tp][256] = gradient w.r.t. the unit embeddings (overwritten); logits (optional) f32 [B][T][C]. */
+int eend_head_bce_f32(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
+                      float inv_frames, float* logits, float* da, float* de, float* ws, long ws_floats,
+                      float* loss_out, int B, int T, int Tp, int C, void* stream);
+
+/* x / ||x|| backward (FS model :41): y unit rows f32, dy f32, inv_norm from the forward -> dx bf16, rows t >= T zero. */
+int eend_l2norm_bwd_bf16(const float* y, const float* dy, const float* inv_norm, void* dx_bf16, int B, int T, int Tp,
+                         void* stream);
+
+/* `convert` fan-out backward (FS model :113-114): gsum bf16 [B*Tp][256] = sum over speaker slots of g0,
+ * dpc f32 [C][256] = sum over (b, t) of g0 per slot. */
+int eend_convert_fanout_bwd_f32(const float* g0, void* gsum_bf16, float* ws, long ws_floats, float* dpc, int B, int Tp,
+                                int C, void* stream);
+/* mode 0: pc[c] = W[:, 256:] pe[c] + bias (the forward's per-slot constant); mode 1: dW[:, 256:] and dbias from dpc.
+ * W / dW: the (256, 512) convert weight. */
+int eend_convert_const_f32(int mode, const float* W, const float* bias, const float* pe, float* pc, const float* dpc,
+                           float* dW, float* dbias, int C, void* stream);
+
+/* Speaker-axis attention backward (merge_tfm_encoder.py:388-394): qkv f16 [rows][768] from the forward in-projection,
+ * dO bf16 [rows][256] -> dqkv bf16 [rows][768]. */
+int eend_spk_attn_bwd_bf16(const void* qkv_f16, const void* dO_bf16, void* dqkv_bf16, int B, int C, int Tp, int H,
+                           float scale, void* stream);
+
+/* Train-mode BatchNorm1d statistics over the padded input (FS model :165-166): mean / biased var [F] of all B*T
+ * frames (pad_value for frames beyond each length) and the running-statistics update (momentum, unbiased var). */
+int eend_bn_train_stats_f32(const void* const* x_ptrs, const int* lens, float pad_value, float* ws, long ws_floats,
+                            float* mean, float* var, float* run_mean, float* run_var, float momentum, int B, int T,
+                            int F, void* stream);
+/* BatchNorm weight / bias gradients from dy bf16 [B*Tp][ld] (gradient w.r.t. the BN output). */
+int eend_bn_bwd_f32(const void* const* x_ptrs, const int* lens, float pad_value, const float* mean, const float* var,
+                    float eps, const void* dy_bf16, int ld, float* ws, long ws_floats, float* dgamma, float* dbeta,
+                    int B, int T, int Tp, int F, void* stream);
+
+/* Embedding-consistency loss gradient (FS model :46-57): de f32 [B*Tp][256] += d loss / d emb. */
+int eend_emb_consistency_bwd_f16(const void* emb_f16, const float* labels, const int* lens, float inv_count, float* de,
+                                 int B, int T, int Tp, int D, int C, void* stream);
+
+/* Optimiser on flat f32 buffers (FS-EEND/train_dia.py:83-100,153): sum of squares of the gradient; Adam step with
+ * clip_grad_norm_ folded in (hp = {lr, 1-beta1^t, 1-beta2^t, max_norm} on the device). */
+int eend_grad_sumsq_f32(const float* g, long n, float* ws, long ws_floats, float* out, void* stream);
+int eend_adam_step_f32(float* p, const float* g, float* m, float* v, long n, const float* hp, const float* gsumsq,
+                       float beta1, float beta2, float eps, void* stream);
+
+/* One entry of the weight re-layout table of eend_prep_weights: dst[a][b][c] (dims A x B x Cpad, zero for
+ * c >= C) = convert(src[off + a*sa + b*sb + c*sc] * (a < nscale ? scale : 1)); dtype 0 f16, 1 bf16, 2 f32. */
+typedef struct eend_prep_entry {
+    const float* src;
+    long off;
+    void* dst;
+    int A, B, C, Cpad;
+    long sa, sb, sc;
+    int dtype, nscale;
+    float scale;
+    int reserved;
+} eend_prep_entry;
+/* MFMA-operand copies of all parameters (f16 forward layouts, bf16 transposed backward layouts) in one launch;
+ * `table` is a device array of n entries. */
+int eend_prep_weights(const eend_prep_entry* table, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

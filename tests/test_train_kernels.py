@@ -1,0 +1,435 @@
+"""GPU: every backward / optimiser kernel of the training step, one at a time, through the C-ABI, against a plain
+PyTorch fp32 (autograd) reference of the same op on the same device.
+
+Tolerances: gradient tensors travel as bf16 (8 significant bits) and are accumulated in fp32, so element-wise
+comparisons use a tolerance relative to the tensor's scale (`rel`), reductions over many rows much tighter ones.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+F16, BF16, F32, I32 = torch.float16, torch.bfloat16, torch.float32, torch.int32
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def relnorm(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def T(hip_lib, dev):
+    from fs_eend_amd import train
+    return train
+
+
+@pytest.fixture(scope="module")
+def ws(dev):
+    return torch.empty(8 * 1024 * 1024, dtype=F32, device=dev)
+
+
+def g(dev, seed):
+    return torch.Generator(device=dev).manual_seed(seed)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(300, 256, 256, True), (1000, 384, 256, False), (515, 2048, 256, True), (129, 128, 768, False)])
+def test_gemm_bf16(T, dev, M, N, K, bias):
+    gen = g(dev, M + N)
+    A = torch.randn(M, K, device=dev, generator=gen).to(BF16)
+    W = (torch.randn(N, K, device=dev, generator=gen) / math.sqrt(K)).to(BF16)
+    b = torch.randn(N, device=dev, generator=gen) if bias else None
+    out = torch.full((M, N), 7.0, dtype=BF16, device=dev)
+    T._call("eend_gemm_bf16", A, K, W, K, b, out, N, M, N, K)
+    want = A.float() @ W.float().t() + (b if bias else 0)
+    assert rel(out, want) < 6e-3
+
+
+@pytest.mark.parametrize("M,F", [(300, 2048), (64, 256), (1000, 512)])
+def test_gemm_relu_bwd(T, dev, M, F):
+    gen = g(dev, M)
+    dy = (torch.randn(M, 256, device=dev, generator=gen) * 1e-4).to(BF16)
+    w2t = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(BF16)        # [F][256] = W2^T
+    act = torch.relu(torch.randn(M, F, device=dev, generator=gen)).to(F16)
+    out = torch.full((M, F), 3.0, dtype=BF16, device=dev)
+    T._call("eend_gemm_relu_bwd_bf16", dy, 256, w2t, 256, act, F, out, F, M, F, 256)
+    want = (dy.float() @ w2t.float().t()) * (act > 0)
+    assert rel(out, want) < 6e-3
+    assert (out[act == 0] == 0).all()
+
+
+@pytest.mark.parametrize("M,K", [(300, 256), (777, 768), (200, 2048)])
+def test_gemm_acc(T, dev, M, K):
+    gen = g(dev, K)
+    A = (torch.randn(M, K, device=dev, generator=gen) * 1e-3).to(BF16)
+    W = (torch.randn(256, K, device=dev, generator=gen) / math.sqrt(K)).to(BF16)
+    res = torch.randn(M, 256, device=dev, generator=gen) * 1e-3
+    out = res.clone()
+    T._call("eend_gemm_acc_bf16", A, K, W, K, out, 1.0, out, None, M, K)          # in place, as the trainer uses it
+    want = A.float() @ W.float().t() + res
+    assert rel(out, want) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,f16", [(1000, 256, 256, True), (4133, 256, 2048, True), (4133, 2048, 256, False), (70, 768, 256, True),
+                                       (50000, 256, 384, True)])
+def test_wgrad(T, dev, ws, M, N, K, f16):
+    gen = g(dev, M + K)
+    dy = (torch.randn(M, N, device=dev, generator=gen) * 1e-5).to(BF16)
+    x = torch.randn(M, K, device=dev, generator=gen).to(F16 if f16 else BF16)
+    out = torch.full((N, K), 5.0, dtype=F32, device=dev)
+    T._call("eend_wgrad_bf16", dy, N, x, K, 1 if f16 else 0, M, N, K, ws, ws.numel(), out, K, K, 1.0, 0)
+    want = dy.float().t() @ x.to(BF16).float()
+    assert relnorm(out, want) < 2e-3, relnorm(out, want)
+    assert rel(out, want) < 1e-2
+    # transpose-detecting: an asymmetric case is already covered (N != K); accumulate + narrow destination
+    if K == 384:
+        dst = torch.ones(N, 345, dtype=F32, device=dev)
+        T._call("eend_wgrad_bf16", dy, N, x, K, 1, M, N, K, ws, ws.numel(), dst, 345, 345, 2.0, 1)
+        assert relnorm(dst, 2.0 * want[:, :345] + 1.0) < 2e-3
+
+
+def test_colsum(T, dev, ws):
+    gen = g(dev, 5)
+    for M, N, bf in [(1000, 256, True), (3333, 768, True), (500, 2048, False)]:
+        y = torch.randn(M, N, device=dev, generator=gen).to(BF16 if bf else F16)
+        out = torch.zeros(N, dtype=F32, device=dev)
+        T._call("eend_colsum_f32", y, N, M, N, 1 if bf else 0, ws, ws.numel(), out, 1.0, 0)
+        assert rel(out, y.float().sum(0)) < 1e-5
+
+
+def _conv_case(dev, seed, nseq=3, Tp=128, lens=(100, 128, 37)):
+    gen = g(dev, seed)
+    x = torch.randn(nseq, Tp, 256, device=dev, generator=gen)
+    w = torch.randn(256, 256, 19, device=dev, generator=gen) / 70
+    dy = torch.randn(nseq, Tp, 256, device=dev, generator=gen) * 1e-4
+    return x, w, dy, list(lens)
+
+
+def test_conv1d_grads(T, dev, ws):
+    x, w, dy, lens = _conv_case(dev, 11)
+    nseq, Tp = x.shape[0], x.shape[1]
+    Tmax = max(lens)
+    x16 = x.to(F16)
+    dy[:, Tmax:] = 0
+    dy16 = dy.to(BF16)
+    il = torch.tensor(lens, dtype=I32, device=dev)
+    tl = torch.full((nseq,), Tmax, dtype=I32, device=dev)
+    # reference: truncate to ilen (zero beyond), conv over the Tmax frames
+    xr = x16.float().clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    mask = (torch.arange(Tp, device=dev)[None, :] < il[:, None]).float()[..., None]
+    y = Fn.conv1d((xr * mask)[:, :Tmax].transpose(1, 2), wr, padding=9).transpose(1, 2)
+    (y * dy16.float()[:, :Tmax]).sum().backward()
+    # weight gradient
+    tmp = torch.empty(256 * 19 * 256, dtype=F32, device=dev)
+    gw = torch.zeros(256, 256, 19, dtype=F32, device=dev)
+    T._call("eend_conv1d_wgrad_bf16", dy16.view(-1, 256), x16.view(-1, 256), il, nseq, Tp, 256, 19, 9, ws, ws.numel(), tmp, gw)
+    assert relnorm(gw, wr.grad) < 3e-3, relnorm(gw, wr.grad)
+    # data gradient
+    wd = w.permute(1, 2, 0).flip(1).reshape(256, 19 * 256).to(BF16).contiguous()      # [ci][tap'][co], tap' = 18 - tap
+    gx = torch.full((nseq * Tp, 256), 9.0, dtype=F32, device=dev)
+    T._call("eend_conv1d_dgrad_bf16", dy16.view(-1, 256), wd, tl, il, gx, nseq, Tp, 256, 19, 9)
+    want = xr.grad
+    assert relnorm(gx.view(nseq, Tp, 256), want) < 4e-3, relnorm(gx.view(nseq, Tp, 256), want)
+    for b, l in enumerate(lens):
+        assert (gx.view(nseq, Tp, 256)[b, l:] == 0).all()
+
+
+def test_linear_res_ln_train(T, dev):
+    from fs_eend_amd import ops
+    gen = g(dev, 3)
+    M, K = 333, 256
+    a = torch.randn(M, K, device=dev, generator=gen).to(F16)
+    w = (torch.randn(256, K, device=dev, generator=gen) / 16).to(F16)
+    b = torch.randn(256, device=dev, generator=gen) * 0.1
+    res = torch.randn(M, 256, device=dev, generator=gen)
+    gm = 1 + 0.2 * torch.randn(256, device=dev, generator=gen)
+    be = 0.1 * torch.randn(256, device=dev, generator=gen)
+    o32, o16 = torch.empty(M, 256, device=dev), torch.empty(M, 256, dtype=F16, device=dev)
+    xh, rs = torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, device=dev)
+    T._call("eend_linear_res_ln_train_f16", a, K, w, K, b, res, 1.0, gm, be, 1e-5, o32, o16, xh, rs, M, K)
+    s = a.float() @ w.float().t() + b + res
+    mu, var = s.mean(-1, keepdim=True), s.var(-1, unbiased=False, keepdim=True)
+    xhat = (s - mu) / torch.sqrt(var + 1e-5)
+    assert (o32 - (xhat * gm + be)).abs().max() < 2e-4
+    assert (xh.float() - xhat).abs().max() < 3e-3
+    assert rel(rs, 1 / torch.sqrt(var + 1e-5).squeeze(-1)) < 1e-4
+    r32, r16 = torch.empty_like(o32), torch.empty_like(o16)
+    ops.linear_res_ln(a, w, b, res, gm, be, r32, r16)
+    assert torch.equal(r32, o32) and torch.equal(r16, o16)        # same values as the inference epilogue
+
+
+def test_layernorm_bwd(T, dev, ws):
+    gen = g(dev, 4)
+    M = 3001
+    s = torch.randn(M, 256, device=dev, generator=gen) * 2 + 0.3
+    gm = 1 + 0.2 * torch.randn(256, device=dev, generator=gen)
+    be = torch.zeros(256, device=dev)
+    gy = torch.randn(M, 256, device=dev, generator=gen) * 1e-5
+    sr, gr, br = s.clone().requires_grad_(True), gm.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    (Fn.layer_norm(sr, (256,), gr, br, 1e-5) * gy).sum().backward()
+    mu, var = s.mean(-1, keepdim=True), s.var(-1, unbiased=False, keepdim=True)
+    xh = ((s - mu) / torch.sqrt(var + 1e-5)).to(F16)
+    rs = (1 / torch.sqrt(var + 1e-5)).squeeze(-1).contiguous()
+    gbuf = gy.clone()
+    d16 = torch.empty(M, 256, dtype=BF16, device=dev)
+    dg, db = torch.empty(256, device=dev), torch.empty(256, device=dev)
+    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, M)
+    assert rel(gbuf, sr.grad) < 2e-3
+    assert rel(d16, sr.grad) < 6e-3
+    assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 1e-4
+
+
+def _attn_ref(q, k, v, delay, kv_len, scale):
+    """q,k,v (n,H,T,64) fp32 -> output (n,T,256), with the index-predicate mask."""
+    Tq = q.shape[2]
+    i = torch.arange(Tq, device=q.device)[:, None]
+    j = torch.arange(Tq, device=q.device)[None, :]
+    ok = ((j - i) <= delay) & (j < kv_len)
+    s = (q @ k.transpose(-1, -2)) * scale
+    s = s.masked_fill(~ok, float("-inf"))
+    o = torch.softmax(s, -1) @ v
+    return o.transpose(1, 2).reshape(q.shape[0], Tq, 256)
+
+
+@pytest.mark.parametrize("nseq,Tv,delay,prescaled", [(3, 100, 0, True), (2, 500, 0, True), (2, 192, 2, False), (1, 640, 0, True),
+                                                     (2, 130, 1000, True)])
+def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled):
+    from fs_eend_amd import ops
+    gen = g(dev, Tv + delay)
+    Tp = ops.frames_pad(Tv)
+    H = 4
+    qt_ = torch.randn(nseq, H, Tp, 64, device=dev, generator=gen)
+    k_ = torch.randn(nseq, H, Tp, 64, device=dev, generator=gen)
+    v_ = torch.randn(nseq, H, Tp, 64, device=dev, generator=gen)
+    c = ops.QSCALE_LOG2 if prescaled else 1.0
+    q16 = (qt_ * c).to(BF16)
+    k16, v16 = k_.to(BF16), v_.to(BF16)
+    q_true = (q16.float() / c).requires_grad_(True)
+    kr, vr = k16.float().requires_grad_(True), v16.float().requires_grad_(True)
+    o_ref = _attn_ref(q_true, kr, vr, delay, Tv, 0.125)
+    dO = torch.randn(nseq, Tp, 256, device=dev, generator=gen) * 1e-4
+    dO[:, Tv:] = 0
+    dO16 = dO.to(BF16)
+    (o_ref * dO16.float()).sum().backward()
+    O = torch.empty(nseq * Tp, 256, dtype=F16, device=dev)
+    lse = torch.empty(nseq * H * Tp, dtype=F32, device=dev)
+    qT, kT, vT = (t.transpose(-1, -2).contiguous() for t in (q16, k16, v16))
+    scale = ops.LN2 if prescaled else 0.125
+    T._call("eend_attn_causal_lse_bf16", q16, k16, vT, O, lse, nseq, H, Tp, 256, delay, Tv, scale)
+    assert (O.view(nseq, Tp, 256)[:, :Tv].float() - o_ref[:, :Tv]).abs().max() < 2e-2
+    # lse check (log2 domain)
+    s2 = (q_true.detach() @ kr.detach().transpose(-1, -2)) * 0.125 * math.log2(math.e)
+    i = torch.arange(Tp, device=dev)[:, None]
+    j = torch.arange(Tp, device=dev)[None, :]
+    ok = ((j - i) <= delay) & (j < Tv)
+    want_lse = torch.logsumexp(s2.masked_fill(~ok, float("-inf")) * math.log(2), -1) / math.log(2)
+    got_lse = lse.view(nseq, H, Tp)
+    assert (got_lse[:, :, :Tv] - want_lse[:, :, :Tv]).abs().max() < 2e-2
+    dot_ws = torch.empty(nseq * Tp * 256, dtype=BF16, device=dev)
+    dh_ws = torch.empty(nseq * H * Tp, dtype=F32, device=dev)
+    dqkv = torch.full((nseq * Tp, 768), 3.0, dtype=BF16, device=dev)
+    sl = 1.0 if prescaled else 0.125 * math.log2(math.e)
+    sk = ops.LN2 if prescaled else 0.125
+    T._call("eend_attn_causal_bwd_bf16", q16, qT, k16, kT, v16, dO16.view(-1, 256), 256, O, 256, lse, dot_ws, dh_ws, dqkv, 768, nseq, H, Tp,
+            delay, Tv, Tv, sl, 0.125, sk)
+    d = dqkv.view(nseq, Tp, 3, H, 64).float()
+    for idx, (name, ref) in enumerate((("dq", q_true.grad), ("dk", kr.grad), ("dv", vr.grad))):
+        got = d[:, :, idx].permute(0, 2, 1, 3)                    # (n,H,Tp,64)
+        e = relnorm(got[:, :, :Tv], ref[:, :, :Tv])
+        assert e < 1.5e-2, (name, e)
+        assert rel(got[:, :, :Tv], ref[:, :, :Tv]) < 3e-2, name
+        assert (got[:, :, Tv:] == 0).all(), name + " pad rows"
+
+
+@pytest.mark.parametrize("C", [1, 3, 6, 10])
+def test_spk_attn_bwd(T, dev, C):
+    gen = g(dev, C)
+    B, Tp = 2, 64
+    rows = B * C * Tp
+    qkv = torch.randn(rows, 768, device=dev, generator=gen).to(F16)
+    dO = (torch.randn(rows, 256, device=dev, generator=gen) * 1e-4).to(BF16)
+    x = qkv.float().view(B, C, Tp, 3, 4, 64).requires_grad_(True)
+    q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))            # (B,Tp,H,C,64)
+    p = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1)
+    o = (p @ v).permute(0, 3, 1, 2, 4).reshape(rows, 256)
+    (o * dO.float()).sum().backward()
+    out = torch.empty(rows, 768, dtype=BF16, device=dev)
+    T._call("eend_spk_attn_bwd_bf16", qkv, dO, out, B, C, Tp, 4, 0.125)
+    want = x.grad.reshape(rows, 768)
+    assert relnorm(out, want) < 6e-3, relnorm(out, want)
+
+
+def test_head_bce(T, dev, ws):
+    gen = g(dev, 6)
+    B, Tv, Tp, C = 3, 100, 128, 5
+    emb = Fn.normalize(torch.randn(B, Tp, 256, device=dev, generator=gen), dim=-1)
+    attr = torch.randn(B * C * Tp, 256, device=dev, generator=gen) * 3
+    ilens, ncols = [100, 77, 50], [5, 3, 4]
+    lab = (torch.rand(B, Tv, C, device=dev, generator=gen) < 0.3).float()
+    il, nc = torch.tensor(ilens, dtype=I32, device=dev), torch.tensor(ncols, dtype=I32, device=dev)
+    n_frames = sum(ilens)
+    er = emb.clone().requires_grad_(True)
+    ar = attr.clone().requires_grad_(True)
+    a4 = ar.view(B, C, Tp, 256)
+    an = a4 / a4.norm(dim=-1, keepdim=True)
+    logit = (er[:, None] * an).sum(-1).permute(0, 2, 1)                            # (B,Tp,C)
+    loss = 0
+    for b in range(B):
+        y, t = logit[b, :ilens[b], :ncols[b]], lab[b, :ilens[b], :ncols[b]]
+        loss = loss + Fn.binary_cross_entropy_with_logits(y, t) * ilens[b]
+    loss = loss / n_frames
+    loss.backward()
+    logits = torch.zeros(B, Tv, C, device=dev)
+    da, de = torch.full((B * C * Tp, 256), 7.0, device=dev), torch.full((B * Tp, 256), 7.0, device=dev)
+    lo = torch.zeros(1, device=dev)
+    T._call("eend_head_bce_f32", emb, attr, lab, il, nc, 1.0 / n_frames, logits, da, de, ws, ws.numel(), lo, B, Tv, Tp, C)
+    assert abs(lo.item() - loss.item()) < 1e-5
+    assert (logits - logit[:, :Tv].detach()).abs().max() < 1e-5
+    assert rel(da, ar.grad) < 1e-4 and rel(de.view(B, Tp, 256), er.grad) < 1e-4
+    assert (da.view(B, C, Tp, 256)[:, :, Tv:] == 0).all() and (de.view(B, Tp, 256)[:, Tv:] == 0).all()
+
+
+def test_l2norm_bwd(T, dev):
+    gen = g(dev, 7)
+    B, Tv, Tp = 2, 50, 64
+    y = torch.randn(B * Tp, 256, device=dev, generator=gen) * 2
+    yr = y.clone().requires_grad_(True)
+    dy = torch.randn(B * Tp, 256, device=dev, generator=gen) * 1e-4
+    dy.view(B, Tp, 256)[:, Tv:] = 0
+    e = yr / yr.norm(dim=-1, keepdim=True)
+    (e * dy).sum().backward()
+    out = torch.empty(B * Tp, 256, dtype=BF16, device=dev)
+    T._call("eend_l2norm_bwd_bf16", e.detach().contiguous(), dy, (1 / y.norm(dim=-1)).contiguous(), out, B, Tv, Tp)
+    assert rel(out, yr.grad) < 6e-3
+
+
+def test_convert_bwd_and_const(T, dev, ws):
+    gen = g(dev, 8)
+    B, Tp, C = 3, 64, 6
+    g0 = torch.randn(B * C * Tp, 256, device=dev, generator=gen) * 1e-4
+    gsum = torch.empty(B * Tp, 256, dtype=BF16, device=dev)
+    dpc = torch.empty(C, 256, device=dev)
+    T._call("eend_convert_fanout_bwd_f32", g0, gsum, ws, ws.numel(), dpc, B, Tp, C)
+    g4 = g0.view(B, C, Tp, 256)
+    assert rel(gsum.view(B, Tp, 256), g4.sum(1)) < 6e-3
+    assert rel(dpc, g4.sum((0, 2))) < 1e-4
+    W = torch.randn(256, 512, device=dev, generator=gen) / 20
+    bias = torch.randn(256, device=dev, generator=gen)
+    pe = torch.randn(50, 256, device=dev, generator=gen)
+    pc = torch.empty(C, 256, device=dev)
+    T._call("eend_convert_const_f32", 0, W, bias, pe, pc, None, None, None, C)
+    assert rel(pc, pe[:C] @ W[:, 256:].t() + bias) < 1e-5
+    dW = torch.zeros(256, 512, device=dev)
+    dbias = torch.zeros(256, device=dev)
+    T._call("eend_convert_const_f32", 1, None, None, pe, None, dpc, dW, dbias, C)
+    assert rel(dW[:, 256:], dpc.t() @ pe[:C]) < 1e-5 and (dW[:, :256] == 0).all()
+    assert rel(dbias, dpc.sum(0)) < 1e-5
+
+
+def test_bn_train_stats_and_bwd(T, dev, ws):
+    gen = g(dev, 9)
+    F, Tp = 345, 128
+    lens = [100, 64, 7]
+    Tv = max(lens)
+    xs = [torch.randn(l, F, device=dev, generator=gen) * 2 - 3 for l in lens]
+    B = len(xs)
+    ptrs = torch.tensor([x.data_ptr() for x in xs], dtype=torch.int64, device=dev)
+    ln = torch.tensor(lens, dtype=I32, device=dev)
+    mean, var = torch.empty(F, device=dev), torch.empty(F, device=dev)
+    rm, rv = torch.randn(F, device=dev, generator=gen), torch.rand(F, device=dev, generator=gen) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    T._call("eend_bn_train_stats_f32", ptrs, ln, -1.0, ws, ws.numel(), mean, var, rm, rv, 0.1, B, Tv, F)
+    xp = torch.nn.utils.rnn.pad_sequence(xs, batch_first=True, padding_value=-1.0)             # (B,Tv,F)
+    flat = xp.reshape(-1, F)
+    assert (mean - flat.mean(0)).abs().max() < 1e-5 and rel(var, flat.var(0, unbiased=False)) < 1e-5
+    n = flat.shape[0]
+    assert (rm - (0.9 * rm0 + 0.1 * flat.mean(0))).abs().max() < 1e-5
+    assert rel(rv, 0.9 * rv0 + 0.1 * flat.var(0, unbiased=True)) < 1e-5
+    dy = torch.zeros(B * Tp, 384, device=dev)
+    dy.view(B, Tp, 384)[:, :Tv, :F] = torch.randn(B, Tv, F, device=dev, generator=gen) * 1e-4
+    dy16 = dy.to(BF16)
+    dg, db = torch.empty(F, device=dev), torch.empty(F, device=dev)
+    T._call("eend_bn_bwd_f32", ptrs, ln, -1.0, mean, var, 1e-5, dy16, 384, ws, ws.numel(), dg, db, B, Tv, Tp, F)
+    xhat = (xp - flat.mean(0)) / torch.sqrt(flat.var(0, unbiased=False) + 1e-5)
+    d3 = dy16.float().view(B, Tp, 384)[:, :Tv, :F]
+    assert rel(dg, (d3 * xhat).sum((0, 1))) < 1e-4 and rel(db, d3.sum((0, 1))) < 1e-4
+
+
+def test_emb_consistency_bwd(T, dev):
+    from oracle import fs_eend_ref as R                         # checker only
+    gen = g(dev, 10)
+    B, Tv, Tp, C = 2, 150, 192, 4
+    y = torch.randn(B, Tp, 256, device=dev, generator=gen)
+    yr = y.clone().requires_grad_(True)
+    e = yr / yr.norm(dim=-1, keepdim=True)
+    lab = (torch.rand(B, Tv, C, device=dev, generator=gen) < 0.4).float()
+    loss = R.emb_consistency_loss(e[:, :Tv], lab)
+    loss.backward()
+    e_det = e.detach().contiguous()
+    de = torch.zeros(B * Tp, 256, device=dev)
+    T._call("eend_emb_consistency_bwd_f16", e_det.to(F16), lab, None, 0.0, de, B, Tv, Tp, 256, C)
+    # compare after the L2-norm projection (the only way this gradient is consumed)
+    inv = (1 / y.norm(dim=-1)).reshape(-1).contiguous()
+    out = torch.empty(B * Tp, 256, dtype=BF16, device=dev)
+    T._call("eend_l2norm_bwd_bf16", e_det.view(-1, 256), de, inv, out, B, Tv, Tp)
+    want = yr.grad.view(-1, 256)
+    assert relnorm(out, want) < 1e-2, relnorm(out, want)
+
+
+def test_adam_and_sumsq(T, dev, ws):
+    gen = g(dev, 12)
+    n = 100003
+    p0 = torch.randn(n, device=dev, generator=gen)
+    p = p0.clone()
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1.0, betas=(0.9, 0.98), eps=1e-9)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    hp = torch.zeros(4, device=dev)
+    ss = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, device=dev, generator=gen) * (0.5 if step == 1 else 0.001)
+        T._call("eend_grad_sumsq_f32", gr, n, ws, ws.numel(), ss)
+        assert abs(ss.item() - (gr.double() ** 2).sum().item()) < 1e-4 * ss.item()
+        lr = 1e-3 * step
+        ref.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+        for gq in opt.param_groups:
+            gq["lr"] = lr
+        opt.step()
+        hp.copy_(torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.98 ** step, 5.0]))
+        T._call("eend_adam_step_f32", p, gr, m, v, n, hp, ss, 0.9, 0.98, 1e-9)
+        assert (p - ref.detach()).abs().max() < 2e-6, step
+
+
+def test_prep_weights_table(T, dev):
+    from fs_eend_amd import lib as L
+    gen = g(dev, 13)
+    src = torch.randn(256 * 19 * 40 + 7, device=dev, generator=gen)
+    w = src[7:7 + 40 * 256 * 19].view(40, 256, 19)                          # (co, ci, tap)
+    d1 = torch.zeros(256, 19 * 40, dtype=BF16, device=dev)                   # [ci][tap'][co] = w[co][ci][18 - tap']
+    d2 = torch.zeros(40, 384, dtype=F16, device=dev)                          # first 300 of a 4864-wide row, first 8 rows x 2
+    ents = []
+    for dst, dims, strides, off, dt, cpad, ns, sc in ((d1, (256, 19, 40), (19, -1, 256 * 19), 7 + 18, 1, 40, 0, 1.0),
+                                                       (d2, (40, 1, 300), (256 * 19, 0, 1), 7, 0, 384, 8, 2.0)):
+        e = L.PrepEntry()
+        e.src, e.off, e.dst = src.data_ptr(), off, dst.data_ptr()
+        e.A, e.B, e.C, e.Cpad = dims[0], dims[1], dims[2], cpad
+        e.sa, e.sb, e.sc = strides
+        e.dtype, e.nscale, e.scale, e.reserved = dt, ns, sc, 0
+        ents.append(e)
+    arr = (L.PrepEntry * 2)(*ents)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    T._call("eend_prep_weights", tab, 2)
+    want1 = w.permute(1, 2, 0).flip(1).reshape(256, 19 * 40)
+    assert torch.equal(d1, want1.to(BF16))
+    flat = w.reshape(40, -1)[:, :300].clone()
+    flat[:8] *= 2.0
+    assert torch.equal(d2[:, :300], flat.to(F16)) and (d2[:, 300:] == 0).all()
