@@ -31,7 +31,8 @@ DEV u32x4 f16x8_to_bf16x8(u32x4 v) {
     for (int j = 0; j < 4; ++j) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-        const h2 h = __builtin_bit_cast(h2, v[j]);
+        const unsigned x = v[j];       // (bit_cast straight from the vector-element lvalue reads element 0 for every j: hipcc 7.2)
+        const h2 h = __builtin_bit_cast(h2, x);
         b2 o;
         o[0] = (__bf16)(float)h[0];
         o[1] = (__bf16)(float)h[1];

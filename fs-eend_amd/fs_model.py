@@ -179,6 +179,18 @@ class OnlineTransformerDADiarization(nn.Module):
         self._prep_key = None
         self._ws = {}
         self._pc = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
+
+    def refresh_weights(self):
+        """Drop the cached f16 operand copies.  They are keyed on (data_ptr, _version) of every parameter, which sees
+        optimiser steps, load_state_dict and .to(); writes through `.data` (p.data.copy_) do NOT bump _version --
+        call this after such a write."""
+        self._prep = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._prep = None
+        return out
 
     # ------------------------------------------------------------------ weight preparation
     def _fingerprint(self):
@@ -275,7 +287,7 @@ class OnlineTransformerDADiarization(nn.Module):
         il = ws.il
         Me, Md = B * Tp, B * C * Tp
         delay_e = self.enc.mask_delay if self.enc.has_mask else Tp
-        kv_e = Tp if self.enc.has_mask else T
+        kv_e = T          # keys are the T real frames of the padded batch (the reference's mask is (T, T)), never slab padding
 
         # ---- embedding encoder (model :162-188)
         # pad_sequence(-1) (model :165) + BatchNorm + cast + slab padding: one gather launch
@@ -313,7 +325,7 @@ class OnlineTransformerDADiarization(nn.Module):
             F = L["w1"].shape[0]
             ff = ws.ff16[:Md * F].view(Md, F)
             ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
-            ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, Tp, scale=ops.LN2)
+            ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, T, scale=ops.LN2)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
                 ops.fusion_layer_tail(o16, ws.a32, ws.a16, L["out1_w"], L["out1_b"], L["g11"], L["be11"], L["eps11"],
                                       L["in2_w"], L["in2_b"], L["out2_w"], L["out2_b"], L["g21"], L["be21"], L["eps21"],

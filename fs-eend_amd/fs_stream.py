@@ -117,6 +117,16 @@ class StreamingTransformerEDADiarization(nn.Module):
         self._prep = self._prep_key = None
         self._pc, self._sc = {}, None
         self._enc_kv, self._dec_kv = None, None
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
+
+    def refresh_weights(self):
+        """Drop the cached operand copies (needed after writes through `.data`, which do not bump _version)."""
+        self._prep = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._prep = None
+        return out
 
     # ------------------------------------------------------------------ weights
     def _fingerprint(self):
@@ -245,10 +255,11 @@ class StreamingTransformerEDADiarization(nn.Module):
 # parameter transfer (reference FS-EEND/nnet/utils/copy_params.py:7-62)
 # ---------------------------------------------------------------------------------------------
 def _copy_mha(dst: nn.MultiheadAttention, src: nn.MultiheadAttention):
-    dst.in_proj_weight.data.copy_(src.in_proj_weight.data)
-    dst.in_proj_bias.data.copy_(src.in_proj_bias.data)
-    dst.out_proj.weight.data.copy_(src.out_proj.weight.data)
-    dst.out_proj.bias.data.copy_(src.out_proj.bias.data)
+    with torch.no_grad():              # in-place copy_ on the parameters themselves: bumps _version (the weight-cache key)
+        dst.in_proj_weight.copy_(src.in_proj_weight)
+        dst.in_proj_bias.copy_(src.in_proj_bias)
+        dst.out_proj.weight.copy_(src.out_proj.weight)
+        dst.out_proj.bias.copy_(src.out_proj.bias)
 
 
 def _copy_mod(dst: nn.Module, src: nn.Module):

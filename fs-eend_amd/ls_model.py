@@ -268,11 +268,21 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         self._in_size, self._n_heads = in_size, n_heads
         self._prep = self._prep_key = None
         self._ws, self._pc, self._step_scratch = {}, {}, {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
         # back-references for the one-step API (bypass nn.Module registration: no module cycle)
         object.__setattr__(self.enc, "_owner", weakref.ref(self))
         object.__setattr__(self.dec, "_owner", weakref.ref(self))
 
     # ------------------------------------------------------------------ weight preparation
+    def refresh_weights(self):
+        """Drop the cached operand copies (needed after writes through `.data`, which do not bump _version)."""
+        self._prep = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._prep = None
+        return out
+
     def _fingerprint(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
@@ -283,6 +293,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         dev = self.cnn.weight.device
         if dev.type != "cuda":
             raise EendHipError("model parameters must live on the GPU: the HIP path has no CPU fallback")
+        for name, buf in self.named_buffers():
+            # the retention kernels hard-code decay == 1 (log-decay 0) and no rotary shift, as the reference ships
+            # (modules/retention.py:20, :209-213); a checkpoint with another decay must fail loudly, not silently
+            if name.endswith(".decay") and bool((buf != 0).any()):
+                raise NotImplementedError(f"{name} is not all-zero: the HIP retention kernels implement decay == 1 only")
         D = self.n_units
         P = {}
         e = self.enc.encoder

@@ -4,8 +4,8 @@
     pit_loss_multispk          LS-EEND/train/utils/loss.py:350-379
     pad_labels / pad_preds     LS-EEND/train/utils/loss.py:47-71
 
-Same names, arguments and return structure as the reference.  Values only: like the rest of this build the
-loss is not differentiable (training backward is not implemented).  Neither function leaves the GPU for the
+Same names, arguments and return structure as the reference.  Values only: PIT chooses labels, the loss that is
+back-propagated is standard_loss on the permuted labels (train/oln_tfm_enc_dec_spk_pit.py:78-87).  Neither function leaves the GPU for the
 assignment (the reference's pit_loss_multispk copies every cost matrix to the host for scipy).
 """
 import torch
@@ -21,8 +21,10 @@ def _stream():
 
 def _assign(ys, ts, n_speakers_list):
     L = _lib.load()
-    if not ys or not all(t.is_cuda for t in list(ys) + list(ts)):
-        raise _lib.EendHipError("pit: expected GPU tensors (the HIP path has no CPU fallback)")
+    if not ys:
+        raise _lib.EendHipError("pit: empty batch")
+    from .postproc import _to_device
+    ys, ts = [_to_device(t, "ys") for t in ys], [_to_device(t, "ts") for t in ts]      # the callers may hold CPU tensors
     y = nn.utils.rnn.pad_sequence([t.to(torch.float32) for t in ys], padding_value=-1, batch_first=True).contiguous()
     lab = nn.utils.rnn.pad_sequence([t.to(torch.float32) for t in ts], padding_value=-1, batch_first=True).contiguous()
     B, T, C = y.shape
@@ -44,7 +46,7 @@ def batch_pit_n_speaker_loss(ys, ts, n_speakers_list):
     perm, loss = _assign(ys, ts, n_speakers_list)
     n_frames = sum(t.shape[0] for t in ts)
     min_loss = (loss.sum() / n_frames).to(torch.float32)
-    labels_perm = [t[:, perm[b]][:, :n] for b, (t, n) in enumerate(zip(ts, n_speakers_list))]
+    labels_perm = [t[:, perm[b].to(t.device)][:, :n] for b, (t, n) in enumerate(zip(ts, n_speakers_list))]
     return min_loss, labels_perm
 
 
@@ -60,7 +62,7 @@ def pit_loss_multispk(logits, target, n_speakers, detach_attractor_loss=False):
         for t, n in zip(tl, n_speakers):
             t[:, int(n):] = -1
     perm, _ = _assign(logits, tl, [int(n) for n in n_speakers])
-    return [t[:, perm[b]][: logits[b].shape[0], : int(n)] for b, (t, n) in enumerate(zip(tl, n_speakers))]
+    return [t[:, perm[b].to(t.device)][: logits[b].shape[0], : int(n)] for b, (t, n) in enumerate(zip(tl, n_speakers))]
 
 
 def pad_labels(ts, out_size):

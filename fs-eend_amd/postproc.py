@@ -31,6 +31,19 @@ def _gpu_f32(t, name):
     return t
 
 
+def _to_device(t, name):
+    """Drop-in entry points accept what the reference's drivers pass -- CPU tensors (`pred.detach().cpu()`,
+    FS streaming_infer_dia.py:95-99, train/oln_tfm_enc_dec.py:262) -- and move them to the current GPU; with no GPU
+    there is nothing to run on, and that is an error (no CPU fallback)."""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    if t.is_cuda:
+        return t
+    if not torch.cuda.is_available():
+        raise _lib.EendHipError(f"{name}: no GPU available (the HIP path has no CPU fallback)")
+    return t.to(torch.device("cuda", torch.cuda.current_device()))
+
+
 def activity(pred, threshold=0.5, median=11):
     """(T, S) probabilities -> uint8 (T, S): threshold, then median filter along time (make_rttm.py:12-15)."""
     L = _lib.load()
@@ -57,6 +70,7 @@ def segments(act):
 
 
 def make_rttm(rec, pred, frame_shift=80, threshold=0.5, median=11, subsampling=10, sampling_rate=8000):
+    pred = _to_device(pred, "pred")
     rttm = defaultdict(list)
     fmt = "SPEAKER {:s} 1 {:7.2f} {:7.2f} <NA> <NA> {:s} <NA>"
     for spkid, segs in enumerate(segments(activity(pred, threshold, median))):
@@ -86,6 +100,7 @@ def der_counters(pred, label, label_delay=0):
 
 
 def calc_diarization_error(pred, label, label_delay=0):
+    pred, label = _to_device(pred, "pred"), _to_device(label, "label")
     T, C = pred.shape
     v = der_counters(pred, label, label_delay).cpu().tolist()
     res = {}

@@ -35,7 +35,7 @@ def prepare_labels(labels: Sequence[Tensor], clip_lengths: Sequence[int]) -> Lis
     frame_index = torch.arange(1, T + 1, device=lab.device, dtype=lab.dtype)[None, :, None]
     first = frame_index * lab
     first = first.masked_fill(first == 0, float("inf")).min(dim=1)[0]
-    order = torch.argsort(first, dim=1)
+    order = torch.argsort(first, dim=1, stable=True)        # ties (same first frame / never active) keep column order, as the CPU reference sorts them
     lab = torch.gather(lab, 2, order[:, None, :].expand(B, T, max_spk))
     silence = 1.0 - lab.max(dim=-1)[0]
     lab = torch.cat([silence[..., None], lab, torch.zeros(B, T, 1, dtype=lab.dtype, device=lab.device)], dim=-1)
