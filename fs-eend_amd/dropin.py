@@ -45,8 +45,30 @@ def overlay(ns: dict, modname: str, shim_file: str):
     return None
 
 
+def install_namespaces(dirs):
+    """Pre-register the merged top-level namespace packages (`nnet`, `train`, `datasets`, ...) over `dirs` (in
+    priority order).  Needed because a REGULAR package of the same name anywhere on sys.path beats namespace portions
+    (e.g. the Hugging Face `datasets` distribution in site-packages shadows the reference's `datasets/` directory,
+    which has no __init__.py); an explicit sys.modules entry is immune to that.  Sub-packages (`train.utils`,
+    `nnet.model`) then merge by themselves through the parent's __path__."""
+    import importlib.machinery
+    import types
+    names = []
+    for d in dirs[:1]:
+        names = sorted(n for n in os.listdir(d) if os.path.isdir(os.path.join(d, n)) and not n.startswith(("_", ".")))
+    for name in names:
+        portions = [os.path.join(d, name) for d in dirs if os.path.isdir(os.path.join(d, name))]
+        mod = types.ModuleType(name)
+        mod.__path__ = portions
+        mod.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
+        mod.__spec__.submodule_search_locations = portions
+        sys.modules[name] = mod
+    return names
+
+
 def arrange_sys_path(script: str, flavour: str = None):
-    """sys.path = [shim dir, script dir, repo root, ...rest]; returns (shim dir, script dir)."""
+    """sys.path = [shim dir, script dir, repo root, ...rest] and the merged namespaces installed;
+    returns (shim dir, script dir)."""
     script_dir = os.path.dirname(os.path.abspath(script))
     if flavour is None:
         parts = script_dir.split(os.sep)
@@ -56,6 +78,7 @@ def arrange_sys_path(script: str, flavour: str = None):
     sd = shim_dir(flavour)
     rest = [p for p in sys.path if p and os.path.abspath(p) not in (sd, script_dir, ROOT)]
     sys.path[:] = [sd, script_dir, ROOT] + rest
+    install_namespaces([sd, script_dir])
     return sd, script_dir
 
 

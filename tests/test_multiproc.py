@@ -67,28 +67,72 @@ def test_shard_range_properties():
         shard_range(4, 2, 2)
 
 
+def _run_py(code, cwd="/tmp"):
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=cwd)
+
+
 def test_dropin_import_paths():
-    """The reference's import paths resolve to the HIP-backed classes."""
-    code = ("import sys; sys.path.insert(0, r'%s'); "
-            "from nnet.model.onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm import OnlineTransformerDADiarization as A; "
-            "from nnet.model.streaming_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm import StreamingTransformerEDADiarization as S; "
-            "from nnet.utils.copy_params import copy_params_from_masked_to_streaming as C; "
-            "from nnet.modules.merge_tfm_encoder import TransformerEncoderFusionLayer; "
-            "import fs_eend_amd.fs_model as F; assert A is F.OnlineTransformerDADiarization; print('ok')")
-    out = subprocess.run([sys.executable, "-c", code % os.path.join(ROOT, "FS-EEND")], capture_output=True, text=True, cwd="/tmp")
+    """The reference's import paths resolve to the HIP-backed classes once the launcher has arranged sys.path
+    (fs_eend_amd.dropin.arrange_sys_path, what `python -m fs_eend_amd.run <script>` does).
+    Here the "script" lives in an empty directory: the shim trees must also work stand-alone."""
+    pre = "import sys, os; sys.path.insert(0, r'%s'); from fs_eend_amd.dropin import arrange_sys_path; " % ROOT
+    fs = pre + "arrange_sys_path('/tmp/nowhere/FS-EEND/x.py'); "
+    out = _run_py(fs +
+                  "from nnet.model.onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm import OnlineTransformerDADiarization as A; "
+                  "from nnet.model.streaming_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm import StreamingTransformerEDADiarization as S; "
+                  "from nnet.utils.copy_params import copy_params_from_masked_to_streaming as C; "
+                  "from nnet.modules.merge_tfm_encoder import TransformerEncoderFusionLayer; "
+                  "import fs_eend_amd.fs_model as F; assert A is F.OnlineTransformerDADiarization; print('ok')")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
-    code = ("import sys; sys.path.insert(0, r'%s'); "
-            "from nnet.model.onl_conformer_retention_enc_1dcnn_tfm_retention_enc_linear_non_autoreg_pos_enc_l2norm_emb_loss_mask "
-            "import OnlineConformerRetentionDADiarization as A, StreamingConv1d; "
-            "from nnet.conformer.encoder import ConformerEncoder; from nnet.modules.retention import MultiScaleRetention; "
-            "import fs_eend_amd.ls_model as L; assert A is L.OnlineConformerRetentionDADiarization; print('ok')")
-    out = subprocess.run([sys.executable, "-c", code % os.path.join(ROOT, "LS-EEND")], capture_output=True, text=True, cwd="/tmp")
+    ls = pre + "arrange_sys_path('/tmp/nowhere/LS-EEND/x.py'); "
+    out = _run_py(ls +
+                  "from nnet.model.onl_conformer_retention_enc_1dcnn_tfm_retention_enc_linear_non_autoreg_pos_enc_l2norm_emb_loss_mask "
+                  "import OnlineConformerRetentionDADiarization as A, StreamingConv1d; "
+                  "from nnet.conformer.encoder import ConformerEncoder; from nnet.modules.retention import MultiScaleRetention; "
+                  "import fs_eend_amd.ls_model as L; assert A is L.OnlineConformerRetentionDADiarization; print('ok')")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
-    # output-side post-processing (train/utils/make_rttm.py, train/utils/loss.py DER report)
-    for flavour in ("FS-EEND", "LS-EEND"):
-        code = ("import sys; sys.path.insert(0, r'%s'); "
-                "from train.utils.make_rttm import make_rttm; from train.utils.loss import calc_diarization_error, report_diarization_error, batch_pit_n_speaker_loss, pit_loss_multispk, pad_labels; "
-                "from datasets.feature import extract_fbank, splice, subsample; import fs_eend_amd.feature as FE; assert extract_fbank is FE.extract_fbank; "
-                "import fs_eend_amd.postproc as P; assert make_rttm is P.make_rttm and calc_diarization_error is P.calc_diarization_error; print('ok')")
-        out = subprocess.run([sys.executable, "-c", code % os.path.join(ROOT, flavour)], capture_output=True, text=True, cwd="/tmp")
+    # output-side post-processing (train/utils/make_rttm.py, train/utils/loss.py DER report), input-side features
+    for pre_ in (fs, ls):
+        out = _run_py(pre_ +
+                      "from train.utils.make_rttm import make_rttm; from train.utils.loss import calc_diarization_error, "
+                      "report_diarization_error, batch_pit_n_speaker_loss, pit_loss_multispk, pad_labels, standard_loss; "
+                      "from datasets.feature import extract_fbank, splice, subsample; import fs_eend_amd.feature as FE; "
+                      "assert extract_fbank is FE.extract_fbank; import fs_eend_amd.postproc as P; "
+                      "assert make_rttm is P.make_rttm and calc_diarization_error is P.calc_diarization_error; print('ok')")
         assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/FS-EEND"), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("flavour,script,model_mod,kept", [
+    ("FS-EEND", "streaming_infer_dia.py", "nnet.model.onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm",
+     ["train.oln_tfm_enc_dec", "train.oln_tfm_enc_dec_spk_pit", "datasets.diarization_dataset", "datasets.kaldi_data",
+      "utlis.scheduler", "nnet.model.offl_tfm_enc_lstm_enc_dec"]),
+    ("LS-EEND", "streaming_infer_dia.py",
+     "nnet.model.onl_conformer_retention_enc_1dcnn_tfm_retention_enc_linear_non_autoreg_pos_enc_l2norm_emb_loss_mask",
+     ["train.oln_tfm_enc_dec", "train.oln_tfm_enc_dec_spk_pit_on_the_fly", "datasets.diarization_dataset_on_the_fly",
+      "data_loaders.utils.my_distributed_sampler", "nnet.conformer.attention"])])
+def test_dropin_binds_next_to_the_reference(flavour, script, model_mod, kept):
+    """With the reference's project root present (the launcher's situation): the hot-path modules resolve to THIS
+    repository, everything the shims do not provide still resolves to the reference's own files, and the modules the
+    shims overlay (train/utils/loss.py) expose the reference's names next to the accelerated ones."""
+    ref = f"/root/reference/{flavour}"
+    code = ("import sys, os, importlib.util; sys.dont_write_bytecode = True; sys.path.insert(0, r'%s'); "
+            "from fs_eend_amd.dropin import arrange_sys_path; arrange_sys_path(r'%s'); "
+            "m = importlib.util.find_spec('%s'); assert m.origin.startswith(r'%s'), m.origin; "
+            "bad = [n for n in %r if not importlib.util.find_spec(n).origin.startswith(r'%s')]; assert not bad, bad; "
+            "sp = importlib.util.find_spec('train.utils.loss'); assert sp.origin.startswith(r'%s'), sp.origin; "
+            "print('ok')") % (ROOT, os.path.join(ref, script), model_mod, ROOT, kept, ref, ROOT)
+    out = _run_py(code)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr + out.stdout
+    # the overlay: reference definitions + accelerated overrides in one module (torchmetrics is stubbed here only
+    # because this container lacks it; the reference environment has it)
+    code = ("import sys, types; sys.dont_write_bytecode = True; sys.path.insert(0, r'%s'); "
+            "tm = types.ModuleType('torchmetrics'); tm.PermutationInvariantTraining = object; sys.modules['torchmetrics'] = tm; "
+            "from fs_eend_amd.dropin import arrange_sys_path; arrange_sys_path(r'%s'); "
+            "import train.utils.loss as L; import fs_eend_amd.postproc as P, fs_eend_amd.pit as PIT; "
+            "assert L._REFERENCE_FILE.startswith(r'%s'), L._REFERENCE_FILE; "
+            "assert L.standard_loss.__code__.co_filename.startswith(r'%s'); assert hasattr(L, 'batch_pit_loss'); "
+            "assert L.calc_diarization_error is P.calc_diarization_error and L.batch_pit_n_speaker_loss is PIT.batch_pit_n_speaker_loss; "
+            "print('ok')") % (ROOT, os.path.join(ref, script), ref, ref)
+    out = _run_py(code)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr + out.stdout
