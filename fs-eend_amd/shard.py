@@ -1,4 +1,5 @@
-"""Utterance sharding for multi-GPU inference (one process per GPU, no data-path collective).
+"""Multi-GPU plumbing: utterance sharding for inference (one process per GPU, no data-path collective) and the one
+exchange step of data-parallel training (mean all-reduce of the flat gradient buffer).
 
 Utterances / streams are independent through the whole forward, so rank r of W simply owns a
 contiguous slice of the work list; the only communication is the throughput bookkeeping of a
@@ -27,3 +28,31 @@ def job_throughput(frames_local: float, seconds_local: float, device=None) -> fl
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(f.item() / t.item())
+
+
+def flat_layout(named_shapes, align: int = 4):
+    """Offsets of every parameter in the flat f32 buffers of the training step (named_parameters order, each slice
+    aligned to `align` elements = 16 bytes).  Returns ({name: offset}, total elements).  Every rank derives the same
+    layout from the same model, so ONE all-reduce of the gradient buffer is the whole exchange."""
+    offsets, off = {}, 0
+    for name, shape in named_shapes:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        offsets[name] = off
+        off += (n + align - 1) // align * align
+    return offsets, off
+
+
+def all_reduce_mean(buf, group=None):
+    """DDP's gradient exchange on the flat buffer: sum over ranks, then / world (in place).  RCCL over xGMI when
+    `buf` lives on a GPU (torch.distributed backend "nccl"), gloo on CPU tensors (tests).  No-op without a group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return buf
+    world = dist.get_world_size(group)
+    if world == 1:
+        return buf
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf.mul_(1.0 / world)
+    return buf

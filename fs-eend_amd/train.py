@@ -67,12 +67,9 @@ class FlatState:
         dev = named[0][1].device
         if dev.type != "cuda":
             raise EendHipError("training needs the model on the GPU: the HIP path has no CPU fallback")
+        from .shard import flat_layout
         self.names = [n for n, _ in named]
-        self.offsets: Dict[str, int] = {}
-        off = 0
-        for n, p in named:
-            self.offsets[n] = off
-            off += (p.numel() + 3) // 4 * 4                      # 16-byte aligned slices
+        self.offsets, off = flat_layout([(n, tuple(p.shape)) for n, p in named])      # 16-byte aligned slices
         self.numel = off
         self.params = torch.zeros(off, dtype=F32, device=dev)
         self.grads = torch.zeros(off, dtype=F32, device=dev)
@@ -523,14 +520,8 @@ class FsTrainStep:
     # ------------------------------------------------------------------ optimiser
     def all_reduce_grads(self):
         """Data parallelism: ONE all-reduce (mean) of the flat gradient buffer over RCCL (torch.distributed 'nccl')."""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        ws = dist.get_world_size(self.group)
-        if ws == 1:
-            return
-        dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.grads.mul_(1.0 / ws)
+        from .shard import all_reduce_mean
+        all_reduce_mean(self.flat.grads, self.group)
 
     def optimizer_step(self):
         self.opt_step += 1

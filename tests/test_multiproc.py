@@ -53,6 +53,75 @@ def test_two_rank_sharding_and_throughput(n_items):
     assert g0 == [(a0, b0), (a1, b1)]
 
 
+def _dp_worker(rank, world, port, q):
+    """One data-parallel training step on CPU: gradients of this rank's utterance shard from the oracle, the PRODUCT's
+    flat layout + mean all-reduce (gloo), the oracle's Adam on the averaged flat gradient."""
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    from fs_eend_amd.fs_model import OnlineTransformerDADiarization
+    from fs_eend_amd.shard import all_reduce_mean, flat_layout, shard_range
+    from oracle import fixtures as FX
+    from oracle import train_ref as TR
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = dict(n_units=256, n_heads=4, enc_n_layers=1, dec_n_layers=1, dropout=0.0, has_mask=True, max_seqlen=500,
+               dec_dim_feedforward=256, mask_delay=0)
+    torch.manual_seed(5)
+    m = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **cfg)
+    lens, nspk = [60, 60, 60, 60], [2, 3, 2, 1]
+    feats, labels = FX.make_src(lens, 345, 1), FX.make_labels(lens, nspk, 2)
+    a, b = shard_range(len(lens), rank, world)
+    tr = TR.TrainRef(m.state_dict(), cfg, warmup=25, clip=5.0)
+    shapes = [(k, tuple(tr.sd[k].shape)) for k in tr.pnames]
+    offsets, total = flat_layout(shapes)
+
+    def flat_grads(lo, hi):
+        leaves = {k: tr.sd[k].clone().requires_grad_(True) for k in tr.pnames}
+        sd = dict(tr.sd)
+        sd.update(leaves)
+        tot, *_ = TR.train_loss(sd, feats[lo:hi], labels[lo:hi], cfg, None, {})
+        gs = torch.autograd.grad(tot, [leaves[k] for k in tr.pnames], allow_unused=True)
+        buf = torch.zeros(total)
+        for k, g in zip(tr.pnames, gs):
+            if g is not None:
+                buf[offsets[k]:offsets[k] + g.numel()] = g.flatten()
+        return buf
+
+    mine = flat_grads(a, b)
+    reduced = all_reduce_mean(mine.clone())
+    # what DDP computes: the mean of the per-rank gradients (each rank normalises its own loss, local BN statistics)
+    want = sum(flat_grads(*shard_range(len(lens), r, world)) for r in range(world)) / world
+    # Adam on the averaged gradient (same arithmetic on every rank -> bit-identical parameters)
+    p = torch.cat([tr.sd[k].flatten() for k in tr.pnames])
+    gcat = torch.cat([reduced[offsets[k]:offsets[k] + tr.sd[k].numel()] for k in tr.pnames])
+    lr = TR.noam_lr(1, 256, 25)
+    mom, var = 0.1 * gcat, 0.02 * gcat * gcat
+    p_new = p - (lr / 0.1) * (mom / (var.sqrt() / (0.02 ** 0.5) + 1e-9))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, p_new)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, float((reduced - want).abs().max()), float(want.abs().max()), bool(torch.equal(gathered[0], gathered[1])),
+           float((mine - want).abs().max())))
+
+
+def test_two_rank_data_parallel_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, scale, same, local_diff in res:
+        assert err <= 1e-7 * max(scale, 1.0), (rank, err)        # all-reduced buffer == mean of the shard gradients
+        assert same                                               # both ranks end with bit-identical parameters
+        assert local_diff > 1e-4 * scale                          # ...although their local gradients differed
+
+
 def test_shard_range_properties():
     sys.path.insert(0, ROOT)
     from fs_eend_amd.shard import shard_range
