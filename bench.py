@@ -437,12 +437,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         backend = os.environ.get("EEND_DIST_BACKEND", "nccl")       # "gloo": single-GPU rehearsal of the N > 1 path
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -165,8 +165,8 @@ int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws
                     float scale, int accumulate, void* stream) {
     if (!Y || !ws || !out || M <= 0 || N <= 0 || ws_floats < N) return EEND_EINVAL;
     long ns = ws_floats / N;
-    if (ns > 256) ns = 256;
-    if (ns > M) ns = M;
+    if (ns > 1024) ns = 1024;
+    if (ns > (M + 63) / 64) ns = (M + 63) / 64;          // at least 64 rows per split
     int rc = eend_launch_colsum_partial(Y, ld, M, N, is_bf16, (int)ns, ws, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     return eend_launch_wgrad_reduce(ws, N, (int)ns, 1, N, N, out, N, scale, accumulate, (hipStream_t)stream);
@@ -184,11 +184,12 @@ int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rs
 }
 
 int eend_head_bce_f32(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
-                      float inv_frames, float* logits, float* da, float* de, float* ws, long ws_floats,
+                      float inv_frames, const float* dlogits_in, float* logits, float* da, float* de, float* ws, long ws_floats,
                       float* loss_out, int B, int T, int Tp, int C, void* stream) {
     const long nb = ((long)B * Tp + 3) / 4;
     if (!ws || !loss_out || ws_floats < nb) return EEND_EINVAL;
-    int rc = eend_launch_head_bce(emb, attr, labels, ilens, ncols, inv_frames, logits, da, de, ws, B, T, Tp, C, (hipStream_t)stream);
+    int rc = eend_launch_head_bce(emb, attr, labels, ilens, ncols, inv_frames, dlogits_in, logits, da, de, ws, B, T, Tp, C,
+                                  (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     return eend_launch_scalar_sum(ws, nb, 1.0f, loss_out, (hipStream_t)stream);
 }

@@ -244,8 +244,8 @@ int eend_launch_heads_transpose(const void* in, int ld, void* out, int nseq, int
 int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, const float* gamma, float* ds32, void* ds16,
                        float* partial, int* nblocks_out, long M, hipStream_t stream);
 int eend_launch_head_bce(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
-                         float inv_frames, float* logits, float* da, float* de, float* loss_partial, int B, int T, int Tp, int C,
-                         hipStream_t stream);
+                         float inv_frames, const float* dlogits_in, float* logits, float* da, float* de, float* loss_partial, int B,
+                         int T, int Tp, int C, hipStream_t stream);
 int eend_launch_l2norm_bwd(const float* y, const float* dy, const float* inv_norm, void* dx16, int B, int T, int Tp, hipStream_t stream);
 int eend_launch_slot_sum(const float* g0, void* gsum16, float* partial, int* nblocks_out, int B, int Tp, int C, hipStream_t stream);
 int eend_launch_convert_const(int mode, const float* W, const float* bias, const float* pe, float* pc, const float* dpc, float* dW,

@@ -59,11 +59,13 @@ void ln_bwd_kernel(const float* g, const _Float16* __restrict__ xhat, const floa
 //   de     += dlogit * a_hat_c ;  da_c = dlogit * (e - a_hat_c * logit_c) / |a_c|
 // emb e f32 [B][Tp][256] (unit rows), a f32 slab rows (b*C + c)*Tp + t.  Rows t >= T get zero gradients.
 // ---------------------------------------------------------------------------------------------------------------
+// With `dlogits_in` (f32 [B][T][C], the caller's d loss / d logits, e.g. from torch autograd over its own loss) the BCE
+// part is skipped and that gradient is propagated instead.
 __global__ __launch_bounds__(256)
 void head_bce_kernel(const float* __restrict__ emb, const float* __restrict__ attr, const float* __restrict__ labels,
                      const int* __restrict__ ilens, const int* __restrict__ ncols, float inv_frames,
-                     float* __restrict__ logits, float* __restrict__ da, float* __restrict__ de,
-                     float* __restrict__ loss_partial, int B, int T, int Tp, int C) {
+                     const float* __restrict__ dlogits_in, float* __restrict__ logits, float* __restrict__ da,
+                     float* __restrict__ de, float* __restrict__ loss_partial, int B, int T, int Tp, int C) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long frame = (long)blockIdx.x * 4 + wave;
@@ -75,7 +77,7 @@ void head_bce_kernel(const float* __restrict__ emb, const float* __restrict__ at
             for (int c = 0; c < C; ++c) *(float4*)(da + (((size_t)b * C + c) * Tp + t) * D + lane * 4) = dev;
         } else {
             const float4 e = *(const float4*)(emb + frame * D + lane * 4);
-            const int il = ilens[b], nc = ncols[b];
+            const int il = dlogits_in ? T : ilens[b], nc = dlogits_in ? C : ncols[b];
             const float w = inv_frames / (float)nc;
             for (int c = 0; c < C; ++c) {
                 const size_t row = ((size_t)b * C + c) * Tp + t;
@@ -86,7 +88,9 @@ void head_bce_kernel(const float* __restrict__ emb, const float* __restrict__ at
                 const float y = dot * inv;
                 if (logits && lane == 0) logits[((size_t)b * T + t) * C + c] = y;
                 float dl = 0.f;
-                if (t < il && c < nc) {
+                if (dlogits_in) {
+                    dl = dlogits_in[((size_t)b * T + t) * C + c];
+                } else if (t < il && c < nc) {
                     const float lab = labels[((size_t)b * T + t) * C + c];
                     const float ay = __builtin_fabsf(y);
                     const float sp = log1pf(__expf(-ay));          // log(1 + exp(-|y|))
@@ -381,13 +385,13 @@ int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, co
 }
 
 int eend_launch_head_bce(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
-                         float inv_frames, float* logits, float* da, float* de, float* loss_partial, int B, int T, int Tp, int C,
-                         hipStream_t stream) {
-    if (!emb || !attr || !labels || !ilens || !ncols || !da || !de || !loss_partial || B <= 0 || T <= 0 || Tp < T || C <= 0)
-        return EEND_EINVAL;
+                         float inv_frames, const float* dlogits_in, float* logits, float* da, float* de, float* loss_partial, int B,
+                         int T, int Tp, int C, hipStream_t stream) {
+    if (!emb || !attr || !da || !de || !loss_partial || B <= 0 || T <= 0 || Tp < T || C <= 0) return EEND_EINVAL;
+    if (!dlogits_in && (!labels || !ilens || !ncols)) return EEND_EINVAL;
     const long nb = ((long)B * Tp + 3) / 4;
-    hipLaunchKernelGGL(head_bce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, emb, attr, labels, ilens, ncols, inv_frames, logits,
-                       da, de, loss_partial, B, T, Tp, C);
+    hipLaunchKernelGGL(head_bce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, emb, attr, labels, ilens, ncols, inv_frames, dlogits_in,
+                       logits, da, de, loss_partial, B, T, Tp, C);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

@@ -147,33 +147,70 @@ void wgrad_reduce_kernel(const float* __restrict__ partial, long split_stride, i
     *o = v;
 }
 
+// Few outputs, many partials (LayerNorm / bias gradients: <= a few thousand outputs, up to 1024 partials): 8 lane
+// groups walk the partials in parallel (coalesced over 32 consecutive outputs) and are combined in a fixed order.
+__global__ __launch_bounds__(256)
+void wgrad_reduce_small_kernel(const float* __restrict__ partial, long split_stride, int nsplit, int N, int K, int K_out,
+                               float* __restrict__ out, int ld_out, float scale, int accumulate) {
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long idx = (long)blockIdx.x * 32 + o;
+    const bool live = idx < (long)N * K_out;
+    float s = 0.f;
+    if (live) {
+        const int n = (int)(idx / K_out), k = (int)(idx - (long)n * K_out);
+        const float* src = partial + (size_t)n * K + k;
+        float s0 = 0.f, s1 = 0.f;
+        int sp = g;
+        for (; sp + 8 < nsplit; sp += 16) {
+            s0 += src[(size_t)sp * split_stride];
+            s1 += src[(size_t)(sp + 8) * split_stride];
+        }
+        if (sp < nsplit) s0 += src[(size_t)sp * split_stride];
+        s = s0 + s1;
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g == 0 && live) {
+        const int n = (int)(idx / K_out), k = (int)(idx - (long)n * K_out);
+        float v = (((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]))) * scale;
+        float* dst = out + (size_t)n * ld_out + k;
+        if (accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
 // Column sums of a 2-byte-float matrix [M][N] (bias gradients): partial[s][n] = sum over the split's rows.
-// Thread = 2 adjacent columns, two row phases per block.
+// A block covers 256 columns (32 threads x 16-byte loads) in 8 row phases; N % 8 == 0.
 template <bool IS_BF16>
 __global__ __launch_bounds__(256)
-void colsum_partial_kernel(const unsigned* __restrict__ Y, int ld /* in 2-byte elements */, long M, int N, long rows_per_split,
+void colsum_partial_kernel(const unsigned short* __restrict__ Y, int ld /* in 2-byte elements */, long M, int N, long rows_per_split,
                            float* __restrict__ partial) {
-    __shared__ float red[2][256];
-    const int cp = threadIdx.x & 127, ph = threadIdx.x >> 7;
-    const int col = blockIdx.x * 256 + cp * 2;
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + cg * 8;
     const long r0 = (long)blockIdx.y * rows_per_split;
     long r1 = r0 + rows_per_split;
     if (r1 > M) r1 = M;
-    float a0 = 0.f, a1 = 0.f;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < N) {
-        for (long r = r0 + ph; r < r1; r += 2) {
-            const unsigned v = Y[(r * ld + col) >> 1];
-            if (IS_BF16) { a0 += bf16_lo(v); a1 += bf16_hi(v); }
-            else { a0 += f16_lo(v); a1 += f16_hi(v); }
+        for (long r = r0 + ph; r < r1; r += 8) {
+            const u32x4 v = *(const u32x4*)(Y + r * ld + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned x = v[j];
+                if (IS_BF16) { a[2 * j] += bf16_lo(x); a[2 * j + 1] += bf16_hi(x); }
+                else { a[2 * j] += f16_lo(x); a[2 * j + 1] += f16_hi(x); }
+            }
         }
     }
-    red[ph][cp * 2] = a0;
-    red[ph][cp * 2 + 1] = a1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ph][cg * 8 + e] = a[e];
     __syncthreads();
-    if (ph == 0 && col < N) {
-        partial[(size_t)blockIdx.y * N + col] = red[0][cp * 2] + red[1][cp * 2];
-        partial[(size_t)blockIdx.y * N + col + 1] = red[0][cp * 2 + 1] + red[1][cp * 2 + 1];
-    }
+    const int c = threadIdx.x;
+    if (blockIdx.x * 256 + c < N)
+        partial[(size_t)blockIdx.y * N + blockIdx.x * 256 + c] =
+            ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
 }
 
 // cnn.weight gradient back to the parameter's own layout: g[co][ci][tap] = tmp[co][tap*cin + ci]
@@ -218,20 +255,24 @@ int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit
                              int ld_out, float scale, int accumulate, hipStream_t stream) {
     if (!partial || !out || nsplit <= 0 || N <= 0 || K <= 0 || K_out <= 0 || K_out > K || ld_out < K_out) return EEND_EINVAL;
     const long n = (long)N * K_out;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, split_stride,
-                       nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+    if (n <= 16384 && nsplit >= 16)
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, partial, split_stride,
+                           nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, split_stride,
+                           nsplit, N, K, K_out, out, ld_out, scale, accumulate);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
 int eend_launch_colsum_partial(const void* Y, int ld, long M, int N, int is_bf16, int nsplit, float* partial,
                                hipStream_t stream) {
-    if (!Y || !partial || M <= 0 || N <= 0 || (N & 1) || (ld & 1) || nsplit <= 0) return EEND_EINVAL;
+    if (!Y || !partial || M <= 0 || N <= 0 || (N & 7) || (ld & 7) || nsplit <= 0 || nsplit > 65535) return EEND_EINVAL;
     const long rps = (M + nsplit - 1) / nsplit;
     const dim3 grid((N + 255) / 256, nsplit);
     if (is_bf16)
-        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, stream, (const unsigned*)Y, ld, M, N, rps, partial);
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, stream, (const unsigned short*)Y, ld, M, N, rps, partial);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, stream, (const unsigned*)Y, ld, M, N, rps, partial);
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, stream, (const unsigned short*)Y, ld, M, N, rps, partial);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

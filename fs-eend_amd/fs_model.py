@@ -366,11 +366,13 @@ class OnlineTransformerDADiarization(nn.Module):
         return output, embs, attractors
 
     def forward(self, src, tgt, ilens):
-        """reference model :32-65 (values only: the HIP path is forward-only this round, so this
-        must run under torch.no_grad(); training backward is not implemented yet)."""
+        """reference model :32-65.  Under torch.no_grad(): values only (eval-mode numerics).  With gradients enabled
+        (the reference's training_step, FS-EEND/train/oln_tfm_enc_dec.py:49): the HIP forward runs inside a
+        torch.autograd.Function whose backward is the hand-written HIP backward (autograd.py) -- `loss.backward()`
+        fills `.grad` of every parameter, so the reference's LightningModule / any torch optimiser trains this model."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("fs-eend_amd: backward kernels are not implemented yet; "
-                                      "call under torch.no_grad()")
+            from .autograd import fs_forward_with_grad
+            return fs_forward_with_grad(self, src, tgt, ilens)
         n_speakers = [t.shape[1] for t in tgt]
         C = max(n_speakers)
         logits, emb, attr, T, Tp = self._run(src, ilens, C)

@@ -310,9 +310,14 @@ class FsTrainStep:
         _call("eend_attn_causal_lse_bf16", sv.q, sv.k, sv.vt, sv.ctx, sv.lse, nseq, H, Tp, D, mask_delay, kv_len, ops.LN2)
 
     # ------------------------------------------------------------------ forward (saves activations)
-    def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False):
-        """Train-mode model.forward + losses + the gradient w.r.t. the head inputs.  labels: prepared (T_i, nspk_i+2)
-        tensors (oln_tfm_enc_dec.py:53-75).  Returns the device scalars (bce, emb_loss)."""
+    def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False,
+                fused_loss: bool = True):
+        """Train-mode model.forward with every activation the backward needs saved.  labels: prepared (T_i, nspk_i+2)
+        tensors (oln_tfm_enc_dec.py:53-75).
+        fused_loss=True : also standard_loss + emb-consistency loss and their gradients w.r.t. attractors / embeddings
+                          (bf.loss = [bce, emb_loss]); `backward(bf)` then completes the step.
+        fused_loss=False: stop at the head (bf.logits_full (B,T,C), bf.attr_n (B,T,C,D), bf.loss[1] = emb_loss): the
+                          caller computes its own loss on the logits and passes d loss / d logits to `backward`."""
         m, W, dev = self.model, self.W, self.dev
         srcs = [s.to(device=dev, dtype=F32).contiguous() for s in src]
         B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
@@ -322,15 +327,21 @@ class FsTrainStep:
         bf = self._buffers(B, Tp, C)
         Me, Md = B * Tp, B * C * Tp
         il = [min(int(l), T) for l in ilens]
-        bf.il = torch.tensor(il, dtype=I32, device=dev)
-        bf.tl = torch.full((B,), T, dtype=I32, device=dev)
-        bf.nc = torch.tensor(ncols, dtype=I32, device=dev)
+        key = (tuple(il), tuple(ncols), T)
+        if getattr(bf, "len_key", None) != key:              # cached: no H2D copies in the steady state
+            bf.il = torch.tensor(il, dtype=I32, device=dev)
+            bf.tl = torch.full((B,), T, dtype=I32, device=dev)
+            bf.nc = torch.tensor(ncols, dtype=I32, device=dev)
+            bf.len_key = key
         bf.shape = (B, T, Tp, C)
         bf.srcs = srcs
         n_frames = sum(int(l.shape[0]) for l in labels)
-        lab = torch.zeros(B, T, C, dtype=F32, device=dev)
-        for b_, l in enumerate(labels):
-            lab[b_, :l.shape[0], :l.shape[1]] = l.to(device=dev, dtype=F32)
+        if all(tuple(l.shape) == (T, C) for l in labels):    # equal-length chunks (the training set-up): one stack
+            lab = torch.stack([l.to(device=dev, dtype=F32) for l in labels]).contiguous()
+        else:
+            lab = torch.zeros(B, T, C, dtype=F32, device=dev)
+            for b_, l in enumerate(labels):
+                lab[b_, :l.shape[0], :l.shape[1]] = l.to(device=dev, dtype=F32)
         bf.labels = lab
         enc = m.enc
         delay_e = enc.mask_delay if enc.has_mask else Tp
@@ -384,11 +395,17 @@ class FsTrainStep:
             x16 = sv["s22"].out16
 
         # ---- head + BCE (+ PIT label choice) + emb-consistency loss, and their gradients w.r.t. attractors / embeddings
+        if not fused_loss:
+            bf.logits_full = torch.empty(B, T, C, dtype=F32, device=dev)
+            bf.attr_n = torch.empty(B, T, C, D, dtype=F32, device=dev)
+            ops.head_l2dot(bf.emb32, bf.a32, bf.attr_n, bf.logits_full, B, T, Tp, C, D)
+            bf.loss[1] = ops.emb_consistency(bf.emb32.view(B, Tp, D), lab, T)
+            return bf
         if pit:
             lab = self._pit_labels(bf, lab, il, ncols)
             bf.labels = lab
-        _call("eend_head_bce_f32", bf.emb32, bf.a32, lab, bf.il, bf.nc, 1.0 / float(n_frames), bf.logits, bf.g32, bf.de32, self.ws,
-              WS_FLOATS, bf.loss[0:1], B, T, Tp, C)
+        _call("eend_head_bce_f32", bf.emb32, bf.a32, lab, bf.il, bf.nc, 1.0 / float(n_frames), None, bf.logits, bf.g32, bf.de32,
+              self.ws, WS_FLOATS, bf.loss[0:1], B, T, Tp, C)
         emb_loss = ops.emb_consistency(bf.emb32.view(B, Tp, D), lab, T)
         bf.loss[1] = emb_loss
         _call("eend_emb_consistency_bwd_f16", bf.emb16, lab, None, 0.0, bf.de32, B, T, Tp, D, C)
@@ -450,10 +467,21 @@ class FsTrainStep:
         self._wgrad(dqkv16, x_in16, M, 3 * D, D, p_in + "_weight")
         _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
 
-    def backward(self, bf: _Buffers):
-        """Gradients of (bce + emb_loss) w.r.t. every parameter -> self.flat.grads."""
+    def backward(self, bf: _Buffers, dlogits: Optional[Tensor] = None, emb_loss_grad: float = 1.0):
+        """Gradients w.r.t. every parameter -> self.flat.grads.  After forward(fused_loss=True): of bce + emb_loss.
+        After forward(fused_loss=False): of the caller's loss, given dlogits = d loss / d logits (B, T, C) f32 and
+        emb_loss_grad = d loss / d emb_loss."""
         W = self.W
         B, T, Tp, C = bf.shape
+        if dlogits is not None:
+            dl = dlogits.to(device=self.dev, dtype=F32).contiguous()
+            if tuple(dl.shape) != (B, T, C):
+                raise EendHipError(f"backward: dlogits must be ({B}, {T}, {C})")
+            _call("eend_head_bce_f32", bf.emb32, bf.a32, None, None, None, 0.0, dl, None, bf.g32, bf.de32, self.ws, WS_FLOATS,
+                  bf.loss[2:3], B, T, Tp, C)
+            if emb_loss_grad != 0.0:
+                _call("eend_emb_consistency_bwd_f16", bf.emb16, bf.labels, None, float(emb_loss_grad) / (float(B) * T * T), bf.de32,
+                      B, T, Tp, D, C)
         Me, Md = B * Tp, B * C * Tp
         m = self.model
         dm = m.dec.mask_delay

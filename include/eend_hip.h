@@ -374,10 +374,12 @@ int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rs
 /* Head forward + standard_loss + their gradient in one pass (FS model :43,:60; train/utils/loss.py:119-125 with
  * label_delay = 0): labels f32 [B][T][C] (prepared: silence / speakers / none columns, zero padded), ilens / ncols
  * [B]; loss_out[0] = BCE loss; da f32 slab [(b*C+c)*Tp+t][256] = gradient w.r.t. the un-normalised attractors,
- * de f32 [B*Tp][256] = gradient w.r.t. the unit embeddings (overwritten); logits (optional) f32 [B][T][C]. */
+ * de f32 [B*Tp][256] = gradient w.r.t. the unit embeddings (overwritten); logits (optional) f32 [B][T][C].
+ * With dlogits_in (f32 [B][T][C]: the caller's own d loss / d logits, e.g. torch autograd over the reference's
+ * standard_loss) the loss part is skipped and that gradient is propagated (labels / ilens / ncols may be null). */
 int eend_head_bce_f32(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
-                      float inv_frames, float* logits, float* da, float* de, float* ws, long ws_floats,
-                      float* loss_out, int B, int T, int Tp, int C, void* stream);
+                      float inv_frames, const float* dlogits_in, float* logits, float* da, float* de, float* ws,
+                      long ws_floats, float* loss_out, int B, int T, int Tp, int C, void* stream);
 
 /* x / ||x|| backward (FS model :41): y unit rows f32, dy f32, inv_norm from the forward -> dx bf16, rows t >= T zero. */
 int eend_l2norm_bwd_bf16(const float* y, const float* dy, const float* inv_norm, void* dx_bf16, int B, int T, int Tp,

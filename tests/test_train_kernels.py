@@ -290,11 +290,18 @@ def test_head_bce(T, dev, ws):
     logits = torch.zeros(B, Tv, C, device=dev)
     da, de = torch.full((B * C * Tp, 256), 7.0, device=dev), torch.full((B * Tp, 256), 7.0, device=dev)
     lo = torch.zeros(1, device=dev)
-    T._call("eend_head_bce_f32", emb, attr, lab, il, nc, 1.0 / n_frames, logits, da, de, ws, ws.numel(), lo, B, Tv, Tp, C)
+    T._call("eend_head_bce_f32", emb, attr, lab, il, nc, 1.0 / n_frames, None, logits, da, de, ws, ws.numel(), lo, B, Tv, Tp, C)
     assert abs(lo.item() - loss.item()) < 1e-5
     assert (logits - logit[:, :Tv].detach()).abs().max() < 1e-5
     assert rel(da, ar.grad) < 1e-4 and rel(de.view(B, Tp, 256), er.grad) < 1e-4
     assert (da.view(B, C, Tp, 256)[:, :, Tv:] == 0).all() and (de.view(B, Tp, 256)[:, Tv:] == 0).all()
+    # external d loss / d logits (the autograd drop-in path): same gradients from the gradient autograd would hand over
+    lg = logit[:, :Tv].detach().clone().requires_grad_(True)
+    l2 = sum(Fn.binary_cross_entropy_with_logits(lg[b, :ilens[b], :ncols[b]], lab[b, :ilens[b], :ncols[b]]) * ilens[b] for b in range(B)) / n_frames
+    l2.backward()
+    da2, de2 = torch.full_like(da, 3.0), torch.full_like(de, 3.0)
+    T._call("eend_head_bce_f32", emb, attr, None, None, None, 0.0, lg.grad.contiguous(), None, da2, de2, ws, ws.numel(), lo, B, Tv, Tp, C)
+    assert rel(da2, ar.grad) < 1e-4 and rel(de2.view(B, Tp, 256), er.grad) < 1e-4
 
 
 def test_l2norm_bwd(T, dev):

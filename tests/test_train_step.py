@@ -95,6 +95,43 @@ def test_train_step_vs_reference(hip_lib, dev, name):
         assert np.abs(bn.running_var.cpu().numpy() - arr[f"s{s}_bn_var"]).max() < 1e-3
 
 
+def test_autograd_dropin_matches_reference(hip_lib, dev):
+    """The reference's own training recipe on the mirror model: model(feats, labels, ilens) with autograd enabled,
+    torch standard_loss + emb_loss, loss.backward(), clip_grad_norm_, torch.optim.Adam -- the backward that runs is
+    the HIP one.  Same golden bars as the native step."""
+    from fs_eend_amd.trainer import prepare_labels
+    from oracle import train_ref as TR
+    meta, arr = FX.load_case("fs_train_small")
+    m = build_fs_mirror(meta).to(dev).train()
+    feats = [f.to(dev) for f in FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])]
+    raw = [l.to(dev) for l in FX.make_labels(meta["lengths"], meta["nspk"], meta["lseed"])]
+    opt = torch.optim.Adam(m.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9)
+    for s in range(2):
+        labels = prepare_labels(raw, meta["lengths"])
+        opt.zero_grad()
+        preds, emb_loss, embs, attrs = m(feats, labels, meta["lengths"])
+        loss = TR.standard_loss(preds, labels) + emb_loss
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), meta["clip"])
+        want = arr[f"s{s}_loss"]
+        assert abs(float(loss) - want[0]) < 1e-4, (float(loss), want[0])
+        assert abs(float(gn) - arr[f"s{s}_gradnorm"][0]) < 1e-2 * arr[f"s{s}_gradnorm"][0]
+        if s == 0:
+            tot = arr["s0_gradnorm"][0]
+            for i, (k, p) in enumerate(m.named_parameters()):
+                if k in meta["nograd"]:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0
+                    continue
+                ref = arr["grad_norms"][i]
+                assert abs(float(p.grad.double().norm()) - ref) / max(ref, 1e-3 * tot) < 1e-2, k
+        for gq in opt.param_groups:
+            gq["lr"] = float(arr[f"s{s}_lr"][0])
+        opt.step()
+    with pytest.raises(Exception):
+        m.eval()
+        m(feats, labels, meta["lengths"])                 # gradient-enabled eval-mode call: refused loudly
+
+
 def test_label_preparation_matches_oracle(dev):
     from fs_eend_amd.trainer import prepare_labels
     from oracle import train_ref as TR
