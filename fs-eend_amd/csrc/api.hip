@@ -230,7 +230,8 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
 
 int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
                              void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq, int H,
-                             int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid, void* stream) {
+                             int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid, const float* state_in,
+                             float* state_out, void* stream) {
     if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !St_ws || !kv_ws || !cscale_ws || !sexp_ws || L <= 0) return EEND_EINVAL;
     RetParams p;
     p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws; p.kv_ws = kv_ws; p.kv_ws = kv_ws;
@@ -241,6 +242,7 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
     const bool use_full = use_full_env && L <= 512 && (L & 3) == 0 && (ldo & 7) == 0;
     const int Tv = (use_full && T_valid > 0 && T_valid < Tp) ? T_valid : Tp;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tv + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
+    p.state_in = state_in; p.state_out = state_out;
     int rc = eend_launch_ret_state_scan(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     if (use_full) return eend_launch_ret_chunk_full(p, (hipStream_t)stream);
@@ -255,9 +257,9 @@ int eend_layernorm_f16(const float* x, const float* gamma, const float* beta, fl
 
 int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_weight, const float* bn_bias,
                              const float* bn_mean, const float* bn_var, float eps, void* out_f16, int nseq, int Tp,
-                             int D, int k, void* stream) {
+                             int D, int k, const void* halo_f16, void* stream) {
     if (!x_f16 || !w || !bn_weight || !bn_bias || !bn_mean || !bn_var || !out_f16) return EEND_EINVAL;
-    return eend_launch_dwconv_bn_swish(x_f16, w, bn_weight, bn_bias, bn_mean, bn_var, eps, out_f16, nseq, Tp, D, k,
+    return eend_launch_dwconv_bn_swish(x_f16, w, bn_weight, bn_bias, bn_mean, bn_var, eps, out_f16, nseq, Tp, D, k, halo_f16,
                                        (hipStream_t)stream);
 }
 

@@ -117,6 +117,8 @@ struct RetParams {
     float* kv_ws;     // [nseq][H][nc][64][64] f32 per-chunk K^T V (workspace)
     int nseq, H, Tp, L, nc, ldo, ldg;
     float gn_eps;
+    const float* state_in;   // optional: unscaled chunk state S = sum k (x) v before the first chunk, f32 [nseq][H][64 kd][64 hd]
+    float* state_out;        // optional: the state after the last chunk (same layout)
 };
 
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
@@ -126,7 +128,7 @@ int eend_launch_layernorm_f16(const float* x, const float* gamma, const float* b
                               long M, int D, hipStream_t stream);
 int eend_launch_dwconv_bn_swish(const void* x16, const float* w, const float* bn_w, const float* bn_b,
                                 const float* bn_mean, const float* bn_var, float eps, void* out16, int nseq,
-                                int Tp, int D, int k, hipStream_t stream);
+                                int Tp, int D, int k, const void* halo16, hipStream_t stream);
 int eend_launch_attn_causal(const AttnParams& p, hipStream_t stream);
 int eend_launch_spk_attn(const SpkAttnParams& p, hipStream_t stream);
 int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b, const float* bn_mean,

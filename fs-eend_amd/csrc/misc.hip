@@ -155,7 +155,7 @@ template <int K>
 __global__ __launch_bounds__(256)
 void dwconv_bn_swish_win_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bw,
                                 const float* __restrict__ bb, const float* __restrict__ bm, const float* __restrict__ bv,
-                                float eps, _Float16* __restrict__ out, int Tp, int D) {
+                                float eps, _Float16* __restrict__ out, int Tp, int D, const _Float16* __restrict__ halo) {
     const int seq = blockIdx.y, t0 = blockIdx.x * 64;
     const int c = blockIdx.z * 256 + threadIdx.x;
     if (c >= D) return;
@@ -169,7 +169,8 @@ void dwconv_bn_swish_win_kernel(const _Float16* __restrict__ x, const float* __r
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
         const int ts = t0 - (K - 1) + j;
-        win[j] = ts >= 0 ? (float)xs[(size_t)ts * D] : 0.f;
+        // frames before the slab: zero (start of the recording) or the K-1 frames carried over from the previous call
+        win[j] = ts >= 0 ? (float)xs[(size_t)ts * D] : (halo ? (float)halo[((size_t)seq * (K - 1) + (ts + K - 1)) * D + c] : 0.f);
     }
     for (int tb = t0; tb < t0 + 64 && tb < Tp; tb += 8) {
         float xn[8];
@@ -192,7 +193,7 @@ void dwconv_bn_swish_win_kernel(const _Float16* __restrict__ x, const float* __r
 __global__ __launch_bounds__(256)
 void dwconv_bn_swish_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bw,
                             const float* __restrict__ bb, const float* __restrict__ bm, const float* __restrict__ bv,
-                            float eps, _Float16* __restrict__ out, int Tp, int D, int k) {
+                            float eps, _Float16* __restrict__ out, int Tp, int D, int k, const _Float16* __restrict__ halo) {
     const int seq = blockIdx.y, t0 = blockIdx.x * 64;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         const float sc = bw[c] / __builtin_sqrtf(bv[c] + eps);
@@ -204,6 +205,7 @@ void dwconv_bn_swish_kernel(const _Float16* __restrict__ x, const float* __restr
             for (int j = 0; j < k; ++j) {
                 const int ts = t - (k - 1) + j;
                 if (ts >= 0) y = __builtin_fmaf(wc[j], (float)xs[(size_t)ts * D], y);
+                else if (halo) y = __builtin_fmaf(wc[j], (float)halo[((size_t)seq * (k - 1) + (ts + k - 1)) * D + c], y);
             }
             y = y * sc + sh;
             out[((size_t)seq * Tp + t) * D + c] = to_f16_sat(y / (1.0f + __expf(-y)));
@@ -223,19 +225,19 @@ int eend_launch_layernorm_f16(const float* x, const float* gamma, const float* b
 
 int eend_launch_dwconv_bn_swish(const void* x16, const float* w, const float* bn_w, const float* bn_b,
                                 const float* bn_mean, const float* bn_var, float eps, void* out16, int nseq,
-                                int Tp, int D, int k, hipStream_t stream) {
+                                int Tp, int D, int k, const void* halo16, hipStream_t stream) {
     if (nseq <= 0 || nseq > 65535 || Tp <= 0 || D <= 0 || k <= 0) return EEND_EINVAL;
     const dim3 grid((Tp + 63) / 64, nseq, (D + 255) / 256);
 #define DW_CASE(KK)                                                                                                    \
     case KK:                                                                                                           \
         hipLaunchKernelGGL(dwconv_bn_swish_win_kernel<KK>, grid, dim3(256), 0, stream, (const _Float16*)x16, w, bn_w,   \
-                           bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D);                                       \
+                           bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D, (const _Float16*)halo16);              \
         break;
     switch (k) {
         DW_CASE(16) DW_CASE(7) DW_CASE(15) DW_CASE(31) DW_CASE(32)
         default:
             hipLaunchKernelGGL(dwconv_bn_swish_kernel, dim3((Tp + 63) / 64, nseq), dim3(256), 0, stream, (const _Float16*)x16,
-                               w, bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D, k);
+                               w, bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, Tp, D, k, (const _Float16*)halo16);
     }
 #undef DW_CASE
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

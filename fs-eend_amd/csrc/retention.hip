@@ -109,6 +109,11 @@ void ret_state_scan_kernel(const RetParams p) {
     float st[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = 0.f;
+    if (p.state_in) {                                    // state carried in from the previous call (long-form, chunk at a time)
+        const float* __restrict__ S0 = p.state_in + sh * 4096 + kd * 64 + hd0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = S0[i];
+    }
     _Float16* __restrict__ St = (_Float16*)p.St + sh * p.nc * 2 * 4096;
     for (int c = 0; c < p.nc; ++c) {
         // |S| column sums over kd and the global max
@@ -152,13 +157,18 @@ void ret_state_scan_kernel(const RetParams p) {
             p.cscale[sh * p.nc + c] = __builtin_fmaxf(1.0f, colmax * inv_sqrtL);
             p.sexp[sh * p.nc + c] = ldexpf(1.0f, e);
         }
-        if (c == p.nc - 1) break;
+        if (c == p.nc - 1 && !p.state_out) break;
         const float* __restrict__ KV = p.kv_ws + (sh * p.nc + c) * 4096 + kd * 64 + hd0;
 #pragma unroll
         for (int i = 0; i < 16; i += 4) {
             const float4 v = *(const float4*)(KV + i);
             st[i] += v.x; st[i + 1] += v.y; st[i + 2] += v.z; st[i + 3] += v.w;
         }
+    }
+    if (p.state_out) {                                   // state after the last chunk of this call: [kd][hd] f32
+        float* __restrict__ S1 = p.state_out + sh * 4096 + kd * 64 + hd0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S1[i] = st[i];
     }
 }
 
@@ -354,8 +364,9 @@ int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream) {
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc < 1 || p.nc > (p.Tp + p.L - 1) / p.L ||
         !p.kv_ws)
         return EEND_EINVAL;
-    if (p.nc > 1) {
-        hipLaunchKernelGGL(ret_kv_chunk_kernel, dim3(p.nc - 1, p.H, p.nseq), dim3(256), 0, stream, p);   // last chunk's KV is never used
+    const int nkv = p.state_out ? p.nc : p.nc - 1;       // the last chunk's KV only matters when the state is carried out
+    if (nkv > 0) {
+        hipLaunchKernelGGL(ret_kv_chunk_kernel, dim3(nkv, p.H, p.nseq), dim3(256), 0, stream, p);
         if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
     }
     hipLaunchKernelGGL(ret_state_scan_kernel, dim3(p.H, p.nseq), dim3(256), 0, stream, p);

@@ -152,10 +152,11 @@ class _Workspace:
         self.k = e(Mx * D, dt=bf16)
         self.vt = e(Mx * D, dt=bf16)
         self.o16 = e(Mx, D, dt=f16)
-        self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
+        # hidden activations / speaker qkv only exist in HBM on the un-fused A/B paths (EEND_FFN_FUSED=0 / EEND_SPK_FUSED=0)
+        self.ff16 = e(max(Me * F_enc, Md * F_dec) if not FUSED_FFN else 0, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
         self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
-        self.qkv16 = e(Md, 3 * D, dt=f16)
+        self.qkv16 = e(Md if not FUSED_SPK else 0, 3 * D, dt=f16)
 
 
 class OnlineTransformerDADiarization(nn.Module):
@@ -298,7 +299,7 @@ class OnlineTransformerDADiarization(nn.Module):
         o16 = ws.o16[:Me]
         for L in P["enc.layers"]:
             F = L["w1"].shape[0]
-            ff = ws.ff16[:Me * F].view(Me, F)
+            ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
             ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
             ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
             if FUSED_FFN and FUSED_ATTNOUT:   # out_proj + norm1 + FFN + norm2 in one launch (x never leaves the CU)
@@ -323,7 +324,7 @@ class OnlineTransformerDADiarization(nn.Module):
         o16 = ws.o16[:Md]
         for L in P["dec.layers"]:
             F = L["w1"].shape[0]
-            ff = ws.ff16[:Md * F].view(Md, F)
+            ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
             ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
             ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, T, scale=ops.LN2)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch

@@ -37,12 +37,12 @@ PROTOTYPES = {
     "eend_pit_cost_f64": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "eend_pit_assign_i32": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_retention_step_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "eend_dwconv_step_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "eend_layernorm_f16": [_vp, _vp, _vp, _f, _vp, _i, _i, _vp],
-    "eend_dwconv_bn_swish_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "eend_dwconv_bn_swish_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp],
     "eend_linear_res_scale_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_conv1d_l2norm_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_convert_fanout_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

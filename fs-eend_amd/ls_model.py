@@ -12,7 +12,7 @@ in libeend_hip.so through ops.py.
 """
 import math
 import weakref
-from typing import Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -233,10 +233,11 @@ class _Workspace:
         self.g = e(Mx, D, dt=f16)
         self.o16 = torch.zeros(Mx, D, dtype=f16, device=dev)     # rows of skipped padding chunks are never written: keep them finite
         self.glu16, self.dw16 = e(Me, D, dt=f16), e(Me, D, dt=f16)
-        self.ff16 = e(max(Me * F_enc, Md * F_dec), dt=f16)
+        # hidden activations / speaker qkv only exist in HBM on the un-fused A/B paths (EEND_FFN_FUSED=0 / EEND_SPK_FUSED=0)
+        self.ff16 = e(max(Me * F_enc, Md * F_dec) if not FUSED_FFN else 0, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
         self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
-        self.qkv16 = e(Md, 3 * D, dt=f16)
+        self.qkv16 = e(Md if not FUSED_SPK else 0, 3 * D, dt=f16)
         nseq = max(B, B * C)
         self.st = e(nseq * H * nc * 2 * 4096, dt=f16)
         self.cscale, self.sexp = e(nseq * H * nc, dt=f32), e(nseq * H * nc, dt=f32)
@@ -404,7 +405,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             if i == 0:
                 ops.layernorm_f16(ws.h32, Bk["lna"][0], Bk["lna"][1], ws.x16, Bk["lna"][2])
             F = Bk["w1a"].shape[0]
-            ff = ws.ff16[:Me * F].view(Me, F)
+            ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
             # x += fa * FFN(LN_a x)                      -> x16 = LN_b(x)
             if FUSED_FFN:
                 ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
@@ -445,7 +446,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         g, o16 = ws.g[:Md], ws.o16[:Md]
         for Ld in P["dec.layers"]:
             F = Ld["w1"].shape[0]
-            ff = ws.ff16[:Md * F].view(Md, F)
+            ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
             ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
             ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tpad)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
@@ -475,6 +476,119 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
         ops.head_l2dot(emb32, ws.a32, attr, logits, B, T, Tp, C, D)
         return logits, emb32.view(B, Tp, D), attr, T, Tp
+
+    # ------------------------------------------------------------------ long-form: a few chunks at a time (BASELINE config 5)
+    @torch.no_grad()
+    def test_chunked(self, src, ilens, max_nspks=6, chunk_frames: Optional[int] = None, return_attractors: bool = True):
+        """`test()` for long recordings with O(chunk) activation memory: the recording is walked in super-chunks of
+        `chunk_frames` frames; what the reference's batch form carries implicitly is carried explicitly between calls
+        -- per retention layer the f32 chunk state (retention.py:176-180), per Conformer conv module the k-1 input frames
+        in front of the super-chunk (convolution.py:65-68).  The encoder output (0.5 KB/frame) is kept for the whole
+        recording because the look-ahead Conv1d (LS model :86) needs 9 future frames at every super-chunk edge; it and the
+        embeddings are the only O(T) buffers besides the outputs.
+
+        chunk_frames must be a multiple of lcm(recurrent_chunk_size, 64) (8000 for the shipped configs): then every
+        kernel sees each frame at the same position modulo its tile sizes as in the monolithic call, and the results are
+        BIT-IDENTICAL to `test()` (tests/test_ls_longform.py)."""
+        P = self._prepare()
+        dev = self.cnn.weight.device
+        D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
+        unit = L * 64 // math.gcd(L, 64)
+        if chunk_frames is None:
+            chunk_frames = unit
+        if chunk_frames % unit:
+            raise ValueError(f"chunk_frames must be a multiple of lcm(recurrent_chunk_size, 64) = {unit}")
+        srcs = [s.to(device=dev, dtype=torch.float32).contiguous() for s in src]
+        B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
+        C = max_nspks
+        Tpad = math.ceil(T / L) * L
+        Tp_full = ops.frames_pad(Tpad)
+        f16, f32 = torch.float16, torch.float32
+        il = torch.tensor([min(int(l), T) for l in ilens], dtype=torch.int32, device=dev)
+        enc16 = torch.zeros(B * Tp_full, D, dtype=f16, device=dev)            # encoder output, whole recording
+        nb, nd = len(P["blocks"]), len(P["dec.layers"])
+        K1 = self.enc.encoder._conv_kernel_size - 1
+        enc_state = [torch.zeros(B, H, 64, 64, dtype=f32, device=dev) for _ in range(nb)]
+        enc_halo = [None] * nb
+        spans = [(s0, min(s0 + chunk_frames, Tpad)) for s0 in range(0, Tpad, chunk_frames)]
+
+        # ---- pass 1: Conformer-retention encoder, super-chunk by super-chunk
+        for s0, s1 in spans:
+            Tc = s1 - s0
+            Tp = ops.frames_pad(Tc)
+            nc = (Tp + L - 1) // L
+            ws = self._workspace(dev, B, Tp, C, nc)
+            Me = B * Tp
+            part = [x[s0:min(s1, x.shape[0])] if x.shape[0] > s0 else x[:0] for x in srcs]     # may be empty: all pad (0)
+            ops.gather_bn_cast_pad(part, None, ws.xin16, Tc, Tp, 0.0, False)
+            ops.linear_res_ln(ws.xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], ws.h32, ws.h16, P["in.eps"])
+            q, k, kt, vt = ws.q[:Me * D], ws.k[:Me * D], ws.kt[:Me * D], ws.vt[:Me * D]
+            g, o16 = ws.g[:Me], ws.o16[:Me]
+            for i, Bk in enumerate(P["blocks"]):
+                if i == 0:
+                    ops.layernorm_f16(ws.h32, Bk["lna"][0], Bk["lna"][1], ws.x16, Bk["lna"][2])
+                ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
+                              ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
+                ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
+                ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tc,
+                                    state_in=enc_state[i], state_out=enc_state[i])
+                ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
+                                          ws.h32, ws.x16, Bk["lnc"][2])
+                ops.linear_glu(ws.x16, Bk["pw1"], Bk["pb1"], ws.glu16)
+                ops.dwconv_bn_swish(ws.glu16, Bk["dw"], Bk["bn"], ws.dw16, B, Tp, Bk["bn_eps"], halo16=enc_halo[i])
+                enc_halo[i] = ws.glu16.view(B, Tp, D)[:, Tc - K1:Tc].contiguous()          # next call's left context
+                ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
+                                          ws.h32, ws.x16, Bk["lnd"][2])
+                ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
+                              ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
+                if i + 1 < nb:
+                    nx = P["blocks"][i + 1]["lna"]
+                    ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
+            enc16.view(B, Tp_full, D)[:, s0:s1] = ws.h16.view(B, Tp, D)[:, :Tc]
+
+        # ---- look-ahead conv + L2 norm over the whole recording (one launch; 1.5 KB/frame)
+        emb32 = torch.empty(B * Tp_full, D, dtype=f32, device=dev)
+        emb16 = torch.empty(B * Tp_full, D, dtype=f16, device=dev)
+        ops.conv1d_l2norm(enc16, P["cnn.w"], P["cnn.b"], il, emb32, emb16, B, Tp_full, D, P["cnn.k"], P["cnn.pad"])
+        del enc16
+
+        # ---- pass 2: attractor decoder + head, super-chunk by super-chunk
+        logits = torch.empty(B, T, C, dtype=f32, device=dev)
+        attr = torch.empty(B, T, C, D, dtype=f32, device=dev) if return_attractors else None
+        dec_state = [torch.zeros(B * C, H, 64, 64, dtype=f32, device=dev) for _ in range(nd)]
+        pc = self._convert_const(C)
+        for s0, s1 in spans:
+            Tc = s1 - s0
+            Tv = min(s1, T) - s0                                   # real frames of this super-chunk
+            Tp = ops.frames_pad(Tc)
+            nc = (Tp + L - 1) // L
+            ws = self._workspace(dev, B, Tp, C, nc)
+            Md = B * C * Tp
+            e16 = torch.zeros(B, Tp, D, dtype=f16, device=dev)
+            e32 = torch.zeros(B, Tp, D, dtype=f32, device=dev)
+            e16[:, :Tc] = emb16.view(B, Tp_full, D)[:, s0:s1]
+            e32[:, :Tc] = emb32.view(B, Tp_full, D)[:, s0:s1]
+            ops.convert_fanout(e16.view(-1, D), P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
+            q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
+            g, o16 = ws.g[:Md], ws.o16[:Md]
+            for j, Ld in enumerate(P["dec.layers"]):
+                ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
+                ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
+                                    state_in=dec_state[j], state_out=dec_state[j])
+                ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
+                ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
+                ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
+                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
+            if Tv > 0:
+                lg = torch.empty(B, Tv, C, dtype=f32, device=dev)
+                at = torch.empty(B, Tv, C, D, dtype=f32, device=dev)
+                ops.head_l2dot(e32.view(-1, D), ws.a32, at, lg, B, Tv, Tp, C, D)
+                logits[:, s0:s0 + Tv] = lg
+                if return_attractors:
+                    attr[:, s0:s0 + Tv] = at
+        emb = emb32.view(B, Tp_full, D)
+        return ([logits[b, :l] for b, l in enumerate(ilens)], [emb[b, :l] for b, l in enumerate(ilens)],
+                [attr[b, :l] for b, l in enumerate(ilens)] if return_attractors else None)
 
     @torch.no_grad()
     def test(self, src, ilens, max_nspks=6):

@@ -112,11 +112,15 @@ def retention_proj(a16, wqkvg16, bias, q, k, kt, vt, g, nseq, Tp, H):
 _KV_WS = {}
 
 
-def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp, chunk, gn_eps=1e-6, t_valid=0):
+def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp, chunk, gn_eps=1e-6, t_valid=0,
+                    state_in=None, state_out=None):
     L = _lib.load()
     for t, n in ((q, "q"), (k, "k"), (kt, "kt"), (vt, "vt"), (g, "g"), (o16, "o16"), (st_ws, "st_ws")):
         _chk(t, F16, n)
-    _chk(cscale_ws, F32, "cscale_ws"); _chk(sexp_ws, F32, "sexp_ws")
+    _chk(cscale_ws, F32, "cscale_ws"); _chk(sexp_ws, F32, "sexp_ws"); _chk(state_in, F32, "state_in"); _chk(state_out, F32, "state_out")
+    for st_ in (state_in, state_out):
+        if st_ is not None and st_.numel() < nseq * H * 4096:
+            raise _lib.EendHipError("retention_chunk: carried state must be (nseq, H, 64, 64) f32")
     nc = (Tp + chunk - 1) // chunk
     if st_ws.numel() < nseq * H * nc * 2 * 4096 or cscale_ws.numel() < nseq * H * nc or sexp_ws.numel() < nseq * H * nc:
         raise _lib.EendHipError("retention_chunk: workspace too small")
@@ -127,7 +131,7 @@ def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp
         _KV_WS[str(q.device)] = kv_ws
     _lib.check(L.eend_retention_chunk_f16(_p(q), _p(k), _p(kt), _p(vt), _p(g), _p(o16), _p(st_ws), _p(kv_ws),
                                           _p(cscale_ws), _p(sexp_ws), nseq, H, Tp, chunk, o16.stride(0), g.stride(0),
-                                          gn_eps, int(t_valid), _stream()), "eend_retention_chunk_f16")
+                                          gn_eps, int(t_valid), _p(state_in), _p(state_out), _stream()), "eend_retention_chunk_f16")
 
 
 def layernorm_f16(x32, gamma, beta, out16, eps=1e-5):
@@ -137,15 +141,18 @@ def layernorm_f16(x32, gamma, beta, out16, eps=1e-5):
     _lib.check(L.eend_layernorm_f16(_p(x32), _p(gamma), _p(beta), eps, _p(out16), M, D, _stream()), "eend_layernorm_f16")
 
 
-def dwconv_bn_swish(x16, w, bn, out16, nseq, Tp, eps=1e-5):
-    """x16/out16 f16 (nseq*Tp, D); w f32 (D, k); bn = (weight, bias, mean, var)."""
+def dwconv_bn_swish(x16, w, bn, out16, nseq, Tp, eps=1e-5, halo16=None):
+    """x16/out16 f16 (nseq*Tp, D); w f32 (D, k); bn = (weight, bias, mean, var); halo16 f16 (nseq, k-1, D) or None."""
     L = _lib.load()
     _chk(x16, F16, "x16"); _chk(w, F32, "w"); _chk(out16, F16, "out16")
     for t in bn:
         _chk(t, F32, "bn")
     D, k = w.shape
+    _chk(halo16, F16, "halo16")
+    if halo16 is not None and tuple(halo16.shape) != (nseq, k - 1, D):
+        raise _lib.EendHipError("dwconv_bn_swish: halo must be (nseq, k-1, D)")
     _lib.check(L.eend_dwconv_bn_swish_f16(_p(x16), _p(w), _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), eps, _p(out16),
-                                          nseq, Tp, D, k, _stream()), "eend_dwconv_bn_swish_f16")
+                                          nseq, Tp, D, k, _p(halo16), _stream()), "eend_dwconv_bn_swish_f16")
 
 
 def linear_res_ln(a16, w16, bias, res, gamma, beta, out32, out16, eps=1e-5, alpha=1.0):

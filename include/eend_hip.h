@@ -236,10 +236,14 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
  * [nseq][H][nc][2][64][64], kv_ws f32 [nseq][H][nc][64][64], cscale_ws / sexp_ws f32 [nseq][H][nc],
  * nc = ceil(Tp / L).  Three launches: chunk-parallel K_c^T V_c, per-(seq,head) prefix scan, core.
  * T_valid (0 = Tp): frames at or beyond it are slab padding (Tp rounds the chunk-padded length up to 64);
- * chunks that start there are skipped and their rows of O are left untouched. */
+ * chunks that start there are skipped and their rows of O are left untouched.
+ * state_in / state_out (optional, f32 [nseq][H][64][64], the reference's `prev_key_value` before its scaling,
+ * retention.py:176-180): the chunk state before the first / after the last chunk of this call, so a long recording
+ * can be processed a few chunks at a time with the state carried across calls (BASELINE config 5). */
 int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
                              void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq,
-                             int H, int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid, void* stream);
+                             int H, int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid,
+                             const float* state_in, float* state_out, void* stream);
 
 /* Stand-alone LayerNorm f32 [M][D] -> f16 (D <= 1024): second of two back-to-back LayerNorms
  * (conformer/encoder.py:110 then feed_forward.py:48; encoder.py:196 then feed_forward.py:48). */
@@ -247,10 +251,11 @@ int eend_layernorm_f16(const float* x, const float* gamma, const float* beta, fl
                        int D, void* stream);
 
 /* Causal depthwise Conv1d (k taps, left context k-1, no bias) -> BatchNorm1d(eval) -> Swish
- * (conformer/convolution.py:65-68,143-147).  x,out f16 [nseq][Tp][D]; w f32 [D][k]. */
+ * (conformer/convolution.py:65-68,143-147).  x,out f16 [nseq][Tp][D]; w f32 [D][k].  halo_f16 (optional,
+ * [nseq][k-1][D]): the k-1 input frames preceding the slab (carried from the previous call); null = zeros. */
 int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_weight, const float* bn_bias,
                              const float* bn_mean, const float* bn_var, float eps, void* out_f16, int nseq,
-                             int Tp, int D, int k, void* stream);
+                             int Tp, int D, int k, const void* halo_f16, void* stream);
 
 /* Incremental self-attention of FS-EEND streaming (FS-EEND/nnet/modules/streaming_tfm.py:15-37,
  * used by StreamingTransformerEncoderLayer :61-66 and StreamingAttractorDecoderLayer :197-201): the

@@ -1,0 +1,75 @@
+"""GPU: BASELINE config 5 -- one hour of 8 kHz audio (T = 36 000 frames of 100 ms), 8 speakers (+2 slots), LS-EEND.
+`test_chunked` walks the recording 8 000 frames at a time with the retention state / conv context carried between
+calls; it must equal the monolithic `test()` BIT FOR BIT on every valid frame, at a fraction of the memory."""
+import pytest
+import torch
+
+from oracle import fixtures as FX
+
+pytestmark = pytest.mark.gpu
+
+LS_CFG = dict(n_units=256, n_heads=4, enc_n_layers=4, dec_n_layers=2, dropout=0.1, max_seqlen=1000,
+              recurrent_chunk_size=500, feed_forward_expansion_factor=4, dec_dim_feedforward=2048,
+              conv_expansion_factor=2, conv_kernel_size=16, half_step_residual=True, conv_delay=9)
+
+
+def _model(dev, **over):
+    from fs_eend_amd.ls_model import OnlineConformerRetentionDADiarization
+    cfg = dict(LS_CFG)
+    cfg.update(over)
+    torch.manual_seed(0)
+    m = OnlineConformerRetentionDADiarization(n_speakers=None, in_size=345, **cfg).eval()
+    FX.perturb_(m, 5)
+    return m.to(dev)
+
+
+def test_one_hour_chunked_equals_monolithic(hip_lib, dev):
+    m = _model(dev)
+    T, C = 36000, 10
+    src = [s.to(dev) for s in FX.make_src([T], 345, 4321)]
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    lg, em, at = m.test_chunked(src, [T], C)
+    torch.cuda.synchronize()
+    peak_chunked = torch.cuda.max_memory_allocated(dev) - base
+    lg_c, em_c, at_c = lg[0].clone(), em[0].clone(), at[0].clone()
+    del lg, em, at
+    m._ws.clear()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    lg, em, at = m.test(src, [T], C)
+    torch.cuda.synchronize()
+    peak_mono = torch.cuda.max_memory_allocated(dev) - base
+    print(f"peak activation memory: chunked {peak_chunked / 2**30:.2f} GiB (of which outputs {(at_c.numel() + lg_c.numel() + em_c.numel()) * 4 / 2**30:.2f}), "
+          f"monolithic {peak_mono / 2**30:.2f} GiB")
+    assert torch.isfinite(lg_c).all()
+    assert torch.equal(lg_c, lg[0]) and torch.equal(em_c, em[0]) and torch.equal(at_c, at[0])
+    assert peak_chunked < 1.5 * 2**30 and peak_chunked < 0.25 * peak_mono
+    # without the (T, C, D) attractor output the whole hour fits in well under 1 GB
+    m._ws.clear()
+    del lg, em, at
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    lg2, _, none = m.test_chunked(src, [T], C, return_attractors=False)
+    torch.cuda.synchronize()
+    peak2 = torch.cuda.max_memory_allocated(dev) - base
+    print(f"peak activation memory without attractor output: {peak2 / 2**30:.2f} GiB")
+    assert none is None and torch.equal(lg2[0], lg_c) and peak2 < 1.0 * 2**30
+
+
+def test_chunked_ragged_batch_and_partial_last_chunk(hip_lib, dev):
+    """two recordings of different length, neither a multiple of the chunk sizes; the shorter one ends inside the
+    first super-chunk"""
+    m = _model(dev, enc_n_layers=2, dec_n_layers=1, dec_dim_feedforward=512)
+    lens = [17234, 6100]
+    src = [s.to(dev) for s in FX.make_src(lens, 345, 99)]
+    a = m.test_chunked(src, lens, 5)
+    b = m.test(src, lens, 5)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    with pytest.raises(ValueError):
+        m.test_chunked(src, lens, 5, chunk_frames=4000)
