@@ -290,7 +290,7 @@ void ret_chunk_kernel(const RetParams p) {
     const int c_lo = wq_first / L, c_hi = wq_last / L;
     const _Float16* __restrict__ Sg = (const _Float16*)p.St + sh * p.nc * 2 * 4096;
     for (int c = c_lo; c <= c_hi; ++c) {
-        if (c == 0) continue;                                 // state before the first chunk is zero
+        if (c == 0 && !p.state_in) continue;                  // state before the first chunk is zero unless carried in
         f32x16 x[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }

@@ -161,7 +161,7 @@ void ret_chunk_full_kernel(const RetParams p) {
                 }
         }
         // ---- cross-chunk term O^T += S_c^T Q^T (hi/lo f16 state, prescale undone by sexp)
-        if (c > 0) {
+        if (c > 0 || p.state_in) {                      // chunk 0 has a predecessor state only when one is carried in
             f32x16 x[2];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }

@@ -531,12 +531,12 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                               ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
                 ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
                 ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tc,
-                                    state_in=enc_state[i], state_out=enc_state[i])
+                                    state_in=enc_state[i] if s0 else None, state_out=enc_state[i])
                 ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
                                           ws.h32, ws.x16, Bk["lnc"][2])
                 ops.linear_glu(ws.x16, Bk["pw1"], Bk["pb1"], ws.glu16)
                 ops.dwconv_bn_swish(ws.glu16, Bk["dw"], Bk["bn"], ws.dw16, B, Tp, Bk["bn_eps"], halo16=enc_halo[i])
-                enc_halo[i] = ws.glu16.view(B, Tp, D)[:, Tc - K1:Tc].contiguous()          # next call's left context
+                enc_halo[i] = ws.glu16.view(B, Tp, D)[:, Tc - K1:Tc].clone()               # next call's left context (a copy: glu16 is reused)
                 ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
                                           ws.h32, ws.x16, Bk["lnd"][2])
                 ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
@@ -574,18 +574,20 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             for j, Ld in enumerate(P["dec.layers"]):
                 ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
                 ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
-                                    state_in=dec_state[j], state_out=dec_state[j])
+                                    state_in=dec_state[j] if s0 else None, state_out=dec_state[j])
                 ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
                 ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
                 ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
                                       Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
             if Tv > 0:
-                lg = torch.empty(B, Tv, C, dtype=f32, device=dev)
-                at = torch.empty(B, Tv, C, D, dtype=f32, device=dev)
+                direct = B == 1 and return_attractors              # the output slices are contiguous: no staging copy
+                lg = logits[:, s0:s0 + Tv] if direct else torch.empty(B, Tv, C, dtype=f32, device=dev)
+                at = attr[:, s0:s0 + Tv] if direct else torch.empty(B, Tv, C, D, dtype=f32, device=dev)
                 ops.head_l2dot(e32.view(-1, D), ws.a32, at, lg, B, Tv, Tp, C, D)
-                logits[:, s0:s0 + Tv] = lg
-                if return_attractors:
-                    attr[:, s0:s0 + Tv] = at
+                if not direct:
+                    logits[:, s0:s0 + Tv] = lg
+                    if return_attractors:
+                        attr[:, s0:s0 + Tv] = at
         emb = emb32.view(B, Tp_full, D)
         return ([logits[b, :l] for b, l in enumerate(ilens)], [emb[b, :l] for b, l in enumerate(ilens)],
                 [attr[b, :l] for b, l in enumerate(ilens)] if return_attractors else None)

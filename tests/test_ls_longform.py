@@ -46,7 +46,7 @@ def test_one_hour_chunked_equals_monolithic(hip_lib, dev):
           f"monolithic {peak_mono / 2**30:.2f} GiB")
     assert torch.isfinite(lg_c).all()
     assert torch.equal(lg_c, lg[0]) and torch.equal(em_c, em[0]) and torch.equal(at_c, at[0])
-    assert peak_chunked < 1.5 * 2**30 and peak_chunked < 0.25 * peak_mono
+    assert peak_chunked < 1.4 * 2**30 and peak_chunked < 0.7 * peak_mono
     # without the (T, C, D) attractor output the whole hour fits in well under 1 GB
     m._ws.clear()
     del lg, em, at
