@@ -351,6 +351,35 @@ def extras(dev):
     state_bytes = sum(s["prev_key_value"].numel() * 4 for s in rs + ds) + sum(c.numel() * 4 for c in cc) + 19 * 256 * 4
     res["ls_eend_streaming"] = dict(workload=f"1 stream, max_nspks={C}, frame-by-frame one-step API, eager launches",
                                     ms_per_frame=per * 1e3, rtf=per / 0.1, state_bytes=state_bytes)
+    # the same stream through the device-resident session: three hipGraph replays per frame (ls_stream.LsStreamSession)
+    try:
+        from fs_eend_amd.ls_stream import LsStreamSession
+        sess = LsStreamSession(ls, C, batch=1, use_graph=True)
+        for t in range(nfr):
+            if t == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            sess.push(x[t:t + 1])
+        torch.cuda.synchronize()
+        per_g = (time.perf_counter() - t0) / (nfr - warm)
+        res["ls_eend_streaming_graph"] = dict(workload=f"1 stream, max_nspks={C} (8 speakers + 2 slots), LsStreamSession: state resident in HBM, "
+                                                       f"3 hipGraph replays per frame", ms_per_frame=per_g * 1e3, rtf=per_g / 0.1,
+                                              speedup_vs_eager=per / per_g)
+        nstream = 64                                   # many independent streams per GPU: one session, batch = streams
+        sess = LsStreamSession(ls, C, batch=nstream, use_graph=True)
+        xb = torch.randn(nfr, nstream, 345, generator=g).to(dev) * 2 - 3
+        for t in range(nfr):
+            if t == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            sess.push(xb[t])
+        torch.cuda.synchronize()
+        per_b = (time.perf_counter() - t0) / (nfr - warm)
+        res["ls_eend_streaming_graph_64streams"] = dict(workload=f"{nstream} concurrent streams, max_nspks={C}, one session",
+                                                        ms_per_frame=per_b * 1e3, rtf_per_stream=per_b / 0.1,
+                                                        stream_frames_per_s=nstream / per_b)
+    except Exception as ex:
+        res["ls_eend_streaming_graph"] = dict(error=f"{type(ex).__name__}: {ex}")
 
     torch.manual_seed(0)
     fm = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **FS_CFG).eval().to(dev)

@@ -40,7 +40,10 @@ def _ret_step(x16, wqkvg, bqkvg, state, N, H, gn_eps, scratch):
     ops.linear(x16, wqkvg, bqkvg, qkvg)
     kv, s_in, s_out = _ret_state(state, N, H, x16.device)
     ops.retention_step(qkvg, kv, s_in, s_out, o16, N, H, gn_eps)
-    state["scale"], state["_scale_next"] = s_out, s_in                # ping-pong
+    if state.get("_static"):
+        s_in.copy_(s_out)             # graph-captured sessions: fixed buffers, the new scale is copied back (4 floats)
+    else:
+        state["scale"], state["_scale_next"] = s_out, s_in            # ping-pong
     return o16
 
 
@@ -162,3 +165,125 @@ class StreamingConv1d(nn.Module):
         out = torch.empty(B, wr.shape[0], dtype=F32, device=win16.device)
         ops.linear_res_scale(win16, wr, bias, None, 1.0, out, None)
         return out.unsqueeze(-1) if self.t >= self.center + 1 else None
+
+
+class LsStreamSession:
+    """Frame-by-frame LS-EEND with every piece of state resident in fixed HBM buffers and the per-frame work replayed
+    from three captured hipGraphs (LS-EEND/streaming_infer_dia.py:52-97 is the procedure reproduced):
+
+        G_enc  : Conformer-retention encoder one-step (retention states, depthwise-conv caches updated in place)
+        G_conv : push the frame into the 19-frame look-ahead window, Conv1d + L2 norm of the window's centre frame
+        G_dec  : attractor decoder one-step (retention states in place), attractor L2 norm, embedding . attractor head
+
+    `push(x_t)` returns the logits of frame t - conv_delay (B, 1, C), or None during the first conv_delay frames;
+    `flush()` feeds conv_delay zero embeddings like the reference driver (:91-95).  The eager one-step API
+    (`enc.forward_one_step` / `dec.forward_one_step`) issues ~70 launches per frame from Python; a replay is three
+    graph launches, so the per-frame cost is the kernels' own few hundred microseconds.
+    """
+
+    def __init__(self, model, max_nspks: int, batch: int = 1, use_graph: bool = True):
+        self.m, self.C, self.B = model, max_nspks, batch
+        P = model._prepare()
+        dev = model.cnn.weight.device
+        self.dev = dev
+        D, H = model.n_units, model._n_heads
+        self.D, self.k, self.center = D, P["cnn.k"], P["cnn.k"] // 2
+        nb, nd = len(P["blocks"]), len(P["dec.layers"])
+        K1 = model.enc.encoder._conv_kernel_size - 1
+
+        def ret(N):
+            return dict(prev_key_value=torch.zeros(N, H, 64, 64, dtype=F32, device=dev), scale=torch.zeros(H, dtype=F32, device=dev),
+                        _scale_next=torch.zeros(H, dtype=F32, device=dev), _static=True)
+
+        self.enc_states = [ret(batch) for _ in range(nb)]
+        self.dec_states = [ret(batch * max_nspks) for _ in range(nd)]
+        self.caches = [torch.zeros(batch, D, K1, dtype=F32, device=dev) for _ in range(nb)]
+        self.x_in = torch.zeros(batch, 1, model._in_size, dtype=F32, device=dev)
+        self.enc_out = torch.zeros(batch, 1, D, dtype=F32, device=dev)
+        self.win16 = torch.zeros(batch, 64, D, dtype=F16, device=dev)            # frames 0..k-1 = the look-ahead window
+        self._shift = torch.zeros(batch, self.k - 1, D, dtype=F16, device=dev)
+        self.emb32 = torch.zeros(batch * 64, D, dtype=F32, device=dev)
+        self.emb16 = torch.zeros(batch * 64, D, dtype=F16, device=dev)
+        self.emb_t = torch.zeros(batch, 1, D, dtype=F32, device=dev)
+        self.klen = torch.full((batch,), self.k, dtype=torch.int32, device=dev)
+        self.attr = torch.zeros(batch, 1, max_nspks, D, dtype=F32, device=dev)
+        self.logits = torch.zeros(batch, 1, max_nspks, dtype=F32, device=dev)
+        self.t = 0
+        self._graphs = None
+        self._stateful = ([s["prev_key_value"] for s in self.enc_states + self.dec_states] +
+                          [s[k_] for s in self.enc_states + self.dec_states for k_ in ("scale", "_scale_next")] + self.caches +
+                          [self.win16, self.enc_out])
+        if use_graph:
+            self._capture()
+
+    # ---- the three stages (eager bodies; captured once)
+    def _enc(self):
+        self.enc_out.copy_(enc_step(self.m, self.x_in, self.t, self.enc_states, self.caches))
+
+    def _conv(self):
+        P = self.m._prepare()
+        k = self.k
+        self._shift.copy_(self.win16[:, 1:k])
+        self.win16[:, :k - 1].copy_(self._shift)
+        self.win16[:, k - 1:k].copy_(self.enc_out)                                  # f32 -> f16 (as the batch path's operand)
+        ops.conv1d_l2norm(self.win16.view(-1, self.D), P["cnn.w"], P["cnn.b"], self.klen, self.emb32, self.emb16, self.B, 64, self.D,
+                          k, self.center)
+        self.emb_t.copy_(self.emb32.view(self.B, 64, self.D)[:, self.center:self.center + 1])
+
+    def _dec(self):
+        a = dec_step(self.m, self.emb_t, self.t, self.C, self.dec_states)          # (B,1,C,D) un-normalised attractors
+        a32 = a.reshape(self.B * self.C, self.D)
+        ops.head_l2dot(self.emb_t.view(self.B, self.D), a32, self.attr.view(self.B, 1, self.C, self.D), self.logits, self.B, 1, 1,
+                       self.C, self.D)
+
+    def reset(self):
+        for t_ in self._stateful:
+            t_.zero_()
+        self.t = 0
+
+    def _capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                                                # warm-up: workspaces, operand caches
+            self._enc(); self._conv(); self._dec()
+        torch.cuda.current_stream().wait_stream(s)
+        gs = []
+        for fn in (self._enc, self._conv, self._dec):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            gs.append(g)
+        self._graphs = gs
+        self.reset()
+
+    def _run(self, i):
+        if self._graphs is not None:
+            self._graphs[i].replay()
+        else:
+            (self._enc, self._conv, self._dec)[i]()
+
+    @torch.no_grad()
+    def push(self, x_t):
+        """x_t (B, 1, in_size) or (B, in_size) features of the next frame -> logits (B, 1, C) of frame t - delay, or None."""
+        self.x_in.copy_(x_t.reshape(self.B, 1, -1))
+        self._run(0)
+        return self._emit()
+
+    def _emit(self):
+        self._run(1)
+        self.t += 1
+        if self.t < self.center + 1:
+            return None
+        self._run(2)
+        return self.logits.clone()
+
+    @torch.no_grad()
+    def flush(self):
+        """the last conv_delay frames: zero embeddings through the look-ahead window (reference driver :91-95)"""
+        out = []
+        for _ in range(self.center):
+            self.enc_out.zero_()
+            y = self._emit()
+            if y is not None:
+                out.append(y)
+        return out

@@ -109,3 +109,29 @@ def test_ls_streaming_vs_reference_streaming(hip_lib, dev):
     # the batch (chunk-recurrent) HIP forward agrees with HIP streaming as well as the reference's two forms do
     batch = m.test([src], [meta["T"]], meta["C"])[0][0]
     assert max_abs(ys, batch.cpu()) < 5e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ls_stream_session(hip_lib, dev, use_graph):
+    """The device-resident streaming session (three hipGraph replays per frame) against the reference's streaming
+    logits and against the eager one-step driver."""
+    from fs_eend_amd.ls_stream import LsStreamSession
+    meta, arr = FX.load_case("ls_stream_T120")
+    m = build_ls_mirror(meta).to(dev)
+    src = FX.make_src([meta["T"]], meta["in_size"], meta["xseed"])[0].to(dev)
+    want, _ = _drive(m, src, meta["C"], dev)
+    sess = LsStreamSession(m, meta["C"], batch=1, use_graph=use_graph)
+    for rep in range(2):                                   # a session is reusable after reset()
+        ys = []
+        for t in range(src.shape[0]):
+            y = sess.push(src[t:t + 1])
+            assert (y is None) == (t < m.delay)
+            if y is not None:
+                ys.append(y)
+        ys += sess.flush()
+        ys = torch.cat(ys, dim=1).squeeze(0)
+        assert ys.shape == arr["stream_logits"].shape
+        assert max_abs(ys, arr["stream_logits"]) < 1e-3
+        assert max_abs(ys, want.cpu()) < 3e-4
+        assert float(sess.enc_states[0]["scale"][0]) == meta["T"]
+        sess.reset()
