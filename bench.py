@@ -228,6 +228,23 @@ def extras(dev):
         res["ls_eend_longform"] = dict(workload=f"LS-EEND model.test, 1 x T={Tl} (1 h of audio, 72 chunks of 500, state carried), "
                                                 f"max_nspks={C}", seconds=dl, rtf=dl / (Tl * 0.1),
                                        peak_hbm_bytes=int(torch.cuda.max_memory_allocated(dev)))
+        # the same hour, 8000 frames (16 chunks) at a time with the retention state / conv context carried between
+        # calls (ls_model.test_chunked; bit-identical results, tests/test_ls_longform.py)
+        ls._ws.clear()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        ls.test_chunked(long_src, [Tl], C)
+        torch.cuda.synchronize()
+        peak_c = int(torch.cuda.max_memory_allocated(dev) - base)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            ls.test_chunked(long_src, [Tl], C)
+        torch.cuda.synchronize()
+        dc = (time.perf_counter() - t0) / 2
+        res["ls_eend_longform_chunked"] = dict(workload=f"LS-EEND test_chunked, 1 x T={Tl}, super-chunks of 8000 frames, state carried, "
+                                                        f"max_nspks={C}; outputs (logits, emb, attractors (T,C,256) f32 = 0.37 GB) included",
+                                               seconds=dc, rtf=dc / (Tl * 0.1), peak_activation_bytes=peak_c)
         del long_src
     except Exception as ex:                      # never let a side measurement take the headline number down
         res["ls_eend_longform"] = dict(error=f"{type(ex).__name__}: {ex}")
