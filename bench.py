@@ -144,7 +144,12 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(777)
     src = [torch.randn(T, 345, generator=g) * 2 - 3 for _ in range(batch)]
-    ncpu = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1                      # hardware threads; physical cores are reported separately below
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or ncpu
+    except Exception:
+        phys = ncpu
     cands = sorted({1, min(8, ncpu), min(32, ncpu)})
     t_start, results = time.perf_counter(), {}
     with torch.no_grad():
@@ -165,7 +170,9 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
             results[th] = batch * T / ts[len(ts) // 2]
     best = max(results, key=results.get)
     return dict(value=results[best], unit="frames/s", cores=best, kind="port",
-                sample=f"oracle fs_test fp32 on host CPU ({ncpu} hw threads), B={batch} x T={T}, C={C}; frames/s by "
+                host_physical_cores=phys, host_hw_threads=ncpu,
+                sample=f"oracle fs_test fp32 on host CPU ({phys} physical cores / {ncpu} hw threads; `cores` = torch threads of the best run), "
+                       f"B={batch} x T={T}, C={C}; frames/s by "
                        f"torch threads: " + ", ".join(f"{k}: {v:.0f}" for k, v in results.items()) +
                        f"; {time.perf_counter() - t_start:.1f} s of CPU work")
 

@@ -358,11 +358,19 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         return P
 
     def _convert_const(self, C):
+        """pc[c] = convert.weight[:, D:] pe[c] + convert.bias  (a (C, D) constant of the weights): eend_convert_const_f32."""
         if C not in self._pc:
-            D = self.n_units
-            pe = self.dec.pos_enc.pe[0, :C].to(torch.float32)
-            w2 = self.dec.convert.weight.detach()[:, D:].to(torch.float32)
-            self._pc[C] = (pe @ w2.t() + self.dec.convert.bias.detach().to(torch.float32)).contiguous()
+            from . import lib as _lib
+            D = self.enc.n_units if hasattr(self.enc, "n_units") else self.n_units
+            dev = self.dec.convert.weight.device
+            W = self.dec.convert.weight.detach().to(torch.float32).contiguous()
+            b = self.dec.convert.bias.detach().to(torch.float32).contiguous()
+            pe = self.dec.pos_enc.pe[0, :C].to(device=dev, dtype=torch.float32).contiguous()
+            pc = torch.empty(C, D, dtype=torch.float32, device=dev)
+            L = _lib.load()
+            _lib.check(L.eend_convert_const_f32(0, W.data_ptr(), b.data_ptr(), pe.data_ptr(), pc.data_ptr(), None, None, None, C,
+                                                torch.cuda.current_stream().cuda_stream), "eend_convert_const_f32")
+            self._pc[C] = pc
         return self._pc[C]
 
     def _workspace(self, dev, B, Tp, C, nc):
