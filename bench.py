@@ -341,7 +341,7 @@ def extras(dev):
         torch.cuda.reset_peak_memory_stats(dev)
         eng, dtt, loss = time_train(dev, 64, 500, 4, steps=10, warmup=3)
         res["fs_eend_train_step"] = dict(workload="FS-EEND training step, 64 utterances x T=500, 4-speaker mixtures (C=6), shipped yaml "
-                                                  "shapes, dropout 0, Adam x Noam, clip 5; eager launches, 1 GPU",
+                                                  f"shapes, dropout {eng.drop_p}, Adam x Noam, clip 5; eager launches, 1 GPU",
                                          ms_per_step=dtt / 10 * 1e3, frames_per_s=64 * 500 * 10 / dtt, final_loss=loss,
                                          peak_hbm_bytes=int(torch.cuda.max_memory_allocated(dev)))
         del eng
@@ -434,19 +434,21 @@ def synthetic_labels(lengths, n_spk, seed, dev):
 
 def train_setup(dev, B, T, n_spk, rank=0):
     """BASELINE config 4: FS-EEND training step, 4-speaker simulated mixtures, the shipped yaml's shapes and optimiser
-    (Adam betas (0.9, 0.98) eps 1e-9 x Noam(warm 100000), clip 5).  dropout = 0: the training kernels do not implement
-    the reference's dropout (0.1) -- stated in `config.dropout` of the output line."""
+    (Adam betas (0.9, 0.98) eps 1e-9 x Noam(warm 100000), clip 5) and its dropout (0.1, all ten sites; counter-hash masks
+    applied in the kernels' epilogues, include/eend_hip.h `eend_dropout`).  EEND_TRAIN_DROPOUT overrides the ratio (A/B)."""
     from fs_eend_amd import config as CFG
     from fs_eend_amd.fs_model import OnlineTransformerDADiarization
     from fs_eend_amd.train import FsTrainStep
     from fs_eend_amd.trainer import prepare_labels
     cfg = CFG.load(CFG.FS_EEND_SIMU)
     kw = CFG.model_kwargs(cfg)
-    kw["dropout"] = 0.0
+    if os.environ.get("EEND_TRAIN_DROPOUT"):
+        kw["dropout"] = float(os.environ["EEND_TRAIN_DROPOUT"])
     torch.manual_seed(0)
     model = OnlineTransformerDADiarization(**kw).to(dev).train()
     tr = cfg["training"]
-    eng = FsTrainStep(model, warmup=tr["warm_steps"], lr=tr["lr"], schedule_scale=tr["schedule_scale"], grad_clip=tr["grad_clip"])
+    eng = FsTrainStep(model, warmup=tr["warm_steps"], lr=tr["lr"], schedule_scale=tr["schedule_scale"], grad_clip=tr["grad_clip"],
+                      drop_seed=int(tr.get("seed", 0) or 0) * 1000003 + rank)
     g = torch.Generator().manual_seed(777 + rank)
     feats = [(torch.randn(T, 345, generator=g) * 2 - 3).to(dev) for _ in range(B)]
     labels = prepare_labels(synthetic_labels([T] * B, n_spk, 778 + rank, dev), [T] * B)
@@ -465,6 +467,118 @@ def time_train(dev, B, T, n_spk, steps, warmup, rank=0, fence=None):
     (fence or torch.cuda.synchronize)()
     dt = time.perf_counter() - t0
     return eng, dt, float(out["loss"])
+
+
+class TrainCallTimer:
+    """Brackets every C-ABI call of the training step (fs_eend_amd.train._call and the ops.* forward wrappers it uses)
+    with HIP events on the launch stream, for a few instrumented steps after the timed region."""
+    INT_ARGS = {"eend_wgrad_bf16": (5, 6, 7), "eend_gemm_bf16": (7, 8, 9), "eend_gemm_relu_bwd_bf16": (8, 9, 10),
+                "eend_linear_relu_train_f16": (7, 8, 9)}
+
+    def __init__(self, T):
+        self.T, self.rec = T, []
+
+    def __enter__(self):
+        from fs_eend_amd import train as TR
+        self.TR, self.orig = TR, TR._call
+
+        def timed(name, *a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.orig(name, *a)
+            e.record()
+            if name in self.INT_ARGS:
+                shape = tuple(int(a[i]) for i in self.INT_ARGS[name])
+            elif name == "eend_gemm_acc_bf16":
+                shape = (int(a[8]), 256, int(a[9]))
+            elif name == "eend_linear_res_ln_train_f16":
+                shape = (int(a[14]), 256, int(a[15]))
+            elif name == "eend_attn_causal_bwd_bf16":
+                shape = (int(a[14]), int(a[15]))
+            elif name == "eend_attn_causal_lse_bf16":
+                shape = (int(a[5]), int(a[6]))
+            elif name == "eend_inproj_heads_train_bf16":
+                shape = (int(a[10]) * int(a[11]), 768, 256)
+            else:
+                shape = ()
+            self.rec.append((name, shape, s, e))
+        TR._call = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.TR._call = self.orig
+
+    def flops(self, name, shape):
+        if name in ("eend_wgrad_bf16", "eend_gemm_bf16", "eend_gemm_relu_bwd_bf16", "eend_gemm_acc_bf16",
+                    "eend_linear_relu_train_f16", "eend_linear_res_ln_train_f16", "eend_inproj_heads_train_bf16"):
+            M, N, K = shape
+            return 2.0 * M * N * K
+        if name == "eend_attn_causal_lse_bf16":        # causal-useful flops, 2 products
+            return shape[0] * 2.0 * (shape[1] * 64) * self.T * (self.T + 1)
+        if name == "eend_attn_causal_bwd_bf16":        # 5 products (S, dP, dQ, dK, dV), causal-useful
+            return shape[0] * 5.0 * (shape[1] * 64) * self.T * (self.T + 1)
+        return 0.0
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, shape, s, e in self.rec:
+            d = agg.setdefault((name, shape), [0.0, 0])
+            d[0] += s.elapsed_time(e)
+            d[1] += 1
+        out = []
+        for (name, shape), (ms, n) in agg.items():
+            fl = self.flops(name, shape)
+            out.append(dict(call=name, shape=list(shape), launches_per_step=n / steps, avg_ms=ms / n, ms_per_step=ms / steps,
+                            tflops=(fl / (ms / n * 1e-3) / 1e12) if fl else None))
+        return sorted(out, key=lambda d: -d["ms_per_step"])
+
+
+def cpu_baseline_train(T, n_spk, batch=2, budget_s=25.0):
+    """The training oracle (oracle/train_ref.TrainRef: forward, loss, torch-autograd backward, clip, Adam; pinned to the
+    reference's own training_step by tests/golden/fs_train_*.npz) timed on the host cores, bounded sample."""
+    from fs_eend_amd import config as CFG
+    from fs_eend_amd.fs_model import OnlineTransformerDADiarization
+    from oracle import train_ref as TR
+    cfg = CFG.load(CFG.FS_EEND_SIMU)
+    kw = CFG.model_kwargs(cfg)
+    torch.manual_seed(0)
+    m = OnlineTransformerDADiarization(**kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ocfg = dict(n_units=kw["n_units"], n_heads=kw["n_heads"], enc_n_layers=kw["enc_n_layers"], dec_n_layers=kw["dec_n_layers"],
+                has_mask=kw["has_mask"], mask_delay=kw.get("mask_delay", 0))
+    g = torch.Generator().manual_seed(777)
+    feats = [torch.randn(T, 345, generator=g) * 2 - 3 for _ in range(batch)]
+    labels = synthetic_labels([T] * batch, n_spk, 778, "cpu")
+    ncpu = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or ncpu
+    except Exception:
+        phys = ncpu
+    cands = sorted({min(8, ncpu), min(32, ncpu)})
+    t_start, results = time.perf_counter(), {}
+    for th in cands:
+        torch.set_num_threads(th)
+        ref = TR.TrainRef(sd, ocfg, warmup=cfg["training"]["warm_steps"], clip=cfg["training"]["grad_clip"])
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            ref.step(feats, labels)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                ts.append(dt)
+            if time.perf_counter() - t_start > budget_s * (cands.index(th) + 1) / len(cands):
+                if not ts:
+                    ts.append(dt)
+                break
+        ts.sort()
+        results[th] = batch * T / ts[len(ts) // 2]
+    best = max(results, key=results.get)
+    return dict(value=results[best], unit="frames/s", cores=best, kind="port", host_physical_cores=phys, host_hw_threads=ncpu,
+                sample=f"oracle TrainRef.step fp32 (dropout off) on host CPU, B={batch} x T={T}, {n_spk} speakers; frames/s by torch "
+                       f"threads: " + ", ".join(f"{k}: {v:.0f}" for k, v in results.items()) +
+                       f"; {time.perf_counter() - t_start:.1f} s of CPU work")
 
 
 def main():
@@ -531,10 +645,29 @@ def main():
                                       f"T={T} x 345, {args.speakers}-speaker mixtures (C={args.speakers + 2} label columns), forward + "
                                       f"BCE/emb-consistency loss + backward + clip 5 + Adam(0.9,0.98,1e-9) x Noam + operand re-layout, "
                                       f"random init (seed 0)",
-                          "batch_per_gpu": B, "global_batch": B * world, "frames": T, "dropout": 0.0,
+                          "batch_per_gpu": B, "global_batch": B * world, "frames": T, "dropout": eng.drop_p,
                           "parallelism": f"dp{world}: one all-reduce of the flat {eng.flat.numel * 4 / 1e6:.1f} MB f32 gradient buffer per step",
                           "launch": "eager ctypes launches"},
                "final_loss": loss, "peak_hbm_bytes": int(torch.cuda.max_memory_allocated(dev))}
+        if rank == 0 and not args.no_breakdown:
+            # dominant kernel: HIP events around every C-ABI call of 2 extra steps (same stream, same inputs)
+            _, feats, labels = train_setup(dev, B, T, args.speakers, rank)
+            with TrainCallTimer(T) as tm:
+                for _ in range(2):
+                    eng.step(feats, labels, [T] * B)
+            calls = tm.summary(2)
+            tot = sum(c["ms_per_step"] for c in calls)
+            out["breakdown"] = [dict(c, share=c["ms_per_step"] / tot) for c in calls[:16]]
+            out["kernel_ms_per_step"] = tot
+            top = next((c for c in calls if c["tflops"]), None)
+            if top is not None:
+                out["roofline"] = {"kernel": f"{top['call']} {top['shape']}", "bound": "mfma", "achieved": top["tflops"],
+                                   "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_MFMA_TFLOPS,
+                                   "traffic": None, "avg_launch_ms": top["avg_ms"],
+                                   "note": "largest time share among the step's MFMA calls; algorithmic flops 2*M*N*K (GEMM family) "
+                                           "or 5*D*T*(T+1) per sequence (attention backward); in-situ HIP events on the launch stream"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_train(T, args.speakers)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

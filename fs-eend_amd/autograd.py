@@ -44,7 +44,7 @@ def fs_forward_with_grad(model, src, tgt, ilens):
     eng = getattr(model, "_autograd_engine", None)
     if eng is None:
         from .train import FsTrainStep
-        eng = FsTrainStep(model)                               # raises for dropout != 0: no silent deviation from the config
+        eng = FsTrainStep(model, drop_seed=torch.initial_seed() & 0xFFFFFFFF)   # dropout masks follow torch.manual_seed
         object.__setattr__(model, "_autograd_engine", eng)
     params = [p for _, p in model.named_parameters()]
     holder = dict(eng=eng, src=src, tgt=tgt, ilens=ilens)

@@ -11,7 +11,7 @@ GemmParams base_params(const void* A, int lda, const void* W, int ldw, const flo
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldo = N; p.Tp = 64; p.H = 4; p.dh = 64; p.C = 1;
-    p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0;
+    p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0; p.drop.scale = 1.0f;
     const char* d = getenv("EEND_GEMM_DBG");          // perf-study ablations only; unset in normal use
     p.dbg = d ? atoi(d) : 0;
     return p;
@@ -297,6 +297,7 @@ int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_
     AttnParams p;
     p.Q = Q; p.K = K; p.Vt = Vt; p.O = O_f16; p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo;
     p.mask_delay = mask_delay; p.kv_len = kv_len; p.scale_log2 = scale * 1.4426950408889634f; p.Lse = nullptr;
+    p.drop = DropSpec{0u, 0u, 1.0f};
     return eend_launch_attn_causal(p, (hipStream_t)stream);
 }
 
@@ -311,7 +312,7 @@ int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const fl
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale, void* stream) {
     if (!qkv || !O_f16) return EEND_EINVAL;
     SpkAttnParams p;
-    p.qkv = qkv; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.H = H; p.scale = scale;
+    p.qkv = qkv; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.H = H; p.scale = scale; p.drop = DropSpec{0u, 0u, 1.0f};
     return eend_launch_spk_attn(p, (hipStream_t)stream);
 }
 

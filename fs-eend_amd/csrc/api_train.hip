@@ -11,8 +11,15 @@ GemmParams gemm_base(const void* A, int lda, const void* W, int ldw, const float
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldo = N; p.Tp = 64; p.H = 4; p.dh = 64; p.C = 1;
-    p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0;
+    p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0; p.drop.scale = 1.0f;
     return p;
+}
+
+// NULL / p == 0 -> no dropout (thresh24 == 0 switches every kernel's mask off, scale 1 keeps the backward scaling neutral)
+DropSpec drop_spec(const eend_dropout* d) {
+    DropSpec s{0u, 0u, 1.0f};
+    if (d && d->thresh24) { s.seed = d->seed; s.thresh24 = d->thresh24; s.scale = d->scale; }
+    return s;
 }
 
 // split the token axis so that about 512 workgroups run, within the workspace
@@ -38,12 +45,29 @@ extern "C" {
 
 int eend_linear_res_ln_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
                                  float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
-                                 void* out_f16, void* xhat_f16, float* rstd, int M, int K, void* stream) {
+                                 void* out_f16, void* xhat_f16, float* rstd, int M, int K, const eend_dropout* drop,
+                                 void* stream) {
     if (!A || !W || !out_f32 || !out_f16 || !xhat_f16 || !rstd || !gamma || !beta) return EEND_EINVAL;
     GemmParams p = gemm_base(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
-    p.xhat16 = xhat_f16; p.rstat = rstd;
+    p.xhat16 = xhat_f16; p.rstat = rstd; p.drop = drop_spec(drop);
     return eend_launch_gemm(p, EPI_RES_LN_TRAIN, (hipStream_t)stream);
+}
+
+int eend_linear_relu_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
+                               int M, int N, int K, const eend_dropout* drop, void* stream) {
+    if (!A || !W || !out_f16 || (ldo & 3)) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, bias, M, N, K);
+    p.out16 = out_f16; p.ldo = ldo; p.drop = drop_spec(drop);
+    return eend_launch_gemm(p, EPI_PLAIN_RELU_F16, (hipStream_t)stream);
+}
+
+int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
+                            const eend_dropout* drop, void* stream) {
+    if (!qkv || !O_f16 || H != 4) return EEND_EINVAL;
+    SpkAttnParams p;
+    p.qkv = qkv; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.H = H; p.scale = scale; p.drop = drop_spec(drop);
+    return eend_launch_spk_attn(p, (hipStream_t)stream);
 }
 
 int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bias, const int* ilens, float* out_f32,
@@ -72,18 +96,20 @@ int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const fl
 }
 
 int eend_attn_causal_lse_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, float* lse, int nseq, int H,
-                              int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream) {
+                              int Tp, int ldo, int mask_delay, int kv_len, float scale, const eend_dropout* drop,
+                              void* stream) {
     if (!Q || !K || !Vt || !O_f16 || !lse || nseq > 65535 || H > 65535) return EEND_EINVAL;
     AttnParams p;
     p.Q = Q; p.K = K; p.Vt = Vt; p.O = O_f16; p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo;
     p.mask_delay = mask_delay; p.kv_len = kv_len; p.scale_log2 = scale * 1.4426950408889634f; p.Lse = lse;
+    p.drop = drop_spec(drop);
     return eend_launch_attn_causal(p, (hipStream_t)stream);
 }
 
 int eend_attn_causal_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
                               const void* dO, int ldo, const void* O_f16, int ldout, const float* lse, void* dOt_ws,
                               float* dh_ws, void* dQKV, int ldg, int nseq, int H, int Tp, int mask_delay, int kv_len,
-                              int q_len, float scale_log2, float sq, float sk, void* stream) {
+                              int q_len, float scale_log2, float sq, float sk, const eend_dropout* drop, void* stream) {
     if (!dO || !O_f16 || !dOt_ws || !dh_ws || H != 4 || ldo != 256 || ldout != 256) return EEND_EINVAL;
     int rc = eend_launch_attn_rowdot(dO, O_f16, dh_ws, nseq, H, Tp, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
@@ -93,7 +119,7 @@ int eend_attn_causal_bwd_bf16(const void* Q, const void* Qt, const void* K, cons
     memset(&p, 0, sizeof(p));
     p.Q = Q; p.Qt = Qt; p.K = K; p.Kt = Kt; p.V = V; p.dO = dO; p.dOt = dOt_ws; p.Lse = lse; p.Dh = dh_ws; p.dQKV = dQKV;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.ldg = ldg; p.mask_delay = mask_delay; p.kv_len = kv_len; p.q_len = q_len;
-    p.scale_log2 = scale_log2; p.sq = sq; p.sk = sk;
+    p.scale_log2 = scale_log2; p.sq = sq; p.sk = sk; p.drop = drop_spec(drop);
     return eend_launch_attn_bwd(p, (hipStream_t)stream);
 }
 
@@ -106,10 +132,11 @@ int eend_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* 
 }
 
 int eend_gemm_relu_bwd_bf16(const void* A, int lda, const void* W, int ldw, const void* act, int ldact,
-                            void* out_bf16, int ldo, int M, int N, int K, void* stream) {
+                            void* out_bf16, int ldo, int M, int N, int K, float drop_scale, void* stream) {
     if (!A || !W || !act || !out_bf16 || (ldo & 7) || (ldact & 7)) return EEND_EINVAL;
     GemmParams p = gemm_base(A, lda, W, ldw, nullptr, M, N, K);
     p.bf16 = 1; p.out16 = out_bf16; p.ldo = ldo; p.mask = act; p.ldmask = ldact;
+    p.drop.scale = drop_scale > 0.f ? drop_scale : 1.0f;    // `act` is the dropped activation: its zeros are the mask
     return eend_launch_gemm(p, EPI_MASK_BF16, (hipStream_t)stream);
 }
 
@@ -173,10 +200,11 @@ int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws
 }
 
 int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rstd, const float* gamma, float* ds_f32,
-                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M, void* stream) {
+                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M,
+                           const eend_dropout* drop, void* stream) {
     if (!ws || !dgamma || !dbeta || ws_floats < 1024L * 512) return EEND_EINVAL;
     int nb = 0;
-    int rc = eend_launch_ln_bwd(g, xhat_f16, rstd, gamma, ds_f32, ds_bf16, ws, &nb, M, (hipStream_t)stream);
+    int rc = eend_launch_ln_bwd(g, xhat_f16, rstd, gamma, ds_f32, ds_bf16, ws, &nb, M, drop_spec(drop), (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     rc = eend_launch_wgrad_reduce(ws, 512, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
@@ -214,9 +242,9 @@ int eend_convert_const_f32(int mode, const float* W, const float* bias, const fl
 }
 
 int eend_spk_attn_bwd_bf16(const void* qkv_f16, const void* dO_bf16, void* dqkv_bf16, int B, int C, int Tp, int H,
-                           float scale, void* stream) {
+                           float scale, const eend_dropout* drop, void* stream) {
     if (H != 4) return EEND_EINVAL;
-    return eend_launch_spk_attn_bwd(qkv_f16, dO_bf16, dqkv_bf16, B, C, Tp, scale, (hipStream_t)stream);
+    return eend_launch_spk_attn_bwd(qkv_f16, dO_bf16, dqkv_bf16, B, C, Tp, scale, drop_spec(drop), (hipStream_t)stream);
 }
 
 int eend_bn_train_stats_f32(const void* const* x_ptrs, const int* lens, float pad_value, float* ws, long ws_floats,

@@ -141,6 +141,14 @@ void attn_causal_kernel(const AttnParams p) {
                 }
             l_run = l_run * alpha + lsum;
             m_run = m_new;
+            if (p.drop.thresh24) {                         // training: dropout of the probabilities (row sum un-dropped)
+                const unsigned da = (unsigned)(sh * p.Tp + qc);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
             // P^T fragments (B operand of O^T): elem j of k-step (kb,kk) = reg kk*8 + j
@@ -234,9 +242,10 @@ void spk_attn_kernel(const SpkAttnParams p) {
         for (int c2 = 0; c2 < C; ++c2) { s[c2] = __expf(s[c2] - mx); den += s[c2]; }
         const float inv = 1.0f / den;
         float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned da = ((unsigned)frame * 4u + (unsigned)(lane >> 4)) * 16u + (unsigned)c;
 #pragma unroll
         for (int c2 = 0; c2 < C; ++c2) {
-            const float pw = s[c2] * inv;
+            const float pw = drop_apply(p.drop, s[c2] * inv, da, (unsigned)c2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(pw, vf[c2][e], o[e]);
         }

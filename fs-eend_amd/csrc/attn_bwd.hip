@@ -118,7 +118,9 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
                 for (int i = 0; i < 16; ++i) {
                     const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
                     const float pv = key <= lim ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], p.scale_log2, -L2)) : 0.f;
-                    s[kb][i] = pv * (dp[kb][i] - Dq);
+                    // forward: O = (P o keep * scale) V  ->  dP = (dO V^T) o keep * scale
+                    const float dpe = drop_apply(p.drop, dp[kb][i], (unsigned)(sh * p.Tp + qc), (unsigned)key);
+                    s[kb][i] = pv * (dpe - Dq);
                 }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -258,8 +260,10 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
                 const int qi = qw0 + (r & 7) + 8 * hi + 16 * (r >> 3);
                 const bool ok = key <= qi + p.mask_delay && key < p.kv_len && qi < qlim;
                 const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_log2, -l2v[r])) : 0.f;
-                pf[r >> 3][r & 7] = (__bf16)pv;
-                sf[r >> 3][r & 7] = (__bf16)(pv * (dp[r] - dv[r]));
+                float kf = 1.0f;                               // the forward's dropout factor of this (query, key) pair
+                if (p.drop.thresh24) kf = drop_keep(p.drop, (unsigned)(sh * p.Tp + qi), (unsigned)key) ? p.drop.scale : 0.f;
+                pf[r >> 3][r & 7] = (__bf16)(pv * kf);
+                sf[r >> 3][r & 7] = (__bf16)(pv * (dp[r] * kf - dv[r]));
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)

@@ -57,6 +57,7 @@ void attn_causal_full_kernel(const AttnParams p) {
     const __bf16* __restrict__ Vg = (const __bf16*)p.Vt + sh * 64 * p.Tp;
 
     // ---- load the head's whole K and V^T once: Tp*8 16-byte chunks each, all in flight
+#ifndef EEND_ATT_NOLOAD          // (perf-study ablation: phase costs)
     {
         const int nch = p.Tp * 8;                    // chunks per operand (<= 4096 -> <= 8 per thread)
         u32x4 kr[8], vr[8];
@@ -80,6 +81,7 @@ void attn_causal_full_kernel(const AttnParams p) {
             }
         }
     }
+#endif
     __syncthreads();
 
     const int nq = p.Tp / 32;                        // query blocks of 32 rows
@@ -106,7 +108,11 @@ void attn_causal_full_kernel(const AttnParams p) {
 
         int last_key = qw0 + 31 + p.mask_delay;
         last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
+#ifdef EEND_ATT_NOCOMP
+        const int jend = 0;
+#else
         const int jend = last_key < 0 ? 0 : last_key / KB + 1;
+#endif
 
         if constexpr (LAZY) {
             f32x16 mneg;                                 // -m_ref of this lane's query in every entry
@@ -165,8 +171,16 @@ void attn_causal_full_kernel(const AttnParams p) {
                     lsum1 += s[1][i];
                 }
                 l_run += lsum0 + lsum1;
+                if (p.drop.thresh24) {                     // training: dropout of the probabilities (the row sum stays un-dropped)
+                    const unsigned da = (unsigned)(sh * p.Tp + q);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
                         bf16x8 pf;
@@ -178,6 +192,7 @@ void attn_causal_full_kernel(const AttnParams p) {
                             oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
                         }
                     }
+                }
             }
             m_ref_final = -mneg[0];
         } else
@@ -227,6 +242,14 @@ void attn_causal_full_kernel(const AttnParams p) {
                 }
             l_run = l_run * alpha + lsum;
             m_run = m_new;
+            if (p.drop.thresh24) {
+                const unsigned da = (unsigned)(sh * p.Tp + q);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
 #pragma unroll

@@ -57,3 +57,20 @@ DEV int xcd_remap(int bid, int nblocks) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// ---- dropout (training step): counter-based, stateless.  keep(a, b) is a pure function of (seed, a, b), so the
+// backward kernels regenerate the mask of any forward site instead of storing it.  a = row-like index, b = column-like.
+// murmur3 finaliser over a * golden + b; keep probability 1 - thresh24 / 2^24.
+struct DropSpec {
+    unsigned seed;        // per-site seed (host: step seed mixed with the site id)
+    unsigned thresh24;    // round(p * 2^24); 0 = dropout off
+    float scale;          // 1 / (1 - p)
+};
+DEV bool drop_keep(const DropSpec d, unsigned a, unsigned b) {
+    unsigned h = (a * 0x9E3779B1u + b) ^ d.seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (h >> 8) >= d.thresh24;
+}
+DEV float drop_apply(const DropSpec d, float v, unsigned a, unsigned b) {
+    return d.thresh24 == 0 ? v : (drop_keep(d, a, b) ? v * d.scale : 0.f);
+}

@@ -265,9 +265,16 @@ void gemm_f16_kernel(const GemmParams p) {
             for (int j = 0; j < FL; ++j) {
                 if (!SWAP) { const float bb = p.bias ? p.bias[L0 + j * 16] : 0.f; b = make_float4(bb, bb, bb, bb); }
                 float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+                if (EPI == EPI_MASK_BF16) { const float a_ = p.drop.scale; v0 *= a_; v1 *= a_; v2 *= a_; v3 *= a_; }
                 if (EPI == EPI_PLAIN_RELU_F16) {
                     v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
                     v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
+                    if (p.drop.thresh24) {                  // training: dropout after the activation (FFN `self.dropout`)
+                        static_assert(EPI != EPI_PLAIN_RELU_F16 || SWAP, "dropout indices assume SWAP");
+                        const unsigned m = (unsigned)(m0 + l_tile_row0 + j * 16 + frow), n = (unsigned)(n0 + r_tile_row0 + i * 16 + fkg * 4);
+                        v0 = drop_apply(p.drop, v0, m, n); v1 = drop_apply(p.drop, v1, m, n + 1);
+                        v2 = drop_apply(p.drop, v2, m, n + 2); v3 = drop_apply(p.drop, v3, m, n + 3);
+                    }
                 }
                 if (EPI == EPI_PLAIN_SWISH_F16) {
                     v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
@@ -363,10 +370,18 @@ void gemm_f16_kernel(const GemmParams p) {
                 float4 r = make_float4(0, 0, 0, 0);
                 if (!L2K && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
                 const float s = L2K ? 1.0f : p.alpha;
-                acc[i][j][0] = (acc[i][j][0] + bias4[i].x) * s + r.x;
-                acc[i][j][1] = (acc[i][j][1] + bias4[i].y) * s + r.y;
-                acc[i][j][2] = (acc[i][j][2] + bias4[i].z) * s + r.z;
-                acc[i][j][3] = (acc[i][j][3] + bias4[i].w) * s + r.w;
+                float a0 = acc[i][j][0] + bias4[i].x, a1 = acc[i][j][1] + bias4[i].y, a2 = acc[i][j][2] + bias4[i].z, a3 = acc[i][j][3] + bias4[i].w;
+                if constexpr (EPI == EPI_RES_LN_TRAIN) {
+                    if (p.drop.thresh24) {                  // dropout of the sub-layer output (dropout1 / dropout2 / dropout11 / ...)
+                        const unsigned n = (unsigned)(R0 + i * 16);
+                        a0 = drop_apply(p.drop, a0, (unsigned)m, n); a1 = drop_apply(p.drop, a1, (unsigned)m, n + 1);
+                        a2 = drop_apply(p.drop, a2, (unsigned)m, n + 2); a3 = drop_apply(p.drop, a3, (unsigned)m, n + 3);
+                    }
+                }
+                acc[i][j][0] = a0 * s + r.x;
+                acc[i][j][1] = a1 * s + r.y;
+                acc[i][j][2] = a2 * s + r.z;
+                acc[i][j][3] = a3 * s + r.w;
             }
         }
         float mean[FL], scale[FL];

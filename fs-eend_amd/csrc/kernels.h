@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/eend_hip.h"
+#include "common.h"
 
 enum GemmEpilogue {
     EPI_PLAIN_F16 = 0,       // out16[m][n] = f16(acc + bias)
@@ -57,6 +58,8 @@ struct GemmParams {
     const int* mask_lens; // EPI_F32_ROWMASK: frames per sequence that receive a gradient
     void* xhat16;       // EPI_RES_LN_TRAIN: normalised rows before the affine, [M][ldo]
     float* rstat;       // EPI_*_TRAIN: 1/sigma or 1/||x|| per row, [M]
+    DropSpec drop;      // EPI_RES_LN_TRAIN: dropout of (acc + bias) before the residual add; EPI_PLAIN_RELU_F16: of the
+                        // activation; EPI_MASK_BF16: only .scale is used (the saved activation already carries the zeros)
 };
 
 struct AttnParams {
@@ -69,6 +72,7 @@ struct AttnParams {
     int kv_len;      // number of real key frames (<= Tp)
     float scale_log2;  // (1/sqrt(dh)) * log2(e)
     float* Lse;        // optional (training): f32 [nseq][H][Tp], log2-domain log-sum-exp of every query row
+    DropSpec drop;     // training: dropout of the attention probabilities (a = (seq*H + h)*Tp + q, b = key)
 };
 
 struct SpkAttnParams {
@@ -76,6 +80,7 @@ struct SpkAttnParams {
     void* O;          // f16 [nrows][D]
     int B, C, Tp, H;  // D = H*64
     float scale;      // 1/sqrt(dh)
+    DropSpec drop;    // training: dropout of the probabilities (a = ((b*Tp + t)*4 + head)*16 + query slot, b = key slot)
 };
 
 struct SpkFusedParams {
@@ -239,12 +244,13 @@ struct AttnBwdParams {        // attn_bwd.hip
     int mask_delay, kv_len, q_len;
     float scale_log2;         // as the forward
     float sq, sk;             // output scales of dQ and dK
+    DropSpec drop;            // the forward's probability dropout
 };
 int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream);
 int eend_launch_heads_transpose(const void* in, int ld, void* out, int nseq, int H, int Tp, hipStream_t stream);
 
 int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, const float* gamma, float* ds32, void* ds16,
-                       float* partial, int* nblocks_out, long M, hipStream_t stream);
+                       float* partial, int* nblocks_out, long M, DropSpec drop, hipStream_t stream);
 int eend_launch_head_bce(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
                          float inv_frames, const float* dlogits_in, float* logits, float* da, float* de, float* loss_partial, int B,
                          int T, int Tp, int C, hipStream_t stream);
@@ -252,7 +258,8 @@ int eend_launch_l2norm_bwd(const float* y, const float* dy, const float* inv_nor
 int eend_launch_slot_sum(const float* g0, void* gsum16, float* partial, int* nblocks_out, int B, int Tp, int C, hipStream_t stream);
 int eend_launch_convert_const(int mode, const float* W, const float* bias, const float* pe, float* pc, const float* dpc, float* dW,
                               float* dbias, int C, hipStream_t stream);
-int eend_launch_spk_attn_bwd(const void* qkv16, const void* dO16, void* dqkv16, int B, int C, int Tp, float scale, hipStream_t stream);
+int eend_launch_spk_attn_bwd(const void* qkv16, const void* dO16, void* dqkv16, int B, int C, int Tp, float scale, DropSpec drop,
+                             hipStream_t stream);
 int eend_launch_bn_colstats(const float* const* x_ptrs, const int* lens, float pad_value, const float* shift, float* partial,
                             int B, int T, int F, int nsplit, hipStream_t stream);
 int eend_launch_bn_finalize(int pass, const float* sums, float n, float* mean, float* var, float* run_mean, float* run_var,

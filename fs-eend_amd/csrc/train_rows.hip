@@ -18,7 +18,8 @@ constexpr int D = 256;
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* g, const _Float16* __restrict__ xhat, const float* __restrict__ rstd,
-                   const float* __restrict__ gamma, float* ds32, __bf16* __restrict__ ds16, float* __restrict__ partial, long M) {
+                   const float* __restrict__ gamma, float* ds32, __bf16* __restrict__ ds16, float* __restrict__ partial, long M,
+                   const DropSpec drop) {
     __shared__ float red[4][2][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 gm = *(const float4*)(gamma + lane * 4);
@@ -35,9 +36,12 @@ void ln_bwd_kernel(const float* g, const _Float16* __restrict__ xhat, const floa
         const float o2 = rs * (d2 - c1 - x2 * c2), o3 = rs * (d3 - c1 - x3 * c2);
         if (ds32) *(float4*)(ds32 + row * D + lane * 4) = make_float4(o0, o1, o2, o3);
         if (ds16) {
+            // ds16 feeds the sub-layer branch (the linear in front of this LayerNorm): the forward dropped its output
+            // with the same (row, column) mask; the residual path (ds32) is not masked
+            const unsigned n = (unsigned)(lane * 4);
             uint2 pk;
-            pk.x = pack_bf16(o0, o1);
-            pk.y = pack_bf16(o2, o3);
+            pk.x = pack_bf16(drop_apply(drop, o0, (unsigned)row, n), drop_apply(drop, o1, (unsigned)row, n + 1));
+            pk.y = pack_bf16(drop_apply(drop, o2, (unsigned)row, n + 2), drop_apply(drop, o3, (unsigned)row, n + 3));
             *(uint2*)(ds16 + row * D + lane * 4) = pk;
         }
         dg[0] += gy.x * x0; dg[1] += gy.y * x1; dg[2] += gy.z * x2; dg[3] += gy.w * x3;
@@ -206,7 +210,7 @@ void convert_const_kernel(int mode, const float* __restrict__ W, const float* __
 template <int C>
 __global__ __launch_bounds__(256)
 void spk_attn_bwd_kernel(const _Float16* __restrict__ qkv, const __bf16* __restrict__ dO, __bf16* __restrict__ dqkv,
-                         int B, int Tp, float scale) {
+                         int B, int Tp, float scale, const DropSpec drop) {
     const int lane = threadIdx.x & 63;
     const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (frame >= (long)B * Tp) return;
@@ -250,8 +254,16 @@ void spk_attn_bwd_kernel(const _Float16* __restrict__ qkv, const __bf16* __restr
         for (int c2 = 0; c2 < C; ++c2) { s[c2] = __expf(s[c2] - mx); den += s[c2]; }
         const float inv = 1.0f / den;
         float dsum = 0.f;
+        float pd[C];                                               // dropped probabilities (what multiplied V in the forward)
+        const unsigned da = ((unsigned)frame * 4u + (unsigned)(lane >> 4)) * 16u + (unsigned)c;
 #pragma unroll
-        for (int c2 = 0; c2 < C; ++c2) { s[c2] *= inv; dsum = __builtin_fmaf(s[c2], dp[c2], dsum); }
+        for (int c2 = 0; c2 < C; ++c2) {
+            s[c2] *= inv;
+            const float kf = drop.thresh24 == 0 ? 1.0f : (drop_keep(drop, da, (unsigned)c2) ? drop.scale : 0.f);
+            pd[c2] = s[c2] * kf;
+            dp[c2] *= kf;
+            dsum = __builtin_fmaf(s[c2], dp[c2], dsum);
+        }
         float dq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c2 = 0; c2 < C; ++c2) {
@@ -260,7 +272,7 @@ void spk_attn_bwd_kernel(const _Float16* __restrict__ qkv, const __bf16* __restr
             for (int e = 0; e < 4; ++e) {
                 dq[e] = __builtin_fmaf(ds, k[c2][e], dq[e]);
                 dk[c2][e] = __builtin_fmaf(ds, q[c][e], dk[c2][e]);
-                dv[c2][e] = __builtin_fmaf(s[c2], go[c][e], dv[c2][e]);
+                dv[c2][e] = __builtin_fmaf(pd[c2], go[c][e], dv[c2][e]);
             }
         }
         const size_t row = ((size_t)b * C + c) * Tp + t;
@@ -376,11 +388,11 @@ static int persistent_blocks(long rows) {
 }
 
 int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, const float* gamma, float* ds32, void* ds16,
-                       float* partial, int* nblocks_out, long M, hipStream_t stream) {
+                       float* partial, int* nblocks_out, long M, DropSpec drop, hipStream_t stream) {
     if (!g || !xhat16 || !rstd || !gamma || !partial || M <= 0) return EEND_EINVAL;
     const int nb = persistent_blocks(M);
     if (nblocks_out) *nblocks_out = nb;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, g, (const _Float16*)xhat16, rstd, gamma, ds32, (__bf16*)ds16, partial, M);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, g, (const _Float16*)xhat16, rstd, gamma, ds32, (__bf16*)ds16, partial, M, drop);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
@@ -424,11 +436,12 @@ int eend_launch_convert_const(int mode, const float* W, const float* bias, const
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-int eend_launch_spk_attn_bwd(const void* qkv16, const void* dO16, void* dqkv16, int B, int C, int Tp, float scale, hipStream_t stream) {
+int eend_launch_spk_attn_bwd(const void* qkv16, const void* dO16, void* dqkv16, int B, int C, int Tp, float scale, DropSpec drop,
+                             hipStream_t stream) {
     if (!qkv16 || !dO16 || !dqkv16 || B <= 0 || Tp <= 0) return EEND_EINVAL;
     const long nb = ((long)B * Tp + 3) / 4;
     switch (C) {
-#define SB_CASE(n) case n: hipLaunchKernelGGL(spk_attn_bwd_kernel<n>, dim3((unsigned)nb), dim3(256), 0, stream, (const _Float16*)qkv16, (const __bf16*)dO16, (__bf16*)dqkv16, B, Tp, scale); break;
+#define SB_CASE(n) case n: hipLaunchKernelGGL(spk_attn_bwd_kernel<n>, dim3((unsigned)nb), dim3(256), 0, stream, (const _Float16*)qkv16, (const __bf16*)dO16, (__bf16*)dqkv16, B, Tp, scale, drop); break;
         SB_CASE(1) SB_CASE(2) SB_CASE(3) SB_CASE(4) SB_CASE(5) SB_CASE(6) SB_CASE(7) SB_CASE(8) SB_CASE(9) SB_CASE(10) SB_CASE(11) SB_CASE(12)
 #undef SB_CASE
         default: return EEND_EINVAL;

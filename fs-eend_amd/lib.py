@@ -50,24 +50,26 @@ PROTOTYPES = {
     "eend_spk_attn_f16": [_vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_head_l2dot_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     # ---- training step
-    "eend_linear_res_ln_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "eend_linear_res_ln_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "eend_linear_relu_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "eend_spk_attn_train_f16": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "eend_conv1d_l2norm_train_f16": [_vp] * 7 + [_i] * 5 + [_vp],
     "eend_inproj_heads_train_bf16": [_vp, _i, _vp, _vp] + [_vp] * 6 + [_i, _i, _i, _vp],
-    "eend_attn_causal_lse_bf16": [_vp] * 5 + [_i] * 6 + [_f, _vp],
-    "eend_attn_causal_bwd_bf16": [_vp] * 5 + [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i] + [_i] * 6 + [_f, _f, _f, _vp],
+    "eend_attn_causal_lse_bf16": [_vp] * 5 + [_i] * 6 + [_f, _vp, _vp],
+    "eend_attn_causal_bwd_bf16": [_vp] * 5 + [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i] + [_i] * 6 + [_f, _f, _f, _vp, _vp],
     "eend_gemm_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    "eend_gemm_relu_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "eend_gemm_relu_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_gemm_acc_bf16": [_vp, _i, _vp, _i, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_conv1d_dgrad_bf16": [_vp] * 5 + [_i] * 5 + [_vp],
     "eend_wgrad_bf16": [_vp, _i, _vp, _i, _i, _l, _i, _i, _vp, _l, _vp, _i, _i, _f, _i, _vp],
     "eend_conv1d_wgrad_bf16": [_vp] * 3 + [_i] * 5 + [_vp, _l, _vp, _vp, _vp],
     "eend_colsum_f32": [_vp, _i, _l, _i, _i, _vp, _l, _vp, _f, _i, _vp],
-    "eend_layernorm_bwd_f32": [_vp] * 6 + [_vp, _l, _vp, _vp, _l, _vp],
+    "eend_layernorm_bwd_f32": [_vp] * 6 + [_vp, _l, _vp, _vp, _l, _vp, _vp],
     "eend_head_bce_f32": [_vp] * 5 + [_f] + [_vp] * 4 + [_vp, _l, _vp] + [_i] * 4 + [_vp],
     "eend_l2norm_bwd_bf16": [_vp] * 4 + [_i] * 3 + [_vp],
     "eend_convert_fanout_bwd_f32": [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _vp],
     "eend_convert_const_f32": [_i] + [_vp] * 7 + [_i, _vp],
-    "eend_spk_attn_bwd_bf16": [_vp] * 3 + [_i] * 4 + [_f, _vp],
+    "eend_spk_attn_bwd_bf16": [_vp] * 3 + [_i] * 4 + [_f, _vp, _vp],
     "eend_bn_train_stats_f32": [_vp, _vp, _f, _vp, _l] + [_vp] * 4 + [_f, _i, _i, _i, _vp],
     "eend_bn_bwd_f32": [_vp, _vp, _f, _vp, _vp, _f, _vp, _i, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_emb_consistency_bwd_f16": [_vp, _vp, _vp, _f, _vp] + [_i] * 5 + [_vp],
@@ -83,6 +85,12 @@ class PrepEntry(ctypes.Structure):
                 ("A", ctypes.c_int), ("B", ctypes.c_int), ("C", ctypes.c_int), ("Cpad", ctypes.c_int),
                 ("sa", ctypes.c_long), ("sb", ctypes.c_long), ("sc", ctypes.c_long),
                 ("dtype", ctypes.c_int), ("nscale", ctypes.c_int), ("scale", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+class Dropout(ctypes.Structure):
+    """eend_dropout of include/eend_hip.h."""
+    _fields_ = [("seed", ctypes.c_uint), ("thresh24", ctypes.c_uint), ("scale", ctypes.c_float)]
+
 
 _lib = None
 

@@ -16,8 +16,11 @@ Design:
     zero gradient with zero moments is exactly zero -- the reference's Adam skips them because .grad is None);
   * MFMA operand copies of the weights (f16 forward layouts, bf16 transposed backward layouts) are rebuilt from the
     updated f32 parameters by one table-driven launch per step;
-  * dropout: the reference's drop masks cannot be matched by any other implementation; the training step runs with
-    dropout = 0 and refuses anything else loudly.
+  * dropout (all ten nn.Dropout / attention-dropout sites of the two layer types) is applied inside the producing
+    kernels' epilogues from a counter-based hash of (seed, element index) -- include/eend_hip.h `eend_dropout` -- and
+    recomputed, not stored, by the backward.  The reference's masks come from torch's Philox stream and cannot be
+    matched by any other implementation, so parity with dropout is pinned against the oracle driven with the SAME
+    hash masks (tests/test_train_step.py), and the p = 0 path against the reference's own gradients.
 
 There is no autograd / eager fallback: everything below is a call into libeend_hip.so.
 """
@@ -51,6 +54,26 @@ def _call(name: str, *args):
             a.append(x)
     a.append(torch.cuda.current_stream().cuda_stream)
     _lib.check(getattr(L, name)(*a), name)
+
+
+def _fmix32(h: int) -> int:
+    h &= 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def drop_step_seed(seed: int, fwd_count: int) -> int:
+    """Per-forward base seed of the dropout hash."""
+    return _fmix32((seed & 0xFFFFFFFF) ^ _fmix32(fwd_count + 0x9E3779B9))
+
+
+def drop_site_seed(base: int, site: int) -> int:
+    """Seed of one dropout site (`eend_dropout.seed`)."""
+    return _fmix32(base ^ _fmix32(site * 0x9E3779B1 + 0x7F4A7C15))
 
 
 def never_graded(name: str) -> bool:
@@ -157,16 +180,25 @@ class FsTrainStep:
     """One training step of FS-EEND (`OnlineTransformerDADiarization` mirror) entirely in HIP."""
 
     def __init__(self, model, warmup: int = 100000, lr: float = 1.0, schedule_scale: float = 1.0, grad_clip: float = 5.0,
-                 betas=(0.9, 0.98), eps: float = 1e-9, bn_momentum: float = 0.1, process_group=None):
+                 betas=(0.9, 0.98), eps: float = 1e-9, bn_momentum: float = 0.1, process_group=None, drop_seed: int = 0):
         from .fs_model import OnlineTransformerDADiarization
         if not isinstance(model, OnlineTransformerDADiarization):
             raise TypeError("FsTrainStep drives fs_eend_amd.fs_model.OnlineTransformerDADiarization")
-        for mod in model.modules():
-            if isinstance(mod, torch.nn.Dropout) and mod.p != 0.0:
-                raise NotImplementedError("training kernels run with dropout = 0 (the reference's drop masks cannot be "
-                                          "reproduced); build the model with dropout=0.0")
-            if isinstance(mod, torch.nn.MultiheadAttention) and mod.dropout != 0.0:
-                raise NotImplementedError("training kernels run with dropout = 0; build the model with dropout=0.0")
+        ps = set()
+        for name, mod in model.named_modules():
+            if name.endswith("pos_enc.dropout") or name.endswith("pos_encoder.dropout"):
+                continue                     # PositionalEncoding.forward returns the table un-dropped (model :218-224)
+            if isinstance(mod, torch.nn.Dropout):
+                ps.add(float(mod.p))
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                ps.add(float(mod.dropout))
+        if len(ps) > 1:
+            raise NotImplementedError(f"one dropout ratio for the whole model (the reference's constructor), got {sorted(ps)}")
+        self.drop_p = ps.pop() if ps else 0.0
+        if not 0.0 <= self.drop_p < 1.0:
+            raise ValueError("dropout ratio must be in [0, 1)")
+        self.drop_seed = int(drop_seed) & 0xFFFFFFFF
+        self._fwd_count = 0
         if model.enc.mask_delay != model.dec.mask_delay:
             raise NotImplementedError
         self.model = model
@@ -301,17 +333,37 @@ class FsTrainStep:
     def _G(self, name):          # f32 gradient view
         return self.flat.g(name)
 
-    def _linear_ln(self, a16, w, bias, res, ln, site: _Site, out32, M, K):
-        _call("eend_linear_res_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, res, 1.0, self._P(ln + ".weight"),
-              self._P(ln + ".bias"), 1e-5, out32, site.out16, site.xhat, site.rstd, M, K)
+    # ------------------------------------------------------------------ dropout sites
+    # site ids: encoder layer i -> 16*i + k, decoder layer i -> 4096 + 16*i + k, with k:
+    SITE_ATT, SITE_OUT1, SITE_SPK, SITE_OUT2, SITE_FF, SITE_FFOUT = 0, 1, 2, 3, 4, 5
 
-    def _attn_fwd(self, x16, w, bias, sv: _AttnSave, nseq, Tp, mask_delay, kv_len):
+    def _drop(self, bf, site: int):
+        """eend_dropout of one site for the forward that filled `bf` (None <=> no dropout): the seed is a hash of
+        (drop_seed, forward count, site id), so the backward asks for the same spec and gets the same mask."""
+        if bf.drop_base is None:
+            return None
+        spec = bf.drop_specs.get(site)
+        if spec is None:
+            spec = _lib.Dropout(drop_site_seed(bf.drop_base, site), int(round(self.drop_p * (1 << 24))), 1.0 / (1.0 - self.drop_p))
+            bf.drop_specs[site] = spec
+        return ctypes.byref(spec)
+
+    def _linear_ln(self, a16, w, bias, res, ln, site: _Site, out32, M, K, drop=None):
+        _call("eend_linear_res_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, res, 1.0, self._P(ln + ".weight"),
+              self._P(ln + ".bias"), 1e-5, out32, site.out16, site.xhat, site.rstd, M, K, drop)
+
+    def _linear_relu(self, a16, w, bias, out16, drop=None):
+        M, K = a16.shape
+        N = out16.shape[1]
+        _call("eend_linear_relu_train_f16", a16, a16.stride(0), w, w.stride(0), bias, out16, out16.stride(0), M, N, K, drop)
+
+    def _attn_fwd(self, x16, w, bias, sv: _AttnSave, nseq, Tp, mask_delay, kv_len, drop=None):
         _call("eend_inproj_heads_train_bf16", x16, x16.stride(0), w, bias, sv.q, sv.qt, sv.k, sv.kt, sv.v, sv.vt, nseq, Tp, H)
-        _call("eend_attn_causal_lse_bf16", sv.q, sv.k, sv.vt, sv.ctx, sv.lse, nseq, H, Tp, D, mask_delay, kv_len, ops.LN2)
+        _call("eend_attn_causal_lse_bf16", sv.q, sv.k, sv.vt, sv.ctx, sv.lse, nseq, H, Tp, D, mask_delay, kv_len, ops.LN2, drop)
 
     # ------------------------------------------------------------------ forward (saves activations)
     def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False,
-                fused_loss: bool = True):
+                fused_loss: bool = True, dropout: bool = True):
         """Train-mode model.forward with every activation the backward needs saved.  labels: prepared (T_i, nspk_i+2)
         tensors (oln_tfm_enc_dec.py:53-75).
         fused_loss=True : also standard_loss + emb-consistency loss and their gradients w.r.t. attractors / embeddings
@@ -335,6 +387,10 @@ class FsTrainStep:
             bf.len_key = key
         bf.shape = (B, T, Tp, C)
         bf.srcs = srcs
+        self._fwd_count += 1
+        bf.drop_base = drop_step_seed(self.drop_seed, self._fwd_count) if (dropout and self.drop_p > 0.0) else None
+        bf.drop_specs = {}
+        dr = lambda site: self._drop(bf, site)
         n_frames = sum(int(l.shape[0]) for l in labels)
         if all(tuple(l.shape) == (T, C) for l in labels):    # equal-length chunks (the training set-up): one stack
             lab = torch.stack([l.to(device=dev, dtype=F32) for l in labels]).contiguous()
@@ -361,12 +417,13 @@ class FsTrainStep:
         x16 = bf.site0.out16
         for i, sv in enumerate(bf.enc):
             p_ = f"enc.transformer_encoder.layers.{i}."
-            self._attn_fwd(x16, W[f"e{i}.in_w"], W[f"e{i}.in_b"], sv["att"], B, Tp, delay_e, kv_e)
+            so = 16 * i
+            self._attn_fwd(x16, W[f"e{i}.in_w"], W[f"e{i}.in_b"], sv["att"], B, Tp, delay_e, kv_e, dr(so + self.SITE_ATT))
             self._linear_ln(sv["att"].ctx, W[f"e{i}.out_w"], self._P(p_ + "self_attn.out_proj.bias"), bf.h32, p_ + "norm1", sv["s1"],
-                            bf.h32, Me, D)
-            ops.linear(sv["s1"].out16, W[f"e{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], relu=True)
+                            bf.h32, Me, D, dr(so + self.SITE_OUT1))
+            self._linear_relu(sv["s1"].out16, W[f"e{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], dr(so + self.SITE_FF))
             self._linear_ln(sv["hid"], W[f"e{i}.w2"], self._P(p_ + "linear2.bias"), bf.h32, p_ + "norm2", sv["s2"], bf.h32, Me,
-                            sv["hid"].shape[1])
+                            sv["hid"].shape[1], dr(so + self.SITE_FFOUT))
             x16 = sv["s2"].out16
         bf.enc_out16 = x16
 
@@ -382,16 +439,17 @@ class FsTrainStep:
         dm = m.dec.mask_delay
         for i, sv in enumerate(bf.dec):
             p_ = f"dec.attractor_decoder.layers.{i}."
-            self._attn_fwd(x16, W[f"d{i}.in1_w"], W[f"d{i}.in1_b"], sv["att"], B * C, Tp, dm, T)
+            so = 4096 + 16 * i
+            self._attn_fwd(x16, W[f"d{i}.in1_w"], W[f"d{i}.in1_b"], sv["att"], B * C, Tp, dm, T, dr(so + self.SITE_ATT))
             self._linear_ln(sv["att"].ctx, W[f"d{i}.out1_w"], self._P(p_ + "self_attn1.out_proj.bias"), bf.a32, p_ + "norm11",
-                            sv["s11"], bf.a32, Md, D)
+                            sv["s11"], bf.a32, Md, D, dr(so + self.SITE_OUT1))
             ops.linear(sv["s11"].out16, W[f"d{i}.in2_w"], self._P(p_ + "self_attn2.in_proj_bias"), sv["qkv"])
-            ops.spk_attn(sv["qkv"], sv["o2"], B, C, Tp, H)
+            _call("eend_spk_attn_train_f16", sv["qkv"], sv["o2"], B, C, Tp, H, 0.125, dr(so + self.SITE_SPK))
             self._linear_ln(sv["o2"], W[f"d{i}.out2_w"], self._P(p_ + "self_attn2.out_proj.bias"), bf.a32, p_ + "norm21", sv["s21"],
-                            bf.a32, Md, D)
-            ops.linear(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], relu=True)
+                            bf.a32, Md, D, dr(so + self.SITE_OUT2))
+            self._linear_relu(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], dr(so + self.SITE_FF))
             self._linear_ln(sv["hid"], W[f"d{i}.w2"], self._P(p_ + "linear2.bias"), bf.a32, p_ + "norm22", sv["s22"], bf.a32, Md,
-                            sv["hid"].shape[1])
+                            sv["hid"].shape[1], dr(so + self.SITE_FFOUT))
             x16 = sv["s22"].out16
 
         # ---- head + BCE (+ PIT label choice) + emb-consistency loss, and their gradients w.r.t. attractors / embeddings
@@ -438,31 +496,33 @@ class FsTrainStep:
         _call("eend_wgrad_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS, g,
               K if ld_out is None else ld_out, K if k_out is None else k_out, 1.0, 0)
 
-    def _ln_bwd(self, g32, site: _Site, ln, ds16, M):
+    def _ln_bwd(self, g32, site: _Site, ln, ds16, M, drop=None):
+        """`drop`: the spec of the sub-layer output dropout in front of this LayerNorm's residual sum -- the bf16 branch
+        gradient ds16 gets the mask, the f32 residual-stream gradient g32 does not."""
         _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
-              self._G(ln + ".weight"), self._G(ln + ".bias"), M)
+              self._G(ln + ".weight"), self._G(ln + ".bias"), M, drop)
 
-    def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm):
+    def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm, drop_scale=1.0):
         """backward of x -> LN(x + W2 relu(W1 x + b1) + b2); g32 in/out (gradient w.r.t. output -> w.r.t. x)."""
         W = self.W
         Fh = hid.shape[1]
         dh = dh16[:M * Fh].view(M, Fh)
         _call("eend_colsum_f32", ds16, D, M, D, 1, self.ws, WS_FLOATS, self._G(p_ + "linear2.bias"), 1.0, 0)
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
-        _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D)
+        _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D, drop_scale)
         self._bias_grad(dh, M, Fh, p_ + "linear1.bias")
         self._wgrad(dh, x_in16, M, Fh, D, p_ + "linear1.weight")
         _call("eend_gemm_acc_bf16", dh, Fh, W[wkey + ".w1T"], Fh, g32, 1.0, g32, None, M, Fh)
 
     def _attn_bwd(self, g32, ds16, dctx16, dqkv16, sv: _AttnSave, x_in16, nseq, Tp, M, w_outT, w_inT, p_out, p_in, bf, delay,
-                  kv_len, T):
+                  kv_len, T, drop=None):
         """backward of x -> x + out_proj(causal_mha(in_proj x)) given ds16 = gradient w.r.t. that sum (bf16) and
         g32 = the same in f32 (residual path); g32 += gradient through the attention branch."""
         self._bias_grad(ds16, M, D, p_out + ".bias")
         self._wgrad(ds16, sv.ctx, M, D, D, p_out + ".weight")
         _call("eend_gemm_bf16", ds16, D, w_outT, D, None, dctx16, D, M, D, D)
         _call("eend_attn_causal_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, dctx16, D, sv.ctx, D, sv.lse, bf.dot_ws, bf.dh_ws, dqkv16,
-              3 * D, nseq, H, Tp, delay, kv_len, T, 1.0, 0.125, ops.LN2)
+              3 * D, nseq, H, Tp, delay, kv_len, T, 1.0, 0.125, ops.LN2, drop)
         self._bias_grad(dqkv16, M, 3 * D, p_in + "_bias")
         self._wgrad(dqkv16, x_in16, M, 3 * D, D, p_in + "_weight")
         _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
@@ -486,6 +546,8 @@ class FsTrainStep:
         m = self.model
         dm = m.dec.mask_delay
         ds16, dctx16, dqkv16 = bf.ds16, bf.dctx16, bf.dqkv16
+        dr = lambda site: self._drop(bf, site)
+        ff_scale = 1.0 / (1.0 - self.drop_p) if bf.drop_base is not None else 1.0
 
         # ---- decoder layers, last to first; bf.g32 = gradient w.r.t. the layer output
         g32 = bf.g32
@@ -494,21 +556,23 @@ class FsTrainStep:
             p_ = f"dec.attractor_decoder.layers.{i}."
             x_in16 = bf.dec[i - 1]["s22"].out16 if i > 0 else bf.a16
             dsd = ds16[:Md]
-            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md)
-            self._ffn_bwd(g32, dsd, bf.dh16, sv["hid"], sv["s21"].out16, Md, f"d{i}", p_, "norm22")
+            so = 4096 + 16 * i
+            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + self.SITE_FFOUT))
+            self._ffn_bwd(g32, dsd, bf.dh16, sv["hid"], sv["s21"].out16, Md, f"d{i}", p_, "norm22", ff_scale)
             # speaker-axis attention block (merge_tfm_encoder.py:373, :388-394)
-            self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md)
+            self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md, dr(so + self.SITE_OUT2))
             self._bias_grad(dsd, Md, D, p_ + "self_attn2.out_proj.bias")
             self._wgrad(dsd, sv["o2"], Md, D, D, p_ + "self_attn2.out_proj.weight")
             _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
-            _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125)
+            _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125, dr(so + self.SITE_SPK))
             self._bias_grad(dqkv16[:Md], Md, 3 * D, p_ + "self_attn2.in_proj_bias")
             self._wgrad(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight")
             _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
             # time-axis attention block (:364, :379-385)
-            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md)
+            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + self.SITE_OUT1))
             self._attn_bwd(g32, dsd, dctx16[:Md], dqkv16[:Md], sv["att"], x_in16, B * C, Tp, Md, W[f"d{i}.out1_wT"],
-                           W[f"d{i}.in1_wT"], p_ + "self_attn1.out_proj", p_ + "self_attn1.in_proj", bf, dm, T, T)
+                           W[f"d{i}.in1_wT"], p_ + "self_attn1.out_proj", p_ + "self_attn1.in_proj", bf, dm, T, T,
+                           dr(so + self.SITE_ATT))
 
         # ---- convert fan-out (model :113-114, factored): g32 = gradient w.r.t. attr0
         _call("eend_convert_fanout_bwd_f32", g32, bf.gsum16, self.ws, WS_FLOATS, bf.dpc, B, Tp, C)
@@ -530,11 +594,12 @@ class FsTrainStep:
             sv = bf.enc[i]
             p_ = f"enc.transformer_encoder.layers.{i}."
             x_in16 = bf.enc[i - 1]["s2"].out16 if i > 0 else bf.site0.out16
-            self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me)
-            self._ffn_bwd(g32, dse, bf.dh16, sv["hid"], sv["s1"].out16, Me, f"e{i}", p_, "norm2")
-            self._ln_bwd(g32, sv["s1"], p_ + "norm1", dse, Me)
+            so = 16 * i
+            self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me, dr(so + self.SITE_FFOUT))
+            self._ffn_bwd(g32, dse, bf.dh16, sv["hid"], sv["s1"].out16, Me, f"e{i}", p_, "norm2", ff_scale)
+            self._ln_bwd(g32, sv["s1"], p_ + "norm1", dse, Me, dr(so + self.SITE_OUT1))
             self._attn_bwd(g32, dse, dctx16[:Me], dqkv16[:Me], sv["att"], x_in16, B, Tp, Me, W[f"e{i}.out_wT"], W[f"e{i}.in_wT"],
-                           p_ + "self_attn.out_proj", p_ + "self_attn.in_proj", bf, bf.delay_e, bf.kv_e, T)
+                           p_ + "self_attn.out_proj", p_ + "self_attn.in_proj", bf, bf.delay_e, bf.kv_e, T, dr(so + self.SITE_ATT))
 
         # ---- input projection + LayerNorm + BatchNorm (model :166,:173-174)
         self._ln_bwd(g32, bf.site0, "enc.encoder_norm", dse, Me)

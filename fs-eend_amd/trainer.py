@@ -86,9 +86,16 @@ class SpeakerDiarization:
             from .train import FsTrainStep
             h = _hyper(self.opt, self.scheduler, self.hparams)
             self._step = FsTrainStep(self.model, warmup=h["warmup"] if h["noam"] else 1, lr=h["lr"], schedule_scale=h["scale"],
-                                     grad_clip=h["clip"], betas=h["betas"], eps=h["eps"])
+                                     grad_clip=h["clip"], betas=h["betas"], eps=h["eps"], drop_seed=self._drop_seed())
             self._noam = h["noam"]
         return self._step
+
+    def _drop_seed(self):
+        """Seed of the dropout hash: the run's `training.seed` (train_dia.py seeds torch from it) offset by the rank, so
+        data-parallel replicas draw different masks."""
+        seed = int((self.hparams.get("training") or {}).get("seed", 0) or 0)
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        return seed * 1000003 + rank
 
     def to(self, device):
         self.model.to(device)

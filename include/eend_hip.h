@@ -311,12 +311,35 @@ int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, fl
  * gradients are written in fixed summation order (no atomics), so a step is bit-reproducible.
  * ====================================================================================================== */
 
+/* Dropout (torch.nn.Dropout in train mode: FS model :147 / merge_tfm_encoder.py:209-219,385,394,398-399,609-614 and
+ * nn.MultiheadAttention(dropout=p)).  The reference draws its masks from torch's Philox stream, which no other
+ * implementation can reproduce; here a mask is a pure function of (seed, element index), so the backward recomputes it
+ * instead of storing it and a step stays bit-reproducible:
+ *   h = fmix32((a * 0x9E3779B1 + b) ^ seed)   (murmur3 finaliser),   keep <=> (h >> 8) >= thresh24
+ * with (a, b) = (row, column) of the element (attention: a = (seq*H + head)*Tp + query, b = key; speaker attention:
+ * a = ((b*Tp + t)*4 + head)*16 + query slot, b = key slot).  thresh24 = round(p * 2^24), scale = 1/(1-p).
+ * A null pointer or thresh24 == 0 means no dropout.  Host struct, read at call time. */
+typedef struct eend_dropout {
+    unsigned seed;
+    unsigned thresh24;
+    float scale;
+} eend_dropout;
+
 /* eend_linear_res_ln_f16 that also saves what LayerNorm backward needs: xhat_f16 [M][256] = the normalised
  * row before the affine, rstd [M] = 1/sigma.  (torch.nn.LayerNorm inside nn.TransformerEncoderLayer, FS model
- * :147,:174; merge_tfm_encoder.py:364,373-374.) */
+ * :147,:174; merge_tfm_encoder.py:364,373-374.)  `drop` acts on (A W^T + bias) before the residual (dropout1 /
+ * dropout2 / dropout11 / dropout21), element (row m, column n). */
 int eend_linear_res_ln_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
                                  float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
-                                 void* out_f16, void* xhat_f16, float* rstd, int M, int K, void* stream);
+                                 void* out_f16, void* xhat_f16, float* rstd, int M, int K, const eend_dropout* drop,
+                                 void* stream);
+/* relu(A W^T + bias) with dropout after the activation (the FFN's inner `self.dropout`, merge_tfm_encoder.py:398,613);
+ * the stored activation is the dropped one, so its zeros are the ReLU-and-dropout mask of the backward. */
+int eend_linear_relu_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
+                               int M, int N, int K, const eend_dropout* drop, void* stream);
+/* eend_spk_attn_f16 with dropout of the attention probabilities. */
+int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
+                            const eend_dropout* drop, void* stream);
 
 /* eend_conv1d_l2norm_f16 that also saves inv_norm [nseq*Tp] = 1/||conv output|| (FS model :40-41). */
 int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bias, const int* ilens, float* out_f32,
@@ -328,28 +351,32 @@ int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bia
 int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const float* bias, void* Q, void* Qt,
                                  void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream);
 
-/* eend_attn_causal_bf16 that also writes lse [nseq][H][Tp]: the log2-domain log-sum-exp of every query row. */
+/* eend_attn_causal_bf16 that also writes lse [nseq][H][Tp]: the log2-domain log-sum-exp of every query row.
+ * `drop`: dropout of the softmax probabilities (the normaliser stays un-dropped, as in torch). */
 int eend_attn_causal_lse_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, float* lse, int nseq, int H,
-                              int Tp, int ldo, int mask_delay, int kv_len, float scale, void* stream);
+                              int Tp, int ldo, int mask_delay, int kv_len, float scale, const eend_dropout* drop,
+                              void* stream);
 
 /* Backward of the causal time-axis attention (torch autograd through nn.MultiheadAttention's core: FS model :147,
  * merge_tfm_encoder.py:379-385).  dO bf16 [nseq*Tp][ldo] (gradient w.r.t. the concatenated head outputs), O f16
  * the forward output; dQKV bf16 [nseq*Tp][ldg] receives dQ | dK | dV at columns 0 / 256 / 512 (+ h*64).
  * dOt_ws (bf16, nseq*Tp*256) and dh_ws (f32, nseq*H*Tp) are scratch.  scale_log2 as given to the forward
  * (its `scale` * log2 e); sq / sk: factors applied to dQ / dK (for the pre-scaled-q convention of
- * eend_attn_causal_bf16: scale_log2 = 1, sq = 1/sqrt(dh), sk = ln 2). */
+ * eend_attn_causal_bf16: scale_log2 = 1, sq = 1/sqrt(dh), sk = ln 2).  `drop`: the forward's spec; O_f16 is the
+ * forward output (computed from the dropped probabilities), which keeps D_i = <dO_i, O_i> valid. */
 int eend_attn_causal_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
                               const void* dO, int ldo, const void* O_f16, int ldout, const float* lse, void* dOt_ws,
                               float* dh_ws, void* dQKV, int ldg, int nseq, int H, int Tp, int mask_delay, int kv_len,
-                              int q_len, float scale_log2, float sq, float sk, void* stream);
+                              int q_len, float scale_log2, float sq, float sk, const eend_dropout* drop, void* stream);
 
 /* Gradient GEMMs, bf16 operands, f32 accumulate (autograd of every torch.nn.Linear on the path):
  *   out = A W^T (+ bias)            -> bf16 [M][ldo]                 N % 128 == 0, K % 64 == 0 */
 int eend_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_bf16, int ldo,
                    int M, int N, int K, void* stream);
-/*   out = (A W^T) where act != 0    (ReLU backward; act = the saved forward activation, any 2-byte float) */
+/*   out = drop_scale * (A W^T) where act != 0    (ReLU [+ dropout] backward; act = the saved forward activation, any
+ *   2-byte float; drop_scale = 1/(1-p) of eend_linear_relu_train_f16, or 1) */
 int eend_gemm_relu_bwd_bf16(const void* A, int lda, const void* W, int ldw, const void* act, int ldact,
-                            void* out_bf16, int ldo, int M, int N, int K, void* stream);
+                            void* out_bf16, int ldo, int M, int N, int K, float drop_scale, void* stream);
 /*   out_f32 = (A W^T) * alpha + res_f32 (N = 256; the residual-gradient stream), optional bf16 copy */
 int eend_gemm_acc_bf16(const void* A, int lda, const void* W, int ldw, const float* res_f32, float alpha,
                        float* out_f32, void* out_bf16, int M, int K, void* stream);
@@ -372,9 +399,12 @@ int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws
                     float scale, int accumulate, void* stream);
 
 /* LayerNorm backward (autograd of torch.nn.LayerNorm): g = gradient w.r.t. the output (f32 [M][256]); writes the
- * gradient w.r.t. the input as f32 (ds_f32, may alias g) and bf16, and dgamma / dbeta [256]. */
+ * gradient w.r.t. the input as f32 (ds_f32, may alias g) and bf16, and dgamma / dbeta [256].  `drop`: the spec of the
+ * producing eend_linear_res_ln_train_f16 -- applied to the bf16 copy only (the branch gradient), not to ds_f32 (the
+ * residual stream). */
 int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rstd, const float* gamma, float* ds_f32,
-                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M, void* stream);
+                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M,
+                           const eend_dropout* drop, void* stream);
 
 /* Head forward + standard_loss + their gradient in one pass (FS model :43,:60; train/utils/loss.py:119-125 with
  * label_delay = 0): labels f32 [B][T][C] (prepared: silence / speakers / none columns, zero padded), ilens / ncols
@@ -402,7 +432,7 @@ int eend_convert_const_f32(int mode, const float* W, const float* bias, const fl
 /* Speaker-axis attention backward (merge_tfm_encoder.py:388-394): qkv f16 [rows][768] from the forward in-projection,
  * dO bf16 [rows][256] -> dqkv bf16 [rows][768]. */
 int eend_spk_attn_bwd_bf16(const void* qkv_f16, const void* dO_bf16, void* dqkv_bf16, int B, int C, int Tp, int H,
-                           float scale, void* stream);
+                           float scale, const eend_dropout* drop, void* stream);
 
 /* Train-mode BatchNorm1d statistics over the padded input (FS model :165-166): mean / biased var [F] of all B*T
  * frames (pad_value for frames beyond each length) and the running-statistics update (momentum, unbiased var). */

@@ -1,0 +1,94 @@
+"""TEST ORACLE (not product code): the counter-hash dropout masks of the HIP training kernels, restated in torch.
+
+The reference's dropout (nn.Dropout / nn.MultiheadAttention(dropout=p): FS-EEND/nnet/modules/merge_tfm_encoder.py:
+209-219,385,394,398-399 and torch's nn.TransformerEncoderLayer) draws Bernoulli(1-p) masks from torch's Philox stream and
+scales the kept elements by 1/(1-p).  No other implementation can reproduce THOSE masks, so the parity statement for
+dropout is: given the same masks, the HIP forward/backward equals the oracle's.  This module produces the masks the
+kernels produce -- include/eend_hip.h `eend_dropout`:
+
+    h = fmix32((a * 0x9E3779B1 + b) ^ seed)   (murmur3 finaliser, 32-bit wrap-around),   keep <=> (h >> 8) >= thresh24
+
+with (a, b) per site as documented there -- and hands them to oracle/fs_eend_ref.py's `drop` hook.  The statistical
+claim (keep rate 1-p, independence across sites) is tested separately (tests/test_train_step.py).
+parity unpinned against the reference for p > 0 (by construction); pinned for p = 0 by tests/golden/fs_train_*.npz.
+"""
+import torch
+
+M32 = 0xFFFFFFFF
+
+
+def fmix32_int(h: int) -> int:
+    h &= M32
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M32
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M32
+    h ^= h >> 16
+    return h
+
+
+def step_seed(seed: int, fwd_count: int) -> int:
+    return fmix32_int((seed & M32) ^ fmix32_int(fwd_count + 0x9E3779B9))
+
+
+def site_seed(base: int, site: int) -> int:
+    return fmix32_int(base ^ fmix32_int(site * 0x9E3779B1 + 0x7F4A7C15))
+
+
+def keep_mask(a: torch.Tensor, b: torch.Tensor, seed: int, thresh24: int) -> torch.Tensor:
+    """a, b: int64 tensors (broadcastable) of the element indices -> bool keep mask."""
+    h = ((a * 0x9E3779B1 + b) & M32) ^ seed
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M32
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M32
+    h = h ^ (h >> 16)
+    return (h >> 8) >= thresh24
+
+
+class HashDropout:
+    """The `drop` hook of fs_eend_ref.fs_forward for one forward pass (fwd_count-th forward of a trainer seeded `seed`)."""
+    SITE_ATT, SITE_OUT1, SITE_SPK, SITE_OUT2, SITE_FF, SITE_FFOUT = 0, 1, 2, 3, 4, 5
+
+    def __init__(self, p: float, seed: int, fwd_count: int, Tp: int, n_heads: int = 4):
+        self.p, self.Tp, self.H = p, Tp, n_heads
+        self.base = step_seed(seed, fwd_count)
+        self.thresh24 = int(round(p * (1 << 24)))
+        self.scale = 1.0 / (1.0 - p)
+
+    def _apply(self, x, site, a, b):
+        keep = keep_mask(a, b, site_seed(self.base, site), self.thresh24)
+        return x * (keep.to(x.dtype) * self.scale)
+
+    def seq_rows(self, nseq, T, device):
+        """slab row of frame t of sequence n: n*Tp + t, shape (nseq, T)."""
+        return torch.arange(nseq, device=device)[:, None] * self.Tp + torch.arange(T, device=device)[None, :]
+
+    def slot_rows(self, B, T, C, device):
+        """decoder slab row of (b, t, c): (b*C + c)*Tp + t, shape (B*T, C)."""
+        b = torch.arange(B, device=device)[:, None, None]
+        t = torch.arange(T, device=device)[None, :, None]
+        c = torch.arange(C, device=device)[None, None, :]
+        return ((b * C + c) * self.Tp + t).reshape(B * T, C)
+
+    def rows(self, x, site, rows):
+        """x (..., F) with rows (...) = the slab row of each leading index: element (row, column)."""
+        cols = torch.arange(x.shape[-1], device=x.device)
+        return self._apply(x, site, rows[..., None].to(torch.int64), cols)
+
+    def attn(self, p, site):
+        """time-axis attention probabilities (N, H, L, S): a = (n*H + h)*Tp + query, b = key."""
+        N, H, L, S = p.shape
+        dev = p.device
+        a = ((torch.arange(N, device=dev)[:, None, None] * H + torch.arange(H, device=dev)[None, :, None]) * self.Tp
+             + torch.arange(L, device=dev)[None, None, :])
+        return self._apply(p, site, a[..., None], torch.arange(S, device=dev))
+
+    def spk(self, p, site, B, T):
+        """speaker-axis attention probabilities (B*T, H, C, C): a = ((b*Tp + t)*4 + h)*16 + query slot, b = key slot."""
+        _, H, C, _ = p.shape
+        dev = p.device
+        frame = (torch.arange(B, device=dev)[:, None] * self.Tp + torch.arange(T, device=dev)[None, :]).reshape(B * T)
+        a = ((frame[:, None, None] * 4 + torch.arange(H, device=dev)[None, :, None]) * 16
+             + torch.arange(C, device=dev)[None, None, :])
+        return self._apply(p, site, a[..., None], torch.arange(C, device=dev))

@@ -67,7 +67,7 @@ def causal_allowed(T: int, mask_delay: int = 0, device=None) -> Tensor:
 
 def mha(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor,
         n_heads: int, allowed: Optional[Tensor], q=_id, role="mha",
-        kv: Optional[Tensor] = None) -> Tensor:
+        kv: Optional[Tensor] = None, pdrop=None) -> Tensor:
     """torch.nn.MultiheadAttention(x,x,x) on (N, L, D) batch-first data.
 
     packed in-proj (3D x D), per-head scaled dot product with scale 1/sqrt(dh),
@@ -91,6 +91,8 @@ def mha(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor,
     if allowed is not None:
         s = s.masked_fill(~allowed, float("-inf"))
     p = torch.softmax(s, dim=-1)
+    if pdrop is not None:                                       # nn.MultiheadAttention(dropout=p): dropout of the probabilities
+        p = pdrop(p)
     o = q(p, role + ".p") @ q(vh, role + ".v")                 # (N,H,L,dh)
     o = o.transpose(1, 2).reshape(N, L, D)
     return linear(o, out_w, out_b, q, role + ".out")
@@ -111,21 +113,30 @@ def sinusoid_pe(n_rows: int, d_model: int, dtype=torch.float32) -> Tensor:
 # the batch (masked) model
 # ----------------------------------------------------------------------------
 def encoder_layer(x: Tensor, sd: Dict[str, Tensor], pfx: str, n_heads: int,
-                  allowed: Optional[Tensor], q=_id) -> Tensor:
+                  allowed: Optional[Tensor], q=_id, drop=None, site0: int = 0) -> Tensor:
     """Post-norm nn.TransformerEncoderLayer, ReLU (model :147).
-    x = LN1(x + MHA(x)); x = LN2(x + W2 relu(W1 x))."""
+    x = LN1(x + drop1(MHA(x))); x = LN2(x + drop2(W2 drop(relu(W1 x)))); the attention probabilities are dropped
+    too.  ``drop`` (oracle/dropout_ref.HashDropout or None) supplies the masks; x: (B, T, D)."""
+    N, T, _ = x.shape
     a = mha(x, sd[pfx + "self_attn.in_proj_weight"], sd[pfx + "self_attn.in_proj_bias"],
             sd[pfx + "self_attn.out_proj.weight"], sd[pfx + "self_attn.out_proj.bias"],
-            n_heads, allowed, q, "enc.mha")
+            n_heads, allowed, q, "enc.mha",
+            pdrop=None if drop is None else (lambda p: drop.attn(p, site0 + drop.SITE_ATT)))
+    if drop is not None:
+        a = drop.rows(a, site0 + drop.SITE_OUT1, drop.seq_rows(N, T, x.device))
     x = layer_norm(x + a, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     h = torch.relu(linear(x, sd[pfx + "linear1.weight"], sd[pfx + "linear1.bias"], q, "enc.ff1"))
+    if drop is not None:
+        h = drop.rows(h, site0 + drop.SITE_FF, drop.seq_rows(N, T, x.device))
     f = linear(h, sd[pfx + "linear2.weight"], sd[pfx + "linear2.bias"], q, "enc.ff2")
+    if drop is not None:
+        f = drop.rows(f, site0 + drop.SITE_FFOUT, drop.seq_rows(N, T, x.device))
     return layer_norm(x + f, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
 
 
 def encoder(src: Sequence[Tensor], sd: Dict[str, Tensor], n_heads: int, n_layers: int,
             has_mask: bool = True, mask_delay: int = 0, q=_id, dtype=torch.float32,
-            taps: Optional[dict] = None, bn_batch_stats: Optional[dict] = None) -> Tensor:
+            taps: Optional[dict] = None, bn_batch_stats: Optional[dict] = None, drop=None) -> Tensor:
     """MaskedTransformerEncoderModel.forward (model :162-188).
 
     pad(-1) -> BatchNorm1d -> Linear -> LN -> n_layers causal post-norm Transformer layers.
@@ -152,7 +163,7 @@ def encoder(src: Sequence[Tensor], sd: Dict[str, Tensor], n_heads: int, n_layers
         taps["enc_in"] = x
     allowed = causal_allowed(x.shape[1], mask_delay, x.device) if has_mask else None
     for i in range(n_layers):
-        x = encoder_layer(x, sd, f"enc.transformer_encoder.layers.{i}.", n_heads, allowed, q)
+        x = encoder_layer(x, sd, f"enc.transformer_encoder.layers.{i}.", n_heads, allowed, q, drop, 16 * i)
         if taps is not None:
             taps[f"enc_l{i}"] = x
     return x
@@ -177,28 +188,40 @@ def lookahead_conv_l2(enc_out: Tensor, ilens: Sequence[int], sd: Dict[str, Tenso
 
 
 def fusion_layer(x: Tensor, sd: Dict[str, Tensor], pfx: str, n_heads: int,
-                 allowed: Optional[Tensor], q=_id) -> Tensor:
+                 allowed: Optional[Tensor], q=_id, drop=None, site0: int = 0) -> Tensor:
     """TransformerEncoderFusionLayer.forward (modules/merge_tfm_encoder.py:356-376),
-    post-norm branch.  x: (B, T, C, D)."""
+    post-norm branch.  x: (B, T, C, D).  ``drop``: the six dropout sites of the layer (:385 dropout11 + self_attn1's
+    probabilities, :394 dropout21 + self_attn2's probabilities, :398 dropout, :399 dropout2)."""
     B, T, C, D = x.shape
     y = x.transpose(1, 2).reshape(B * C, T, D)
     a = mha(y, sd[pfx + "self_attn1.in_proj_weight"], sd[pfx + "self_attn1.in_proj_bias"],
             sd[pfx + "self_attn1.out_proj.weight"], sd[pfx + "self_attn1.out_proj.bias"],
-            n_heads, allowed, q, "dec.mha_t")
+            n_heads, allowed, q, "dec.mha_t",
+            pdrop=None if drop is None else (lambda p: drop.attn(p, site0 + drop.SITE_ATT)))
+    if drop is not None:
+        a = drop.rows(a, site0 + drop.SITE_OUT1, drop.seq_rows(B * C, T, x.device))
     y = layer_norm(y + a, sd[pfx + "norm11.weight"], sd[pfx + "norm11.bias"])      # :364
     y = y.reshape(B, C, T, D).transpose(1, 2).reshape(B * T, C, D)
     a = mha(y, sd[pfx + "self_attn2.in_proj_weight"], sd[pfx + "self_attn2.in_proj_bias"],
             sd[pfx + "self_attn2.out_proj.weight"], sd[pfx + "self_attn2.out_proj.bias"],
-            n_heads, None, q, "dec.mha_s")
+            n_heads, None, q, "dec.mha_s",
+            pdrop=None if drop is None else (lambda p: drop.spk(p, site0 + drop.SITE_SPK, B, T)))
+    rows = None if drop is None else drop.slot_rows(B, T, C, x.device)              # (B*T, C) slab rows (b*C + c)*Tp + t
+    if drop is not None:
+        a = drop.rows(a, site0 + drop.SITE_OUT2, rows)
     y = layer_norm(y + a, sd[pfx + "norm21.weight"], sd[pfx + "norm21.bias"])      # :373
     h = torch.relu(linear(y, sd[pfx + "linear1.weight"], sd[pfx + "linear1.bias"], q, "dec.ff1"))
+    if drop is not None:
+        h = drop.rows(h, site0 + drop.SITE_FF, rows)
     f = linear(h, sd[pfx + "linear2.weight"], sd[pfx + "linear2.bias"], q, "dec.ff2")
+    if drop is not None:
+        f = drop.rows(f, site0 + drop.SITE_FFOUT, rows)
     y = layer_norm(y + f, sd[pfx + "norm22.weight"], sd[pfx + "norm22.bias"])      # :374
     return y.reshape(B, T, C, D)
 
 
 def decoder(emb: Tensor, max_nspks: int, sd: Dict[str, Tensor], n_heads: int, n_layers: int,
-            mask_delay: int = 0, q=_id, taps: Optional[dict] = None) -> Tensor:
+            mask_delay: int = 0, q=_id, taps: Optional[dict] = None, drop=None) -> Tensor:
     """MaskedTransformerDecoderModel.forward (model :112-118).
     attr0[b,t,c] = convert([emb[b,t]; pe[c]]), then n_layers fusion layers.
     NB the decoder always applies the causal mask (:116), whatever has_mask."""
@@ -211,7 +234,7 @@ def decoder(emb: Tensor, max_nspks: int, sd: Dict[str, Tensor], n_heads: int, n_
         taps["attr0"] = x
     allowed = causal_allowed(T, mask_delay, emb.device)
     for i in range(n_layers):
-        x = fusion_layer(x, sd, f"dec.attractor_decoder.layers.{i}.", n_heads, allowed, q)
+        x = fusion_layer(x, sd, f"dec.attractor_decoder.layers.{i}.", n_heads, allowed, q, drop, 4096 + 16 * i)
         if taps is not None:
             taps[f"dec_l{i}"] = x
     return x
@@ -253,16 +276,17 @@ def emb_consistency_loss(emb: Tensor, tgt_pad: Tensor) -> Tensor:
 def fs_forward(src: Sequence[Tensor], tgt: Sequence[Tensor], ilens: Sequence[int],
                sd: Dict[str, Tensor], *, n_heads: int, enc_n_layers: int, dec_n_layers: int,
                has_mask: bool = True, mask_delay: int = 0, q=_id, dtype=torch.float32,
-               bn_batch_stats: Optional[dict] = None):
-    """OnlineTransformerDADiarization.forward (model :32-65), dropout off; BN running stats
-    (eval) or, with ``bn_batch_stats`` a dict, batch statistics (train mode, see encoder())."""
+               bn_batch_stats: Optional[dict] = None, drop=None):
+    """OnlineTransformerDADiarization.forward (model :32-65); BN running stats (eval) or, with
+    ``bn_batch_stats`` a dict, batch statistics (train mode, see encoder()).  Dropout is off unless ``drop`` is
+    an oracle/dropout_ref.HashDropout (the masks are then the HIP path's counter-hash masks, NOT torch's)."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     n_speakers = [t.shape[1] for t in tgt]
     C = max(n_speakers)
     enc_out = encoder(src, sd, n_heads, enc_n_layers, has_mask, mask_delay, q, dtype,
-                      bn_batch_stats=bn_batch_stats)
+                      bn_batch_stats=bn_batch_stats, drop=drop)
     emb = lookahead_conv_l2(enc_out, ilens, sd, q)
-    attr = decoder(emb, C, sd, n_heads, dec_n_layers, mask_delay, q)
+    attr = decoder(emb, C, sd, n_heads, dec_n_layers, mask_delay, q, drop=drop)
     attr = attr / torch.linalg.vector_norm(attr, dim=-1, keepdim=True)
     tgt_pad = [torch.nn.functional.pad(t.to(dtype), (0, C - t.shape[1])) for t in tgt]
     tgt_pad = torch.nn.utils.rnn.pad_sequence(tgt_pad, padding_value=0.0, batch_first=True)

@@ -64,14 +64,15 @@ def clip_coef(total_norm: float, max_norm: float) -> float:
     return min(1.0, max_norm / (total_norm + 1e-6))
 
 
-def train_loss(sd: Dict[str, Tensor], feats, labels_raw, cfg: dict, pit_labels=None, bn_stats=None, dtype=torch.float32):
+def train_loss(sd: Dict[str, Tensor], feats, labels_raw, cfg: dict, pit_labels=None, bn_stats=None, dtype=torch.float32,
+               drop=None):
     """One reference training_step forward: returns (total, bce, emb_loss, logits, prepared labels)."""
     ilens = [int(f.shape[0]) for f in feats]
     labels = prepare_labels([l.to(dtype) for l in labels_raw], ilens)
     logits, emb_loss, _, _ = R.fs_forward(feats, labels, ilens, sd, n_heads=cfg["n_heads"],
                                           enc_n_layers=cfg["enc_n_layers"], dec_n_layers=cfg["dec_n_layers"],
                                           has_mask=cfg["has_mask"], mask_delay=cfg["mask_delay"], dtype=dtype,
-                                          bn_batch_stats=bn_stats if bn_stats is not None else {})
+                                          bn_batch_stats=bn_stats if bn_stats is not None else {}, drop=drop)
     use = labels
     if pit_labels is not None:
         use = pit_labels(logits, labels)

@@ -63,3 +63,27 @@ def test_label_preparation_properties():
     assert out[0][:, 1:4].tolist() == [[1, 0, 0], [1, 1, 0], [0, 0, 0], [0, 0, 1]]
     assert out[0][:, 0].tolist() == [0, 0, 1, 0] and out[0][:, -1].tolist() == [0, 0, 0, 0]
     assert out[1][:, 0].tolist() == [1, 0, 0, 1]
+
+
+def test_dropout_hash_restatement_matches_host_seeds():
+    """oracle/dropout_ref.py and the product's host-side seed derivation (fs_eend_amd.train) agree, and the torch
+    restatement of the kernels' hash has the advertised keep rate."""
+    import importlib
+    from oracle import dropout_ref as DR
+    tr = importlib.import_module("fs_eend_amd.train")
+    for seed, cnt, site in ((0, 1, 0), (777000000 + 3, 12345, 4096 + 16 + 5), (2 ** 32 - 1, 2 ** 31, 35)):
+        base = tr.drop_step_seed(seed, cnt)
+        assert base == DR.step_seed(seed, cnt)
+        assert tr.drop_site_seed(base, site) == DR.site_seed(base, site)
+    d = DR.HashDropout(0.25, 5, 1, 64)
+    x = torch.ones(3, 40, 512, dtype=torch.float64)
+    y = d.rows(x, 4, d.seq_rows(3, 40, "cpu"))
+    assert abs(float((y == 0).double().mean()) - 0.25) < 5e-3 and abs(float(y.max()) - 1 / 0.75) < 1e-12
+    y2 = d.rows(x, 5, d.seq_rows(3, 40, "cpu"))
+    assert abs(float(((y == 0) & (y2 == 0)).double().mean()) - 0.0625) < 5e-3
+    # scalar reference of the hash for one element (the C expression of csrc/common.h drop_keep, 32-bit wrap-around)
+    a, b, s = 123457, 201, DR.site_seed(d.base, 4)
+    h = ((a * 0x9E3779B1 + b) & DR.M32) ^ s
+    keep = (DR.fmix32_int(h) >> 8) >= d.thresh24
+    got = DR.keep_mask(torch.tensor([a]), torch.tensor([b]), s, d.thresh24)
+    assert bool(got[0]) == keep

@@ -59,7 +59,7 @@ def test_gemm_relu_bwd(T, dev, M, F):
     w2t = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(BF16)        # [F][256] = W2^T
     act = torch.relu(torch.randn(M, F, device=dev, generator=gen)).to(F16)
     out = torch.full((M, F), 3.0, dtype=BF16, device=dev)
-    T._call("eend_gemm_relu_bwd_bf16", dy, 256, w2t, 256, act, F, out, F, M, F, 256)
+    T._call("eend_gemm_relu_bwd_bf16", dy, 256, w2t, 256, act, F, out, F, M, F, 256, 1.0)
     want = (dy.float() @ w2t.float().t()) * (act > 0)
     assert rel(out, want) < 6e-3
     assert (out[act == 0] == 0).all()
@@ -154,7 +154,7 @@ def test_linear_res_ln_train(T, dev):
     be = 0.1 * torch.randn(256, device=dev, generator=gen)
     o32, o16 = torch.empty(M, 256, device=dev), torch.empty(M, 256, dtype=F16, device=dev)
     xh, rs = torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, device=dev)
-    T._call("eend_linear_res_ln_train_f16", a, K, w, K, b, res, 1.0, gm, be, 1e-5, o32, o16, xh, rs, M, K)
+    T._call("eend_linear_res_ln_train_f16", a, K, w, K, b, res, 1.0, gm, be, 1e-5, o32, o16, xh, rs, M, K, None)
     s = a.float() @ w.float().t() + b + res
     mu, var = s.mean(-1, keepdim=True), s.var(-1, unbiased=False, keepdim=True)
     xhat = (s - mu) / torch.sqrt(var + 1e-5)
@@ -181,13 +181,72 @@ def test_layernorm_bwd(T, dev, ws):
     gbuf = gy.clone()
     d16 = torch.empty(M, 256, dtype=BF16, device=dev)
     dg, db = torch.empty(256, device=dev), torch.empty(256, device=dev)
-    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, M)
+    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, M, None)
     assert rel(gbuf, sr.grad) < 2e-3
     assert rel(d16, sr.grad) < 6e-3
     assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 1e-4
 
 
-def _attn_ref(q, k, v, delay, kv_len, scale):
+def test_sublayer_dropout_fwd_and_ln_bwd(T, dev, ws):
+    """dropout1/dropout2 (FS model :147; merge_tfm_encoder.py:385,394,399): y = LN(res + drop(a W^T + b)); the backward
+    masks the branch gradient (bf16) and leaves the residual-stream gradient (f32) alone."""
+    import ctypes
+    gen = g(dev, 31)
+    M, K = 777, 256
+    spec, dgen = _drop_spec(0.25, 64, site=5)
+    a = torch.randn(M, K, device=dev, generator=gen).to(F16)
+    w = (torch.randn(256, K, device=dev, generator=gen) / 16).to(F16)
+    b = torch.randn(256, device=dev, generator=gen) * 0.1
+    res = torch.randn(M, 256, device=dev, generator=gen)
+    gm = 1 + 0.2 * torch.randn(256, device=dev, generator=gen)
+    be = 0.1 * torch.randn(256, device=dev, generator=gen)
+    o32, o16 = torch.empty(M, 256, device=dev), torch.empty(M, 256, dtype=F16, device=dev)
+    xh, rs = torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, device=dev)
+    T._call("eend_linear_res_ln_train_f16", a, K, w, K, b, res, 1.0, gm, be, 1e-5, o32, o16, xh, rs, M, K, ctypes.byref(spec))
+    rows = torch.arange(M, device=dev)
+    branch = dgen.rows(a.float() @ w.float().t() + b, 5, rows)
+    sref = (branch + res).requires_grad_(True)
+    y = Fn.layer_norm(sref, (256,), gm, be, 1e-5)
+    assert (o32 - y.detach()).abs().max() < 3e-4
+    gy = torch.randn(M, 256, device=dev, generator=gen) * 1e-5
+    (y * gy).sum().backward()
+    gbuf = gy.clone()
+    d16 = torch.empty(M, 256, dtype=BF16, device=dev)
+    dg, db = torch.empty(256, device=dev), torch.empty(256, device=dev)
+    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, M, ctypes.byref(spec))
+    assert rel(gbuf, sref.grad) < 3e-3                               # residual stream: un-masked
+    want = dgen.rows(sref.grad, 5, rows)                             # branch: masked and scaled
+    assert rel(d16, want) < 6e-3
+    assert ((d16 == 0) == (want == 0)).all()
+
+
+def test_ffn_hidden_dropout_fwd_bwd(T, dev):
+    """the FFN's inner dropout (merge_tfm_encoder.py:398,613): h = drop(relu(x W1^T + b1)); backward: dz = scale * (dy W2)
+    where h != 0."""
+    import ctypes
+    gen = g(dev, 32)
+    M, F = 1000, 1024
+    spec, dgen = _drop_spec(0.25, 64, site=4)
+    x = torch.randn(M, 256, device=dev, generator=gen).to(F16)
+    w1 = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(F16)
+    b1 = torch.randn(F, device=dev, generator=gen) * 0.1
+    h = torch.empty(M, F, dtype=F16, device=dev)
+    T._call("eend_linear_relu_train_f16", x, 256, w1, 256, b1, h, F, M, F, 256, ctypes.byref(spec))
+    z = x.float() @ w1.float().t() + b1
+    want = dgen.rows(torch.relu(z), 4, torch.arange(M, device=dev))
+    assert rel(h, want) < 3e-3
+    sure = z.abs() > 1e-2                                            # away from the ReLU kink the zero patterns agree
+    assert ((h == 0) == (want == 0))[sure].all()
+    dy = (torch.randn(M, 256, device=dev, generator=gen) * 1e-4).to(BF16)
+    w2t = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(BF16)
+    out = torch.empty(M, F, dtype=BF16, device=dev)
+    T._call("eend_gemm_relu_bwd_bf16", dy, 256, w2t, 256, h, F, out, F, M, F, 256, spec.scale)
+    wantg = (dy.float() @ w2t.float().t()) * (h != 0) * spec.scale
+    assert rel(out, wantg) < 6e-3
+    assert (out[h == 0] == 0).all()
+
+
+def _attn_ref(q, k, v, delay, kv_len, scale, pdrop=None):
     """q,k,v (n,H,T,64) fp32 -> output (n,T,256), with the index-predicate mask."""
     Tq = q.shape[2]
     i = torch.arange(Tq, device=q.device)[:, None]
@@ -195,14 +254,32 @@ def _attn_ref(q, k, v, delay, kv_len, scale):
     ok = ((j - i) <= delay) & (j < kv_len)
     s = (q @ k.transpose(-1, -2)) * scale
     s = s.masked_fill(~ok, float("-inf"))
-    o = torch.softmax(s, -1) @ v
+    p = torch.softmax(s, -1)
+    if pdrop is not None:
+        p = pdrop(p)
+    o = p @ v
     return o.transpose(1, 2).reshape(q.shape[0], Tq, 256)
 
 
+def _drop_spec(p_drop, Tp, site=3):
+    """(ctypes eend_dropout or None, matching oracle mask generator or None)"""
+    if not p_drop:
+        return None, None
+    from fs_eend_amd import lib as L
+    from oracle import dropout_ref as DR
+    d = DR.HashDropout(p_drop, 42, 7, Tp)
+    return L.Dropout(DR.site_seed(d.base, site), d.thresh24, d.scale), d
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
 @pytest.mark.parametrize("nseq,Tv,delay,prescaled", [(3, 100, 0, True), (2, 500, 0, True), (2, 192, 2, False), (1, 640, 0, True),
                                                      (2, 130, 1000, True)])
-def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled):
+def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled, p_drop):
+    import ctypes
     from fs_eend_amd import ops
+    spec, dgen = _drop_spec(p_drop, ops.frames_pad(Tv))
+    dref = None if spec is None else ctypes.byref(spec)
+    pdrop = None if spec is None else (lambda p: dgen.attn(p, 3))
     gen = g(dev, Tv + delay)
     Tp = ops.frames_pad(Tv)
     H = 4
@@ -214,7 +291,7 @@ def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled):
     k16, v16 = k_.to(BF16), v_.to(BF16)
     q_true = (q16.float() / c).requires_grad_(True)
     kr, vr = k16.float().requires_grad_(True), v16.float().requires_grad_(True)
-    o_ref = _attn_ref(q_true, kr, vr, delay, Tv, 0.125)
+    o_ref = _attn_ref(q_true, kr, vr, delay, Tv, 0.125, pdrop)
     dO = torch.randn(nseq, Tp, 256, device=dev, generator=gen) * 1e-4
     dO[:, Tv:] = 0
     dO16 = dO.to(BF16)
@@ -223,7 +300,7 @@ def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled):
     lse = torch.empty(nseq * H * Tp, dtype=F32, device=dev)
     qT, kT, vT = (t.transpose(-1, -2).contiguous() for t in (q16, k16, v16))
     scale = ops.LN2 if prescaled else 0.125
-    T._call("eend_attn_causal_lse_bf16", q16, k16, vT, O, lse, nseq, H, Tp, 256, delay, Tv, scale)
+    T._call("eend_attn_causal_lse_bf16", q16, k16, vT, O, lse, nseq, H, Tp, 256, delay, Tv, scale, dref)
     assert (O.view(nseq, Tp, 256)[:, :Tv].float() - o_ref[:, :Tv]).abs().max() < 2e-2
     # lse check (log2 domain)
     s2 = (q_true.detach() @ kr.detach().transpose(-1, -2)) * 0.125 * math.log2(math.e)
@@ -239,7 +316,7 @@ def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled):
     sl = 1.0 if prescaled else 0.125 * math.log2(math.e)
     sk = ops.LN2 if prescaled else 0.125
     T._call("eend_attn_causal_bwd_bf16", q16, qT, k16, kT, v16, dO16.view(-1, 256), 256, O, 256, lse, dot_ws, dh_ws, dqkv, 768, nseq, H, Tp,
-            delay, Tv, Tv, sl, 0.125, sk)
+            delay, Tv, Tv, sl, 0.125, sk, dref)
     d = dqkv.view(nseq, Tp, 3, H, 64).float()
     for idx, (name, ref) in enumerate((("dq", q_true.grad), ("dk", kr.grad), ("dv", vr.grad))):
         got = d[:, :, idx].permute(0, 2, 1, 3)                    # (n,H,Tp,64)
@@ -249,20 +326,29 @@ def test_attn_fwd_lse_and_bwd(T, dev, nseq, Tv, delay, prescaled):
         assert (got[:, :, Tv:] == 0).all(), name + " pad rows"
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
 @pytest.mark.parametrize("C", [1, 3, 6, 10])
-def test_spk_attn_bwd(T, dev, C):
+def test_spk_attn_fwd_bwd(T, dev, C, p_drop):
+    import ctypes
     gen = g(dev, C)
     B, Tp = 2, 64
+    spec, dgen = _drop_spec(p_drop, Tp, site=2)
+    dref = None if spec is None else ctypes.byref(spec)
     rows = B * C * Tp
     qkv = torch.randn(rows, 768, device=dev, generator=gen).to(F16)
     dO = (torch.randn(rows, 256, device=dev, generator=gen) * 1e-4).to(BF16)
     x = qkv.float().view(B, C, Tp, 3, 4, 64).requires_grad_(True)
     q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))            # (B,Tp,H,C,64)
     p = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1)
+    if dgen is not None:                                          # (B,Tp,H,C,C) -> the oracle's (B*T, H, C, C) with T = Tp
+        p = dgen.spk(p.reshape(B * Tp, 4, C, C), 2, B, Tp).reshape(B, Tp, 4, C, C)
     o = (p @ v).permute(0, 3, 1, 2, 4).reshape(rows, 256)
     (o * dO.float()).sum().backward()
+    ofwd = torch.empty(rows, 256, dtype=F16, device=dev)
+    T._call("eend_spk_attn_train_f16", qkv, ofwd, B, C, Tp, 4, 0.125, dref)
+    assert relnorm(ofwd, o.detach()) < 3e-3
     out = torch.empty(rows, 768, dtype=BF16, device=dev)
-    T._call("eend_spk_attn_bwd_bf16", qkv, dO, out, B, C, Tp, 4, 0.125)
+    T._call("eend_spk_attn_bwd_bf16", qkv, dO, out, B, C, Tp, 4, 0.125, dref)
     want = x.grad.reshape(rows, 768)
     assert relnorm(out, want) < 6e-3, relnorm(out, want)
 
