@@ -37,11 +37,27 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // scores exceed it by more than 2^8 (exact result either way: numerator and denominator share m_ref),
 // and -m_ref is the C operand of the first QK^T MFMA, so the scores leave the matrix pipe already
 // re-referenced -- no per-score scale, subtract or rescale of O on the common path.
-template <bool LAZY>
+typedef __attribute__((address_space(3))) char lds_char;
+
+// Perf-study build (-DEEND_ATT_TRACE, tools/attn_trace.py): p.Lse is a u64 buffer [blocks][8 waves][16 stamps] of
+// s_memtime values at the phase boundaries below; never defined in the shipped library.
+#ifdef EEND_ATT_TRACE
+#define ATT_STAMP(k)                                                                                             \
+    do {                                                                                                         \
+        if (lane == 0)                                                                                           \
+            ((unsigned long long*)p.Lse)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + (k)] = \
+                __builtin_amdgcn_s_memtime();                                                                    \
+    } while (0)
+#else
+#define ATT_STAMP(k) do {} while (0)
+#endif
+
+template <bool LAZY, bool DROP>
 __global__ __launch_bounds__(512)
 void attn_causal_full_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntiles = p.Tp / KB;                    // <= 8
+    const int ng = (ntiles + 1) >> 1;                // key groups of 2 tiles (128 keys): the unit of the load pipeline
     char* Ks = smem;                                 // [ntiles][64 keys][128 B]
     char* Vs = smem + ntiles * TILE;                 // [ntiles][64 d][128 B] (64 keys of that tile)
     char* Os = smem + 2 * ntiles * TILE;             // [8 waves][32][128 B]; Tp = 512 -> 160 KB in total
@@ -56,178 +72,159 @@ void attn_causal_full_kernel(const AttnParams p) {
     const __bf16* __restrict__ Kg = (const __bf16*)p.K + sh * p.Tp * 64;
     const __bf16* __restrict__ Vg = (const __bf16*)p.Vt + sh * 64 * p.Tp;
 
-    // ---- load the head's whole K and V^T once: Tp*8 16-byte chunks each, all in flight
-#ifndef EEND_ATT_NOLOAD          // (perf-study ablation: phase costs)
-    {
-        const int nch = p.Tp * 8;                    // chunks per operand (<= 4096 -> <= 8 per thread)
-        u32x4 kr[8], vr[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = tid + i * 512;
-            if (c < nch) {
-                kr[i] = *(const u32x4*)(Kg + (size_t)c * 8);                               // row = c>>3, chunk = c&7
-                const int d = c / (p.Tp >> 3), kc = c - d * (p.Tp >> 3);                   // V^T row d, 8-key chunk kc
-                vr[i] = *(const u32x4*)(Vg + (size_t)d * p.Tp + kc * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = tid + i * 512;
-            if (c < nch) {
-                const int row = c >> 3;
-                *(u32x4*)(Ks + (row >> 6) * TILE + swz128(row & 63, c & 7)) = kr[i];
-                const int d = c / (p.Tp >> 3), kc = c - d * (p.Tp >> 3);
-                *(u32x4*)(Vs + (kc >> 3) * TILE + swz128(d, kc & 7)) = vr[i];
-            }
-        }
-    }
-#endif
-    __syncthreads();
-
     const int nq = p.Tp / 32;                        // query blocks of 32 rows
     const int krow = swap23(lq);
     char* Ow = Os + wave * OSTG;
 
-    for (int pass = 0; pass < 2; ++pass) {
-        const int qb = pass == 0 ? wave : nq - 1 - wave;
-        if (qb < 0 || qb >= nq) continue;
-        if (pass == 1 && qb <= wave) continue;       // already done (or the pair coincides)
-        if (pass == 0 && wave > nq - 1 - wave) continue;
-        const int qw0 = qb * 32;
-        const int q = qw0 + lq;
+    // Causal load balance: the query blocks are dealt to the 8 waves in pairs (nq-1-w, w).  The LATE block of the
+    // pair runs first and walks the key groups in order, so it can start on keys 0..127 as soon as those have
+    // landed while the other three quarters of K / V^T are still in flight; the early block follows with
+    // everything resident.
+    const int qb_big = nq - 1 - wave, qb_small = wave;
+    const bool has_big = qb_big >= qb_small;         // (false: fewer blocks than waves, this wave's pair is done by another)
+    const bool has_small = qb_small < qb_big;        // (false: the pair coincides)
 
-        bf16x8 qf[4];
+    // ---- the head's whole K and V^T, once, by LDS-DMA (no staging registers, no ds_write pass): 32 pieces of 1 KB
+    // per key group (16 of K, 16 of V^T), 4 per wave; the swz128 image is produced by permuting the per-lane
+    // SOURCE address (every global row is still read as full 128-byte lines).  Group 0 and the late block's Q
+    // fragments are requested first and waited for together; the other groups are requested behind them and
+    // land while the first tiles are being computed: `group_ready(g)` is the per-group completion wait (VMEM
+    // returns in order) + workgroup barrier.
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.Tp * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, p.Tp * 128, 0x00020000);
+    // a piece is 8 tile rows; LDS slot s of tile row r holds source chunk s ^ ((r >> 1) & 7) (common.h swz128)
+    const int r8 = lane >> 3;
+    const int vok = r8 * 128;                            // K: row r8 of the piece
+    const int vov = r8 * p.Tp * 2;                       // V^T: d-row r8 of the piece
+    auto dma_group = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)q * 64 + ks * 16 + hi * 8);
-
-        f32x16 oT[2];
+        for (int i = 0; i < 4; ++i) {
+            const int idx = wave * 4 + i;                // 0..15: K pieces, 16..31: V^T pieces of this group
+            int t = 2 * g + ((idx >> 3) & 1);
+            t = t < ntiles ? t : ntiles - 1;             // odd tile count: the last group re-fetches its only tile
+            const int sp = idx & 7;
+            const int chunk = (lane & 7) ^ (((sp * 8 + r8) >> 1) & 7);
+            if (idx < 16)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_char*)(Ks + t * TILE + sp * 1024), 16, vok + chunk * 16,
+                                                         (t * 64 + sp * 8) * 128, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_char*)(Vs + t * TILE + sp * 1024), 16, vov + chunk * 16,
+                                                         sp * 8 * p.Tp * 2 + t * 128, 0, 0);
+        }
+    };
+    bf16x8 qf[4];
+    ATT_STAMP(0);
+#ifndef EEND_ATT_NOLOAD          // (perf-study ablation: phase costs)
+    dma_group(0);
+#endif
+    {
+        const int qrow = (has_big ? qb_big : 0) * 32 + lq;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; }
-        float m_run = -INFINITY, l_run = 0.f;
-        float m_ref_final = 0.f;                       // softmax reference the accumulated l / O are relative to
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow * 64 + ks * 16 + hi * 8);
+    }
+    // the fragments are pinned here, so that their wait (which, VMEM being in order, is also group 0's) is not
+    // re-inserted by the compiler in front of every use behind the later groups' requests
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    ATT_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    ATT_STAMP(2);
+#ifndef EEND_ATT_NOLOAD
+    for (int g = 1; g < ng; ++g) dma_group(g);
+#endif
+    ATT_STAMP(3);
+    auto group_ready = [&](int g) __attribute__((always_inline)) {       // g >= 1
+#ifndef EEND_ATT_NOLOAD
+        switch (ng - 1 - g) {                            // DMA instructions of later groups that may stay in flight
+            case 2: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        }
+#endif
+    };
 
+    // per-pass state
+    f32x16 oT[2];
+    f32x16 mneg;                                     // LAZY: -m_ref of this lane's query in every entry
+    float m_run, l_run, m_ref_final;
+    int qw0, q;
+
+    auto begin_pass = [&](int qb) __attribute__((always_inline)) {
+        qw0 = qb * 32;
+        q = qw0 + lq;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; mneg[i] = 0.f; }
+        m_run = -INFINITY; l_run = 0.f; m_ref_final = 0.f;
+    };
+    auto tiles_of = [&]() __attribute__((always_inline)) -> int {
         int last_key = qw0 + 31 + p.mask_delay;
         last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
 #ifdef EEND_ATT_NOCOMP
-        const int jend = 0;
+        return 0;
 #else
-        const int jend = last_key < 0 ? 0 : last_key / KB + 1;
+        return last_key < 0 ? 0 : last_key / KB + 1;
 #endif
+    };
 
-        if constexpr (LAZY) {
-            f32x16 mneg;                                 // -m_ref of this lane's query in every entry
+    // one 64-key tile of the flash loop
+    auto tile = [&](int j) __attribute__((always_inline)) {
+        const int key0 = j * KB;
+        const char* kb_ = Ks + j * TILE;
+        const char* vb_ = Vs + j * TILE;
+        f32x16 s[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mneg[i] = 0.f;
-            for (int j = 0; j < jend; ++j) {
-                const int key0 = j * KB;
-                const char* kb_ = Ks + j * TILE;
-                const char* vb_ = Vs + j * TILE;
-                f32x16 s[2];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
-                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? mneg : s[kb], 0, 0, 0);
-                    }
-                }
-                const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
-                if (key0 + KB - 1 > wlim) {
-                    const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
-                            if (key > lim) s[kb][i] = -INFINITY;
-                        }
-                }
-                float tmax = s[0][0];
-#pragma unroll
-                for (int i = 1; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[0][i]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[1][i]);
-                tmax = wave_xor_max(tmax, 32);
-                // move the reference only when a row outgrows it by 2^8 (or, on the first tile, sits far below it)
-                const bool move = tmax > 8.0f || (j == 0 && tmax < -8.0f);
-                if (__builtin_amdgcn_ballot_w64(move) != 0) {
-                    float d = j == 0 ? tmax : __builtin_fmaxf(tmax, 0.f);
-                    d = d == -INFINITY ? 0.f : d;
-                    const float alpha = __builtin_amdgcn_exp2f(-d);
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        oT[0][i] *= alpha; oT[1][i] *= alpha;
-                        s[0][i] -= d; s[1][i] -= d;
-                        mneg[i] -= d;
-                    }
-                }
-                float lsum0 = 0.f, lsum1 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    s[0][i] = __builtin_amdgcn_exp2f(s[0][i]);
-                    s[1][i] = __builtin_amdgcn_exp2f(s[1][i]);
-                    lsum0 += s[0][i];
-                    lsum1 += s[1][i];
-                }
-                l_run += lsum0 + lsum1;
-                if (p.drop.thresh24) {                     // training: dropout of the probabilities (the row sum stays un-dropped)
-                    const unsigned da = (unsigned)(sh * p.Tp + q);
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
-                }
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        bf16x8 pf;
-#pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][kk * 8 + jj];
-#pragma unroll
-                        for (int db = 0; db < 2; ++db) {
-                            const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(db * 32 + lq, kb * 4 + kk * 2 + hi));
-                            oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            m_ref_final = -mneg[0];
-        } else
-        for (int j = 0; j < jend; ++j) {
-            const int key0 = j * KB;
-            const char* kb_ = Ks + j * TILE;
-            const char* vb_ = Vs + j * TILE;
-            f32x16 s[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (!LAZY) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+            }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], (LAZY && ks == 0) ? mneg : s[kb], 0, 0, 0);
+            }
+        }
+        const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
+        if (key0 + KB - 1 > wlim) {
+            const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
+                    if (key > lim) s[kb][i] = -INFINITY;
+                }
+        }
+        float tmax = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[1][i]);
+        tmax = wave_xor_max(tmax, 32);
+        if constexpr (LAZY) {
+            // move the reference only when a row outgrows it by 2^8 (or, on the first tile, sits far below it)
+            const bool move = tmax > 8.0f || (j == 0 && tmax < -8.0f);
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                float d = j == 0 ? tmax : __builtin_fmaxf(tmax, 0.f);
+                d = d == -INFINITY ? 0.f : d;
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    oT[0][i] *= alpha; oT[1][i] *= alpha;
+                    s[0][i] -= d; s[1][i] -= d;
+                    mneg[i] -= d;
                 }
             }
-            const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
-            if (key0 + KB - 1 > wlim) {
-                const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
+            float lsum0 = 0.f, lsum1 = 0.f;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
-                        if (key > lim) s[kb][i] = -INFINITY;
-                    }
+            for (int i = 0; i < 16; ++i) {
+                s[0][i] = __builtin_amdgcn_exp2f(s[0][i]);
+                s[1][i] = __builtin_amdgcn_exp2f(s[1][i]);
+                lsum0 += s[0][i];
+                lsum1 += s[1][i];
             }
-            float tmax = s[0][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[0][i]);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tmax = __builtin_fmaxf(tmax, s[1][i]);
-            tmax = wave_xor_max(tmax, 32);
+            l_run += lsum0 + lsum1;
+        } else {
             const float m_new = __builtin_fmaxf(m_run, tmax * p.scale_log2);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -242,37 +239,41 @@ void attn_causal_full_kernel(const AttnParams p) {
                 }
             l_run = l_run * alpha + lsum;
             m_run = m_new;
-            if (p.drop.thresh24) {
-                const unsigned da = (unsigned)(sh * p.Tp + q);
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
-            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
+        }
+        if constexpr (DROP) {                          // training: dropout of the probabilities (the row sum stays un-dropped)
+            const unsigned da = (unsigned)(sh * p.Tp + q);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][kk * 8 + jj];
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(db * 32 + lq, kb * 4 + kk * 2 + hi));
-                        oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
-                    }
-                }
-            m_ref_final = m_run;
+                for (int i = 0; i < 16; ++i)
+                    s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
         }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 pf;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][kk * 8 + jj];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(db * 32 + lq, kb * 4 + kk * 2 + hi));
+                    oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                }
+            }
+    };
 
-        // ---- O[q][d] = O^T / l: stage the wave's 32 x 64 f16 tile, then 128-byte rows to HBM
+    // O[q][d] = O^T / l: stage the wave's 32 x 64 f16 tile, then 128-byte rows to HBM
+    auto end_pass = [&]() __attribute__((always_inline)) {
+        if constexpr (LAZY) m_ref_final = -mneg[0]; else m_ref_final = m_run;
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
+#ifndef EEND_ATT_TRACE
         if (p.Lse && hi == 0)                          // training: log2-domain log-sum-exp of the row, for the backward
             p.Lse[sh * p.Tp + q] = m_ref_final + __builtin_amdgcn_logf(l_tot);
+#endif
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -295,7 +296,38 @@ void attn_causal_full_kernel(const AttnParams p) {
             *(uint4*)(Og + (size_t)row * p.ldo + ch * 8) = v;
         }
         __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- late block of the pair: group by group behind the load stream (every wave takes part in every
+    // group_ready, whatever its own tile count)
+    bf16x8 qs[4];
+    {
+        begin_pass(has_big ? qb_big : 0);
+        const int jend = has_big ? tiles_of() : 0;
+        for (int g = 0; g < ng; ++g) {
+            if (g > 0) { ATT_STAMP(2 + 2 * g); group_ready(g); ATT_STAMP(3 + 2 * g); }
+            if (g == ng - 1 && has_small) {              // everything has landed: the early block's Q rides under the last tiles
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qs[ks] = *(const bf16x8*)(Qg + (size_t)(qb_small * 32 + lq) * 64 + ks * 16 + hi * 8);
+            }
+            if (2 * g < jend) tile(2 * g);
+            if (2 * g + 1 < jend) tile(2 * g + 1);
+        }
+        ATT_STAMP(10);
+        if (has_big) end_pass();
+        ATT_STAMP(11);
     }
+    // ---- early block: everything is resident
+    if (has_small) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qs[ks];
+        begin_pass(qb_small);
+        const int jend = tiles_of();
+        for (int j = 0; j < jend; ++j) tile(j);
+        ATT_STAMP(12);
+        end_pass();
+    }
+    ATT_STAMP(13);
 }
 
 }  // namespace
@@ -305,17 +337,21 @@ int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream) {
     const int smem = 2 * (p.Tp / KB) * TILE + NW * OSTG;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn_causal_full_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * (TMAX / KB) * TILE + NW * OSTG) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attn_causal_full_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * (TMAX / KB) * TILE + NW * OSTG) != hipSuccess)
+        const int cap = 2 * (TMAX / KB) * TILE + NW * OSTG;
+        if (hipFuncSetAttribute((const void*)attn_causal_full_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_causal_full_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_causal_full_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_causal_full_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
             return EEND_ELAUNCH;
         attr_done = true;
     }
     const float dev1 = p.scale_log2 - 1.0f;
-    if (dev1 < 1e-6f && dev1 > -1e-6f)       // scores arrive in the log2 domain (scale folded into the q projection)
-        hipLaunchKernelGGL(attn_causal_full_kernel<true>, dim3(p.H, p.nseq), dim3(512), smem, stream, p);
-    else
-        hipLaunchKernelGGL(attn_causal_full_kernel<false>, dim3(p.H, p.nseq), dim3(512), smem, stream, p);
+    const bool lazy = dev1 < 1e-6f && dev1 > -1e-6f;   // scores arrive in the log2 domain (scale folded into the q projection)
+    const bool drop = p.drop.thresh24 != 0;            // training-time dropout of the probabilities: its own instantiation
+    const dim3 grid(p.H, p.nseq), block(512);
+    if (lazy && !drop) hipLaunchKernelGGL((attn_causal_full_kernel<true, false>), grid, block, smem, stream, p);
+    else if (lazy) hipLaunchKernelGGL((attn_causal_full_kernel<true, true>), grid, block, smem, stream, p);
+    else if (!drop) hipLaunchKernelGGL((attn_causal_full_kernel<false, false>), grid, block, smem, stream, p);
+    else hipLaunchKernelGGL((attn_causal_full_kernel<false, true>), grid, block, smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
