@@ -44,7 +44,7 @@ def flops_per_launch(name, shape, T):
     if name == "attnout_ffn_fused":    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
-    if name in ("linear", "linear_res_ln", "linear_res_scale", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
+    if name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16", "retention_proj", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
         M, N, K = shape
         return 2.0 * M * N * K
     return 0.0
@@ -84,7 +84,9 @@ class OpTimer:
             e.record()
             if name == "attn_causal":
                 shape = (a[4], a[5])
-            elif name in ("linear", "linear_res_ln", "linear_res_scale"):
+            elif name == "retention_proj":
+                shape = (a[0].shape[0], 1024, 256)
+            elif name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16"):
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "ffn_fused":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
@@ -108,7 +110,10 @@ class OpTimer:
 
     def __enter__(self):
         for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
-                  "convert_fanout", "attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot"):
+                  "convert_fanout", "attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
+                  "dwconv_bn_swish", "layernorm_f16"):
+            if not hasattr(self.ops, n):
+                continue
             self.orig[n] = getattr(self.ops, n)
             setattr(self.ops, n, self._wrap(n, self.orig[n]))
         return self
@@ -218,6 +223,23 @@ def extras(dev):
     dt = (time.perf_counter() - t0) / n
     res["ls_eend_batch"] = dict(workload=f"LS-EEND model.test, {B} x T={T} (4 chunks of 500), max_nspks={C}, {ls_launch}",
                                 frames_per_s=B * T / dt, ms_per_step=dt * 1e3, rtf=dt / (B * T * 0.1))
+    try:                                         # dominant LS kernel, in-situ HIP events over 3 eager steps
+        from fs_eend_amd import ops as _ops
+        with OpTimer(_ops, T) as tm:
+            for _ in range(3):
+                ls.test(src, [T] * B, C)
+            ks = tm.summary()
+        tot = sum(k["total_ms"] for k in ks)
+        dom = next(k for k in ks if k["tflops"] is not None)
+        res["ls_eend_batch"]["kernel_breakdown"] = [dict(kernel=k["kernel"], shape=k["shape"], launches_per_step=k["launches"] // 3,
+                                                         avg_ms=round(k["avg_ms"], 4), share=round(k["total_ms"] / tot, 4),
+                                                         tflops=None if k["tflops"] is None else round(k["tflops"], 1)) for k in ks[:8]]
+        res["ls_eend_batch"]["instrumented_share_of_step"] = tot / 3 / (dt * 1e3)
+        res["ls_eend_batch"]["roofline"] = {"kernel": f"{dom['kernel']} {dom['shape']}", "bound": "mfma", "achieved": dom["tflops"],
+                                            "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_MFMA_TFLOPS,
+                                            "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+    except Exception as ex:
+        res["ls_eend_batch"]["roofline"] = dict(error=f"{type(ex).__name__}: {ex}")
 
     # BASELINE config 5: one hour of 8 kHz audio (36 000 frames of 100 ms), 8 speakers (+2 slots), processed as
     # 72 chunks of 500 with the retention state carried across chunks -- one model.test call
@@ -419,6 +441,21 @@ def extras(dev):
     per = (time.perf_counter() - t0) / (nfr - warm)
     res["fs_eend_streaming"] = dict(workload=f"1 stream, max_nspks=6, K/V-cache decode attention, frames {warm}..{nfr}",
                                     ms_per_frame=per * 1e3, rtf=per / 0.1)
+    try:
+        from fs_eend_amd.fs_stream import FsStreamSession
+        ses = FsStreamSession(sm, 6, cap=1024, use_graph=True)
+        for t in range(nfr):
+            if t == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ses.push(x[t])
+        torch.cuda.synchronize()
+        per_g = (time.perf_counter() - t0) / (nfr - warm)
+        res["fs_eend_streaming_graph"] = dict(workload="1 stream, max_nspks=6, FsStreamSession: K/V caches + device-side history counters "
+                                                       "resident in HBM, 3 hipGraph replays per frame (one capture per cache-capacity bucket)",
+                                              ms_per_frame=per_g * 1e3, rtf=per_g / 0.1, speedup_vs_eager=per / per_g)
+    except Exception as ex:
+        res["fs_eend_streaming_graph"] = dict(error=f"{type(ex).__name__}: {ex}")
     return res
 
 

@@ -20,6 +20,10 @@ bool proj_xres_enabled() {          // EEND_PROJ_XRES=0: A/B switch back to the 
     static const bool on = !(getenv("EEND_PROJ_XRES") && atoi(getenv("EEND_PROJ_XRES")) == 0);
     return on;
 }
+bool skinny_enabled() {              // EEND_SKINNY=0: A/B switch back to the tiled GEMM for M <= 16 rows
+    static const bool on = [] { const char* e = getenv("EEND_SKINNY"); return !(e && e[0] == '0'); }();
+    return on;
+}
 }  // namespace
 
 extern "C" {
@@ -47,6 +51,8 @@ int eend_gather_bn_cast_pad_f16(const void* const* x_ptrs, const int* lens, floa
 int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
                     int M, int N, int K, int act, void* stream) {
     if (!A || !W || !out_f16 || (ldo & 3) || act < 0 || act > 2) return EEND_EINVAL;
+    if (skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))        // streaming steps: a few rows, weights spread over the chip
+        return eend_launch_skinny_plain(A, lda, W, ldw, bias, out_f16, ldo, M, N, K, act, (hipStream_t)stream);
     if (act == 0 && K == 256 && ldw == 256 && bias && (N % 256) == 0 && N <= 1024 && (ldo & 7) == 0 && proj_xres_enabled()) {
         ProjParams q;                                     // X-resident projection kernel (proj.hip)
         memset(&q, 0, sizeof(q));
@@ -63,6 +69,8 @@ int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float*
 int eend_linear_glu_f16(const void* A, int lda, const void* Wi, int ldw, const float* bias_i, void* out_f16,
                         int ldo, int M, int N2, int K, void* stream) {
     if (!A || !Wi || !bias_i || !out_f16 || (ldo & 1) || (N2 & 1)) return EEND_EINVAL;
+    if (skinny_enabled() && eend_skinny_ok(A, lda, Wi, ldw, M, K))
+        return eend_launch_skinny_glu(A, lda, Wi, ldw, bias_i, out_f16, ldo, M, N2, K, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, Wi, ldw, bias_i, M, N2, K);
     p.out16 = out_f16; p.ldo = ldo;
     return eend_launch_gemm(p, EPI_GLU_F16, (hipStream_t)stream);
@@ -95,6 +103,8 @@ int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const
                            float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
                            void* out_f16, int M, int K, void* stream) {
     if (!A || !W || (!out_f32 && !out_f16) || ((gamma == nullptr) != (beta == nullptr))) return EEND_EINVAL;
+    if (out_f32 && skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))
+        return eend_launch_skinny_res(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 1, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_LN, (hipStream_t)stream);
@@ -104,6 +114,8 @@ int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ld
                                    const float* res, float alpha, const float* gamma, const float* beta, float eps,
                                    float* out_f32, void* out_f16, int M, int K, void* stream) {
     if (!A || !W || !out_f32 || !out_f16 || !gamma || !beta) return EEND_EINVAL;
+    if (skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))
+        return eend_launch_skinny_res(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 2, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_SCALE_LN16, (hipStream_t)stream);
@@ -267,6 +279,8 @@ int eend_linear_res_scale_f16(const void* A, int lda, const void* W, int ldw, co
                               const float* res, float alpha, float* out_f32, void* out_f16, int M, int K,
                               void* stream) {
     if (!A || !W || (!out_f32 && !out_f16)) return EEND_EINVAL;
+    if (skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))
+        return eend_launch_skinny_res(A, lda, W, ldw, bias, res, alpha, nullptr, nullptr, 0.f, out_f32, out_f16, M, K, 0, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_RES_SCALE, (hipStream_t)stream);
@@ -325,7 +339,17 @@ int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, fl
 int eend_attn_decode_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap, int t,
                          float scale, void* stream) {
     if (!qkv || !K_cache || !V_cache || !out_f16) return EEND_EINVAL;
-    return eend_launch_attn_decode(qkv, K_cache, V_cache, out_f16, N, H, cap, t, scale, (hipStream_t)stream);
+    return eend_launch_attn_decode(qkv, K_cache, V_cache, out_f16, N, H, cap, t, nullptr, scale, (hipStream_t)stream);
+}
+
+int eend_attn_decode_dev_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap,
+                             const int* t_dev, float scale, void* stream) {
+    if (!qkv || !K_cache || !V_cache || !out_f16 || !t_dev) return EEND_EINVAL;
+    return eend_launch_attn_decode(qkv, K_cache, V_cache, out_f16, N, H, cap, 0, t_dev, scale, (hipStream_t)stream);
+}
+
+int eend_counter_add_i32(int* counter, int inc, void* stream) {
+    return eend_launch_counter_add(counter, inc, (hipStream_t)stream);
 }
 
 int eend_retention_step_f16(const void* qkvg, float* kv_state, const float* scale_in, float* scale_out,

@@ -127,6 +127,18 @@ struct RetParams {
 };
 
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+
+// skinny.hip: linear layers with M <= EEND_SKINNY_MAX_M rows (the frame-by-frame streaming steps); same epilogue
+// semantics as the gemm.hip epilogues they replace.  EEND_SKINNY=0 in the environment keeps the tiled GEMM (A/B).
+#define EEND_SKINNY_MAX_M 16
+bool eend_skinny_ok(const void* A, int lda, const void* W, int ldw, int M, int K);
+int eend_launch_skinny_plain(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo,
+                             int M, int N, int K, int act, hipStream_t stream);
+int eend_launch_skinny_glu(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo,
+                           int M, int N2, int K, hipStream_t stream);
+int eend_launch_skinny_res(const void* A, int lda, const void* W, int ldw, const float* bias, const float* res, float alpha,
+                           const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K,
+                           int mode, hipStream_t stream);
 int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream);
 int eend_launch_ret_chunk(const RetParams& p, hipStream_t stream);
 int eend_launch_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out16,
@@ -146,8 +158,9 @@ int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, flo
 int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const float* bn_w, const float* bn_b,
                             const float* bn_mean, const float* bn_var, float eps, void* out16, int B, int D, int k,
                             hipStream_t stream);
-int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t,
+int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t, const int* t_dev,
                             float scale, hipStream_t stream);
+int eend_launch_counter_add(int* c, int inc, hipStream_t stream);
 int eend_launch_gather_bn_cast_pad(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w,
                                    const float* bn_b, const float* bn_mean, const float* bn_var, float eps, void* out16,
                                    int B, int T, int Tp, int Fin, int Fpad, int apply_bn, hipStream_t stream);

@@ -88,12 +88,17 @@ void dwconv_step_kernel(const _Float16* __restrict__ x, float* __restrict__ cach
 // O(t) instead of O(t * D^2) per frame.  qkv f16 [N][3*D] (packed in-proj of the new token);
 // caches f16 [N][H][cap][64]; `t` = tokens already cached.  One wave per (n, h): appends the new
 // k/v row, then an online softmax over 64-key chunks (lane = key for the scores, lane = d for PV).
+// t_dev (optional): the token count lives in device memory, so that a captured hipGraph of the frame step stays
+// valid while the history grows (the host only re-captures when the cache capacity changes); a count that has
+// reached the capacity turns the launch into a no-op instead of an out-of-bounds append.
 __global__ __launch_bounds__(256)
 void attn_decode_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ Kc, _Float16* __restrict__ Vc,
-                        _Float16* __restrict__ out, int N, int H, int cap, int t, float scale) {
+                        _Float16* __restrict__ out, int N, int H, int cap, int t, const int* __restrict__ t_dev, float scale) {
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= N * H) return;
+    if (t_dev) t = __builtin_amdgcn_readfirstlane(*t_dev);
+    if (t >= cap) return;
     const int n = idx / H, h = idx - n * H;
     const int D = H * 64;
     const _Float16* row = qkv + (size_t)n * 3 * D + h * 64;
@@ -153,13 +158,23 @@ void attn_decode_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__
     out[(size_t)n * D + h * 64 + lane] = to_f16_sat(o / l_run);
 }
 
+__global__ void counter_add_kernel(int* c, int inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
+}
+
 }  // namespace
 
-int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t,
+int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t, const int* t_dev,
                             float scale, hipStream_t stream) {
-    if (N <= 0 || H <= 0 || cap <= 0 || t < 0 || t >= cap) return EEND_EINVAL;
+    if (N <= 0 || H <= 0 || cap <= 0 || (!t_dev && (t < 0 || t >= cap))) return EEND_EINVAL;
     hipLaunchKernelGGL(attn_decode_kernel, dim3((N * H + 3) / 4), dim3(256), 0, stream, (const _Float16*)qkv, (_Float16*)Kc,
-                       (_Float16*)Vc, (_Float16*)out16, N, H, cap, t, scale);
+                       (_Float16*)Vc, (_Float16*)out16, N, H, cap, t, t_dev, scale);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_counter_add(int* c, int inc, hipStream_t stream) {
+    if (!c) return EEND_EINVAL;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, stream, c, inc);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

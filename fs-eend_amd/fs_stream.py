@@ -166,11 +166,19 @@ class StreamingTransformerEDADiarization(nn.Module):
         return P
 
     def _convert_const(self, C):
+        """pc[c] = convert.weight[:, D:] pe[c] + convert.bias (a (C, D) constant of the weights): eend_convert_const_f32."""
         if C not in self._pc:
+            from . import lib as _lib
             D = self.n_units
-            pe = self.dec.pos_enc.pe[0, :C].to(F32)
-            w2 = self.dec.convert.weight.detach()[:, D:].to(F32)
-            self._pc[C] = (pe @ w2.t() + self.dec.convert.bias.detach().to(F32)).contiguous()
+            dev = self.dec.convert.weight.device
+            W = self.dec.convert.weight.detach().to(F32).contiguous()
+            b = self.dec.convert.bias.detach().to(F32).contiguous()
+            pe = self.dec.pos_enc.pe[0, :C].to(device=dev, dtype=F32).contiguous()
+            pc = torch.empty(C, D, dtype=F32, device=dev)
+            L = _lib.load()
+            _lib.check(L.eend_convert_const_f32(0, W.data_ptr(), b.data_ptr(), pe.data_ptr(), pc.data_ptr(), None, None, None, C,
+                                                torch.cuda.current_stream().cuda_stream), "eend_convert_const_f32")
+            self._pc[C] = pc
         return self._pc[C]
 
     def reset_streaming_state(self):
@@ -249,6 +257,179 @@ class StreamingTransformerEDADiarization(nn.Module):
         y = torch.empty(1, 1, C, dtype=F32, device=dev)
         ops.head_l2dot(e32, a32, attr, y, 1, 1, 1, C, D)
         return y
+
+
+class FsStreamSession:
+    """Frame-by-frame FS-EEND with all streaming state in fixed HBM buffers and the per-frame work replayed from three
+    captured hipGraphs (FS-EEND/streaming_infer_dia.py's per-frame loop is the procedure reproduced):
+
+        G_enc  : BatchNorm + input projection + the incremental encoder layers (K/V caches appended in place)
+        G_conv : push the frame into the 19-frame look-ahead window, Conv1d, L2 norm
+        G_dec  : `convert` fan-out, incremental decoder layers (time-axis K/V caches, speaker-axis attention), head
+
+    The history length lives in device memory (`eend_attn_decode_dev_f16` reads it, `eend_counter_add_i32` bumps it
+    inside the graph), so one capture serves every frame until a K/V cache is full; the caches then double and the
+    graphs are captured again (one capture per capacity bucket).  Outputs are bit-identical to the eager
+    `StreamingTransformerEDADiarization.test` (tests/test_fs_streaming.py), which issues ~60 launches per frame from
+    Python."""
+
+    def __init__(self, model: "StreamingTransformerEDADiarization", max_nspks: int = 6, cap: int = 1024, use_graph: bool = True):
+        self.m, self.C, self.use_graph = model, max_nspks, use_graph
+        P = model._prepare()
+        dev = model.cnn.conv.weight.device
+        self.dev, self.D, self.H = dev, model.n_units, model._H
+        D, H, C = self.D, self.H, max_nspks
+        self.k = model.cnn.kernel_size
+        self.center = model.cnn.center
+        self.Fmax = max([l["w1"].shape[0] for l in P["enc"] + P["dec"]] + [1])
+        e = lambda *s_, dt=F16: torch.zeros(*s_, dtype=dt, device=dev)
+        N = max(1, C)
+        self.x_in = e(1, 1, model._in_size, dt=F32)
+        self.xin16 = e(1, P["Fin_pad"])
+        self.h32, self.h16 = e(N, D, dt=F32), e(N, D)
+        self.qkv, self.o16, self.ff = e(N, 3 * D), e(N, D), e(N * self.Fmax)
+        self.enc_out = e(1, D, dt=F32)
+        self.win16 = e(1, self.k * D)                                   # [tap*D + c]: the look-ahead window, oldest tap first
+        self._shift = e(1, (self.k - 1) * D)
+        self.conv32 = e(1, D, dt=F32)
+        self.e32, self.e16 = e(1, D, dt=F32), e(1, D)
+        self.attr = e(1, 1, C, D, dt=F32)
+        self.logits = e(1, 1, C, dt=F32)
+        self.t_enc = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.t_dec = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cap = 0
+        self._alloc_caches(cap, keep=False)
+        self.reset()
+
+    # ---- state
+    def _alloc_caches(self, cap, keep):
+        P = self.m._prepare()
+        old = (getattr(self, "enc_kv", None), getattr(self, "dec_kv", None), self.cap)
+        mk = lambda N: tuple(torch.zeros(N, self.H, cap, 64, dtype=F16, device=self.dev) for _ in range(2))
+        self.enc_kv = [mk(1) for _ in P["enc"]]
+        self.dec_kv = [mk(self.C) for _ in P["dec"]]
+        if keep:
+            for new, prev in zip(self.enc_kv + self.dec_kv, old[0] + old[1]):
+                for a, b in zip(new, prev):
+                    a[:, :, :old[2]] = b
+        self.cap = cap
+        self._graphs = None
+
+    def reset(self):
+        """Start of a new stream."""
+        self.t_enc.zero_(); self.t_dec.zero_()
+        self.win16.zero_(); self.enc_out.zero_()
+        self.n_enc = self.n_dec = self.t = 0                             # host mirrors of the device counters / frames pushed
+
+    # ---- the three stages (eager bodies; captured once per cache capacity)
+    def _enc(self):
+        P, H = self.m._prepare(), self.H
+        h32, h16, qkv, o16 = self.h32[:1], self.h16[:1], self.qkv[:1], self.o16[:1]
+        ops.bn_cast_pad(self.x_in, P["bn"], self.xin16, 1, 1, True, P["bn.eps"])
+        ops.linear_res_ln(self.xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], h32, h16, P["in.eps"])
+        for L, (kc, vc) in zip(P["enc"], self.enc_kv):
+            Fi = L["w1"].shape[0]
+            ff = self.ff[:Fi].view(1, Fi)
+            ops.linear(h16, L["att"][0], L["att"][1], qkv)
+            ops.attn_decode_dev(qkv, kc, vc, o16, 1, H, self.cap, self.t_enc)
+            ops.linear_res_ln(o16, L["att"][2], L["att"][3], h32, L["n1"][0], L["n1"][1], h32, h16, L["n1"][2])
+            ops.linear(h16, L["w1"], L["b1"], ff, relu=True)
+            ops.linear_res_ln(ff, L["w2"], L["b2"], h32, L["n2"][0], L["n2"][1], h32, h16, L["n2"][2])
+        ops.counter_add(self.t_enc, 1)
+        self.enc_out.copy_(h32)
+
+    def _conv(self):
+        D, k = self.D, self.k
+        self._shift.copy_(self.win16[:, D:])
+        self.win16[:, :(k - 1) * D].copy_(self._shift)
+        self.win16[:, (k - 1) * D:].copy_(self.enc_out)                  # f32 -> f16, as StreamingConv1d casts its window
+        wr, bias = self.m.cnn._weights()
+        ops.linear_res_scale(self.win16, wr, bias, None, 1.0, self.conv32, None)
+        torch.div(self.conv32, torch.linalg.vector_norm(self.conv32, dim=-1, keepdim=True), out=self.e32)   # reference :50
+        self.e16.copy_(self.e32)
+
+    def _dec(self):
+        P, H, C, D = self.m._prepare(), self.H, self.C, self.D
+        a32, a16, qkv, o16 = self.h32[:C], self.h16[:C], self.qkv[:C], self.o16[:C]
+        ops.convert_fanout(self.e16, P["convert.w1"], self.m._convert_const(C), a32, a16, 1, 1, C)
+        for L, (kc, vc) in zip(P["dec"], self.dec_kv):
+            Fi = L["w1"].shape[0]
+            ff = self.ff[:C * Fi].view(C, Fi)
+            ops.linear(a16, L["att"][0], L["att"][1], qkv)
+            ops.attn_decode_dev(qkv, kc, vc, o16, C, H, self.cap, self.t_dec)
+            ops.linear_res_ln(o16, L["att"][2], L["att"][3], a32, L["n1"][0], L["n1"][1], a32, a16, L["n1"][2])
+            ops.linear(a16, L["spk"][0], L["spk"][1], qkv)
+            ops.spk_attn(qkv, o16, 1, C, 1, H)
+            ops.linear_res_ln(o16, L["spk"][2], L["spk"][3], a32, L["n2"][0], L["n2"][1], a32, a16, L["n2"][2])
+            ops.linear(a16, L["w1"], L["b1"], ff, relu=True)
+            ops.linear_res_ln(ff, L["w2"], L["b2"], a32, L["n3"][0], L["n3"][1], a32, a16, L["n3"][2])
+        ops.counter_add(self.t_dec, 1)
+        ops.head_l2dot(self.e32, a32, self.attr, self.logits, 1, 1, 1, C, D)
+
+    def _capture(self):
+        keep = [t_.clone() for t_ in (self.t_enc, self.t_dec, self.win16, self.enc_out, self.x_in)]
+        snap = [[c.clone() for c in kv] for kv in self.enc_kv + self.dec_kv] if (self.n_enc or self.n_dec) else None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                                        # warm-up: workspaces, operand caches
+            self._enc(); self._conv(); self._dec()
+        torch.cuda.current_stream().wait_stream(s)
+        gs = []
+        for fn in (self._enc, self._conv, self._dec):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            gs.append(g)
+        self._graphs = gs
+        for dst, src in zip((self.t_enc, self.t_dec, self.win16, self.enc_out, self.x_in), keep):    # undo the warm-up's effects
+            dst.copy_(src)
+        if snap is not None:
+            for kv, sv in zip(self.enc_kv + self.dec_kv, snap):
+                for a, b in zip(kv, sv):
+                    a.copy_(b)
+
+    def _run(self, i):
+        if not self.use_graph:
+            return (self._enc, self._conv, self._dec)[i]()
+        if self._graphs is None:
+            self._capture()
+        self._graphs[i].replay()
+
+    def _room(self):
+        if max(self.n_enc, self.n_dec) + 1 >= self.cap:                   # next capacity bucket: bigger caches, new graphs
+            self._alloc_caches(2 * self.cap, keep=True)
+
+    @torch.no_grad()
+    def push(self, x_t):
+        """x_t: features of the next frame ((1,1,in) / (1,in) / (in,)) -> logits (1,1,C) of frame t - conv_delay, or None
+        during the first conv_delay frames."""
+        self._room()
+        self.x_in.copy_(x_t.reshape(1, 1, -1))
+        self._run(0)
+        self.n_enc += 1
+        return self._emit()
+
+    def _emit(self):
+        self._run(1)
+        self.t += 1
+        if self.t < self.center + 1:
+            return None
+        self._run(2)
+        self.n_dec += 1
+        return self.logits.clone()
+
+    @torch.no_grad()
+    def flush(self):
+        """the last conv_delay frames: zero embeddings through the look-ahead window (the reference driver's
+        `dummy_conv_input=True` calls)"""
+        out = []
+        for _ in range(self.center):
+            self._room()
+            self.enc_out.zero_()
+            y = self._emit()
+            if y is not None:
+                out.append(y)
+        return out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -39,6 +39,8 @@ PROTOTYPES = {
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "eend_attn_decode_dev_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
+    "eend_counter_add_i32": [_vp, _i, _vp],
     "eend_retention_step_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "eend_dwconv_step_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "eend_layernorm_f16": [_vp, _vp, _vp, _f, _vp, _i, _i, _vp],

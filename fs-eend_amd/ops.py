@@ -278,6 +278,21 @@ def attn_decode(qkv16, k_cache, v_cache, out16, N, H, cap, t):
                                       1.0 / math.sqrt(64.0), _stream()), "eend_attn_decode_f16")
 
 
+def attn_decode_dev(qkv16, k_cache, v_cache, out16, N, H, cap, t_dev):
+    """attn_decode with the token count in device memory (int32 tensor of one element): graph-capturable."""
+    L = _lib.load()
+    _chk(qkv16, F16, "qkv16"); _chk(k_cache, F16, "k_cache"); _chk(v_cache, F16, "v_cache"); _chk(out16, F16, "out16")
+    _chk(t_dev, torch.int32, "t_dev")
+    _lib.check(L.eend_attn_decode_dev_f16(_p(qkv16), _p(k_cache), _p(v_cache), _p(out16), N, H, cap, _p(t_dev),
+                                          1.0 / math.sqrt(64.0), _stream()), "eend_attn_decode_dev_f16")
+
+
+def counter_add(counter_i32, inc=1):
+    L = _lib.load()
+    _chk(counter_i32, torch.int32, "counter")
+    _lib.check(L.eend_counter_add_i32(_p(counter_i32), inc, _stream()), "eend_counter_add_i32")
+
+
 _PTR_TABLES = {}
 
 

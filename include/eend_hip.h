@@ -264,6 +264,12 @@ int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_
  * tokens.  out f16 [N][H*64]. */
 int eend_attn_decode_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap,
                          int t, float scale, void* stream);
+/* The same with the token count read from device memory (*t_dev), so that a captured hipGraph of the frame step
+ * (FS-EEND/streaming_infer_dia.py's per-frame loop) stays valid while the history grows; *t_dev >= cap makes the
+ * launch a no-op.  eend_counter_add_i32: *counter += inc on the stream (the graph's own "t += 1"). */
+int eend_attn_decode_dev_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap,
+                             const int* t_dev, float scale, void* stream);
+int eend_counter_add_i32(int* counter, int inc, void* stream);
 
 /* One frame of MultiScaleRetention.recurrent_forward (retention.py:126-144, decay 1) + per-head
  * LayerNorm + swish gate, state updated in place.  qkvg f16 [N][4*H*64] = [q | k*dk^-0.5 | v | g];

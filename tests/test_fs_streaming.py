@@ -77,3 +77,42 @@ def test_cache_growth(hip_lib, dev):
         kv.t += 1
         outs.append(out.clone())
     assert kv.cap >= 32 and all(torch.isfinite(o).all() for o in outs)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_fs_stream_session_matches_eager(hip_lib, dev, use_graph):
+    """FsStreamSession (state in fixed HBM buffers, device-side history counters, three hipGraphs per cache-capacity
+    bucket) reproduces the eager frame-by-frame API bit for bit -- across two cache growths (cap 16 -> 32 -> 64), the
+    flush frames, and a second stream after reset."""
+    from fs_eend_amd.fs_stream import (FsStreamSession, StreamingTransformerEDADiarization,
+                                       copy_params_from_masked_to_streaming)
+    meta, arr = FX.load_case("fs_stream_T60")
+    m = build_fs_mirror(meta).to(dev)
+    sm = StreamingTransformerEDADiarization(in_size=meta["in_size"], **meta["cfg"]).eval().to(dev)
+    copy_params_from_masked_to_streaming(m, sm)
+    src = FX.make_src([meta["T"]], meta["in_size"], meta["xseed"])[0].to(dev)
+    want = []
+    for t in range(meta["T"]):
+        y = sm.test(src[t].view(1, 1, -1), meta["C"])
+        if y is not None:
+            want.append(y)
+    for _ in range(m.delay):
+        y = sm.test(src[0].view(1, 1, -1), meta["C"], dummy_conv_input=True)
+        if y is not None:
+            want.append(y)
+    want = torch.cat(want, dim=1)
+    ses = FsStreamSession(sm, meta["C"], cap=16, use_graph=use_graph)
+    for rep in range(2):
+        got = []
+        for t in range(meta["T"]):
+            y = ses.push(src[t])
+            assert (y is None) == (t < 9)
+            if y is not None:
+                got.append(y)
+        got += ses.flush()
+        got = torch.cat(got, dim=1)
+        assert got.shape == want.shape
+        assert torch.equal(got, want), f"stream {rep}: max diff {float((got - want).abs().max()):.3e}"
+        assert ses.cap == 64 and int(ses.t_enc) == meta["T"] and int(ses.t_dec) == meta["T"]
+        ses.reset()
+    assert max_abs(want[0], arr["stream_logits"]) < 1e-3
