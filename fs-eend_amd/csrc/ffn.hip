@@ -33,6 +33,24 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+#ifndef EEND_FFN_PRE_SRC
+#define EEND_FFN_PRE_SRC 2       // how the plain PRE kernel fetches its A rows (see proj_ln_phase); 0 = the older per-wave form (A/B)
+#endif
+
+// Perf-study build (-DEEND_FFN_TRACE, tools/ffn_trace.py): s_memtime stamps of the tile phases of thread 0 of every
+// workgroup, read back through eend_debug_ffn_trace; never defined in the shipped library.
+#ifdef EEND_FFN_TRACE
+__device__ unsigned long long g_ffn_trace[256 * 16 * 12];
+#define FFN_STAMP(k)                                                                                              \
+    do {                                                                                                          \
+        if (threadIdx.x == 0 && (tile - (int)blockIdx.x) / (int)gridDim.x < 16)                                    \
+            g_ffn_trace[((size_t)blockIdx.x * 16 + (tile - (int)blockIdx.x) / (int)gridDim.x) * 12 + (k)] =        \
+                __builtin_amdgcn_s_memtime();                                                                     \
+    } while (0)
+#else
+#define FFN_STAMP(k) do {} while (0)
+#endif
+
 constexpr int BM = 128;
 constexpr int KD = 256;            // model dim (K of GEMM1, N of GEMM2)
 constexpr int FC = 64;             // hidden chunk
@@ -233,6 +251,7 @@ void ffn_fused_kernel(const FfnParams p) {
             return m0 + r < p.M ? (long)(m0 + r) : (long)p.M - 1;
         }
     };
+    FFN_STAMP(0);
     if (tile != (int)blockIdx.x) {
         // every wave is done reading the LN scratch at the start of LDS before the weight DMA lands there
         // (raw barrier: __syncthreads() would also wait for the previous tile's global stores)
@@ -339,10 +358,25 @@ void ffn_fused_kernel(const FfnParams p) {
                 part[j] = red[row] + red[BM + row] + red[2 * BM + row] + red[3 * BM + row];
             }
         };
+        // SRC: 0 = A fragments straight from global (each of the 4 n-waves of a token group fetches the same rows),
+        //      1 = A is the f16 tile already in the staging region (LAYER),
+        //      2 = plain PRE tiles: A rows are fetched ONCE (compact, 8 x 16 B per thread) and shared through the staging
+        //          tile, and Wo arrives in two halves -- k-tiles 0/1 with the inputs, k-tiles 2/3 (whose LDS image
+        //          overlaps the staging tile) behind the fragment reads, under the first half of the GEMM.  The input
+        //          wait of a tile is ingest-bound (~12 B/clk/CU with every CU fetching at once: s_memtime trace,
+        //          tools/ffn_trace.py); this form ingests 320 KB per tile instead of 512 KB.
         auto proj_ln_phase = [&](const void* Wo, const float* bo, const float* g, const float* be, const float eps,
-                                 const float* resp, auto SRC_LDS, auto LAST) __attribute__((always_inline)) {
-            constexpr bool src_lds = decltype(SRC_LDS)::value, last = decltype(LAST)::value;
+                                 const float* resp, auto SRC, auto LAST) __attribute__((always_inline)) {
+            constexpr int src = decltype(SRC)::value;
+            constexpr bool src_lds = src == 1, compact = src == 2, last = decltype(LAST)::value;
             f16x8 af[8][4];                                  // A fragments [k-step][token frag]
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)Wo, 0, KD * KD * 2, 0x00020000);
+            auto dma_wo_piece = [&](int piece) __attribute__((always_inline)) {      // Wo -> LDS [4 k-tiles][256 n][128 B], 128 pieces of 1 KB
+                const int kt = piece >> 5, row = (piece & 31) * 8 + drow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_char*)(smem + piece * 1024), 16,
+                                                         (row * KD + kt * 64 + (dslot ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+            };
+            u32x4 ar[compact ? 8 : 1];
             if constexpr (src_lds) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
@@ -351,15 +385,20 @@ void ffn_fused_kernel(const FfnParams p) {
                         af[ks][j] = *(const f16x8*)(Xst + (ks >> 1) * (BM * 128) + swz128(g2m + j * 16 + frow, (ks & 1) * 4 + fkg));
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave holds its fragments: the tile may be overwritten
             }
-            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)Wo, 0, KD * KD * 2, 0x00020000);
+            if constexpr (compact) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {                   // Wo -> LDS [4 k-tiles][256 n][128 B], 128 pieces of 1 KB
-                const int piece = wave * 16 + i;
-                const int kt = piece >> 5, row = (piece & 31) * 8 + drow;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_char*)(smem + piece * 1024), 16,
-                                                         (row * KD + kt * 64 + (dslot ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) dma_wo_piece(wave * 8 + i);              // k-tiles 0, 1
+                const _Float16* __restrict__ A = (const _Float16*)p.A;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = tid + i * NT;
+                    ar[i] = *(const u32x4*)(A + (size_t)rowclamp(q >> 5) * p.lda + (q & 31) * 8);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dma_wo_piece(wave * 16 + i);
             }
-            if constexpr (!src_lds) {
+            if constexpr (src == 0) {
                 const _Float16* __restrict__ A = (const _Float16*)p.A;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -379,9 +418,8 @@ void ffn_fused_kernel(const FfnParams p) {
                     acc[i][j] = f32x4{r.x + b4.x, r.y + b4.y, r.z + b4.z, r.w + b4.w};
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            auto gemm_ks = [&](auto KS) __attribute__((always_inline)) {
+                constexpr int ks = decltype(KS)::value;
                 f16x8 a[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -390,6 +428,33 @@ void ffn_fused_kernel(const FfnParams p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], af[ks][j], acc[i][j], 0, 0, 0);
+            };
+            if constexpr (compact) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = tid + i * NT;
+                    *(u32x4*)(Xst + ((q & 31) >> 3) * (BM * 128) + swz128(q >> 5, q & 7)) = ar[i];
+                }
+                FFN_STAMP(1);
+                __syncthreads();                             // A tile visible; Wo k-tiles 0/1 and the residual have landed
+                FFN_STAMP(2);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        af[ks][j] = *(const f16x8*)(Xst + (ks >> 1) * (BM * 128) + swz128(g2m + j * 16 + frow, (ks & 1) * 4 + fkg));
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // staging tile free: Wo k-tiles 2/3 land there
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dma_wo_piece(64 + wave * 8 + i);
+                FFN_STAMP(3);
+                static_for<4>([&](auto KS) __attribute__((always_inline)) { gemm_ks(KS); });
+                FFN_STAMP(4);
+                __syncthreads();                             // (vmcnt(0): k-tiles 2/3 complete in every wave)
+                FFN_STAMP(5);
+                static_for<4>([&](auto KS) __attribute__((always_inline)) { gemm_ks(std::integral_constant<int, decltype(KS)::value + 4>{}); });
+            } else {
+                __syncthreads();
+                static_for<8>([&](auto KS) __attribute__((always_inline)) { gemm_ks(KS); });
             }
             float part[4], mean[4], rstd[4];
 #pragma unroll
@@ -449,10 +514,10 @@ void ffn_fused_kernel(const FfnParams p) {
         };
 
         if constexpr (!LAYER) {
-            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::false_type{}, std::true_type{});
+            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::integral_constant<int, EEND_FFN_PRE_SRC>{}, std::true_type{});
         } else {
             // ---- x1 = LN11(A1 Wo1^T + bo1 + res): f16 -> staging tile, fp32 -> out32 stream
-            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::false_type{}, std::false_type{});
+            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::integral_constant<int, 0>{}, std::false_type{});
             __syncthreads();
             f16x8 xs[4][2][2];                               // x1 fragments of the wave's 32 tokens
 #pragma unroll
@@ -577,7 +642,7 @@ void ffn_fused_kernel(const FfnParams p) {
             }
             __syncthreads();
             // ---- x2 = LN21(o Wo2^T + bo2 + x1): x1 is read back from the out32 stream (same thread, same addresses)
-            proj_ln_phase(p.Wo2, p.bo2, p.g21, p.be21, p.eps21, p.out32, std::true_type{}, std::true_type{});
+            proj_ln_phase(p.Wo2, p.bo2, p.g21, p.be21, p.eps21, p.out32, std::integral_constant<int, 1>{}, std::true_type{});
         }
     }
     if constexpr (LAYER) {
@@ -588,6 +653,7 @@ void ffn_fused_kernel(const FfnParams p) {
         bofs = g1f + fkg * 4;
         dma_offsets();
     }
+    FFN_STAMP(6);
     float4 bcur[2];
     bcur[0] = *(const float4*)(p.b1 + bofs);
     bcur[1] = *(const float4*)(p.b1 + bofs + 16);
@@ -689,6 +755,7 @@ void ffn_fused_kernel(const FfnParams p) {
         bcur[1] = *(const float4*)(p.b1 + FC + bofs + 16);
     }
     __syncthreads();
+    FFN_STAMP(7);
 
     // iteration c: DMA W1(c+2), W2(c+1) | GEMM1(c+1) -> Hs[(c+1)&1] | GEMM2(c) | barrier
     // The 64 MFMAs of an iteration are issued as 16 items of 4 (one GEMM1 k-step or one GEMM2 W2
@@ -807,8 +874,10 @@ void ffn_fused_kernel(const FfnParams p) {
     }
     __syncthreads();
 
+    FFN_STAMP(8);
     if constexpr (LAYER) ffn_epilogue<EPI>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_g);
     else ffn_epilogue<EPI>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
+    FFN_STAMP(9);
     }
 }
 
@@ -833,6 +902,12 @@ int launch(const FfnParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef EEND_FFN_TRACE
+extern "C" int eend_debug_ffn_trace(void* dst, void* stream) {
+    return hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_ffn_trace), sizeof(g_ffn_trace), 0, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.W1 || !p.W2 || !p.b1 || !p.b2 || !p.gamma ||
