@@ -33,6 +33,10 @@ def flops_per_launch(name, shape, T):
     if name == "attn_causal":          # 2*D*T*(T+1) causal-useful flops per sequence, D = H*64
         nseq, H = shape
         return nseq * 2.0 * (H * 64) * T * (T + 1)
+    if name == "inproj_attn_causal":   # packed in-projection (2*Tp*768*256 per sequence) + the causal-useful attention flops
+        nseq, H = shape
+        Tp = (T + 63) // 64 * 64
+        return nseq * (2.0 * (H * 64) * T * (T + 1) + 2.0 * Tp * 768 * 256)
     if name == "ffn_fused":
         M, F, K = shape
         return 4.0 * M * F * K
@@ -84,6 +88,8 @@ class OpTimer:
             e.record()
             if name == "attn_causal":
                 shape = (a[4], a[5])
+            elif name == "inproj_attn_causal":
+                shape = (a[5], a[6])
             elif name == "retention_proj":
                 shape = (a[0].shape[0], 1024, 256)
             elif name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16"):
@@ -110,7 +116,7 @@ class OpTimer:
 
     def __enter__(self):
         for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
-                  "convert_fanout", "attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
+                  "convert_fanout", "attn_causal", "inproj_attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):
                 continue
@@ -788,7 +794,27 @@ def main():
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
                            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
-        if att:
+        fus = [k for k in ksum if k["kernel"] == "inproj_attn_causal" and k["shape"][0] == B]
+        if fus:
+            # the encoder's time-axis attention as it runs now: in-projection + QK^T / PV in one kernel, K and V on chip.
+            # flops: the packed in-projection (2*Tp*768*256 per sequence, executed on the padded rows) + the causal-useful
+            # attention flops 2*D*T*(T+1); `attention_only_*` prices the kernel's WHOLE time against the attention flops
+            # alone (the figure comparable with the stand-alone kernel of round 1).
+            a = fus[0]
+            fl = flops_per_launch("inproj_attn_causal", tuple(a["shape"]), T)
+            fl_att = flops_per_launch("attn_causal", tuple(a["shape"]), T)
+            Tp_ = (T + 63) // 64 * 64
+            byt = a["shape"][0] * (Tp_ * 256 * 2 * 2.0 + 2 * Tp_ * 256 * 2.0)   # X read once + O written once (+ Q scratch round trip, L2)
+            tf = fl / (a["avg_ms"] * 1e-3) / 1e12
+            out["roofline_attention"] = {
+                "kernel": f"encoder inproj_attn_causal (in-projection + causal MHA fused) nseq={a['shape'][0]} H=4 T={T}", "bound": "mfma",
+                "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS,
+                "traffic": None, "avg_launch_ms": a["avg_ms"], "mfma_TFLOPs": tf, "mfma_frac": tf / PEAK_MFMA_TFLOPS,
+                "attention_only_TFLOPs": fl_att / (a["avg_ms"] * 1e-3) / 1e12,
+                "attention_only_mfma_frac": fl_att / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                "algorithmic_hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9,
+                "intensity_flop_per_byte": fl / byt, "ridge_flop_per_byte": PEAK_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS}
+        elif att:
             a = att[0]
             fl = flops_per_launch("attn_causal", tuple(a["shape"]), T)
             byt = a["shape"][0] * 4.0 * T * 256 * 2            # Q,K,V read + O written once, 2-byte elements

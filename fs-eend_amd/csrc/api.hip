@@ -315,6 +315,15 @@ int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_
     return eend_launch_attn_causal(p, (hipStream_t)stream);
 }
 
+int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, const float* b_in, void* Q_scratch_bf16,
+                                void* O_f16, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream) {
+    if (!X_f16 || !W_in || !b_in || !Q_scratch_bf16 || !O_f16 || nseq > 16383) return EEND_EINVAL;
+    InprojAttnParams p;
+    p.X = X_f16; p.ldx = ldx; p.W = W_in; p.bias = b_in; p.Qs = Q_scratch_bf16; p.O = O_f16;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.mask_delay = mask_delay; p.kv_len = kv_len;
+    return eend_launch_inproj_attn(p, (hipStream_t)stream);
+}
+
 int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
                           int B, int C, int Tp, int H, float scale, void* stream) {
     if (H != 4) return EEND_EINVAL;

@@ -128,6 +128,17 @@ struct RetParams {
 
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 
+// attn_fused.hip: packed in-projection + causal attention of one (sequence, head) per workgroup (Tp <= 512, H = 4)
+struct InprojAttnParams {
+    const void* X; int ldx;      // f16 [nseq*Tp][ldx], 256 model dims
+    const void* W;               // f16 [768][256] packed in_proj_weight, q rows pre-scaled (ops.QSCALE_LOG2)
+    const float* bias;           // [768]
+    void* Qs;                    // bf16 scratch [nseq][4][Tp][64]
+    void* O;                     // f16 [nseq*Tp][ldo]
+    int nseq, H, Tp, ldo, mask_delay, kv_len;
+};
+int eend_launch_inproj_attn(const InprojAttnParams& p, hipStream_t stream);
+
 // skinny.hip: linear layers with M <= EEND_SKINNY_MAX_M rows (the frame-by-frame streaming steps); same epilogue
 // semantics as the gemm.hip epilogues they replace.  EEND_SKINNY=0 in the environment keeps the tiled GEMM (A/B).
 #define EEND_SKINNY_MAX_M 16

@@ -36,6 +36,9 @@ FUSED_SPK = __import__("os").environ.get("EEND_SPK_FUSED", "1") != "0"
 # B=64, C=6, T=500 -- with one 160 KB block per CU every extra phase is exposed latency, and the gathered
 # 126-row tiles need a 7th round on 256 CUs.
 FUSED_TAIL = __import__("os").environ.get("EEND_TAIL_FUSED", "0") == "1"
+# time-axis attention: in-projection + causal attention in one launch per layer, K / V never leave the CU (attn_fused.hip;
+# chunks up to 512 frames).  EEND_ATTN_FUSED=0 keeps the two-kernel path (A/B, and the only path for longer chunks).
+FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
 
 
 class PositionalEncoding(nn.Module):
@@ -307,8 +310,11 @@ class OnlineTransformerDADiarization(nn.Module):
         for L in P["enc.layers"]:
             F = L["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
-            ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
-            ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
+            if FUSED_INPROJ_ATTN and Tp <= 512:
+                ops.inproj_attn_causal(ws.h16, L["in_w"], L["in_b"], q, o16, B, H, Tp, delay_e, kv_e)
+            else:
+                ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
+                ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
             if FUSED_FFN and FUSED_ATTNOUT:   # out_proj + norm1 + FFN + norm2 in one launch (x never leaves the CU)
                 ops.attnout_ffn_fused(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
                                       L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], ws.h32, ws.h16)
@@ -332,8 +338,11 @@ class OnlineTransformerDADiarization(nn.Module):
         for L in P["dec.layers"]:
             F = L["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
-            ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
-            ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, T, scale=ops.LN2)
+            if FUSED_INPROJ_ATTN and Tp <= 512:
+                ops.inproj_attn_causal(ws.a16, L["in1_w"], L["in1_b"], q, o16, B * C, H, Tp, self.dec.mask_delay, T)
+            else:
+                ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
+                ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, T, scale=ops.LN2)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
                 ops.fusion_layer_tail(o16, ws.a32, ws.a16, L["out1_w"], L["out1_b"], L["g11"], L["be11"], L["eps11"],
                                       L["in2_w"], L["in2_b"], L["out2_w"], L["out2_b"], L["g21"], L["be21"], L["eps21"],

@@ -208,6 +208,16 @@ def attn_causal(q, k, vt, o16, nseq, H, Tp, mask_delay=0, kv_len=None, scale=1.0
                                        Tp if kv_len is None else kv_len, scale, _stream()), "eend_attn_causal_bf16")
 
 
+def inproj_attn_causal(x16, w_in, b_in, q_scratch, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
+    """o16 = causal MHA of x16 (rows (seq, t)) with the packed in-projection fused (K / V stay in LDS); w_in / b_in with
+    the q rows pre-multiplied by QSCALE_LOG2; q_scratch: bf16 buffer of nseq*Tp*256 elements.  Tp <= 512, H = 4."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(w_in, F16, "w_in"); _chk(b_in, F32, "b_in"); _chk(q_scratch, BF16, "q_scratch"); _chk(o16, F16, "o16")
+    _lib.check(L.eend_inproj_attn_causal_f16(_p(x16), x16.stride(0), _p(w_in), _p(b_in), _p(q_scratch), _p(o16), nseq, H, Tp,
+                                             o16.stride(0), mask_delay, Tp if kv_len is None else kv_len, _stream()),
+               "eend_inproj_attn_causal_f16")
+
+
 def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4):
     """Speaker-axis MHA with its in-projection fused: out = MHA_over_slots(x16 @ w_in.T + b_in)."""
     L = _lib.load()

@@ -291,6 +291,15 @@ int eend_dwconv_step_f16(const void* x_f16, float* cache, const float* w, const 
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                       void* stream);
 
+/* Packed in-projection + causal multi-head attention in one launch (nn.MultiheadAttention(x, x, x) on the time axis:
+ * nn.TransformerEncoderLayer.self_attn, FS model :147; self_attn1 of the fusion layers, merge_tfm_encoder.py:379-385)
+ * for chunks that fit on chip: Tp <= 512, H = 4, d_model = 256.  K and V never reach HBM; Q_scratch (bf16
+ * [nseq][4][Tp][64]) is an L2-resident hand-over buffer.  W_in f16 [768][256] / b_in [768] = in_proj_weight / bias with
+ * the q rows pre-multiplied by 1/sqrt(64) * log2(e); mask: key j visible to query i iff j - i <= mask_delay and
+ * j < kv_len.  Equivalent to eend_inproj_heads_bf16 followed by eend_attn_causal_bf16(scale = ln 2). */
+int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, const float* b_in, void* Q_scratch_bf16,
+                                void* O_f16, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
+
 /* In-projection + attention core of the speaker-axis self-attention in one launch (the [M][768] qkv
  * tensor never reaches HBM): qkv = x W_in^T + b_in, then the unmasked MHA over the C (<= 12) slots of each
  * frame as eend_spk_attn_f16 (nn.MultiheadAttention self_attn2 of the fusion layers, _sa_block2: FS

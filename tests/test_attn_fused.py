@@ -1,0 +1,58 @@
+"""GPU: the fused in-projection + causal attention kernel (csrc/attn_fused.hip) against the two-kernel path it replaces
+(eend_inproj_heads_bf16 -> eend_attn_causal_bf16) and against fp32 torch on the same f16 operands."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F16, BF16, F32 = torch.float16, torch.bfloat16, torch.float32
+
+
+def _case(dev, nseq, Tp, seed):
+    from fs_eend_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(nseq * Tp, 256, generator=g).to(dev).to(F16)
+    w = (torch.randn(768, 256, generator=g) / 16)
+    b = torch.randn(768, generator=g) * 0.1
+    w[:256] *= ops.QSCALE_LOG2
+    b[:256] *= ops.QSCALE_LOG2
+    return x, w.to(dev).to(F16), b.to(dev)
+
+
+def _two_kernel(x, w, b, nseq, Tp, delay, kv_len):
+    from fs_eend_amd import ops
+    dev = x.device
+    q, k, vt = (torch.empty(nseq * Tp * 256, dtype=BF16, device=dev) for _ in range(3))
+    o = torch.empty(nseq * Tp, 256, dtype=F16, device=dev)
+    ops.inproj_heads(x, w, b, q, k, vt, nseq, Tp, 4)
+    ops.attn_causal(q, k, vt, o, nseq, 4, Tp, delay, kv_len, scale=ops.LN2)
+    return o
+
+
+@pytest.mark.parametrize("nseq,Tp,delay,kv_len", [(1, 64, 0, 64), (3, 128, 0, 100), (2, 192, 2, 192), (8, 512, 0, 500), (5, 512, 0, 512),
+                                                  (16, 256, 0, 250), (2, 448, 1000, 448), (1, 512, 3, 470)])
+def test_inproj_attn_fused(hip_lib, dev, nseq, Tp, delay, kv_len):
+    from fs_eend_amd import ops
+    x, w, b = _case(dev, nseq, Tp, nseq * 7 + Tp)
+    qs = torch.empty(nseq * Tp * 256, dtype=BF16, device=dev)
+    o = torch.full((nseq * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.inproj_attn_causal(x, w, b, qs, o, nseq, 4, Tp, delay, kv_len)
+    ref2 = _two_kernel(x, w, b, nseq, Tp, delay, kv_len)
+    # fp32 reference on the same f16 operands (scores in the log2 domain, q rows pre-scaled)
+    y = x.float() @ w.float().t() + b
+    q, k, v = (y[:, i * 256:(i + 1) * 256].view(nseq, Tp, 4, 64).transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * math.log(2.0)
+    i = torch.arange(Tp, device=dev)[:, None]
+    j = torch.arange(Tp, device=dev)[None, :]
+    ok = ((j - i) <= delay) & (j < kv_len)
+    want = (torch.softmax(s.masked_fill(~ok, float("-inf")), -1) @ v).transpose(1, 2).reshape(nseq * Tp, 256)
+    rows = torch.arange(nseq * Tp, device=dev) % Tp < Tp               # every row sees key 0
+    e_ref = (o.float() - want)[rows].abs().max().item()
+    e_two = (o.float() - ref2.float())[rows].abs().max().item()
+    print(f"fused vs fp32 {e_ref:.2e}; fused vs two-kernel {e_two:.2e}")
+    assert torch.isfinite(o).all()
+    assert e_ref < 2e-2 and e_two < 1e-2
+    # the scratch buffer holds the projected, pre-scaled q in head layout
+    qh = qs.view(nseq, 4, Tp, 64).float()
+    assert (qh - q).abs().max() < 2e-2 * max(1.0, float(q.abs().max()))

@@ -25,3 +25,16 @@ for nseq in (64, 384):
     ops.attn_causal(q, k, vt, o, nseq, H, Tp, 0, T, scale=ops.LN2)
     chk = float(o.float().abs().sum())
     print(f"   checksum {chk:.6e}")
+# fused in-projection + attention vs the two kernels it replaces
+for nseq in (64, 384):
+    x = torch.randn(nseq * Tp, 256, generator=g).to(dev).to(torch.float16)
+    w = (torch.randn(768, 256, generator=g) / 16).to(dev).to(torch.float16)
+    b = (torch.randn(768, generator=g) * 0.1).to(dev)
+    q, k, vt = (torch.empty(nseq * Tp * 256, dtype=torch.bfloat16, device=dev) for _ in range(3))
+    o = torch.empty(nseq * Tp, 256, dtype=torch.float16, device=dev)
+    flop = nseq * 2.0 * 256 * T * (T + 1) + 2.0 * nseq * Tp * 768 * 256
+    def two():
+        ops.inproj_heads(x, w, b, q, k, vt, nseq, Tp, H)
+        ops.attn_causal(q, k, vt, o, nseq, H, Tp, 0, T, scale=ops.LN2)
+    timeit(f"inproj + attn nseq={nseq}", two, flop)
+    timeit(f"fused        nseq={nseq}", lambda: ops.inproj_attn_causal(x, w, b, q, o, nseq, H, Tp, 0, T), flop)
