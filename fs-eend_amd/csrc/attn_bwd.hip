@@ -22,6 +22,8 @@
 
 namespace {
 
+typedef __attribute__((address_space(3))) char lds_char;
+
 constexpr int KB = 64;
 constexpr int TILE = KB * 128;       // one [64][64] bf16 tile
 
@@ -161,23 +163,28 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
 // the 16-lane groups of a ds_read_b128 (rows 0-3,12-15,20-27 / 4-11,16-19,28-31) hit 16 distinct bank quads.
 DEV int swz64(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
-__global__ __launch_bounds__(256)
+// Staging of attn_bwd_dkv_kernel: 64 queries (two 32-query sub-blocks) per stage, by LDS-DMA (no staging registers);
+// per sub-block u the four tiles of the round-1 layout -- Q[32][64], dO[32][64] (swz128 images), Q^T[64][32],
+// dO^T[64][32] (swz64 images) -- then one 1 KB slot each for the stage's 64 log-sum-exps and 64 D values.
+constexpr int DKV_SUB = 16384;
+constexpr int DKV_STAGE = 2 * DKV_SUB + 2048;
+
+#ifndef EEND_DKV_WAVES
+#define EEND_DKV_WAVES 4          // waves (32 keys each) per workgroup: 4 -> 128 keys, two workgroups per CU; 8 -> 256 keys, one
+#endif
+constexpr int DKV_NW = EEND_DKV_WAVES;
+
+__global__ __launch_bounds__(DKV_NW * 64, DKV_NW == 4 ? 2 : 1)
 void attn_bwd_dkv_kernel(const AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];     // per stage: Q[32][64], dO[32][64], Q^T[64][32], dO^T[64][32]
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // 2 stages x 34 KB: two workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, seq = blockIdx.z;
-    const int k0 = blockIdx.x * 128, kw0 = k0 + wave * 32;
+    const int k0 = blockIdx.x * (DKV_NW * 32), kw0 = k0 + wave * 32;
     const int lq = lane & 31, hi = lane >> 5;
     const size_t sh = (size_t)seq * p.H + h;
-    const __bf16* __restrict__ Qg = (const __bf16*)p.Q + sh * p.Tp * 64;
-    const __bf16* __restrict__ Qtg = (const __bf16*)p.Qt + sh * 64 * p.Tp;
     const __bf16* __restrict__ Kg = (const __bf16*)p.K + sh * p.Tp * 64;
     const __bf16* __restrict__ Vg = (const __bf16*)p.V + sh * p.Tp * 64;
-    const __bf16* __restrict__ dOg = (const __bf16*)p.dO + (size_t)seq * p.Tp * p.ldo + h * 64;
-    const __bf16* __restrict__ dOtg = (const __bf16*)p.dOt + sh * 64 * p.Tp;
-    const float* __restrict__ Lg = p.Lse + sh * p.Tp;
-    const float* __restrict__ Dg = p.Dh + sh * p.Tp;
 
     const bool active = kw0 < p.Tp;
     const int key = kw0 + lq;                          // this lane's key (B-operand column)
@@ -188,50 +195,66 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
         kf[ks] = *(const bf16x8*)(Kg + (size_t)keyc * 64 + ks * 16 + hi * 8);
         vf[ks] = *(const bf16x8*)(Vg + (size_t)keyc * 64 + ks * 16 + hi * 8);
     }
+    asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
 
     int qlim = p.q_len < p.Tp ? p.q_len : p.Tp;
     const int nqb = (qlim + 31) / 32;
     int qstart = k0 - p.mask_delay;
     if (qstart < 0) qstart = 0;
-    const int qb0 = qstart / 32;
+    const int st0 = qstart / 64, nst = (nqb + 1) / 2;  // stages of 64 queries
 
-    // staging: 4 tiles x 256 chunks of 16 B, one chunk of each per thread
-    const int r8 = tid >> 3, c8 = tid & 7;             // [32][64] tiles
-    const int r4 = tid >> 2, c4 = tid & 3;             // [64][32] tiles
-    uint4 g0, g1, g2, g3;
-#define DKV_GLOAD(qb)                                                                    \
-    do {                                                                                 \
-        const int qr = (qb) * 32 + r8 < p.Tp ? (qb) * 32 + r8 : p.Tp - 1;                \
-        g0 = *(const uint4*)(Qg + (size_t)qr * 64 + c8 * 8);                             \
-        g1 = *(const uint4*)(dOg + (size_t)qr * p.ldo + c8 * 8);                         \
-        g2 = *(const uint4*)(Qtg + (size_t)r4 * p.Tp + (qb) * 32 + c4 * 8);              \
-        g3 = *(const uint4*)(dOtg + (size_t)r4 * p.Tp + (qb) * 32 + c4 * 8);             \
-    } while (0)
-#define DKV_LSTORE(buf)                                                                  \
-    do {                                                                                 \
-        char* b_ = smem + (buf) * 16384;                                                 \
-        *(uint4*)(b_ + swz128(r8, c8)) = g0;                                             \
-        *(uint4*)(b_ + 4096 + swz128(r8, c8)) = g1;                                      \
-        *(uint4*)(b_ + 8192 + swz64(r4, c4)) = g2;                                       \
-        *(uint4*)(b_ + 12288 + swz64(r4, c4)) = g3;                                      \
-    } while (0)
+    // 34 DMA pieces of 1 KB per stage: per sub-block 4 (Q) + 4 (dO) + 4 (Q^T) + 4 (dO^T), then L and D; 8 per wave (+2 on
+    // wave 0).  The swizzled images are produced by permuting the per-lane SOURCE address.
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)((const __bf16*)p.Q + sh * p.Tp * 64), 0, p.Tp * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rqt = __builtin_amdgcn_make_buffer_rsrc((void*)((const __bf16*)p.Qt + sh * 64 * p.Tp), 0, p.Tp * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)((const __bf16*)p.dO + (size_t)seq * p.Tp * p.ldo + h * 64), 0,
+                                                                         (p.Tp - 1) * p.ldo * 2 + 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdot = __builtin_amdgcn_make_buffer_rsrc((void*)((const __bf16*)p.dOt + sh * 64 * p.Tp), 0, p.Tp * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Lse + sh * p.Tp), 0, p.Tp * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Dh + sh * p.Tp), 0, p.Tp * 4, 0x00020000);
+    // [32][64] tiles: a piece = 8 rows x 128 B; [64][32] tiles: a piece = 16 rows x 64 B
+    const int r8 = lane >> 3, c8 = lane & 7, r4 = lane >> 2, c4 = lane & 3;
+    auto dma_stage = [&](int st, int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * DKV_STAGE;
+#pragma unroll
+        for (int i = 0; i < 32 / DKV_NW; ++i) {
+            const int pc = wave * (32 / DKV_NW) + i;   // 0..31
+            const int u = pc >> 4, kind = (pc >> 2) & 3, sp = pc & 3;
+            char* dst = base + u * DKV_SUB + kind * 4096 + sp * 1024;
+            const int q0 = st * 64 + u * 32;
+            if (kind < 2) {                            // Q / dO rows q0 + sp*8 + r8, chunk c8 ^ ((row >> 1) & 7)
+                const int row = sp * 8 + r8, ch = c8 ^ ((row >> 1) & 7);
+                if (kind == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_char*)dst, 16, row * 128 + ch * 16, q0 * 128, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (lds_char*)dst, 16, row * p.ldo * 2 + ch * 16, q0 * p.ldo * 2, 0, 0);
+            } else {                                   // Q^T / dO^T rows d = sp*16 + r4, chunk c4 ^ ((d >> 2) & 3)
+                const int d = sp * 16 + r4, ch = c4 ^ ((d >> 2) & 3);
+                if (kind == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rqt, (lds_char*)dst, 16, d * p.Tp * 2 + ch * 16, q0 * 2, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rdot, (lds_char*)dst, 16, d * p.Tp * 2 + ch * 16, q0 * 2, 0, 0);
+            }
+        }
+        if (wave == 0) {                               // 64 floats each: lanes 0..15 carry them, the rest re-read in range
+            const int off = (lane & 15) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_char*)(base + 2 * DKV_SUB), 16, off, st * 256, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_char*)(base + 2 * DKV_SUB + 1024), 16, off, st * 256, 0, 0);
+        }
+    };
 
     f32x16 dkT[2], dvT[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dkT[0][i] = 0.f; dkT[1][i] = 0.f; dvT[0][i] = 0.f; dvT[1][i] = 0.f; }
 
-    if (qb0 < nqb) {
-        DKV_GLOAD(qb0);
-        DKV_LSTORE(0);
-    }
-    __syncthreads();
+    if (st0 < nst) dma_stage(st0, 0);
     const int qrow = swap23(lq);
-    for (int qb = qb0; qb < nqb; ++qb) {
-        const int buf = (qb - qb0) & 1;
-        if (qb + 1 < nqb) DKV_GLOAD(qb + 1);
-        const int qw0 = qb * 32;
-        if (active && kw0 <= qw0 + 31 + p.mask_delay) {
-            const char* b_ = smem + buf * 16384;
+    for (int st = st0; st < nst; ++st) {
+        const int buf = (st - st0) & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage landed; every wave is past the other buffer
+        if (st + 1 < nst) dma_stage(st + 1, buf ^ 1);
+        const char* sb = smem + buf * DKV_STAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int qw0 = st * 64 + u * 32;
+            if (!(active && qw0 < qlim && kw0 <= qw0 + 31 + p.mask_delay)) continue;
+            const char* b_ = sb + u * DKV_SUB;
             f32x16 s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -243,27 +266,26 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
             }
             // reg r in lane (key, hi) <-> query = qw0 + (r&7) + 8*hi + 16*(r>>3): two runs of 8 consecutive queries
-            float l2v[16], dv[16];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int qb_ = qw0 + 16 * g + 8 * hi;         // multiple of 8 and < Tp (Tp % 64 == 0)
-                const float4 a0 = *(const float4*)(Lg + qb_), a1 = *(const float4*)(Lg + qb_ + 4);
-                const float4 d0 = *(const float4*)(Dg + qb_), d1 = *(const float4*)(Dg + qb_ + 4);
-                l2v[g * 8 + 0] = a0.x; l2v[g * 8 + 1] = a0.y; l2v[g * 8 + 2] = a0.z; l2v[g * 8 + 3] = a0.w;
-                l2v[g * 8 + 4] = a1.x; l2v[g * 8 + 5] = a1.y; l2v[g * 8 + 6] = a1.z; l2v[g * 8 + 7] = a1.w;
-                dv[g * 8 + 0] = d0.x; dv[g * 8 + 1] = d0.y; dv[g * 8 + 2] = d0.z; dv[g * 8 + 3] = d0.w;
-                dv[g * 8 + 4] = d1.x; dv[g * 8 + 5] = d1.y; dv[g * 8 + 6] = d1.z; dv[g * 8 + 7] = d1.w;
-            }
             bf16x8 pf[2], sf[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = qw0 + (r & 7) + 8 * hi + 16 * (r >> 3);
-                const bool ok = key <= qi + p.mask_delay && key < p.kv_len && qi < qlim;
-                const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_log2, -l2v[r])) : 0.f;
-                float kf = 1.0f;                               // the forward's dropout factor of this (query, key) pair
-                if (p.drop.thresh24) kf = drop_keep(p.drop, (unsigned)(sh * p.Tp + qi), (unsigned)key) ? p.drop.scale : 0.f;
-                pf[r >> 3][r & 7] = (__bf16)(pv * kf);
-                sf[r >> 3][r & 7] = (__bf16)(pv * (dp[r] * kf - dv[r]));
+            for (int g = 0; g < 2; ++g) {
+                const float* lp = (const float*)(sb + 2 * DKV_SUB) + u * 32 + 16 * g + 8 * hi;
+                const float* dpt = (const float*)(sb + 2 * DKV_SUB + 1024) + u * 32 + 16 * g + 8 * hi;
+                const float4 a0 = *(const float4*)lp, a1 = *(const float4*)(lp + 4);
+                const float4 d0 = *(const float4*)dpt, d1 = *(const float4*)(dpt + 4);
+                const float l2v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = g * 8 + e;
+                    const int qi = qw0 + e + 8 * hi + 16 * g;
+                    const bool ok = key <= qi + p.mask_delay && key < p.kv_len && qi < qlim;
+                    const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_log2, -l2v[e])) : 0.f;
+                    float kfac = 1.0f;                             // the forward's dropout factor of this (query, key) pair
+                    if (p.drop.thresh24) kfac = drop_keep(p.drop, (unsigned)(sh * p.Tp + qi), (unsigned)key) ? p.drop.scale : 0.f;
+                    pf[g][e] = (__bf16)(pv * kfac);
+                    sf[g][e] = (__bf16)(pv * (dp[r] * kfac - dv[e]));
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -275,11 +297,7 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
                     dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf[kk], dkT[db], 0, 0, 0);
                 }
         }
-        if (qb + 1 < nqb) DKV_LSTORE(buf ^ 1);
-        __syncthreads();
     }
-#undef DKV_GLOAD
-#undef DKV_LSTORE
     // dK[key][h*64 + d], dV likewise; reg i <-> d = db*32 + 8*(i>>2) + 4*hi + (i&3)
     if (active && key < p.Tp) {
         __bf16* __restrict__ out = (__bf16*)p.dQKV + ((size_t)seq * p.Tp + key) * p.ldg + h * 64;
@@ -327,7 +345,13 @@ int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
         return EEND_EINVAL;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE) != hipSuccess)
+            return EEND_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.Tp + DKV_NW * 32 - 1) / (DKV_NW * 32), p.H, p.nseq), dim3(DKV_NW * 64), 2 * DKV_STAGE, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
