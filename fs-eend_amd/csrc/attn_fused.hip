@@ -5,7 +5,7 @@
 // merge_tfm_encoder.py:379-385), so that K and V NEVER reach HBM: the in-projection used to write Q | K | V^T
 // (3 x 2 B x 256 per token: 302 MB per decoder layer at B = 64, C = 6) and the attention kernel read it straight
 // back -- together 19 % of the step, both HBM-bound.  Here a workgroup streams its sequence's X rows ([Tp][256]
-// f16, 32 rows at a time, LDS-DMA, double-buffered) past the head's W_k / W_v / W_q slices held in registers
+// f16, 32 rows at a time, register-staged into a double-buffered LDS tile) past the head's W_k / W_v / W_q slices held in registers
 // (MFMA f16 16x16x32, the A- and B-operand fragments of one 16 x 32 block have the same lane layout, so K -- wanted
 // key-major -- and V^T -- wanted d-major -- come from the SAME X fragments with the operand order swapped), drops
 // the bf16 K / V^T tiles into the XOR-swizzled LDS images the flash loop reads, and then runs that loop
@@ -21,6 +21,10 @@
 
 namespace {
 
+#ifndef EEND_AF_REGSTAGE
+#define EEND_AF_REGSTAGE 1      // X staging through registers (1) or by LDS-DMA (0: the first form, kept for the A/B)
+#endif
+
 constexpr int KB = 64;
 constexpr int TILE = KB * 128;            // one [64][64] bf16 tile
 constexpr int NW = 8;
@@ -30,6 +34,7 @@ constexpr int XBUF = 4 * XR * 128;        // [4 k-tiles][32 rows][128 B] f16
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 DEV int swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
@@ -85,8 +90,10 @@ void inproj_attn_kernel(const InprojAttnParams p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_char*)(dst + (wave * 2 + i) * 1024), 16, vox[i], xt * XR * p.ldx * 2, 0, 0);
         };
         const int nxt = p.Tp / XR;                   // <= 16
+#if !EEND_AF_REGSTAGE
         dma_x(0);
         if (nxt > 1) dma_x(1);
+#endif
         f16x8 wkv[8], wq[8];
         {
             const _Float16* wr = W + (size_t)((1 + kvsel) * 256 + h * 64 + f0 + frow) * 256 + fkg * 8;
@@ -113,17 +120,12 @@ void inproj_attn_kernel(const InprojAttnParams p) {
                           "+v"(bkv), "+v"(bq));
         __bf16* __restrict__ Qs = (__bf16*)p.Qs + sh * p.Tp * 64;
         const int jq = wave >> 2;                    // the token fragment this wave projects Q for
-        for (int xt = 0; xt < nxt; ++xt) {
-            // tile xt has landed: VMEM returns in order; younger than its pieces are at most this wave's Q store of tile
-            // xt-1 and the 2 pieces of tile xt+1
-            if (xt == 0 && nxt > 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-            else if (xt + 1 < nxt) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            const char* xb = Xs + (xt & 1) * XBUF;
+        // one projection step on the 32 X rows in buffer xb: K / V^T fragments -> LDS, Q fragment -> scratch
+        auto proj_step = [&](int xt, const char* xb) __attribute__((always_inline)) {
             f32x4 akv[2] = {bkv, bkv};
             f32x4 aq = bq;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < 8; ++ks) {         // (hoisting all 16 fragment reads in front of the MFMAs measured 3 % slower)
                 f16x8 x[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) x[j] = *(const f16x8*)(xb + (ks >> 1) * (XR * 128) + swz128(j * 16 + frow, (ks & 1) * 4 + fkg));
@@ -151,11 +153,60 @@ void inproj_attn_kernel(const InprojAttnParams p) {
                 const int tok = xt * XR + jq * 16 + frow, d = f0 + fkg * 4;
                 *(u32x2*)(Qs + (size_t)tok * 64 + d) = pack_bf16x4(aq);
             }
+        };
+#if EEND_AF_REGSTAGE
+        // X through REGISTERS: plain global loads ingest faster than LDS-DMA here (the s_memtime traces put the DMA stream
+        // at ~1 KB per 130 cycles per CU however it is scheduled; register-staged loads of the stand-alone attention kernel
+        // ran at more than twice that).  Thread q of the 512 moves chunks q and q + 512 of a tile's 1024 16-byte chunks
+        // (row = chunk >> 5, 16-byte column = chunk & 31); two register sets, so a tile is requested two steps before it is
+        // written to the staging buffer the step before it is read.  One barrier per step.
+        const _Float16* __restrict__ Xg = (const _Float16*)p.X + (size_t)seq * p.Tp * p.ldx;
+        int xsrc[2], xdst[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 512, row = c >> 5, col = c & 31;
+            xsrc[i] = row * p.ldx + col * 8;
+            xdst[i] = (col >> 3) * (XR * 128) + swz128(row, col & 7);
+        }
+        u32x4 ra[2], rb[2];
+        auto gload = [&](int xt, u32x4 (&r)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = *(const u32x4*)(Xg + (size_t)xt * XR * p.ldx + xsrc[i]);
+        };
+        auto lstore = [&](int xt, const u32x4 (&r)[2]) __attribute__((always_inline)) {
+            char* dst = Xs + (xt & 1) * XBUF;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *(u32x4*)(dst + xdst[i]) = r[i];
+        };
+        gload(0, ra);
+        lstore(0, ra);
+        if (nxt > 1) gload(1, ra);
+        __syncthreads();
+        for (int xt = 0; xt < nxt; xt += 2) {
+            if (xt + 2 < nxt) gload(xt + 2, rb);
+            proj_step(xt, Xs);
+            if (xt + 1 < nxt) lstore(xt + 1, ra);
+            __syncthreads();
+            if (xt + 1 >= nxt) break;
+            if (xt + 3 < nxt) gload(xt + 3, ra);
+            proj_step(xt + 1, Xs + XBUF);
+            if (xt + 2 < nxt) lstore(xt + 2, rb);
+            __syncthreads();
+        }
+#else
+        for (int xt = 0; xt < nxt; ++xt) {
+            // tile xt has landed: VMEM returns in order; younger than its pieces are at most this wave's Q store of tile
+            // xt-1 and the 2 pieces of tile xt+1
+            if (xt == 0 && nxt > 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            else if (xt + 1 < nxt) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            proj_step(xt, Xs + (xt & 1) * XBUF);
             if (xt + 2 < nxt) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading this buffer
                 dma_x(xt + 2);
             }
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    // K, V^T complete in LDS; Q complete in L2
     }
 
