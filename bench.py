@@ -55,13 +55,15 @@ def flops_per_launch(name, shape, T):
 
 
 def pmc_traffic(kernel, shape):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     tags = {("fusion_layer_tail", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 2>(FfnParams)",), "131072"),
             ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
+            ("inproj_attn_causal", (64, 4)): (("inproj_attn_kernel",), "131072"),
+            ("inproj_attn_causal", (384, 4)): (("inproj_attn_kernel",), "786432"),
             ("attn_causal", (64, 4)): (("attn_causal_full_kernel",), "131072"),
             ("attn_causal", (384, 4)): (("attn_causal_full_kernel",), "786432"),
             ("linear_res_ln", (196608, 256, 256)): (("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4",), "786432")}
@@ -792,7 +794,7 @@ def main():
                            "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
-                           "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
+                           "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
         fus = [k for k in ksum if k["kernel"] == "inproj_attn_causal" and k["shape"][0] == B]
         if fus:
@@ -809,7 +811,8 @@ def main():
             out["roofline_attention"] = {
                 "kernel": f"encoder inproj_attn_causal (in-projection + causal MHA fused) nseq={a['shape'][0]} H=4 T={T}", "bound": "mfma",
                 "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS,
-                "traffic": None, "avg_launch_ms": a["avg_ms"], "mfma_TFLOPs": tf, "mfma_frac": tf / PEAK_MFMA_TFLOPS,
+                "traffic": pmc_traffic("inproj_attn_causal", a["shape"]), "avg_launch_ms": a["avg_ms"], "mfma_TFLOPs": tf,
+                "mfma_frac": tf / PEAK_MFMA_TFLOPS,
                 "attention_only_TFLOPs": fl_att / (a["avg_ms"] * 1e-3) / 1e12,
                 "attention_only_mfma_frac": fl_att / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                 "algorithmic_hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9,
