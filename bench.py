@@ -694,8 +694,9 @@ def main():
                           "parallelism": f"dp{world}: one all-reduce of the flat {eng.flat.numel * 4 / 1e6:.1f} MB f32 gradient buffer per step",
                           "launch": "eager ctypes launches"},
                "final_loss": loss, "peak_hbm_bytes": int(torch.cuda.max_memory_allocated(dev))}
-        if rank == 0 and not args.no_breakdown:
-            # dominant kernel: HIP events around every C-ABI call of 2 extra steps (same stream, same inputs)
+        if rank == 0 and world == 1 and not args.no_breakdown:
+            # dominant kernel: HIP events around every C-ABI call of 2 extra steps (same stream, same inputs).  N = 1 only: a
+            # training step contains the gradient all-reduce, a collective every rank would have to enter
             _, feats, labels = train_setup(dev, B, T, args.speakers, rank)
             with TrainCallTimer(T) as tm:
                 for _ in range(2):
