@@ -29,7 +29,7 @@ constexpr int TILE = KB * 128;       // one [64][64] bf16 tile
 
 DEV int swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void attn_bwd_dq_kernel(const AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K[2], V[2], K^T[2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -60,40 +60,34 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
     }
     const float L2 = p.Lse[sh * p.Tp + qc], Dq = p.Dh[sh * p.Tp + qc];
 
-    uint4 kr0, kr1, vr0, vr1, tr0, tr1;
-    const int c0row = tid >> 3, c0ch = tid & 7, c1row = c0row + 32;
-#define DQ_GLOAD(j)                                                                   \
-    do {                                                                              \
-        kr0 = *(const uint4*)(Kg + (size_t)((j) * KB + c0row) * 64 + c0ch * 8);       \
-        kr1 = *(const uint4*)(Kg + (size_t)((j) * KB + c1row) * 64 + c0ch * 8);       \
-        vr0 = *(const uint4*)(Vg + (size_t)((j) * KB + c0row) * 64 + c0ch * 8);       \
-        vr1 = *(const uint4*)(Vg + (size_t)((j) * KB + c1row) * 64 + c0ch * 8);       \
-        tr0 = *(const uint4*)(Ktg + (size_t)c0row * p.Tp + (j) * KB + c0ch * 8);      \
-        tr1 = *(const uint4*)(Ktg + (size_t)c1row * p.Tp + (j) * KB + c0ch * 8);      \
-    } while (0)
-#define DQ_LSTORE(buf)                                                                \
-    do {                                                                              \
-        *(uint4*)(smem + (buf) * TILE + swz128(c0row, c0ch)) = kr0;                   \
-        *(uint4*)(smem + (buf) * TILE + swz128(c1row, c0ch)) = kr1;                   \
-        *(uint4*)(smem + (2 + (buf)) * TILE + swz128(c0row, c0ch)) = vr0;             \
-        *(uint4*)(smem + (2 + (buf)) * TILE + swz128(c1row, c0ch)) = vr1;             \
-        *(uint4*)(smem + (4 + (buf)) * TILE + swz128(c0row, c0ch)) = tr0;             \
-        *(uint4*)(smem + (4 + (buf)) * TILE + swz128(c1row, c0ch)) = tr1;             \
+    // staging by LDS-DMA (no staging registers): per 64-key tile 8 pieces each of K, V ([64 keys][128 B]) and K^T
+    // ([64 d][128 B]), swz128 images via the per-lane source address; 6 pieces per wave
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.Tp * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, p.Tp * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)Ktg, 0, p.Tp * 128, 0x00020000);
+    const int r8 = lane >> 3, c8 = lane & 7;
+#define DQ_DMA(j, buf)                                                                                         \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                     \
+            const int pc = wave * 6 + i_, kind = pc >> 3, sp = pc & 7;                                         \
+            const int row = sp * 8 + r8, ch = c8 ^ ((row >> 1) & 7);                                           \
+            char* dst = smem + (2 * kind + (buf)) * TILE + sp * 1024;                                          \
+            if (kind == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_char*)dst, 16, row * 128 + ch * 16, (j) * KB * 128, 0, 0); \
+            else if (kind == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_char*)dst, 16, row * 128 + ch * 16, (j) * KB * 128, 0, 0); \
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_char*)dst, 16, row * p.Tp * 2 + ch * 16, (j) * KB * 2, 0, 0); \
+        }                                                                                                      \
     } while (0)
 
     f32x16 dqT[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dqT[0][i] = 0.f; dqT[1][i] = 0.f; }
 
-    if (ntiles > 0) {
-        DQ_GLOAD(0);
-        DQ_LSTORE(0);
-    }
-    __syncthreads();
+    if (ntiles > 0) DQ_DMA(0, 0);
     const int krow = swap23(lq);
     for (int j = 0; j < ntiles; ++j) {
         const int buf = j & 1;
-        if (j + 1 < ntiles) DQ_GLOAD(j + 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile j landed; every wave is past the other buffer
+        if (j + 1 < ntiles) DQ_DMA(j + 1, buf ^ 1);
         const int key0 = j * KB;
         if (key0 <= qw0 + 31 + p.mask_delay) {
             const char* kb_ = smem + buf * TILE;
@@ -138,11 +132,8 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
                     }
                 }
         }
-        if (j + 1 < ntiles) DQ_LSTORE(buf ^ 1);
-        __syncthreads();
     }
-#undef DQ_GLOAD
-#undef DQ_LSTORE
+#undef DQ_DMA
     // dQ[q][h*64 + d] = sq * dQ^T[d][q]; reg i of dqT[db] <-> d = db*32 + 8*(i>>2) + 4*hi + (i&3)
     if (q < p.Tp) {
         __bf16* __restrict__ out = (__bf16*)p.dQKV + ((size_t)seq * p.Tp + q) * p.ldg + h * 64;
