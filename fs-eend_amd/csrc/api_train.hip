@@ -200,15 +200,17 @@ int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws
 }
 
 int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rstd, const float* gamma, float* ds_f32,
-                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M,
+                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, float* dbias, long M,
                            const eend_dropout* drop, void* stream) {
-    if (!ws || !dgamma || !dbeta || ws_floats < 1024L * 512) return EEND_EINVAL;
+    if (!ws || !dgamma || !dbeta || ws_floats < 1024L * 768 || (dbias && !ds_bf16)) return EEND_EINVAL;
     int nb = 0;
     int rc = eend_launch_ln_bwd(g, xhat_f16, rstd, gamma, ds_f32, ds_bf16, ws, &nb, M, drop_spec(drop), (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws, 512, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
+    rc = eend_launch_wgrad_reduce(ws, 768, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    return eend_launch_wgrad_reduce(ws + 256, 512, nb, 1, 256, 256, dbeta, 256, 1.0f, 0, (hipStream_t)stream);
+    rc = eend_launch_wgrad_reduce(ws + 256, 768, nb, 1, 256, 256, dbeta, 256, 1.0f, 0, (hipStream_t)stream);
+    if (rc != EEND_OK || !dbias) return rc;
+    return eend_launch_wgrad_reduce(ws + 512, 768, nb, 1, 256, 256, dbias, 256, 1.0f, 0, (hipStream_t)stream);
 }
 
 int eend_head_bce_f32(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,

@@ -14,16 +14,17 @@ constexpr int D = 256;
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm backward.  y = x_hat * gamma + beta, x_hat = (s - mean) * rstd:
 //   ds = rstd * (dy*gamma - mean_j(dy*gamma) - x_hat * mean_j(dy*gamma*x_hat));  dgamma = sum_rows dy*x_hat;  dbeta = sum_rows dy
-// g: gradient w.r.t. the LayerNorm output (f32); ds32 may alias g.  partial: [gridDim.x][2][256].
+// g: gradient w.r.t. the LayerNorm output (f32); ds32 may alias g.  partial: [gridDim.x][3][256]: dgamma, dbeta and the
+// column sums of the (dropout-masked) branch gradient = the bias gradient of the linear in front of the LayerNorm.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* g, const _Float16* __restrict__ xhat, const float* __restrict__ rstd,
                    const float* __restrict__ gamma, float* ds32, __bf16* __restrict__ ds16, float* __restrict__ partial, long M,
                    const DropSpec drop) {
-    __shared__ float red[4][2][D];
+    __shared__ float red[4][3][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 gm = *(const float4*)(gamma + lane * 4);
-    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dbr[4] = {0.f, 0.f, 0.f, 0.f};
     for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
         const float4 gy = *(const float4*)(g + row * D + lane * 4);
         const f16x4 xh = *(const f16x4*)(xhat + row * D + lane * 4);
@@ -39,20 +40,24 @@ void ln_bwd_kernel(const float* g, const _Float16* __restrict__ xhat, const floa
             // ds16 feeds the sub-layer branch (the linear in front of this LayerNorm): the forward dropped its output
             // with the same (row, column) mask; the residual path (ds32) is not masked
             const unsigned n = (unsigned)(lane * 4);
+            const float m0 = drop_apply(drop, o0, (unsigned)row, n), m1 = drop_apply(drop, o1, (unsigned)row, n + 1);
+            const float m2 = drop_apply(drop, o2, (unsigned)row, n + 2), m3 = drop_apply(drop, o3, (unsigned)row, n + 3);
             uint2 pk;
-            pk.x = pack_bf16(drop_apply(drop, o0, (unsigned)row, n), drop_apply(drop, o1, (unsigned)row, n + 1));
-            pk.y = pack_bf16(drop_apply(drop, o2, (unsigned)row, n + 2), drop_apply(drop, o3, (unsigned)row, n + 3));
+            pk.x = pack_bf16(m0, m1);
+            pk.y = pack_bf16(m2, m3);
             *(uint2*)(ds16 + row * D + lane * 4) = pk;
+            dbr[0] += m0; dbr[1] += m1; dbr[2] += m2; dbr[3] += m3;
         }
         dg[0] += gy.x * x0; dg[1] += gy.y * x1; dg[2] += gy.z * x2; dg[3] += gy.w * x3;
         db[0] += gy.x; db[1] += gy.y; db[2] += gy.z; db[3] += gy.w;
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[wave][0][lane * 4 + e] = dg[e]; red[wave][1][lane * 4 + e] = db[e]; }
+    for (int e = 0; e < 4; ++e) { red[wave][0][lane * 4 + e] = dg[e]; red[wave][1][lane * 4 + e] = db[e]; red[wave][2][lane * 4 + e] = dbr[e]; }
     __syncthreads();
     const int c = threadIdx.x;
-    partial[((size_t)blockIdx.x * 2 + 0) * D + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
-    partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        partial[((size_t)blockIdx.x * 3 + k) * D + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

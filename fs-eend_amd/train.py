@@ -496,18 +496,18 @@ class FsTrainStep:
         _call("eend_wgrad_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS, g,
               K if ld_out is None else ld_out, K if k_out is None else k_out, 1.0, 0)
 
-    def _ln_bwd(self, g32, site: _Site, ln, ds16, M, drop=None):
+    def _ln_bwd(self, g32, site: _Site, ln, ds16, M, drop=None, bias=None):
         """`drop`: the spec of the sub-layer output dropout in front of this LayerNorm's residual sum -- the bf16 branch
-        gradient ds16 gets the mask, the f32 residual-stream gradient g32 does not."""
+        gradient ds16 gets the mask, the f32 residual-stream gradient g32 does not.  `bias`: the bias parameter of the
+        linear layer in front of the LayerNorm; its gradient (the column sums of ds16) comes out of the same pass."""
         _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
-              self._G(ln + ".weight"), self._G(ln + ".bias"), M, drop)
+              self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, drop)
 
     def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm, drop_scale=1.0):
         """backward of x -> LN(x + W2 relu(W1 x + b1) + b2); g32 in/out (gradient w.r.t. output -> w.r.t. x)."""
         W = self.W
         Fh = hid.shape[1]
         dh = dh16[:M * Fh].view(M, Fh)
-        _call("eend_colsum_f32", ds16, D, M, D, 1, self.ws, WS_FLOATS, self._G(p_ + "linear2.bias"), 1.0, 0)
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
         _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D, drop_scale)
         self._bias_grad(dh, M, Fh, p_ + "linear1.bias")
@@ -518,7 +518,6 @@ class FsTrainStep:
                   kv_len, T, drop=None):
         """backward of x -> x + out_proj(causal_mha(in_proj x)) given ds16 = gradient w.r.t. that sum (bf16) and
         g32 = the same in f32 (residual path); g32 += gradient through the attention branch."""
-        self._bias_grad(ds16, M, D, p_out + ".bias")
         self._wgrad(ds16, sv.ctx, M, D, D, p_out + ".weight")
         _call("eend_gemm_bf16", ds16, D, w_outT, D, None, dctx16, D, M, D, D)
         _call("eend_attn_causal_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, dctx16, D, sv.ctx, D, sv.lse, bf.dot_ws, bf.dh_ws, dqkv16,
@@ -557,11 +556,10 @@ class FsTrainStep:
             x_in16 = bf.dec[i - 1]["s22"].out16 if i > 0 else bf.a16
             dsd = ds16[:Md]
             so = 4096 + 16 * i
-            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + self.SITE_FFOUT))
+            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + self.SITE_FFOUT), p_ + "linear2.bias")
             self._ffn_bwd(g32, dsd, bf.dh16, sv["hid"], sv["s21"].out16, Md, f"d{i}", p_, "norm22", ff_scale)
             # speaker-axis attention block (merge_tfm_encoder.py:373, :388-394)
-            self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md, dr(so + self.SITE_OUT2))
-            self._bias_grad(dsd, Md, D, p_ + "self_attn2.out_proj.bias")
+            self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md, dr(so + self.SITE_OUT2), p_ + "self_attn2.out_proj.bias")
             self._wgrad(dsd, sv["o2"], Md, D, D, p_ + "self_attn2.out_proj.weight")
             _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
             _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125, dr(so + self.SITE_SPK))
@@ -569,7 +567,7 @@ class FsTrainStep:
             self._wgrad(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight")
             _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
             # time-axis attention block (:364, :379-385)
-            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + self.SITE_OUT1))
+            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + self.SITE_OUT1), p_ + "self_attn1.out_proj.bias")
             self._attn_bwd(g32, dsd, dctx16[:Md], dqkv16[:Md], sv["att"], x_in16, B * C, Tp, Md, W[f"d{i}.out1_wT"],
                            W[f"d{i}.in1_wT"], p_ + "self_attn1.out_proj", p_ + "self_attn1.in_proj", bf, dm, T, T,
                            dr(so + self.SITE_ATT))
@@ -595,15 +593,14 @@ class FsTrainStep:
             p_ = f"enc.transformer_encoder.layers.{i}."
             x_in16 = bf.enc[i - 1]["s2"].out16 if i > 0 else bf.site0.out16
             so = 16 * i
-            self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me, dr(so + self.SITE_FFOUT))
+            self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me, dr(so + self.SITE_FFOUT), p_ + "linear2.bias")
             self._ffn_bwd(g32, dse, bf.dh16, sv["hid"], sv["s1"].out16, Me, f"e{i}", p_, "norm2", ff_scale)
-            self._ln_bwd(g32, sv["s1"], p_ + "norm1", dse, Me, dr(so + self.SITE_OUT1))
+            self._ln_bwd(g32, sv["s1"], p_ + "norm1", dse, Me, dr(so + self.SITE_OUT1), p_ + "self_attn.out_proj.bias")
             self._attn_bwd(g32, dse, dctx16[:Me], dqkv16[:Me], sv["att"], x_in16, B, Tp, Me, W[f"e{i}.out_wT"], W[f"e{i}.in_wT"],
                            p_ + "self_attn.out_proj", p_ + "self_attn.in_proj", bf, bf.delay_e, bf.kv_e, T, dr(so + self.SITE_ATT))
 
         # ---- input projection + LayerNorm + BatchNorm (model :166,:173-174)
-        self._ln_bwd(g32, bf.site0, "enc.encoder_norm", dse, Me)
-        self._bias_grad(dse, Me, D, "enc.encoder.bias")
+        self._ln_bwd(g32, bf.site0, "enc.encoder_norm", dse, Me, None, "enc.encoder.bias")
         _call("eend_wgrad_bf16", dse, D, bf.xin16, self.Fin_pad, 1, Me, D, self.Fin_pad, self.ws, WS_FLOATS, self._G("enc.encoder.weight"),
               self.Fin, self.Fin, 1.0, 0)
         _call("eend_gemm_bf16", dse, D, W["enc.in.wT"], D, None, bf.dy_in, self.Fin_pad, Me, self.Fin_pad, D)

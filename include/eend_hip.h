@@ -416,9 +416,10 @@ int eend_colsum_f32(const void* Y, int ld, long M, int N, int is_bf16, float* ws
 /* LayerNorm backward (autograd of torch.nn.LayerNorm): g = gradient w.r.t. the output (f32 [M][256]); writes the
  * gradient w.r.t. the input as f32 (ds_f32, may alias g) and bf16, and dgamma / dbeta [256].  `drop`: the spec of the
  * producing eend_linear_res_ln_train_f16 -- applied to the bf16 copy only (the branch gradient), not to ds_f32 (the
- * residual stream). */
+ * residual stream).  dbias (optional, [256]): column sums of that branch gradient = the bias gradient of the linear layer in
+ * front of the LayerNorm (saves a separate pass over ds_bf16). */
 int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rstd, const float* gamma, float* ds_f32,
-                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, long M,
+                           void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta, float* dbias, long M,
                            const eend_dropout* drop, void* stream);
 
 /* Head forward + standard_loss + their gradient in one pass (FS model :43,:60; train/utils/loss.py:119-125 with

@@ -180,11 +180,16 @@ def test_layernorm_bwd(T, dev, ws):
     rs = (1 / torch.sqrt(var + 1e-5)).squeeze(-1).contiguous()
     gbuf = gy.clone()
     d16 = torch.empty(M, 256, dtype=BF16, device=dev)
-    dg, db = torch.empty(256, device=dev), torch.empty(256, device=dev)
-    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, M, None)
+    dg, db, dbias = torch.empty(256, device=dev), torch.empty(256, device=dev), torch.empty(256, device=dev)
+    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, dbias, M, None)
+    assert rel(dbias, sr.grad.sum(0)) < 2e-3
     assert rel(gbuf, sr.grad) < 2e-3
     assert rel(d16, sr.grad) < 6e-3
     assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 1e-4
+
+
+def want_mask_sum(dgen, grad, rows):
+    return dgen.rows(grad, 5, rows).sum(0)
 
 
 def test_sublayer_dropout_fwd_and_ln_bwd(T, dev, ws):
@@ -213,7 +218,9 @@ def test_sublayer_dropout_fwd_and_ln_bwd(T, dev, ws):
     gbuf = gy.clone()
     d16 = torch.empty(M, 256, dtype=BF16, device=dev)
     dg, db = torch.empty(256, device=dev), torch.empty(256, device=dev)
-    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, M, ctypes.byref(spec))
+    dbias = torch.empty(256, device=dev)
+    T._call("eend_layernorm_bwd_f32", gbuf, xh, rs, gm, gbuf, d16, ws, ws.numel(), dg, db, dbias, M, ctypes.byref(spec))
+    assert rel(dbias, want_mask_sum(dgen, sref.grad, rows)) < 3e-3
     assert rel(gbuf, sref.grad) < 3e-3                               # residual stream: un-masked
     want = dgen.rows(sref.grad, 5, rows)                             # branch: masked and scaled
     assert rel(d16, want) < 6e-3
