@@ -56,3 +56,28 @@ def test_inproj_attn_fused(hip_lib, dev, nseq, Tp, delay, kv_len):
     # the scratch buffer holds the projected, pre-scaled q in head layout
     qh = qs.view(nseq, 4, Tp, 64).float()
     assert (qh - q).abs().max() < 2e-2 * max(1.0, float(q.abs().max()))
+
+
+@pytest.mark.parametrize("B,T,C", [(1, 37, 1), (3, 130, 3), (5, 500, 6), (2, 512, 10), (8, 257, 4)])
+def test_model_fused_vs_two_kernel_path(hip_lib, dev, B, T, C):
+    """model.test through the fused in-projection + attention kernel == through inproj_heads + attn_causal (the path
+    chunks longer than 512 frames still take), ragged lengths included."""
+    from fs_eend_amd import fs_model as FM
+    torch.manual_seed(3)
+    cfg = dict(n_units=256, n_heads=4, enc_n_layers=2, dec_n_layers=2, dropout=0.1, has_mask=True, max_seqlen=500,
+               dec_dim_feedforward=512, conv_delay=9, mask_delay=0, decom_kernel_size=64)
+    m = FM.OnlineTransformerDADiarization(n_speakers=None, in_size=345, **cfg).eval().to(dev)
+    g = torch.Generator().manual_seed(B * 100 + T)
+    lens = [T - (i * 7) % max(1, T // 3) for i in range(B)]
+    src = [(torch.randn(l, 345, generator=g) * 2 - 3).to(dev) for l in lens]
+    was = FM.FUSED_INPROJ_ATTN
+    try:
+        FM.FUSED_INPROJ_ATTN = True
+        a = m.test(src, lens, C)
+        FM.FUSED_INPROJ_ATTN = False
+        b = m.test(src, lens, C)
+    finally:
+        FM.FUSED_INPROJ_ATTN = was
+    for x, y in zip(a[0], b[0]):
+        assert x.shape == y.shape and torch.isfinite(x).all()
+        assert (x - y).abs().max() < 5e-4, float((x - y).abs().max())
