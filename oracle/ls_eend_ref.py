@@ -49,7 +49,7 @@ def retention_chunk(qr: Tensor, kr: Tensor, v: Tensor, L: int, q=_id, role="ret"
     kc = kr.reshape(N, H, nc, L, dk).transpose(1, 2)
     vc = v.reshape(N, nc, L, H, dv).transpose(2, 3)           # (N,nc,H,L,dv)
     qk = (q(qc, role + ".q") @ q(kc, role + ".k").transpose(-1, -2)) * mask            # :161-162
-    inner_scale = qk.abs().sum(dim=-1, keepdim=True).clamp(min=1)                       # :163
+    inner_scale = qk.detach().abs().sum(dim=-1, keepdim=True).clamp(min=1)              # :163 (detached: no gradient)
     qk = qk / inner_scale
     inner = q(qk, role + ".p") @ q(vc, role + ".v")                                     # :165
     kv = kc.transpose(-1, -2) @ (vc / math.sqrt(L))                                     # :168 (N,nc,H,dk,dv)
@@ -60,7 +60,7 @@ def retention_chunk(qr: Tensor, kr: Tensor, v: Tensor, L: int, q=_id, role="ret"
         kv_rec.append(state / scale)
         cross_scale.append(scale)
         state = state + kv[:, c]
-        scale = state.abs().sum(dim=-2, keepdim=True).max(dim=-1, keepdim=True).values.clamp(min=1)
+        scale = state.detach().abs().sum(dim=-2, keepdim=True).max(dim=-1, keepdim=True).values.clamp(min=1)   # :180 (detached)
     kv_rec = torch.stack(kv_rec, dim=1)
     cross_scale = torch.stack(cross_scale, dim=1)
     all_scale = torch.maximum(inner_scale, cross_scale)                                 # :185
@@ -119,10 +119,13 @@ def ffn_module(x: Tensor, sd, pfx: str, q=_id, role="ffn") -> Tensor:
     return linear(h, sd[pfx + "sequential.4.linear.weight"], sd[pfx + "sequential.4.linear.bias"], q, role + "2")
 
 
-def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None):
+def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None, bn_train: Optional[dict] = None):
     """ConformerConvModule (convolution.py:138-167): LN -> 1x1 (D->2D) -> GLU -> causal
-    depthwise k (left context k-1) -> BatchNorm1d(eval) -> Swish -> 1x1.
-    Batch: x (N,T,D).  One-step: x (N,1,D) with cache (N,D,k-1) -> (y, new_cache)."""
+    depthwise k (left context k-1) -> BatchNorm1d -> Swish -> 1x1.
+    Batch: x (N,T,D).  One-step: x (N,1,D) with cache (N,D,k-1) -> (y, new_cache).
+    ``bn_train`` a dict: train mode -- BatchNorm1d normalises with the statistics of this batch (all N*T frames of
+    the zero-padded tensor, biased variance) and records them under bn_train[pfx] for the running-stat update.
+    SyncBatchNorm (train_dia_simu.py:167 `sync_batchnorm`) = the same over the concatenation of all ranks' batches."""
     h = layer_norm(x, sd[pfx + "sequential.0.weight"], sd[pfx + "sequential.0.bias"])
     w1 = sd[pfx + "sequential.2.conv.weight"][:, :, 0]                        # (2D, D)
     h = linear(h, w1, sd[pfx + "sequential.2.conv.bias"], q, "conv.pw1")
@@ -140,7 +143,15 @@ def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None):
         new_cache = xp[:, :, 1:]
         y = (xp * dw).sum(-1)[:, None, :]
     bn = pfx + "sequential.5."
-    y = (y - sd[bn + "running_mean"]) / torch.sqrt(sd[bn + "running_var"] + BN_EPS) * sd[bn + "weight"] + sd[bn + "bias"]
+    if bn_train is None:
+        mu, var = sd[bn + "running_mean"], sd[bn + "running_var"]
+    else:
+        flat = y.reshape(-1, y.shape[-1])
+        n = flat.shape[0]
+        mu = flat.mean(0)
+        var = ((flat - mu) ** 2).mean(0)
+        bn_train[pfx] = dict(mean=mu.detach(), var_biased=var.detach(), count=n)
+    y = (y - mu) / torch.sqrt(var + BN_EPS) * sd[bn + "weight"] + sd[bn + "bias"]
     y = swish(y)
     w2 = sd[pfx + "sequential.7.conv.weight"][:, :, 0]
     y = linear(y, w2, sd[pfx + "sequential.7.conv.bias"], q, "conv.pw2")
@@ -148,14 +159,14 @@ def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None):
 
 
 def conformer_block(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: Optional[dict] = None,
-                    conv_cache: Optional[Tensor] = None):
+                    conv_cache: Optional[Tensor] = None, bn_train: Optional[dict] = None):
     """ConformerEncoderBlock (encoder.py:76-123), half-step residual FFNs."""
     s = pfx + "sequential."
     x = x + 0.5 * ffn_module(x, sd, s + "0.module.", q, "enc.ffa")
     a = s + "1.module."
     h = layer_norm(x, sd[a + "layer_norm.weight"], sd[a + "layer_norm.bias"])           # attention.py:100,115
     x = x + msr(h, sd, a + "self_attn.", H, L, q, "enc.ret", ret_state)
-    y, new_cache = conv_module(x, sd, s + "2.module.", q, conv_cache)
+    y, new_cache = conv_module(x, sd, s + "2.module.", q, conv_cache, bn_train)
     x = x + y
     x = x + 0.5 * ffn_module(x, sd, s + "3.module.", q, "enc.ffb")
     x = layer_norm(x, sd[s + "4.weight"], sd[s + "4.bias"])
@@ -163,7 +174,7 @@ def conformer_block(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: O
 
 
 def encoder(src: Sequence[Tensor], sd, *, H: int, n_layers: int, L: int, q=_id, dtype=torch.float32,
-            taps: Optional[dict] = None) -> Tensor:
+            taps: Optional[dict] = None, bn_train: Optional[dict] = None) -> Tensor:
     """EmbeddingEncoderModule.forward (model :279-285) -> ConformerEncoder.forward (encoder.py:194-201)."""
     x = torch.nn.utils.rnn.pad_sequence([s.to(dtype) for s in src], padding_value=0.0, batch_first=True)
     T = x.shape[1]
@@ -173,7 +184,7 @@ def encoder(src: Sequence[Tensor], sd, *, H: int, n_layers: int, L: int, q=_id, 
                q, "enc.in")
     x = layer_norm(x, sd["enc.encoder.layer_norm.weight"], sd["enc.encoder.layer_norm.bias"])
     for i in range(n_layers):
-        x, _ = conformer_block(x, sd, f"enc.encoder.layers.{i}.", H, L, q)
+        x, _ = conformer_block(x, sd, f"enc.encoder.layers.{i}.", H, L, q, bn_train=bn_train)
         if taps is not None:
             taps[f"enc_l{i}"] = x
     return x
@@ -242,12 +253,13 @@ def ls_test(src: Sequence[Tensor], ilens: Sequence[int], sd, *, n_heads: int, en
 
 
 def ls_forward(src, tgt, ilens, sd, *, n_heads: int, enc_n_layers: int, dec_n_layers: int, chunk: int = 500,
-               conv_delay: int = 9, q=_id, dtype=torch.float32):
-    """OnlineConformerRetentionDADiarization.forward (model :74-122), eval numerics."""
+               conv_delay: int = 9, q=_id, dtype=torch.float32, bn_train: Optional[dict] = None):
+    """OnlineConformerRetentionDADiarization.forward (model :74-122); eval numerics unless ``bn_train`` is a dict
+    (train mode: the conv modules' BatchNorm uses batch statistics, see conv_module)."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     n_speakers = [t.shape[1] for t in tgt]
     C = max(n_speakers)
-    enc_out = encoder(src, sd, H=n_heads, n_layers=enc_n_layers, L=chunk, q=q, dtype=dtype)
+    enc_out = encoder(src, sd, H=n_heads, n_layers=enc_n_layers, L=chunk, q=q, dtype=dtype, bn_train=bn_train)
     emb = lookahead_conv_l2(enc_out, ilens, sd, chunk, conv_delay, q)
     attr = decoder(emb, C, sd, H=n_heads, n_layers=dec_n_layers, L=chunk, q=q)
     attr = attr / torch.linalg.vector_norm(attr, dim=-1, keepdim=True)
