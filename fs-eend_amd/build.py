@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["gemm.hip", "ffn.hip", "proj.hip", "attn.hip", "attn_full.hip", "attn_fused.hip", "spk_fused.hip", "embloss.hip", "postproc.hip", "feature.hip", "pit.hip", "misc.hip", "retention.hip", "retention_full.hip", "stream.hip", "skinny.hip", "api.hip",
            # training step: backward kernels, optimiser
-           "wgrad.hip", "attn_bwd.hip", "train_rows.hip", "embloss_bwd.hip", "optim.hip", "api_train.hip"]
+           "wgrad.hip", "attn_bwd.hip", "train_rows.hip", "embloss_bwd.hip", "optim.hip", "api_train.hip",
+           # LS-EEND training step
+           "ls_train.hip", "retention_bwd.hip"]
 LIB = os.path.join(CSRC, "libeend_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"]

@@ -246,6 +246,7 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
                              float* state_out, void* stream) {
     if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !St_ws || !kv_ws || !cscale_ws || !sexp_ws || L <= 0) return EEND_EINVAL;
     RetParams p;
+    memset(&p, 0, sizeof(p));
     p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws; p.kv_ws = kv_ws; p.kv_ws = kv_ws;
     // chunk sizes that fit on chip (500 in every shipped config) take the chunk-resident kernel, one block per
     // (chunk, head, sequence): there, chunks that start at or beyond T_valid (pure slab padding) are skipped

@@ -304,4 +304,162 @@ int eend_prep_weights(const eend_prep_entry* table, int n, void* stream) {
     return eend_launch_prep_weights(table, n, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LS-EEND training step
+// ---------------------------------------------------------------------------------------------------------------
+int eend_swish_dropout_f16(const void* z_f16, void* a_f16, long M, int F, const eend_dropout* drop, void* stream) {
+    return eend_launch_swish_drop_fwd(z_f16, a_f16, M, F, drop_spec(drop), (hipStream_t)stream);
+}
+
+int eend_swish_bwd_bf16(void* dz_bf16, const void* z_f16, long M, int F, const eend_dropout* drop, void* stream) {
+    return eend_launch_swish_bwd(dz_bf16, z_f16, M, F, drop_spec(drop), (hipStream_t)stream);
+}
+
+int eend_layernorm_train_f16(const float* x, const float* gamma, const float* beta, float eps, void* y_f16,
+                             void* xhat_f16, float* rstd, long M, void* stream) {
+    return eend_launch_layernorm_train(x, gamma, beta, eps, y_f16, xhat_f16, rstd, M, (hipStream_t)stream);
+}
+
+int eend_layernorm_bwd2_f32(const void* g, int g_is_bf16, const void* xhat_f16, const float* rstd, const float* gamma,
+                            float* ds_f32, int accumulate, void* ds_bf16, float alpha16, float* ws, long ws_floats,
+                            float* dgamma, float* dbeta, float* dbias, long M, const eend_dropout* drop, void* stream) {
+    if (!ws || !dgamma || !dbeta || ws_floats < 1024L * 768 || (dbias && !ds_bf16)) return EEND_EINVAL;
+    int nb = 0;
+    int rc = eend_launch_ln_bwd2(g, g_is_bf16, xhat_f16, rstd, gamma, ds_f32, accumulate, ds_bf16, alpha16, ws, &nb, M, drop_spec(drop),
+                                 (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, 768, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws + 256, 768, nb, 1, 256, 256, dbeta, 256, 1.0f, 0, (hipStream_t)stream);
+    if (rc != EEND_OK || !dbias) return rc;
+    return eend_launch_wgrad_reduce(ws + 512, 768, nb, 1, 256, 256, dbias, 256, 1.0f, 0, (hipStream_t)stream);
+}
+
+int eend_resgrad_cast_bf16(const float* g, void* ds_bf16, float alpha, float* ws, long ws_floats, float* dbias, long M,
+                           const eend_dropout* drop, void* stream) {
+    if (!ws || !dbias || ws_floats < 1024L * 256) return EEND_EINVAL;
+    int nb = 0;
+    int rc = eend_launch_resgrad_cast(g, ds_bf16, alpha, ws, &nb, M, drop_spec(drop), (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws, 256, nb, 1, 256, 256, dbias, 256, 1.0f, 0, (hipStream_t)stream);
+}
+
+int eend_linear_res_scale_ln_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                                       const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                                       float* out_f32, void* out_f16, void* xhat_f16, float* rstd, int M, int K,
+                                       const eend_dropout* drop, void* stream) {
+    if (!A || !W || !out_f32 || !out_f16 || !xhat_f16 || !rstd || !gamma || !beta) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, bias, M, 256, K);
+    p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
+    p.xhat16 = xhat_f16; p.rstat = rstd; p.drop = drop_spec(drop);
+    return eend_launch_gemm(p, EPI_RES_SCALE_LN16_TRAIN, (hipStream_t)stream);
+}
+
+int eend_glu_dwconv_f16(const void* P_f16, const float* w, void* c_f16, int nseq, int Tp, int Tv, int k, void* stream) {
+    return eend_launch_glu_dwconv_fwd(P_f16, w, c_f16, nseq, Tp, Tv, k, (hipStream_t)stream);
+}
+
+int eend_bn_batch_stats_f16(const void* c_f16, float* ws, long ws_floats, float* stats, int nseq, int Tp, int Tv,
+                            void* stream) {
+    if (!c_f16 || !ws || !stats || nseq <= 0 || Tv <= 0) return EEND_EINVAL;
+    long nb = ((long)nseq * Tv + 127) / 128;
+    if (nb > 1024) nb = 1024;
+    if (ws_floats < (nb + 1) * 256L) return EEND_EINVAL;
+    float* sum = ws + nb * 256L;
+    const float n = (float)((long)nseq * Tv);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = eend_launch_bn_colstats16(c_f16, nullptr, ws, nseq, Tp, Tv, (int)nb, st);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, 256, (int)nb, 1, 256, 256, sum, 256, 1.0f, 0, st);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_bn_local_mean(sum, n, stats, st);                  // stats[0..255] = mean, stats[512] = n
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_bn_colstats16(c_f16, stats, ws, nseq, Tp, Tv, (int)nb, st);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws, 256, (int)nb, 1, 256, 256, stats + 256, 256, 1.0f, 0, st);
+}
+
+int eend_bn_merge_f32(const float* stats, int R, float* mean, float* var, float* n_out, float* run_mean, float* run_var,
+                      float momentum, void* stream) {
+    return eend_launch_bn_merge(stats, R, mean, var, n_out, run_mean, run_var, momentum, (hipStream_t)stream);
+}
+
+int eend_bn_swish_f16(const void* c_f16, const float* mean, const float* var, float eps, const float* gamma,
+                      const float* beta, void* s_f16, long M, void* stream) {
+    return eend_launch_bn_swish_fwd(c_f16, mean, var, eps, gamma, beta, s_f16, M, (hipStream_t)stream);
+}
+
+int eend_bn_swish_bwd_stats_bf16(const void* ds_bf16, const void* c_f16, const float* mean, const float* var, float eps,
+                                 const float* gamma, const float* beta, float* ws, long ws_floats, float* sums,
+                                 float* dgamma, float* dbeta, int nseq, int Tp, int Tv, void* stream) {
+    if (!ws || !sums || !dgamma || !dbeta || nseq <= 0 || Tv <= 0) return EEND_EINVAL;
+    long nb = ((long)nseq * Tv + 127) / 128;
+    if (nb > 1024) nb = 1024;
+    if (ws_floats < nb * 512L) return EEND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = eend_launch_bn_swish_bwd_stats(ds_bf16, c_f16, mean, var, eps, gamma, beta, ws, nseq, Tp, Tv, (int)nb, st);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, 512, (int)nb, 1, 512, 512, sums, 512, 1.0f, 0, st);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce(ws, 512, (int)nb, 1, 512, 256, dbeta, 256, 1.0f, 0, st);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws + 256, 512, (int)nb, 1, 512, 256, dgamma, 256, 1.0f, 0, st);
+}
+
+int eend_bn_swish_bwd_apply_bf16(void* ds_bf16, const void* c_f16, const float* mean, const float* var, float eps,
+                                 const float* gamma, const float* beta, const float* sums, const float* n_dev, int nseq,
+                                 int Tp, int Tv, void* stream) {
+    return eend_launch_bn_swish_bwd_apply(ds_bf16, c_f16, mean, var, eps, gamma, beta, sums, n_dev, nseq, Tp, Tv, (hipStream_t)stream);
+}
+
+int eend_dwconv_glu_bwd_bf16(const void* dc_bf16, const void* P_f16, const float* w, void* dP_bf16, float* ws,
+                             long ws_floats, float* dw, int nseq, int Tp, int Tv, int k, void* stream) {
+    if (!ws || !dw || nseq <= 0 || Tp <= 0 || k <= 0) return EEND_EINVAL;
+    const long nblk = (long)nseq * ((Tp + 63) / 64);
+    if (ws_floats < nblk * 256L * k) return EEND_EINVAL;
+    int rc = eend_launch_dwconv_glu_bwd(dc_bf16, P_f16, w, dP_bf16, ws, nseq, Tp, Tv, k, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce(ws, 256L * k, (int)nblk, 256, k, k, dw, k, 1.0f, 0, (hipStream_t)stream);
+}
+
+int eend_retention_chunk_train_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
+                                   void* O_f16, void* rhat_f16, float* rc_out, void* St_ws, float* kv_ws, float* cscale_ws,
+                                   float* sexp_ws, int nseq, int H, int Tp, int L, int ldo, int ldg, float gn_eps,
+                                   int T_valid, void* stream) {
+    if (!Q || !K || !Kt || !Vt || !G || !O_f16 || !rhat_f16 || !rc_out || !St_ws || !kv_ws || !cscale_ws || !sexp_ws) return EEND_EINVAL;
+    if (L <= 0 || L > 512 || (L & 3) || (ldo & 7) || T_valid <= 0 || T_valid > Tp || (T_valid % L) != 0) return EEND_EINVAL;
+    RetParams p;
+    memset(&p, 0, sizeof(p));
+    p.Q = Q; p.K = K; p.Kt = Kt; p.Vt = Vt; p.G = G; p.O = O_f16; p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws; p.kv_ws = kv_ws;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = T_valid / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
+    p.Rhat = rhat_f16; p.Rc = rc_out;
+    int rc = eend_launch_ret_state_scan(p, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_ret_chunk_full(p, (hipStream_t)stream);
+}
+
+int eend_retention_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* Vt,
+                            const void* dctx_bf16, const void* g_f16, int ldg, const void* rhat_f16, const float* rc_in,
+                            void* ot_ws, void* ott_ws, float* kv_ws, float* g_ws, void* St_ws, void* dqkvg_bf16, int ldq,
+                            int nseq, int H, int Tp, int L, int T_valid, float sk, void* stream) {
+    if (!Q || !Qt || !K || !Kt || !V || !Vt || !dctx_bf16 || !g_f16 || !rhat_f16 || !rc_in || !ot_ws || !ott_ws || !kv_ws || !g_ws ||
+        !St_ws || !dqkvg_bf16)
+        return EEND_EINVAL;
+    if (H != 4 || L <= 0 || T_valid <= 0 || T_valid > Tp || (T_valid % L) != 0 || ldq < 1024 || (ldq & 7)) return EEND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nc = T_valid / L;
+    int rc = eend_launch_ret_gate_gn_bwd(dctx_bf16, g_f16, ldg, rhat_f16, rc_in, (__bf16*)dqkvg_bf16 + 768, ldq, ot_ws, nseq, Tp, T_valid, st);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_heads_transpose(ot_ws, 256, ott_ws, nseq, H, Tp, st);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_ret_bwd_states(Kt, Vt, Qt, ott_ws, kv_ws, g_ws, St_ws, nseq, H, Tp, L, nc, st);
+    if (rc != EEND_OK) return rc;
+    AttnBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.Q = Q; p.Qt = Qt; p.K = K; p.Kt = Kt; p.V = V; p.dO = ot_ws; p.dOt = ott_ws; p.dQKV = dqkvg_bf16;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = 256; p.ldg = ldq; p.mask_delay = 0; p.kv_len = T_valid; p.q_len = T_valid;
+    p.scale_log2 = 0.f; p.sq = 1.0f; p.sk = sk; p.drop = drop_spec(nullptr); p.L = L; p.nc = nc; p.St = St_ws;
+    return eend_launch_ret_bwd(p, st);
+}
+
 }  // extern "C"

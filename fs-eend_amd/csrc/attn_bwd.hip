@@ -29,6 +29,11 @@ constexpr int TILE = KB * 128;       // one [64][64] bf16 tile
 
 DEV int swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
+// RET: the same two kernels for the LS-EEND retention core (retention.py:146-194 with the detached scales folded into
+// dO = o~ = c_t * d out_t): no softmax -- "dS" is the masked A = o~ V^T itself and "P" the masked S = Q K^T -- the
+// mask is block-diagonal causal over chunks of p.L frames, and the cross-chunk terms come from the 64x64 states of
+// ret_bwd_scan_kernel (retention_bwd.hip):  dQ += o~ Spre^T,  dK += R v,  dV += R^T k.
+template <bool RET>
 __global__ __launch_bounds__(256, 2)
 void attn_bwd_dq_kernel(const AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K[2], V[2], K^T[2]
@@ -51,6 +56,11 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
     int last_key = q0 + 127 + p.mask_delay;
     last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
     const int ntiles = last_key < 0 ? 0 : last_key / KB + 1;
+    // RET: keys start at the chunk of the block's first query; per lane at its own chunk start cs_q
+    const int jt0 = RET ? ((q0 / p.L) * p.L) / KB : 0;
+    const int cs_q = RET ? (qc / p.L) * p.L : 0;
+    const int qw0c = qw0 < p.Tp - 1 ? qw0 : p.Tp - 1;
+    const int w_first_key = RET ? (qw0c / p.L) * p.L : 0;
 
     bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -58,7 +68,7 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
         qf[ks] = *(const bf16x8*)(Qg + (size_t)qc * 64 + ks * 16 + hi * 8);
         dof[ks] = *(const bf16x8*)(dOg + (size_t)qc * p.ldo + ks * 16 + hi * 8);
     }
-    const float L2 = p.Lse[sh * p.Tp + qc], Dq = p.Dh[sh * p.Tp + qc];
+    const float L2 = RET ? 0.f : p.Lse[sh * p.Tp + qc], Dq = RET ? 0.f : p.Dh[sh * p.Tp + qc];
 
     // staging by LDS-DMA (no staging registers): per 64-key tile 8 pieces each of K, V ([64 keys][128 B]) and K^T
     // ([64 d][128 B]), swz128 images via the per-lane source address; 6 pieces per wave
@@ -72,6 +82,7 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
             const int pc = wave * 6 + i_, kind = pc >> 3, sp = pc & 7;                                         \
             const int row = sp * 8 + r8, ch = c8 ^ ((row >> 1) & 7);                                           \
             char* dst = smem + (2 * kind + (buf)) * TILE + sp * 1024;                                          \
+            if (RET && kind == 0) continue;                                                                    \
             if (kind == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_char*)dst, 16, row * 128 + ch * 16, (j) * KB * 128, 0, 0); \
             else if (kind == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_char*)dst, 16, row * 128 + ch * 16, (j) * KB * 128, 0, 0); \
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_char*)dst, 16, row * p.Tp * 2 + ch * 16, (j) * KB * 2, 0, 0); \
@@ -82,14 +93,14 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dqT[0][i] = 0.f; dqT[1][i] = 0.f; }
 
-    if (ntiles > 0) DQ_DMA(0, 0);
+    if (ntiles > jt0) DQ_DMA(jt0, 0);
     const int krow = swap23(lq);
-    for (int j = 0; j < ntiles; ++j) {
-        const int buf = j & 1;
+    for (int j = jt0; j < ntiles; ++j) {
+        const int buf = (j - jt0) & 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile j landed; every wave is past the other buffer
         if (j + 1 < ntiles) DQ_DMA(j + 1, buf ^ 1);
         const int key0 = j * KB;
-        if (key0 <= qw0 + 31 + p.mask_delay) {
+        if (key0 <= qw0 + 31 + p.mask_delay && (!RET || key0 + KB - 1 >= w_first_key)) {
             const char* kb_ = smem + buf * TILE;
             const char* vb_ = smem + (2 + buf) * TILE;
             const char* tb_ = smem + (4 + buf) * TILE;
@@ -100,8 +111,10 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
                 for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                    if constexpr (!RET) {
+                        const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                    }
                     const bf16x8 vf = *(const bf16x8*)(vb_ + swz128(kb * 32 + krow, ks * 2 + hi));
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
                 }
@@ -113,10 +126,14 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3);
-                    const float pv = key <= lim ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], p.scale_log2, -L2)) : 0.f;
-                    // forward: O = (P o keep * scale) V  ->  dP = (dO V^T) o keep * scale
-                    const float dpe = drop_apply(p.drop, dp[kb][i], (unsigned)(sh * p.Tp + qc), (unsigned)key);
-                    s[kb][i] = pv * (dpe - Dq);
+                    if constexpr (RET) {
+                        s[kb][i] = (key <= lim && key >= cs_q) ? dp[kb][i] : 0.f;       // A^T = V o~^T, block-diagonal causal
+                    } else {
+                        const float pv = key <= lim ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], p.scale_log2, -L2)) : 0.f;
+                        // forward: O = (P o keep * scale) V  ->  dP = (dO V^T) o keep * scale
+                        const float dpe = drop_apply(p.drop, dp[kb][i], (unsigned)(sh * p.Tp + qc), (unsigned)key);
+                        s[kb][i] = pv * (dpe - Dq);
+                    }
                 }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -134,6 +151,38 @@ void attn_bwd_dq_kernel(const AttnBwdParams p) {
         }
     }
 #undef DQ_DMA
+    if constexpr (RET) {
+        // cross-chunk term dQ^T += Spre_c o~^T for every chunk c the wave's rows belong to (prefix state, hi/lo bf16)
+        const int c_lo = qw0c / p.L;
+        int wq_last = qw0 + 31;
+        wq_last = wq_last < p.Tp - 1 ? wq_last : p.Tp - 1;
+        const int c_hi = wq_last / p.L, c_q = qc / p.L;
+        for (int c = c_lo; c <= c_hi; ++c) {
+            if (c == 0 || c >= p.nc) continue;
+            const __bf16* __restrict__ Sg = (const __bf16*)p.St + ((sh * p.nc + c) * 6) * 4096;
+            const bool mine = (c_q == c);
+            f32x16 x[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { x[0][i] = 0.f; x[1][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 om = dof[ks];
+                if (!mine) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) om[jj] = (__bf16)0.f;
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 sa = *(const bf16x8*)(Sg + (db * 32 + lq) * 64 + ks * 16 + hi * 8);
+                    const bf16x8 sb = *(const bf16x8*)(Sg + 4096 + (db * 32 + lq) * 64 + ks * 16 + hi * 8);
+                    x[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, om, x[db], 0, 0, 0);
+                    x[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb, om, x[db], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dqT[0][i] += x[0][i]; dqT[1][i] += x[1][i]; }
+        }
+    }
     // dQ[q][h*64 + d] = sq * dQ^T[d][q]; reg i of dqT[db] <-> d = db*32 + 8*(i>>2) + 4*hi + (i&3)
     if (q < p.Tp) {
         __bf16* __restrict__ out = (__bf16*)p.dQKV + ((size_t)seq * p.Tp + q) * p.ldg + h * 64;
@@ -165,6 +214,7 @@ constexpr int DKV_STAGE = 2 * DKV_SUB + 2048;
 #endif
 constexpr int DKV_NW = EEND_DKV_WAVES;
 
+template <bool RET>
 __global__ __launch_bounds__(DKV_NW * 64, DKV_NW == 4 ? 2 : 1)
 void attn_bwd_dkv_kernel(const AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];         // 2 stages x 34 KB: two workgroups per CU
@@ -189,9 +239,21 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
     asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
 
     int qlim = p.q_len < p.Tp ? p.q_len : p.Tp;
-    const int nqb = (qlim + 31) / 32;
     int qstart = k0 - p.mask_delay;
     if (qstart < 0) qstart = 0;
+    int qend = qlim;
+    int ce_key = p.Tp, w_ce = p.Tp;                    // RET: first frame after the chunk of this lane's key / of the wave's last key
+    if constexpr (RET) {
+        int k_last = k0 + DKV_NW * 32 - 1;
+        k_last = k_last < p.Tp - 1 ? k_last : p.Tp - 1;
+        const int be = (k_last / p.L + 1) * p.L;       // queries beyond the chunk of the block's last key see none of its keys
+        qend = be < qlim ? be : qlim;
+        ce_key = (keyc / p.L + 1) * p.L;
+        int kwl = kw0 + 31;
+        kwl = kwl < p.Tp - 1 ? kwl : p.Tp - 1;
+        w_ce = (kwl / p.L + 1) * p.L;
+    }
+    const int nqb = (qend + 31) / 32;
     const int st0 = qstart / 64, nst = (nqb + 1) / 2;  // stages of 64 queries
 
     // 34 DMA pieces of 1 KB per stage: per sub-block 4 (Q) + 4 (dO) + 4 (Q^T) + 4 (dO^T), then L and D; 8 per wave (+2 on
@@ -223,7 +285,7 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rdot, (lds_char*)dst, 16, d * p.Tp * 2 + ch * 16, q0 * 2, 0, 0);
             }
         }
-        if (wave == 0) {                               // 64 floats each: lanes 0..15 carry them, the rest re-read in range
+        if (!RET && wave == 0) {                       // 64 floats each: lanes 0..15 carry them, the rest re-read in range
             const int off = (lane & 15) * 16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_char*)(base + 2 * DKV_SUB), 16, off, st * 256, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_char*)(base + 2 * DKV_SUB + 1024), 16, off, st * 256, 0, 0);
@@ -244,7 +306,7 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int qw0 = st * 64 + u * 32;
-            if (!(active && qw0 < qlim && kw0 <= qw0 + 31 + p.mask_delay)) continue;
+            if (!(active && qw0 < qlim && kw0 <= qw0 + 31 + p.mask_delay && (!RET || qw0 < w_ce))) continue;
             const char* b_ = sb + u * DKV_SUB;
             f32x16 s, dp;
 #pragma unroll
@@ -262,15 +324,20 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
             for (int g = 0; g < 2; ++g) {
                 const float* lp = (const float*)(sb + 2 * DKV_SUB) + u * 32 + 16 * g + 8 * hi;
                 const float* dpt = (const float*)(sb + 2 * DKV_SUB + 1024) + u * 32 + 16 * g + 8 * hi;
-                const float4 a0 = *(const float4*)lp, a1 = *(const float4*)(lp + 4);
-                const float4 d0 = *(const float4*)dpt, d1 = *(const float4*)(dpt + 4);
+                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, d0 = a0, d1 = a0;
+                if constexpr (!RET) { a0 = *(const float4*)lp; a1 = *(const float4*)(lp + 4); d0 = *(const float4*)dpt; d1 = *(const float4*)(dpt + 4); }
                 const float l2v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = g * 8 + e;
                     const int qi = qw0 + e + 8 * hi + 16 * g;
-                    const bool ok = key <= qi + p.mask_delay && key < p.kv_len && qi < qlim;
+                    const bool ok = key <= qi + p.mask_delay && key < p.kv_len && qi < qlim && (!RET || qi < ce_key);
+                    if constexpr (RET) {                           // P := masked S = Q K^T, dS := masked A = o~ V^T
+                        pf[g][e] = (__bf16)(ok ? s[r] : 0.f);
+                        sf[g][e] = (__bf16)(ok ? dp[r] : 0.f);
+                        continue;
+                    }
                     const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_log2, -l2v[e])) : 0.f;
                     float kfac = 1.0f;                             // the forward's dropout factor of this (query, key) pair
                     if (p.drop.thresh24) kfac = drop_keep(p.drop, (unsigned)(sh * p.Tp + qi), (unsigned)key) ? p.drop.scale : 0.f;
@@ -287,6 +354,35 @@ void attn_bwd_dkv_kernel(const AttnBwdParams p) {
                     const bf16x8 qt = *(const bf16x8*)(b_ + 8192 + swz64(db * 32 + lq, kk * 2 + hi));
                     dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf[kk], dkT[db], 0, 0, 0);
                 }
+        }
+    }
+    if constexpr (RET) {
+        // cross-chunk terms from the queries of later chunks: dK^T += R_c V^T, dV^T += R_c^T K^T (suffix state, hi/lo bf16)
+        if (active) {
+            int kwl = kw0 + 31;
+            kwl = kwl < p.Tp - 1 ? kwl : p.Tp - 1;
+            const int c_lo = kw0 / p.L, c_hi = kwl / p.L, c_k = keyc / p.L;
+            for (int c = c_lo; c <= c_hi; ++c) {
+                if (c >= p.nc - 1) continue;                   // no later chunk (or slab padding beyond the last chunk)
+                const __bf16* __restrict__ Rg = (const __bf16*)p.St + ((sh * p.nc + c) * 6 + 2) * 4096;
+                const bool mine = (c_k == c);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 vm = vf[ks], km = kf[ks];
+                    if (!mine) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) { vm[jj] = (__bf16)0.f; km[jj] = (__bf16)0.f; }
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int off = (db * 32 + lq) * 64 + ks * 16 + hi * 8;
+                        dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Rg + off), vm, dkT[db], 0, 0, 0);
+                        dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Rg + 4096 + off), vm, dkT[db], 0, 0, 0);
+                        dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Rg + 2 * 4096 + off), km, dvT[db], 0, 0, 0);
+                        dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Rg + 3 * 4096 + off), km, dvT[db], 0, 0, 0);
+                    }
+                }
+            }
         }
     }
     // dK[key][h*64 + d], dV likewise; reg i <-> d = db*32 + 8*(i>>2) + 4*hi + (i&3)
@@ -334,15 +430,35 @@ int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) || (p.ldo & 7) || (p.ldg & 3) || p.kv_len <= 0 ||
         p.kv_len > p.Tp || p.q_len <= 0)
         return EEND_EINVAL;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE) != hipSuccess)
             return EEND_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.Tp + DKV_NW * 32 - 1) / (DKV_NW * 32), p.H, p.nseq), dim3(DKV_NW * 64), 2 * DKV_STAGE, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((p.Tp + DKV_NW * 32 - 1) / (DKV_NW * 32), p.H, p.nseq), dim3(DKV_NW * 64), 2 * DKV_STAGE, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+// Retention core backward (see the RET note above): p.dO = o~ (bf16 rows), p.dOt its head-transposed copy, p.St the
+// states of ret_bwd_scan_kernel, p.L / p.nc the chunking; only query / key tiles inside the nc * L valid frames run.
+int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream) {
+    if (!p.Q || !p.Qt || !p.K || !p.Kt || !p.V || !p.dO || !p.dOt || !p.St || !p.dQKV) return EEND_EINVAL;
+    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) || (p.ldo & 7) || (p.ldg & 3) || p.L <= 0 || p.nc <= 0 ||
+        (long)p.nc * p.L > p.Tp || p.mask_delay != 0 || p.kv_len != p.nc * p.L || p.q_len != p.nc * p.L)
+        return EEND_EINVAL;
+    // full-slab grids: the blocks beyond the nc * L valid frames only write the zero rows of dQKV
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
+    if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE) != hipSuccess)
+            return EEND_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((p.Tp + DKV_NW * 32 - 1) / (DKV_NW * 32), p.H, p.nseq), dim3(DKV_NW * 64), 2 * DKV_STAGE, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

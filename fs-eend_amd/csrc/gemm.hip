@@ -348,12 +348,14 @@ void gemm_f16_kernel(const GemmParams p) {
             }
         }
     } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE || EPI == EPI_RES_SCALE_LN16 ||
-                         EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN) {
+                         EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN || EPI == EPI_RES_SCALE_LN16_TRAIN) {
         // The block owns complete rows (BN == N, WGM == 1): per-token statistics.
         static_assert(SWAP && WGM == 1, "row-stat epilogues expect SWAP and one wave row");
-        constexpr bool LNK = (EPI == EPI_RES_LN || EPI == EPI_RES_LN_TRAIN || EPI == EPI_RES_SCALE_LN16);   // LayerNorm
+        constexpr bool LNK = (EPI == EPI_RES_LN || EPI == EPI_RES_LN_TRAIN || EPI == EPI_RES_SCALE_LN16 ||
+                              EPI == EPI_RES_SCALE_LN16_TRAIN);                                             // LayerNorm
+        constexpr bool PRENORM = (EPI == EPI_RES_SCALE_LN16 || EPI == EPI_RES_SCALE_LN16_TRAIN);  // out32 stays un-normalised
         constexpr bool L2K = (EPI == EPI_L2NORM || EPI == EPI_L2NORM_TRAIN);                               // x / ||x||
-        constexpr bool TRAINK = (EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN);  // also save the row statistics
+        constexpr bool TRAINK = (EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN || EPI == EPI_RES_SCALE_LN16_TRAIN);  // also save the row statistics
         using O16 = decltype(OutCvt<ET>::cvt(0, 0, 0, 0));
         float* red = (float*)smem;                        // [WGN][BM] (main loop is done with LDS)
         float4 bias4[FR];
@@ -371,7 +373,7 @@ void gemm_f16_kernel(const GemmParams p) {
                 if (!L2K && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
                 const float s = L2K ? 1.0f : p.alpha;
                 float a0 = acc[i][j][0] + bias4[i].x, a1 = acc[i][j][1] + bias4[i].y, a2 = acc[i][j][2] + bias4[i].z, a3 = acc[i][j][3] + bias4[i].w;
-                if constexpr (EPI == EPI_RES_LN_TRAIN) {
+                if constexpr (EPI == EPI_RES_LN_TRAIN || EPI == EPI_RES_SCALE_LN16_TRAIN) {
                     if (p.drop.thresh24) {                  // dropout of the sub-layer output (dropout1 / dropout2 / dropout11 / ...)
                         const unsigned n = (unsigned)(R0 + i * 16);
                         a0 = drop_apply(p.drop, a0, (unsigned)m, n); a1 = drop_apply(p.drop, a1, (unsigned)m, n + 1);
@@ -475,7 +477,7 @@ void gemm_f16_kernel(const GemmParams p) {
                     if constexpr (TRAINK && LNK)            // normalised, pre-affine row: what LayerNorm backward needs
                         xh16[i][j] = OutCvt<ET>::cvt((acc[i][j][0] - mean[j]) * scale[j], (acc[i][j][1] - mean[j]) * scale[j],
                                                      (acc[i][j][2] - mean[j]) * scale[j], (acc[i][j][3] - mean[j]) * scale[j]);
-                    *(f32x4*)(stg + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = EPI == EPI_RES_SCALE_LN16 ? acc[i][j] : v;
+                    *(f32x4*)(stg + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = PRENORM ? acc[i][j] : v;
                 }
             }
             __syncthreads();
@@ -542,7 +544,7 @@ void gemm_f16_kernel(const GemmParams p) {
                 const float v1 = (acc[i][j][1] - mean[j]) * scale[j] * g.y + be.y;
                 const float v2 = (acc[i][j][2] - mean[j]) * scale[j] * g.z + be.z;
                 const float v3 = (acc[i][j][3] - mean[j]) * scale[j] * g.w + be.w;
-                if (EPI == EPI_RES_SCALE_LN16) {           // residual stream stays un-normalised
+                if (PRENORM) {                             // residual stream stays un-normalised
                     if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 } else if (o32) *(float4*)(o32 + (size_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
                 if (o16) *(O16*)(o16 + (size_t)m * p.ldo + n) = OutCvt<ET>::cvt(v0, v1, v2, v3);
@@ -660,6 +662,9 @@ int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
         case EPI_RES_LN_TRAIN:
             if (p.N != 256) return EEND_EINVAL;
             return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN_TRAIN>(p, stream);
+        case EPI_RES_SCALE_LN16_TRAIN:
+            if (p.N != 256 || p.ldo != 256) return EEND_EINVAL;
+            return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE_LN16_TRAIN>(p, stream);
         case EPI_RES_SCALE_LN16:
             if (p.N != 256) return EEND_EINVAL;
             return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE_LN16>(p, stream);

@@ -27,6 +27,8 @@ enum GemmEpilogue {
     EPI_F32_ROWMASK = 15,    // out32[m][n] = acc for frames t < mask_lens[seq], else 0 (ALOAD_CONV: Conv1d data gradient)
     EPI_RES_LN_TRAIN = 16,   // EPI_RES_LN that also saves x_hat (xhat16) and 1/sigma (rstat) of every row
     EPI_L2NORM_TRAIN = 17,   // EPI_L2NORM that also saves 1/||x|| (rstat)
+    EPI_RES_SCALE_LN16_TRAIN = 18,  // EPI_RES_SCALE_LN16 (pre-norm residual blocks, LS-EEND Conformer) with dropout of
+                                    // (acc + bias) and x_hat / 1/sigma of the LayerNorm saved
 };
 
 struct GemmParams {
@@ -124,6 +126,10 @@ struct RetParams {
     float gn_eps;
     const float* state_in;   // optional: unscaled chunk state S = sum k (x) v before the first chunk, f32 [nseq][H][64 kd][64 hd]
     float* state_out;        // optional: the state after the last chunk (same layout)
+    // training forward (chunk-resident kernel only): what the backward needs of the per-head LayerNorm and the scale
+    void* Rhat;              // optional f16 [nseq*Tp][ldo]: normalised retention rows (before the gate)
+    float* Rc;               // optional f32 [nseq*Tp][H]: 1/sigma of the per-head LayerNorm times the detached row scale
+                             // 1/(sqrt(i+1) * max(inner_scale, cross_scale)) (retention.py:163,185 -- no gradient flows into it)
 };
 
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
@@ -269,8 +275,14 @@ struct AttnBwdParams {        // attn_bwd.hip
     float scale_log2;         // as the forward
     float sq, sk;             // output scales of dQ and dK
     DropSpec drop;            // the forward's probability dropout
+    // retention variant (eend_launch_ret_bwd): chunk length, number of valid chunks, states of ret_bwd_scan_kernel
+    int L, nc;
+    const void* St;           // bf16 [nseq][H][nc][6][64][64]: Spre hi/lo [kd][hd], R hi/lo [kd][hd], R^T hi/lo [hd][kd]
 };
 int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream);
+int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream);
+int eend_launch_ret_bwd_states(const void* Kt, const void* Vt, const void* Qt, const void* dOt, float* kv_ws, float* g_ws, void* St,
+                               int nseq, int H, int Tp, int L, int nc, hipStream_t stream);
 int eend_launch_heads_transpose(const void* in, int ld, void* out, int nseq, int H, int Tp, hipStream_t stream);
 
 int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, const float* gamma, float* ds32, void* ds16,
@@ -299,3 +311,32 @@ int eend_launch_scalar_sum(const float* partial, long n, float scale, float* out
 int eend_launch_adam(float* p, const float* g, float* m, float* v, long n, const float* hp, const float* gsumsq, float b1, float b2,
                      float eps, hipStream_t stream);
 int eend_launch_prep_weights(const PrepEntry* tab, int n_entries, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------
+// LS-EEND training step (ls_train.hip, retention_bwd.hip)
+// ---------------------------------------------------------------------------------------------------
+int eend_launch_swish_drop_fwd(const void* z16, void* a16, long M, int F, DropSpec drop, hipStream_t stream);
+int eend_launch_swish_bwd(void* dz16, const void* z16, long M, int F, DropSpec drop, hipStream_t stream);
+int eend_launch_layernorm_train(const float* x, const float* gamma, const float* beta, float eps, void* y16, void* xhat16, float* rstd,
+                                long M, hipStream_t stream);
+int eend_launch_ln_bwd2(const void* g, int g_is_bf16, const void* xhat16, const float* rstd, const float* gamma, float* ds32,
+                        int accumulate, void* ds16, float alpha16, float* partial, int* nblocks_out, long M, DropSpec drop,
+                        hipStream_t stream);
+int eend_launch_resgrad_cast(const float* g, void* ds16, float alpha, float* partial, int* nblocks_out, long M, DropSpec drop,
+                             hipStream_t stream);
+int eend_launch_glu_dwconv_fwd(const void* P16, const float* w, void* c16, int nseq, int Tp, int Tv, int k, hipStream_t stream);
+int eend_launch_bn_colstats16(const void* c16, const float* shift, float* partial, int nseq, int Tp, int Tv, int nblocks,
+                              hipStream_t stream);
+int eend_launch_bn_local_mean(const float* sum, float n, float* stats, hipStream_t stream);
+int eend_launch_bn_merge(const float* stats, int R, float* mean, float* var, float* n_out, float* run_mean, float* run_var, float momentum,
+                         hipStream_t stream);
+int eend_launch_bn_swish_fwd(const void* c16, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                             void* s16, long M, hipStream_t stream);
+int eend_launch_bn_swish_bwd_stats(const void* ds16, const void* c16, const float* mean, const float* var, float eps, const float* gamma,
+                                   const float* beta, float* partial, int nseq, int Tp, int Tv, int nblocks, hipStream_t stream);
+int eend_launch_bn_swish_bwd_apply(void* ds16, const void* c16, const float* mean, const float* var, float eps, const float* gamma,
+                                   const float* beta, const float* sums, const float* n_dev, int nseq, int Tp, int Tv, hipStream_t stream);
+int eend_launch_dwconv_glu_bwd(const void* dc16, const void* P16, const float* w, void* dP16, float* partial, int nseq, int Tp, int Tv,
+                               int k, hipStream_t stream);
+int eend_launch_ret_gate_gn_bwd(const void* dctx16, const void* g16, int ldg, const void* rhat16, const float* rc, void* dg16, int ldq,
+                                void* ot16, int nseq, int Tp, int Tv, hipStream_t stream);

@@ -222,6 +222,31 @@ void ret_chunk_full_kernel(const RetParams p) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (p.Rhat) {
+            // training forward: the normalised rows (input of the gate) and, per (row, head), 1/sigma times the detached
+            // row scale f -- d out_t / d (q_t . prefix) = f exactly because the reference detaches inner_scale / kv_scale
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = to_f16_sat((oT[db][g * 4 + r] - mean) * rstd);
+                    *(f16x4*)(Ow + lq * 128 + (((db * 4 + g) ^ (lq & 7)) << 4) + hi * 8) = o;
+                }
+            __builtin_amdgcn_wave_barrier();
+            _Float16* __restrict__ Rg = (_Float16*)p.Rhat + ((size_t)seq * p.Tp + f0 + qw0) * p.ldo + h * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                if (qw0 + row < n) {
+                    const uint4 v = *(const uint4*)(Ow + row * 128 + ((ch ^ (row & 7)) << 4));
+                    *(uint4*)(Rg + (size_t)row * p.ldo + ch * 8) = v;
+                }
+            }
+            if (p.Rc && hi == 0 && q < n) p.Rc[((size_t)seq * p.Tp + f0 + q) * p.H + h] = rstd * f;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 

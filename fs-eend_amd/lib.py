@@ -79,6 +79,22 @@ PROTOTYPES = {
     "eend_grad_sumsq_f32": [_vp, _l, _vp, _l, _vp, _vp],
     "eend_adam_step_f32": [_vp] * 4 + [_l, _vp, _vp, _f, _f, _f, _vp],
     "eend_prep_weights": [_vp, _i, _vp],
+    # ---- LS-EEND training step
+    "eend_swish_dropout_f16": [_vp, _vp, _l, _i, _vp, _vp],
+    "eend_swish_bwd_bf16": [_vp, _vp, _l, _i, _vp, _vp],
+    "eend_layernorm_train_f16": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _l, _vp],
+    "eend_layernorm_bwd2_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp],
+    "eend_resgrad_cast_bf16": [_vp, _vp, _f, _vp, _l, _vp, _l, _vp, _vp],
+    "eend_linear_res_scale_ln_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "eend_glu_dwconv_f16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "eend_bn_batch_stats_f16": [_vp, _vp, _l, _vp, _i, _i, _i, _vp],
+    "eend_bn_merge_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp],
+    "eend_bn_swish_f16": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _l, _vp],
+    "eend_bn_swish_bwd_stats_bf16": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "eend_bn_swish_bwd_apply_bf16": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "eend_dwconv_glu_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _vp],
+    "eend_retention_chunk_train_f16": [_vp] * 12 + [_i] * 6 + [_f, _i, _vp],
+    "eend_retention_bwd_bf16": [_vp] * 8 + [_i, _vp, _vp] + [_vp] * 6 + [_i] * 6 + [_f, _vp],
 }
 
 

@@ -65,22 +65,20 @@ def pit_loss_multispk(logits, target, n_speakers, detach_attractor_loss=False):
     return [t[:, perm[b].to(t.device)][: logits[b].shape[0], : int(n)] for b, (t, n) in enumerate(zip(tl, n_speakers))]
 
 
+def _widen(t, width):
+    extra = width - t.shape[1]
+    if extra < 0:
+        raise ValueError(f"{t.shape[1]} speaker columns do not fit into {width}")
+    return t if extra == 0 else torch.cat([t, t.new_zeros(t.shape[0], extra)], dim=1)
+
+
 def pad_labels(ts, out_size):
-    for i, t in enumerate(ts):
-        if t.shape[1] < out_size:
-            ts[i] = F.pad(t, (0, out_size - t.shape[1], 0, 0), mode="constant", value=0.)
-        elif t.shape[1] > out_size:
-            raise ValueError
+    """Zero-extend every (T_i, n_i) label tensor to `out_size` speaker columns.  Like the reference helper
+    (train/utils/loss.py:47-57) the list is updated in place and returned; too many columns is a ValueError."""
+    ts[:] = [_widen(t, out_size) for t in ts]
     return ts
 
 
 def pad_preds(ys, out_size):
-    out = []
-    for y in ys:
-        if y.shape[1] < out_size:
-            out.append(torch.cat([y, torch.zeros((y.shape[0], out_size - y.shape[1]), dtype=y.dtype, device=y.device)], dim=1))
-        elif y.shape[1] > out_size:
-            raise ValueError
-        else:
-            out.append(y)
-    return out
+    """Zero-extend every (T_i, n_i) logit tensor to `out_size` columns into a new list (train/utils/loss.py:59-72)."""
+    return [_widen(y, out_size) for y in ys]

@@ -176,14 +176,12 @@ class _Buffers:
         self.loss = torch.zeros(4, dtype=F32, device=dev)         # [bce, emb, -, -]
 
 
-class FsTrainStep:
-    """One training step of FS-EEND (`OnlineTransformerDADiarization` mirror) entirely in HIP."""
+class TrainStepBase:
+    """What the FS-EEND and LS-EEND training steps share: the flat parameter / gradient / Adam buffers, the weight
+    re-layout table, dropout site bookkeeping, the generic backward helpers (LayerNorm, ReLU FFN, bias / weight
+    gradients), the data-parallel gradient exchange and the optimiser."""
 
-    def __init__(self, model, warmup: int = 100000, lr: float = 1.0, schedule_scale: float = 1.0, grad_clip: float = 5.0,
-                 betas=(0.9, 0.98), eps: float = 1e-9, bn_momentum: float = 0.1, process_group=None, drop_seed: int = 0):
-        from .fs_model import OnlineTransformerDADiarization
-        if not isinstance(model, OnlineTransformerDADiarization):
-            raise TypeError("FsTrainStep drives fs_eend_amd.fs_model.OnlineTransformerDADiarization")
+    def _init_common(self, model, warmup, lr, schedule_scale, grad_clip, betas, eps, bn_momentum, process_group, drop_seed):
         ps = set()
         for name, mod in model.named_modules():
             if name.endswith("pos_enc.dropout") or name.endswith("pos_encoder.dropout"):
@@ -199,9 +197,8 @@ class FsTrainStep:
             raise ValueError("dropout ratio must be in [0, 1)")
         self.drop_seed = int(drop_seed) & 0xFFFFFFFF
         self._fwd_count = 0
-        if model.enc.mask_delay != model.dec.mask_delay:
-            raise NotImplementedError
         self.model = model
+        # warmup None: no scheduler -- the optimiser runs at the constant configured lr (train_dia.py:95-100, scheduler = None)
         self.warmup, self.base_lr, self.sched_scale, self.clip = warmup, lr, schedule_scale, grad_clip
         self.b1, self.b2, self.eps, self.bn_momentum = betas[0], betas[1], eps, bn_momentum
         self.opt_step = 0
@@ -212,43 +209,222 @@ class FsTrainStep:
         self.ws = torch.empty(WS_FLOATS, dtype=F32, device=dev)
         self.hp = torch.zeros(4, dtype=F32, device=dev)
         self.gsumsq = torch.zeros(1, dtype=F32, device=dev)
-        self._hp_host = torch.zeros(4, dtype=F32).pin_memory()
-        self._bufs: Dict[tuple, _Buffers] = {}
+        # hyper-parameters travel through a RING of pinned host buffers: a slot is rewritten only after the async copy
+        # that read it has completed (event), so queuing several steps ahead of the GPU never races the H2D copy
+        self._hp_ring = [torch.zeros(4, dtype=F32).pin_memory() for _ in range(8)]
+        self._hp_events = [None] * 8
+        self._bufs = {}
         self._ptr_tables = {}
-        self._build_weight_table()
         self.last = {}
+
+    # ------------------------------------------------------------------ weight re-layout table
+    def _table_begin(self):
+        self.W, self._entries = {}, []
+
+    def _add_entry(self, dst: Tensor, dst_off_elems: int, pname: str, dims, strides, dtype, off=0, cpad=None, nscale=0, scale=1.0):
+        """dst[a][b][c] (contiguous A x B x Cpad at dst + dst_off_elems) = convert(params[off(pname) + off + a*sa + b*sb + c*sc])."""
+        A, B_, C_ = dims
+        e = _lib.PrepEntry()
+        e.src = self.flat.params.data_ptr()
+        e.off = self.flat.offsets[pname] + off
+        e.dst = dst.data_ptr() + dst_off_elems * dst.element_size()
+        e.A, e.B, e.C, e.Cpad = A, B_, C_, C_ if cpad is None else cpad
+        e.sa, e.sb, e.sc = strides
+        e.dtype, e.nscale, e.scale, e.reserved = dtype, nscale, float(scale), 0
+        self._entries.append(e)
+
+    def _add(self, key, pname, dims, strides, dtype, off=0, cpad=None, nscale=0, scale=1.0, alloc=None):
+        A, B_, C_ = dims
+        cpad = C_ if cpad is None else cpad
+        dt = {0: F16, 1: BF16, 2: F32}[dtype]
+        shape = alloc if alloc is not None else (A * B_, cpad)
+        t = torch.zeros(*shape, dtype=dt, device=self.dev)
+        self.W[key] = t
+        self._add_entry(t, 0, pname, dims, strides, dtype, off=off, cpad=cpad, nscale=nscale, scale=scale)
+        return t
+
+    def _plain(self, key, pname, N, K, dtype=0, kpad=None, nscale=0, scale=1.0):        # [N][K] row-major copy
+        return self._add(key, pname, (N, 1, K), (K, 0, 1), dtype, cpad=kpad, nscale=nscale, scale=scale)
+
+    def _transposed(self, key, pname, N, K, ld=None, rows_alloc=None):                 # bf16 [K][N]: dst[k][n] = W[n][k]
+        ld = K if ld is None else ld
+        return self._add(key, pname, (K, 1, N), (1, 0, ld), 1, alloc=(rows_alloc or K, N))
+
+    def _vec(self, key, pname, n, nscale=0, scale=1.0):
+        return self._add(key, pname, (n, 1, 1), (1, 0, 0), 2, nscale=nscale, scale=scale, alloc=(n,))
+
+    def _table_end(self):
+        arr = (_lib.PrepEntry * len(self._entries))(*self._entries)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._table = raw.to(self.dev)
+        self._n_entries = len(self._entries)
+
+    def prep_weights(self):
+        """f32 parameters -> MFMA operand copies (one launch)."""
+        _call("eend_prep_weights", self._table, self._n_entries)
+
+    # ------------------------------------------------------------------ helpers
+    def _table_for(self, srcs, T):
+        key = tuple((s.data_ptr(), s.shape[0]) for s in srcs)
+        tab = self._ptr_tables.get(key)
+        if tab is None:
+            if len(self._ptr_tables) > 64:
+                self._ptr_tables.clear()
+            tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=self.dev),
+                   torch.tensor([min(k[1], T) for k in key], dtype=I32, device=self.dev))
+            self._ptr_tables[key] = tab
+        return tab
+
+    def _P(self, name):          # f32 parameter view
+        return self.flat.p(name)
+
+    def _G(self, name):          # f32 gradient view
+        return self.flat.g(name)
+
+    def _drop(self, bf, site: int):
+        """eend_dropout of one site for the forward that filled `bf` (None <=> no dropout): the seed is a hash of
+        (drop_seed, forward count, site id), so the backward asks for the same spec and gets the same mask."""
+        if bf.drop_base is None:
+            return None
+        spec = bf.drop_specs.get(site)
+        if spec is None:
+            spec = _lib.Dropout(drop_site_seed(bf.drop_base, site), int(round(self.drop_p * (1 << 24))), 1.0 / (1.0 - self.drop_p))
+            bf.drop_specs[site] = spec
+        return ctypes.byref(spec)
+
+    def _linear_ln(self, a16, w, bias, res, ln, site, out32, M, K, drop=None, alpha=1.0):
+        _call("eend_linear_res_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, res, alpha, self._P(ln + ".weight"),
+              self._P(ln + ".bias"), 1e-5, out32, site.out16, site.xhat, site.rstd, M, K, drop)
+
+    def _linear_relu(self, a16, w, bias, out16, drop=None):
+        M, K = a16.shape
+        N = out16.shape[1]
+        _call("eend_linear_relu_train_f16", a16, a16.stride(0), w, w.stride(0), bias, out16, out16.stride(0), M, N, K, drop)
+
+    def _bias_grad(self, dy16, M, N, gname, scale=1.0):
+        _call("eend_colsum_f32", dy16, dy16.stride(0), M, N, 1, self.ws, WS_FLOATS, self._G(gname), scale, 0)
+
+    def _wgrad(self, dy16, x, M, N, K, gname, x_is_f16=True, ld_out=None, k_out=None, goff=0, scale=1.0):
+        g = self._G(gname).view(-1)[goff:]
+        _call("eend_wgrad_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS, g,
+              K if ld_out is None else ld_out, K if k_out is None else k_out, scale, 0)
+
+    def _ln_bwd(self, g32, site, ln, ds16, M, drop=None, bias=None):
+        """`drop`: the spec of the sub-layer output dropout in front of this LayerNorm's residual sum -- the bf16 branch
+        gradient ds16 gets the mask, the f32 residual-stream gradient g32 does not.  `bias`: the bias parameter of the
+        linear layer in front of the LayerNorm; its gradient (the column sums of ds16) comes out of the same pass."""
+        _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
+              self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, drop)
+
+    def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm, drop_scale=1.0):
+        """backward of x -> LN(x + W2 relu(W1 x + b1) + b2); g32 in/out (gradient w.r.t. output -> w.r.t. x)."""
+        W = self.W
+        Fh = hid.shape[1]
+        dh = dh16[:M * Fh].view(M, Fh)
+        self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
+        _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D, drop_scale)
+        self._bias_grad(dh, M, Fh, p_ + "linear1.bias")
+        self._wgrad(dh, x_in16, M, Fh, D, p_ + "linear1.weight")
+        _call("eend_gemm_acc_bf16", dh, Fh, W[wkey + ".w1T"], Fh, g32, 1.0, g32, None, M, Fh)
+
+    def _pit_labels(self, bf, lab, il, ncols):
+        """train/oln_tfm_enc_dec_spk_pit.py:78-87: re-order the speaker columns (1..ncols-2) of the labels by
+        batch_pit_n_speaker_loss on the same columns of the logits (device PIT kernels, pit.py)."""
+        from . import pit as P
+        B, T, Tp, C = bf.shape
+        logits = torch.empty(B, T, C, dtype=F32, device=self.dev)
+        attr = torch.empty(B, T, C, D, dtype=F32, device=self.dev)
+        ops.head_l2dot(bf.emb32, bf.a32, attr, logits, B, T, Tp, C, D)
+        n_spk = [n - 2 for n in ncols]
+        S = max(n_spk)
+        ys = [torch.nn.functional.pad(logits[b, :il[b], 1:1 + n_spk[b]], (0, S - n_spk[b])) for b in range(B)]
+        ts = [torch.nn.functional.pad(lab[b, :il[b], 1:1 + n_spk[b]], (0, S - n_spk[b])) for b in range(B)]
+        perm = self._pit_assign(P, ys, ts, n_spk)
+        out = lab.clone()
+        for b in range(B):
+            out[b, :il[b], 1:1 + n_spk[b]] = perm[b]
+        return out
+
+    def _pit_assign(self, P, ys, ts, n_spk):
+        return P.batch_pit_n_speaker_loss(ys, ts, n_spk)[1]
+
+    # ------------------------------------------------------------------ optimiser
+    def all_reduce_grads(self):
+        """Data parallelism: ONE all-reduce (mean) of the flat gradient buffer over RCCL (torch.distributed 'nccl')."""
+        from .shard import all_reduce_mean
+        all_reduce_mean(self.flat.grads, self.group)
+
+    def current_lr(self, opt_step: int) -> float:
+        if self.warmup is None:
+            return float(self.base_lr)
+        return noam_lr(opt_step, D, self.warmup, self.sched_scale, self.base_lr)
+
+    def optimizer_step(self):
+        self.opt_step += 1
+        lr = self.current_lr(self.opt_step)
+        t = self.opt_step
+        slot = t % len(self._hp_ring)
+        if self._hp_events[slot] is not None:
+            self._hp_events[slot].synchronize()         # the copy that last read this slot has completed
+        host = self._hp_ring[slot]
+        host[0], host[1], host[2], host[3] = lr, 1 - self.b1 ** t, 1 - self.b2 ** t, self.clip
+        self.hp.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hp_events[slot] = ev
+        fl = self.flat
+        _call("eend_grad_sumsq_f32", fl.grads, fl.numel, self.ws, WS_FLOATS, self.gsumsq)
+        _call("eend_adam_step_f32", fl.params, fl.grads, fl.m, fl.v, fl.numel, self.hp, self.gsumsq, self.b1, self.b2, self.eps)
+        self.last_lr = lr
+        self.prep_weights()
+        self.model._prep = None            # the inference-path operand cache is stale now
+        return lr
+
+    def step(self, src, labels, ilens, pit: bool = False):
+        """forward + backward + (all-reduce) + Adam.  Returns dict(loss, bce, emb, lr, gradnorm) of device scalars /
+        floats; nothing here synchronises with the host."""
+        if self.opt_step == 0 and not getattr(self, "_prepped", False):
+            self.prep_weights()
+            self._prepped = True
+        bf = self.forward(src, labels, ilens, pit=pit)
+        self.backward(bf)
+        self.all_reduce_grads()
+        lr = self.optimizer_step()
+        return dict(bce=bf.loss[0], emb=bf.loss[1], loss=bf.loss[0] + bf.loss[1], lr=lr, gradnorm=self.gsumsq.sqrt())
+
+    # ------------------------------------------------------------------ checkpoint state (optimiser side)
+    def optimizer_state(self) -> dict:
+        """Everything beyond the model's state_dict that a resumed run needs: Adam moments, step counters."""
+        return dict(m=self.flat.m.detach().clone(), v=self.flat.v.detach().clone(), opt_step=self.opt_step,
+                    fwd_count=self._fwd_count, names=list(self.flat.names), numel=self.flat.numel)
+
+    def load_optimizer_state(self, st: dict):
+        if list(st["names"]) != list(self.flat.names) or int(st["numel"]) != self.flat.numel:
+            raise EendHipError("optimizer state does not match this model's flat layout")
+        self.flat.m.copy_(st["m"].to(self.dev))
+        self.flat.v.copy_(st["v"].to(self.dev))
+        self.opt_step, self._fwd_count = int(st["opt_step"]), int(st["fwd_count"])
+
+
+class FsTrainStep(TrainStepBase):
+    """One training step of FS-EEND (`OnlineTransformerDADiarization` mirror) entirely in HIP."""
+
+    def __init__(self, model, warmup: Optional[int] = 100000, lr: float = 1.0, schedule_scale: float = 1.0, grad_clip: float = 5.0,
+                 betas=(0.9, 0.98), eps: float = 1e-9, bn_momentum: float = 0.1, process_group=None, drop_seed: int = 0):
+        from .fs_model import OnlineTransformerDADiarization
+        if not isinstance(model, OnlineTransformerDADiarization):
+            raise TypeError("FsTrainStep drives fs_eend_amd.fs_model.OnlineTransformerDADiarization")
+        if model.enc.mask_delay != model.dec.mask_delay:
+            raise NotImplementedError
+        self._init_common(model, warmup, lr, schedule_scale, grad_clip, betas, eps, bn_momentum, process_group, drop_seed)
+        self._build_weight_table()
 
     # ------------------------------------------------------------------ weight operand copies
     def _build_weight_table(self):
         m, fl, dev = self.model, self.flat, self.dev
-        W: Dict[str, Tensor] = {}
-        entries: List[_lib.PrepEntry] = []
-
-        def add(key, pname, dims, strides, dtype, off=0, cpad=None, nscale=0, scale=1.0, alloc=None):
-            A, B_, C_ = dims
-            cpad = C_ if cpad is None else cpad
-            dt = {0: F16, 1: BF16, 2: F32}[dtype]
-            shape = alloc if alloc is not None else (A * B_, cpad)
-            t = torch.zeros(*shape, dtype=dt, device=dev)
-            W[key] = t
-            e = _lib.PrepEntry()
-            e.src = fl.params.data_ptr()
-            e.off = fl.offsets[pname] + off
-            e.dst = t.data_ptr()
-            e.A, e.B, e.C, e.Cpad = A, B_, C_, cpad
-            e.sa, e.sb, e.sc = strides
-            e.dtype, e.nscale, e.scale, e.reserved = dtype, nscale, float(scale), 0
-            entries.append(e)
-
-        def plain(key, pname, N, K, dtype=0, kpad=None, nscale=0, scale=1.0):        # [N][K] row-major copy
-            add(key, pname, (N, 1, K), (K, 0, 1), dtype, cpad=kpad, nscale=nscale, scale=scale)
-
-        def transposed(key, pname, N, K, ld=None, rows_alloc=None):                 # bf16 [K][N]: dst[k][n] = W[n][k]
-            ld = K if ld is None else ld
-            add(key, pname, (K, 1, N), (1, 0, ld), 1, alloc=(rows_alloc or K, N))
-
-        def vec(key, pname, n, nscale=0, scale=1.0):
-            add(key, pname, (n, 1, 1), (1, 0, 0), 2, nscale=nscale, scale=scale, alloc=(n,))
+        self._table_begin()
+        W = self.W
+        add, plain, transposed, vec = self._add, self._plain, self._transposed, self._vec
 
         Fin = m.enc.in_size
         self.Fin, self.Fin_pad = Fin, (Fin + 127) // 128 * 128
@@ -290,18 +466,10 @@ class FsTrainStep:
             transposed(f"d{i}.w1T", p_ + "linear1.weight", Fh, D)
             plain(f"d{i}.w2", p_ + "linear2.weight", D, Fh)
             transposed(f"d{i}.w2T", p_ + "linear2.weight", D, Fh)
-        self.W = W
-        arr = (_lib.PrepEntry * len(entries))(*entries)
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self._table = raw.to(dev)
-        self._n_entries = len(entries)
+        self._table_end()
         self.pe = m.dec.pos_enc.pe[0].to(device=dev, dtype=F32).contiguous()       # (5000, 256) sinusoid rows
 
-    def prep_weights(self):
-        """f32 parameters -> MFMA operand copies (one launch)."""
-        _call("eend_prep_weights", self._table, self._n_entries)
 
-    # ------------------------------------------------------------------ helpers
     def _buffers(self, B, Tp, C) -> _Buffers:
         key = (B, Tp, C)
         b = self._bufs.get(key)
@@ -316,50 +484,15 @@ class FsTrainStep:
             self._bufs[key] = b
         return b
 
-    def _table_for(self, srcs, T):
-        key = tuple((s.data_ptr(), s.shape[0]) for s in srcs)
-        tab = self._ptr_tables.get(key)
-        if tab is None:
-            if len(self._ptr_tables) > 64:
-                self._ptr_tables.clear()
-            tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=self.dev),
-                   torch.tensor([min(k[1], T) for k in key], dtype=I32, device=self.dev))
-            self._ptr_tables[key] = tab
-        return tab
-
-    def _P(self, name):          # f32 parameter view
-        return self.flat.p(name)
-
-    def _G(self, name):          # f32 gradient view
-        return self.flat.g(name)
 
     # ------------------------------------------------------------------ dropout sites
     # site ids: encoder layer i -> 16*i + k, decoder layer i -> 4096 + 16*i + k, with k:
     SITE_ATT, SITE_OUT1, SITE_SPK, SITE_OUT2, SITE_FF, SITE_FFOUT = 0, 1, 2, 3, 4, 5
 
-    def _drop(self, bf, site: int):
-        """eend_dropout of one site for the forward that filled `bf` (None <=> no dropout): the seed is a hash of
-        (drop_seed, forward count, site id), so the backward asks for the same spec and gets the same mask."""
-        if bf.drop_base is None:
-            return None
-        spec = bf.drop_specs.get(site)
-        if spec is None:
-            spec = _lib.Dropout(drop_site_seed(bf.drop_base, site), int(round(self.drop_p * (1 << 24))), 1.0 / (1.0 - self.drop_p))
-            bf.drop_specs[site] = spec
-        return ctypes.byref(spec)
-
-    def _linear_ln(self, a16, w, bias, res, ln, site: _Site, out32, M, K, drop=None):
-        _call("eend_linear_res_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, res, 1.0, self._P(ln + ".weight"),
-              self._P(ln + ".bias"), 1e-5, out32, site.out16, site.xhat, site.rstd, M, K, drop)
-
-    def _linear_relu(self, a16, w, bias, out16, drop=None):
-        M, K = a16.shape
-        N = out16.shape[1]
-        _call("eend_linear_relu_train_f16", a16, a16.stride(0), w, w.stride(0), bias, out16, out16.stride(0), M, N, K, drop)
-
     def _attn_fwd(self, x16, w, bias, sv: _AttnSave, nseq, Tp, mask_delay, kv_len, drop=None):
         _call("eend_inproj_heads_train_bf16", x16, x16.stride(0), w, bias, sv.q, sv.qt, sv.k, sv.kt, sv.v, sv.vt, nseq, Tp, H)
         _call("eend_attn_causal_lse_bf16", sv.q, sv.k, sv.vt, sv.ctx, sv.lse, nseq, H, Tp, D, mask_delay, kv_len, ops.LN2, drop)
+
 
     # ------------------------------------------------------------------ forward (saves activations)
     def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False,
@@ -469,51 +602,7 @@ class FsTrainStep:
         _call("eend_emb_consistency_bwd_f16", bf.emb16, lab, None, 0.0, bf.de32, B, T, Tp, D, C)
         return bf
 
-    def _pit_labels(self, bf, lab, il, ncols):
-        """train/oln_tfm_enc_dec_spk_pit.py:78-87: re-order the speaker columns (1..ncols-2) of the labels by
-        batch_pit_n_speaker_loss on the same columns of the logits (device PIT kernels, pit.py)."""
-        from . import pit as P
-        B, T, Tp, C = bf.shape
-        logits = torch.empty(B, T, C, dtype=F32, device=self.dev)
-        attr = torch.empty(B, T, C, D, dtype=F32, device=self.dev)
-        ops.head_l2dot(bf.emb32, bf.a32, attr, logits, B, T, Tp, C, D)
-        n_spk = [n - 2 for n in ncols]
-        S = max(n_spk)
-        ys = [torch.nn.functional.pad(logits[b, :il[b], 1:1 + n_spk[b]], (0, S - n_spk[b])) for b in range(B)]
-        ts = [torch.nn.functional.pad(lab[b, :il[b], 1:1 + n_spk[b]], (0, S - n_spk[b])) for b in range(B)]
-        _, perm = P.batch_pit_n_speaker_loss(ys, ts, n_spk)
-        out = lab.clone()
-        for b in range(B):
-            out[b, :il[b], 1:1 + n_spk[b]] = perm[b]
-        return out
-
     # ------------------------------------------------------------------ backward
-    def _bias_grad(self, dy16, M, N, gname):
-        _call("eend_colsum_f32", dy16, dy16.stride(0), M, N, 1, self.ws, WS_FLOATS, self._G(gname), 1.0, 0)
-
-    def _wgrad(self, dy16, x, M, N, K, gname, x_is_f16=True, ld_out=None, k_out=None, goff=0):
-        g = self._G(gname).view(-1)[goff:]
-        _call("eend_wgrad_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS, g,
-              K if ld_out is None else ld_out, K if k_out is None else k_out, 1.0, 0)
-
-    def _ln_bwd(self, g32, site: _Site, ln, ds16, M, drop=None, bias=None):
-        """`drop`: the spec of the sub-layer output dropout in front of this LayerNorm's residual sum -- the bf16 branch
-        gradient ds16 gets the mask, the f32 residual-stream gradient g32 does not.  `bias`: the bias parameter of the
-        linear layer in front of the LayerNorm; its gradient (the column sums of ds16) comes out of the same pass."""
-        _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
-              self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, drop)
-
-    def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm, drop_scale=1.0):
-        """backward of x -> LN(x + W2 relu(W1 x + b1) + b2); g32 in/out (gradient w.r.t. output -> w.r.t. x)."""
-        W = self.W
-        Fh = hid.shape[1]
-        dh = dh16[:M * Fh].view(M, Fh)
-        self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
-        _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D, drop_scale)
-        self._bias_grad(dh, M, Fh, p_ + "linear1.bias")
-        self._wgrad(dh, x_in16, M, Fh, D, p_ + "linear1.weight")
-        _call("eend_gemm_acc_bf16", dh, Fh, W[wkey + ".w1T"], Fh, g32, 1.0, g32, None, M, Fh)
-
     def _attn_bwd(self, g32, ds16, dctx16, dqkv16, sv: _AttnSave, x_in16, nseq, Tp, M, w_outT, w_inT, p_out, p_in, bf, delay,
                   kv_len, T, drop=None):
         """backward of x -> x + out_proj(causal_mha(in_proj x)) given ds16 = gradient w.r.t. that sum (bf16) and
@@ -607,34 +696,3 @@ class FsTrainStep:
         _call("eend_bn_bwd_f32", bf.ptrs, bf.lens, -1.0, bf.bn_mean, bf.bn_var, m.enc.bn.eps, bf.dy_in, self.Fin_pad, self.ws, WS_FLOATS,
               self._G("enc.bn.weight"), self._G("enc.bn.bias"), B, T, Tp, self.Fin)
 
-    # ------------------------------------------------------------------ optimiser
-    def all_reduce_grads(self):
-        """Data parallelism: ONE all-reduce (mean) of the flat gradient buffer over RCCL (torch.distributed 'nccl')."""
-        from .shard import all_reduce_mean
-        all_reduce_mean(self.flat.grads, self.group)
-
-    def optimizer_step(self):
-        self.opt_step += 1
-        lr = noam_lr(self.opt_step, D, self.warmup, self.sched_scale, self.base_lr)
-        t = self.opt_step
-        self._hp_host[0], self._hp_host[1], self._hp_host[2], self._hp_host[3] = lr, 1 - self.b1 ** t, 1 - self.b2 ** t, self.clip
-        self.hp.copy_(self._hp_host, non_blocking=True)
-        fl = self.flat
-        _call("eend_grad_sumsq_f32", fl.grads, fl.numel, self.ws, WS_FLOATS, self.gsumsq)
-        _call("eend_adam_step_f32", fl.params, fl.grads, fl.m, fl.v, fl.numel, self.hp, self.gsumsq, self.b1, self.b2, self.eps)
-        self.last_lr = lr
-        self.prep_weights()
-        self.model._prep = None            # the inference-path operand cache is stale now
-        return lr
-
-    def step(self, src, labels, ilens, pit: bool = False):
-        """forward + backward + (all-reduce) + Adam.  Returns dict(loss, bce, emb, lr, gradnorm) of device scalars /
-        floats; nothing here synchronises with the host."""
-        if self.opt_step == 0 and not getattr(self, "_prepped", False):
-            self.prep_weights()
-            self._prepped = True
-        bf = self.forward(src, labels, ilens, pit=pit)
-        self.backward(bf)
-        self.all_reduce_grads()
-        lr = self.optimizer_step()
-        return dict(bce=bf.loss[0], emb=bf.loss[1], loss=bf.loss[0] + bf.loss[1], lr=lr, gradnorm=self.gsumsq.sqrt())

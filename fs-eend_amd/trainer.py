@@ -82,12 +82,21 @@ class SpeakerDiarization:
         self.logged[key] = value
 
     def _engine(self):
+        """The native training step of the model family: FS-EEND (train.FsTrainStep) or LS-EEND (train_ls.LsTrainStep,
+        with `training.sync_batchnorm` as LS-EEND/train_dia_simu.py:167 passes it to Lightning).  scheduler=None runs the
+        optimiser at the constant configured lr, like the reference scripts do (train_dia.py:95-100)."""
         if self._step is None:
-            from .train import FsTrainStep
+            from .ls_model import OnlineConformerRetentionDADiarization as LsModel
             h = _hyper(self.opt, self.scheduler, self.hparams)
-            self._step = FsTrainStep(self.model, warmup=h["warmup"] if h["noam"] else 1, lr=h["lr"], schedule_scale=h["scale"],
-                                     grad_clip=h["clip"], betas=h["betas"], eps=h["eps"], drop_seed=self._drop_seed())
-            self._noam = h["noam"]
+            kw = dict(warmup=h["warmup"] if h["noam"] else None, lr=h["lr"], schedule_scale=h["scale"], grad_clip=h["clip"],
+                      betas=h["betas"], eps=h["eps"], drop_seed=self._drop_seed())
+            if isinstance(self.model, LsModel):
+                from .train_ls import LsTrainStep
+                sync = bool((self.hparams.get("training") or {}).get("sync_batchnorm", True))
+                self._step = LsTrainStep(self.model, sync_batchnorm=sync, **kw)
+            else:
+                from .train import FsTrainStep
+                self._step = FsTrainStep(self.model, **kw)
         return self._step
 
     def _drop_seed(self):

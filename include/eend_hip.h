@@ -486,6 +486,90 @@ typedef struct eend_prep_entry {
  * `table` is a device array of n entries. */
 int eend_prep_weights(const eend_prep_entry* table, int n, void* stream);
 
+/* ======================================================================================================
+ * LS-EEND TRAINING STEP (the LS half of BASELINE config 4: LS-EEND/train/oln_tfm_enc_dec_on_the_fly.py:52-92
+ * training_step under train_dia_simu.py:97-117,159-173).  Same conventions as the FS-EEND training entries above.
+ * Sequence slabs have Tp rows of which the first Tv (the reference's chunk-padded length, LS model :281-283) exist
+ * in the reference; rows t >= Tv never enter a statistic and receive zero gradients.
+ * ====================================================================================================== */
+
+/* a = dropout(swish(z)) (conformer/feed_forward.py:51-52: Swish, nn.Dropout); z f16 [M][F] is the saved
+ * pre-activation.  Backward, in place on the bf16 gradient: dz = da * keep * scale * swish'(z). */
+int eend_swish_dropout_f16(const void* z_f16, void* a_f16, long M, int F, const eend_dropout* drop, void* stream);
+int eend_swish_bwd_bf16(void* dz_bf16, const void* z_f16, long M, int F, const eend_dropout* drop, void* stream);
+
+/* torch.nn.LayerNorm(256) forward keeping x_hat / 1/sigma for its backward (the pre-norm of the first sub-layer of a
+ * Conformer block, feed_forward.py:48, applied to the previous block's output). */
+int eend_layernorm_train_f16(const float* x, const float* gamma, const float* beta, float eps, void* y_f16,
+                             void* xhat_f16, float* rstd, long M, void* stream);
+
+/* LayerNorm backward, general form.  g: gradient w.r.t. the LayerNorm output, f32 or (g_is_bf16) bf16 [M][256].
+ * ds_f32 (optional): the input gradient, overwritten or (accumulate) added to -- the latter is the pre-norm residual
+ * block of conformer/modules.py:32-33, where the LayerNorm sits on the branch.  ds_bf16 (optional) = alpha16 *
+ * dropout(input gradient), dbias (optional, needs ds_bf16) its column sums.  dgamma / dbeta [256] are overwritten. */
+int eend_layernorm_bwd2_f32(const void* g, int g_is_bf16, const void* xhat_f16, const float* rstd, const float* gamma,
+                            float* ds_f32, int accumulate, void* ds_bf16, float alpha16, float* ws, long ws_floats,
+                            float* dgamma, float* dbeta, float* dbias, long M, const eend_dropout* drop, void* stream);
+
+/* Residual-stream gradient g f32 [M][256] -> gradient of a pre-norm branch output: ds_bf16 = alpha * dropout(g)
+ * (ResidualConnectionModule module_factor, the branch's trailing nn.Dropout) and dbias [256] = its column sums. */
+int eend_resgrad_cast_bf16(const float* g, void* ds_bf16, float alpha, float* ws, long ws_floats, float* dbias, long M,
+                           const eend_dropout* drop, void* stream);
+
+/* eend_linear_res_scale_ln16_f16 for training: out_f32 = dropout(A W^T + bias) * alpha + res (un-normalised
+ * residual stream), out_f16 = LayerNorm(out_f32) with x_hat / 1/sigma saved (the next sub-layer's pre-norm). */
+int eend_linear_res_scale_ln_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                                       const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                                       float* out_f32, void* out_f16, void* xhat_f16, float* rstd, int M, int K,
+                                       const eend_dropout* drop, void* stream);
+
+/* ConformerConvModule, train mode (conformer/convolution.py:138-149).  P f16 [nseq*Tp][512] = pointwise-conv-1
+ * output (value | gate); c = causal depthwise conv (k taps, zero left context) of value * sigmoid(gate), f16
+ * [nseq*Tp][256], zero for t >= Tv. */
+int eend_glu_dwconv_f16(const void* P_f16, const float* w, void* c_f16, int nseq, int Tp, int Tv, int k, void* stream);
+/* BatchNorm1d batch statistics of c over the nseq*Tv valid frames, two-pass: stats f32 [513] = mean[256], M2[256]
+ * (sum of squared deviations), n.  The triples of several ranks merge exactly (SyncBatchNorm, train_dia_simu.py:167). */
+int eend_bn_batch_stats_f16(const void* c_f16, float* ws, long ws_floats, float* stats, int nseq, int Tp, int Tv,
+                            void* stream);
+/* stats [R][513] of R ranks -> mean, biased var [256], n_out[1] = total frame count; running statistics updated
+ * like torch BatchNorm1d / SyncBatchNorm in train mode (momentum, unbiased variance) when run_mean is given. */
+int eend_bn_merge_f32(const float* stats, int R, float* mean, float* var, float* n_out, float* run_mean, float* run_var,
+                      float momentum, void* stream);
+/* s = swish(BatchNorm(c)) with the given batch statistics, f16 [M][256]. */
+int eend_bn_swish_f16(const void* c_f16, const float* mean, const float* var, float eps, const float* gamma,
+                      const float* beta, void* s_f16, long M, void* stream);
+/* Backward of the two, pass 1: sums f32 [512] = per-channel sum of d_y and of d_y * c_hat over this rank's valid
+ * frames (d_y = ds * swish'(BN(c))); also written as dbeta / dgamma.  Pass 2 (sums / n may be the all-reduced global
+ * ones): ds <- d_c = gamma * rstd * (d_y - S1/n - c_hat * S2/n), zero for t >= Tv, in place (bf16). */
+int eend_bn_swish_bwd_stats_bf16(const void* ds_bf16, const void* c_f16, const float* mean, const float* var, float eps,
+                                 const float* gamma, const float* beta, float* ws, long ws_floats, float* sums,
+                                 float* dgamma, float* dbeta, int nseq, int Tp, int Tv, void* stream);
+int eend_bn_swish_bwd_apply_bf16(void* ds_bf16, const void* c_f16, const float* mean, const float* var, float eps,
+                                 const float* gamma, const float* beta, const float* sums, const float* n_dev, int nseq,
+                                 int Tp, int Tv, void* stream);
+/* Depthwise conv + GLU backward: dP bf16 [nseq*Tp][512] (gradient of the pointwise-conv-1 output), dw f32 [256][k]. */
+int eend_dwconv_glu_bwd_bf16(const void* dc_bf16, const void* P_f16, const float* w, void* dP_bf16, float* ws,
+                             long ws_floats, float* dw, int nseq, int Tp, int Tv, int k, void* stream);
+
+/* eend_retention_chunk_f16 (chunk-resident kernel, L <= 512) that also saves rhat_f16 [nseq*Tp][ldo] = the per-head
+ * normalised retention rows and rc f32 [nseq*Tp][H] = 1/sigma times the detached row scale (retention.py:163,180,185:
+ * inner_scale / kv_scale carry no gradient). */
+int eend_retention_chunk_train_f16(const void* Q, const void* K, const void* Kt, const void* Vt, const void* G,
+                                   void* O_f16, void* rhat_f16, float* rc, void* St_ws, float* kv_ws, float* cscale_ws,
+                                   float* sexp_ws, int nseq, int H, int Tp, int L, int ldo, int ldg, float gn_eps,
+                                   int T_valid, void* stream);
+/* MultiScaleRetention backward from the gradient of its out_proj input (retention.py:196-228, chunk-recurrent form
+ * :146-194): swish gate and per-head LayerNorm backward, then the linear-attention backward with the detached scales,
+ *   dq_t = sum_{s<=t} (o~_t.v_s) k_s,  dk_s = sum_{t>=s} (o~_t.v_s) q_t,  dv_s = sum_{t>=s} (q_t.k_s) o~_t,
+ * intra-chunk on bf16 MFMA tiles, across chunks through 64x64 prefix / suffix states.  Q..Vt: bf16 head layouts of
+ * eend_inproj_heads_train_bf16 (k rows pre-scaled by dk^-1/2); dqkvg bf16 [nseq*Tp][ldq]: dq | sk*dk | dv | dg at
+ * columns 0 / 256 / 512 / 768.  ot_ws, ott_ws: bf16 scratch [nseq*Tp*256]; kv_ws, g_ws: f32 [nseq*H*nc*4096];
+ * St_ws: bf16 [nseq*H*nc*6*4096]. */
+int eend_retention_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* Vt,
+                            const void* dctx_bf16, const void* g_f16, int ldg, const void* rhat_f16, const float* rc,
+                            void* ot_ws, void* ott_ws, float* kv_ws, float* g_ws, void* St_ws, void* dqkvg_bf16, int ldq,
+                            int nseq, int H, int Tp, int L, int T_valid, float sk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

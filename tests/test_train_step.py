@@ -3,7 +3,8 @@ against the golden vectors produced by the reference's own training_step / stand
 (oracle/gen_golden_train.py), plus size-independent properties at BASELINE config 4's full size.
 
 Bars (VERDICT r01 / north_star): loss within 1e-4; per-parameter gradient norms within 1e-2 relative (plus a small
-absolute floor for parameters whose gradient is ~0); parameters after Adam within a fraction of the learning rate.
+absolute floor for parameters whose gradient is ~0); single gradient entries within ENTRY_BAR of the tensor's gradient
+norm; parameters after Adam within a fraction of the learning rate.
 """
 import math
 
@@ -16,6 +17,7 @@ from tests.helpers import build_fs_mirror
 
 pytestmark = pytest.mark.gpu
 CASES = FX.list_cases("fs_train_")
+ENTRY_BAR = 5e-2        # |entry error| / ||gradient of that tensor||: bf16 gradient operands, a handful of entries per tensor
 
 
 def _slice_index(numel, n=24):
@@ -66,13 +68,13 @@ def test_train_step_vs_reference(hip_lib, dev, name):
                 idx = _slice_index(g.numel())
                 sl = g.flatten()[torch.as_tensor(idx, device=dev)].cpu().numpy()
                 serr = np.abs(sl - arr["grad_slices"][i][:len(idx)]).max() / max(ref, 1e-3 * tot)
-                report.append((serr * 0.2, k + " [entries]", float(np.abs(sl).max()), float(np.abs(arr["grad_slices"][i]).max())))
+                report.append((serr, k + " [entries]", float(np.abs(sl).max()), float(np.abs(arr["grad_slices"][i]).max())))
             report.sort(reverse=True)
             for err, k, a, b in report[:14]:
                 print(f"   {err:.3e}  {k}: {a:.4e} vs {b:.4e}")
             bad = [(e, k) for e, k, _, _ in report if e > 1e-2 and not k.endswith("[entries]")]
             assert not bad, bad[:10]
-            bad = [(e, k) for e, k, _, _ in report if e > 1e-2 and k.endswith("[entries]")]
+            bad = [(e, k) for e, k, _, _ in report if e > ENTRY_BAR and k.endswith("[entries]")]
             assert not bad, bad[:10]
         lr = mod.optimizer_step()
         torch.cuda.synchronize()
