@@ -300,6 +300,10 @@ int eend_adam_step_f32(float* p, const float* g, float* m, float* v, long n, con
     return eend_launch_adam(p, g, m, v, n, hp, gsumsq, beta1, beta2, eps, (hipStream_t)stream);
 }
 
+int eend_grad_accumulate_f32(float* acc, const float* g, float scale, int first, long n, void* stream) {
+    return eend_launch_grad_accumulate(acc, g, scale, first, n, (hipStream_t)stream);
+}
+
 int eend_prep_weights(const eend_prep_entry* table, int n, void* stream) {
     return eend_launch_prep_weights(table, n, (hipStream_t)stream);
 }

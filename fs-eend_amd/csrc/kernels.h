@@ -311,6 +311,7 @@ int eend_launch_scalar_sum(const float* partial, long n, float scale, float* out
 int eend_launch_adam(float* p, const float* g, float* m, float* v, long n, const float* hp, const float* gsumsq, float b1, float b2,
                      float eps, hipStream_t stream);
 int eend_launch_prep_weights(const PrepEntry* tab, int n_entries, hipStream_t stream);
+int eend_launch_grad_accumulate(float* acc, const float* g, float scale, int first, long n, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------
 // LS-EEND training step (ls_train.hip, retention_bwd.hip)

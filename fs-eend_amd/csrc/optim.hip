@@ -66,6 +66,15 @@ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
     p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// acc = (first ? 0 : acc) + scale * g  (gradient accumulation over micro-batches, FS-EEND/train_dia.py:151
+// accumulate_grad_batches: Lightning divides each micro-batch loss by the number of accumulated batches)
+__global__ __launch_bounds__(256)
+void grad_accumulate_kernel(float* __restrict__ acc, const float* __restrict__ g, float scale, int first, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    acc[i] = (first ? 0.f : acc[i]) + scale * g[i];
+}
+
 __global__ __launch_bounds__(256)
 void prep_weights_kernel(const PrepEntry* __restrict__ tab) {
     const PrepEntry e = tab[blockIdx.y];
@@ -107,6 +116,12 @@ int eend_launch_adam(float* p, const float* g, float* m, float* v, long n, const
                      float eps, hipStream_t stream) {
     if (!p || !g || !m || !v || !hp || !gsumsq || n <= 0) return EEND_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, hp, gsumsq, b1, b2, eps);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_grad_accumulate(float* acc, const float* g, float scale, int first, long n, hipStream_t stream) {
+    if (!acc || !g || n <= 0) return EEND_EINVAL;
+    hipLaunchKernelGGL(grad_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc, g, scale, first, n);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

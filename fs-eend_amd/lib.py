@@ -79,6 +79,7 @@ PROTOTYPES = {
     "eend_grad_sumsq_f32": [_vp, _l, _vp, _l, _vp, _vp],
     "eend_adam_step_f32": [_vp] * 4 + [_l, _vp, _vp, _f, _f, _f, _vp],
     "eend_prep_weights": [_vp, _i, _vp],
+    "eend_grad_accumulate_f32": [_vp, _vp, _f, _i, _l, _vp],
     # ---- LS-EEND training step
     "eend_swish_dropout_f16": [_vp, _vp, _l, _i, _vp, _vp],
     "eend_swish_bwd_bf16": [_vp, _vp, _l, _i, _vp, _vp],

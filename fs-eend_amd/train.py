@@ -349,6 +349,18 @@ class TrainStepBase:
         return P.batch_pit_n_speaker_loss(ys, ts, n_spk)[1]
 
     # ------------------------------------------------------------------ optimiser
+    def accumulate_grads(self, index: int, count: int):
+        """Micro-batch `index` of `count` (accumulate_grad_batches, train_dia.py:151): the backward kernels overwrite
+        flat.grads, so the running mean over micro-batches lives in a second flat buffer; after the last one it is
+        moved back and the usual all-reduce / optimiser step follow."""
+        if count <= 1:
+            return
+        if getattr(self, "_gacc", None) is None:
+            self._gacc = torch.zeros_like(self.flat.grads)
+        _call("eend_grad_accumulate_f32", self._gacc, self.flat.grads, 1.0 / count, 1 if index == 0 else 0, self.flat.numel)
+        if index == count - 1:
+            _call("eend_grad_accumulate_f32", self.flat.grads, self._gacc, 1.0, 1, self.flat.numel)
+
     def all_reduce_grads(self):
         """Data parallelism: ONE all-reduce (mean) of the flat gradient buffer over RCCL (torch.distributed 'nccl')."""
         from .shard import all_reduce_mean

@@ -470,6 +470,10 @@ int eend_grad_sumsq_f32(const float* g, long n, float* ws, long ws_floats, float
 int eend_adam_step_f32(float* p, const float* g, float* m, float* v, long n, const float* hp, const float* gsumsq,
                        float beta1, float beta2, float eps, void* stream);
 
+/* Gradient accumulation over micro-batches (Lightning accumulate_grad_batches, FS-EEND/train_dia.py:151):
+ * acc = (first ? 0 : acc) + scale * g on the flat buffers. */
+int eend_grad_accumulate_f32(float* acc, const float* g, float scale, int first, long n, void* stream);
+
 /* One entry of the weight re-layout table of eend_prep_weights: dst[a][b][c] (dims A x B x Cpad, zero for
  * c >= C) = convert(src[off + a*sa + b*sb + c*sc] * (a < nscale ? scale : 1)); dtype 0 f16, 1 bf16, 2 f32. */
 typedef struct eend_prep_entry {

@@ -93,7 +93,8 @@ def test_ls_train_step_vs_reference(hip_lib, dev, name):
         assert n_bad <= 0.03 * n_all, (n_bad, n_all)
         sd = m.state_dict()
         for j, k in enumerate(meta["bn_keys"]):                       # conv-module BatchNorm running statistics
-            tol = 1e-4 if k.endswith("running_mean") else 1e-3
+            # from the second step on the parameters themselves differ by a fraction of lr (see above), and so do the statistics
+            tol = (1e-4 if k.endswith("running_mean") else 1e-3) + 0.5 * lr * s
             assert np.abs(sd[k].cpu().numpy() - arr[f"s{s}_bn"][j]).max() < tol, (k, s)
 
 
