@@ -29,14 +29,19 @@ PEAK_HBM_GBS = 8000.0
 
 
 def flops_per_launch(name, shape, T):
-    """Algorithmic flops of one launch."""
+    """Algorithmic flops of one launch: row-shaped kernels are priced on the T real
+    frames of every sequence, not on the Tp = ceil64(T) slab rows they execute (the 2.4 % padding rows at T = 500 are
+    work the layout adds, not work the reference does)."""
+    Tp_ = (T + 63) // 64 * 64
+    if name not in ("attn_causal", "inproj_attn_causal", "retention_chunk") and shape and shape[0] % Tp_ == 0:
+        shape = (shape[0] // Tp_ * T,) + tuple(shape[1:])
     if name == "attn_causal":          # 2*D*T*(T+1) causal-useful flops per sequence (SURVEY 8d), D = H*64
         nseq, H = shape
         return nseq * 2.0 * (H * 64) * T * (T + 1)
     if name == "inproj_attn_causal":   # packed in-projection (2*Tp*768*256 per sequence) + the causal-useful attention flops
         nseq, H = shape
         Tp = (T + 63) // 64 * 64
-        return nseq * (2.0 * (H * 64) * T * (T + 1) + 2.0 * Tp * 768 * 256)
+        return nseq * (2.0 * (H * 64) * T * (T + 1) + 2.0 * T * 768 * 256)
     if name == "ffn_fused":
         M, F, K = shape
         return 4.0 * M * F * K
@@ -48,6 +53,9 @@ def flops_per_launch(name, shape, T):
     if name == "attnout_ffn_fused":    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
+    if name == "retention_chunk":      # (nseq, H, valid frames, L): QK^T + PV causal-useful per chunk, + state build and cross term
+        nseq, H, Tv, L = shape
+        return nseq * H * (Tv // L) * (2 * 64.0 * L * (L + 1) + 2 * 2.0 * L * 64 * 64)
     if name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16", "retention_proj", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
         M, N, K = shape
         return 2.0 * M * N * K
@@ -94,6 +102,9 @@ class OpTimer:
                 shape = (a[5], a[6])
             elif name == "retention_proj":
                 shape = (a[0].shape[0], 1024, 256)
+            elif name == "retention_chunk":
+                tv = k.get("t_valid") or a[11]
+                shape = (a[9], a[10], tv // a[12] * a[12], a[12])
             elif name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16"):
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "ffn_fused":
@@ -163,7 +174,7 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
         phys = psutil.cpu_count(logical=False) or ncpu
     except Exception:
         phys = ncpu
-    cands = sorted({1, min(8, ncpu), min(32, ncpu)})
+    cands = sorted({1, min(32, ncpu), phys})          # n = 1 and n = all physical cores (+ 32, torch's sweet spot here)
     t_start, results = time.perf_counter(), {}
     with torch.no_grad():
         for th in cands:
@@ -183,7 +194,7 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
             results[th] = batch * T / ts[len(ts) // 2]
     best = max(results, key=results.get)
     return dict(value=results[best], unit="frames/s", cores=best, kind="port",
-                host_physical_cores=phys, host_hw_threads=ncpu,
+                host_physical_cores=phys, host_hw_threads=ncpu, by_threads={str(k): v for k, v in results.items()},
                 sample=f"oracle fs_test fp32 on host CPU ({phys} physical cores / {ncpu} hw threads; `cores` = torch threads of the best run), "
                        f"B={batch} x T={T}, C={C}; frames/s by "
                        f"torch threads: " + ", ".join(f"{k}: {v:.0f}" for k, v in results.items()) +
@@ -246,6 +257,20 @@ def extras(dev):
         res["ls_eend_batch"]["roofline"] = {"kernel": f"{dom['kernel']} {dom['shape']}", "bound": "mfma", "achieved": dom["tflops"],
                                             "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_MFMA_TFLOPS,
                                             "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+        # north_star's "retention chunk recurrence": state build + scan + chunk kernel of one decoder layer, HBM-bound
+        # (intensity ~126 flop/B < ridge 312): algorithmic bytes = q, k, v, g read + gated output written, 2-byte elements
+        rk = [k for k in ks if k["kernel"] == "retention_chunk"]
+        if rk:
+            r = max(rk, key=lambda k: k["shape"][0])
+            nseq_, H_, Tv_, L_ = r["shape"]
+            byt = nseq_ * H_ * Tv_ * 64 * 2.0 * 5
+            gbs = byt / (r["avg_ms"] * 1e-3) / 1e9
+            res["ls_eend_batch"]["roofline_retention"] = {
+                "kernel": f"retention_chunk (ret_kv_chunk + ret_state_scan + ret_chunk_full) nseq={nseq_} H={H_} T={Tv_} L={L_}", "bound": "hbm",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": r["avg_ms"],
+                "mfma_TFLOPs": r["tflops"], "mfma_frac": None if r["tflops"] is None else r["tflops"] / PEAK_MFMA_TFLOPS,
+                "intensity_flop_per_byte": flops_per_launch("retention_chunk", tuple(r["shape"]), T) / byt,
+                "traffic": None, "traffic_source": "profiles/r03_ls_pmc_* (rocprofv3 --pmc passes) when collected"}
     except Exception as ex:
         res["ls_eend_batch"]["roofline"] = dict(error=f"{type(ex).__name__}: {ex}")
 
@@ -477,10 +502,35 @@ def synthetic_labels(lengths, n_spk, seed, dev):
     return out
 
 
-def train_setup(dev, B, T, n_spk, rank=0):
+def train_setup_ls(dev, B, T, n_spk, rank=0):
+    """BASELINE config 4, LS half: LS-EEND training step (conf/spk_onl_conformer_retention_enc_dec_nonautoreg.yaml shapes:
+    T = 1000 chunks = two retention chunks of 500, 4 Conformer-retention blocks + 2 decoder layers, dropout 0.1), same
+    optimiser as FS-EEND (train_dia_simu.py:97-117); SyncBatchNorm statistics are exchanged when world > 1."""
+    from fs_eend_amd import config as CFG
+    from fs_eend_amd.ls_model import OnlineConformerRetentionDADiarization
+    from fs_eend_amd.train_ls import LsTrainStep
+    from fs_eend_amd.trainer import prepare_labels
+    cfg = CFG.load(CFG.LS_EEND_SIMU)
+    kw = CFG.model_kwargs(cfg)
+    if os.environ.get("EEND_TRAIN_DROPOUT"):
+        kw["dropout"] = float(os.environ["EEND_TRAIN_DROPOUT"])
+    torch.manual_seed(0)
+    model = OnlineConformerRetentionDADiarization(**kw).to(dev).train()
+    tr = cfg["training"]
+    eng = LsTrainStep(model, warmup=tr["warm_steps"], lr=tr["lr"], schedule_scale=tr["schedule_scale"], grad_clip=tr["grad_clip"],
+                      drop_seed=int(tr.get("seed", 0) or 0) * 1000003 + rank)
+    g = torch.Generator().manual_seed(777 + rank)
+    feats = [(torch.randn(T, 345, generator=g) * 2 - 3).to(dev) for _ in range(B)]
+    labels = prepare_labels(synthetic_labels([T] * B, n_spk, 778 + rank, dev), [T] * B)
+    return eng, feats, labels
+
+
+def train_setup(dev, B, T, n_spk, rank=0, flavour="fs"):
     """BASELINE config 4: FS-EEND training step, 4-speaker simulated mixtures, the shipped yaml's shapes and optimiser
     (Adam betas (0.9, 0.98) eps 1e-9 x Noam(warm 100000), clip 5) and its dropout (0.1, all ten sites; counter-hash masks
     applied in the kernels' epilogues, include/eend_hip.h `eend_dropout`).  EEND_TRAIN_DROPOUT overrides the ratio (A/B)."""
+    if flavour == "ls":
+        return train_setup_ls(dev, B, T, n_spk, rank)
     from fs_eend_amd import config as CFG
     from fs_eend_amd.fs_model import OnlineTransformerDADiarization
     from fs_eend_amd.train import FsTrainStep
@@ -500,8 +550,8 @@ def train_setup(dev, B, T, n_spk, rank=0):
     return eng, feats, labels
 
 
-def time_train(dev, B, T, n_spk, steps, warmup, rank=0, fence=None):
-    eng, feats, labels = train_setup(dev, B, T, n_spk, rank)
+def time_train(dev, B, T, n_spk, steps, warmup, rank=0, fence=None, flavour="fs"):
+    eng, feats, labels = train_setup(dev, B, T, n_spk, rank, flavour)
     ilens = [T] * B
     for _ in range(warmup):
         eng.step(feats, labels, ilens)
@@ -519,13 +569,31 @@ class TrainCallTimer:
     with HIP events on the launch stream, for a few instrumented steps after the timed region."""
     INT_ARGS = {"eend_wgrad_bf16": (5, 6, 7), "eend_gemm_bf16": (7, 8, 9), "eend_gemm_relu_bwd_bf16": (8, 9, 10),
                 "eend_linear_relu_train_f16": (7, 8, 9)}
+    # ops.* forward wrappers the LS step calls directly (not through _call): name -> shape extractor on the positional args
+    OPS = {"linear": lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]),
+           "retention_proj": lambda a: (a[0].shape[0], 1024, 256), "convert_fanout": lambda a: (a[0].shape[0], 256, 256)}
 
     def __init__(self, T):
         self.T, self.rec = T, []
 
     def __enter__(self):
+        from fs_eend_amd import ops as OPSMOD
         from fs_eend_amd import train as TR
-        self.TR, self.orig = TR, TR._call
+        from fs_eend_amd import train_ls as TL
+        self.TR, self.TL, self.OPSMOD, self.orig = TR, TL, OPSMOD, TR._call
+        self.orig_ops = {k: getattr(OPSMOD, k) for k in self.OPS}
+
+        def wrap_op(k):
+            def w(*a, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = self.orig_ops[k](*a, **kw)
+                e.record()
+                self.rec.append(("ops." + k, tuple(int(x) for x in self.OPS[k](a)), s, e))
+                return r
+            return w
+        for k in self.OPS:
+            setattr(OPSMOD, k, wrap_op(k))
 
         def timed(name, *a):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -544,20 +612,38 @@ class TrainCallTimer:
                 shape = (int(a[5]), int(a[6]))
             elif name == "eend_inproj_heads_train_bf16":
                 shape = (int(a[10]) * int(a[11]), 768, 256)
+            elif name == "eend_linear_res_scale_ln_train_f16":
+                shape = (int(a[14]), 256, int(a[15]))
+            elif name == "eend_retention_bwd_bf16":          # (nseq, H, valid frames, chunk)
+                shape = (int(a[19]), int(a[20]), int(a[23]), int(a[22]))
+            elif name == "eend_retention_chunk_train_f16":
+                shape = (int(a[12]), int(a[13]), int(a[19]), int(a[15]))
             else:
                 shape = ()
             self.rec.append((name, shape, s, e))
         TR._call = timed
+        TL._call = timed
         return self
 
     def __exit__(self, *exc):
         self.TR._call = self.orig
+        self.TL._call = self.orig
+        for k, f in self.orig_ops.items():
+            setattr(self.OPSMOD, k, f)
 
     def flops(self, name, shape):
         if name in ("eend_wgrad_bf16", "eend_gemm_bf16", "eend_gemm_relu_bwd_bf16", "eend_gemm_acc_bf16",
-                    "eend_linear_relu_train_f16", "eend_linear_res_ln_train_f16", "eend_inproj_heads_train_bf16"):
+                    "eend_linear_relu_train_f16", "eend_linear_res_ln_train_f16", "eend_inproj_heads_train_bf16",
+                    "eend_linear_res_scale_ln_train_f16", "ops.linear", "ops.retention_proj", "ops.convert_fanout"):
             M, N, K = shape
             return 2.0 * M * N * K
+        if name in ("eend_retention_bwd_bf16", "eend_retention_chunk_train_f16"):
+            # per chunk-sequence-head: masked products of L x L x 64 (causal-useful L*(L+1)*64*2 flops each) -- forward 2
+            # (QK^T, PV), backward 5 (S, A, dQ, dK, dV) -- plus the cross-chunk terms 2*L*64*64 each (forward 2: state
+            # build + cross; backward 5: two outer products, dQ, dK, dV cross terms)   [SURVEY 8d retention row]
+            nseq, H_, Tv, L = shape
+            nprod = 5.0 if name == "eend_retention_bwd_bf16" else 2.0
+            return nseq * H_ * (Tv // L) * nprod * (64.0 * L * (L + 1) + 2.0 * L * 64 * 64)
         if name == "eend_attn_causal_lse_bf16":        # causal-useful flops, 2 products
             return shape[0] * 2.0 * (shape[1] * 64) * self.T * (self.T + 1)
         if name == "eend_attn_causal_bwd_bf16":        # 5 products (S, dP, dQ, dK, dV), causal-useful
@@ -579,33 +665,48 @@ class TrainCallTimer:
         return sorted(out, key=lambda d: -d["ms_per_step"])
 
 
-def cpu_baseline_train(T, n_spk, batch=2, budget_s=25.0):
-    """The training oracle (oracle/train_ref.TrainRef: forward, loss, torch-autograd backward, clip, Adam; pinned to the
-    reference's own training_step by tests/golden/fs_train_*.npz) timed on the host cores, bounded sample."""
-    from fs_eend_amd import config as CFG
-    from fs_eend_amd.fs_model import OnlineTransformerDADiarization
-    from oracle import train_ref as TR
-    cfg = CFG.load(CFG.FS_EEND_SIMU)
-    kw = CFG.model_kwargs(cfg)
-    torch.manual_seed(0)
-    m = OnlineTransformerDADiarization(**kw)
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
-    ocfg = dict(n_units=kw["n_units"], n_heads=kw["n_heads"], enc_n_layers=kw["enc_n_layers"], dec_n_layers=kw["dec_n_layers"],
-                has_mask=kw["has_mask"], mask_delay=kw.get("mask_delay", 0))
-    g = torch.Generator().manual_seed(777)
-    feats = [torch.randn(T, 345, generator=g) * 2 - 3 for _ in range(batch)]
-    labels = synthetic_labels([T] * batch, n_spk, 778, "cpu")
+def host_cores():
     ncpu = os.cpu_count() or 1
     try:
         import psutil
         phys = psutil.cpu_count(logical=False) or ncpu
     except Exception:
         phys = ncpu
-    cands = sorted({min(8, ncpu), min(32, ncpu)})
-    t_start, results = time.perf_counter(), {}
-    for th in cands:
+    return phys, ncpu
+
+
+def cpu_baseline_train(T, n_spk, budget_s=30.0, flavour="fs"):
+    """The training oracle (oracle/train_ref.TrainRef / train_ls_ref.LsTrainRef: forward, loss, torch-autograd backward,
+    clip, Adam; pinned to the reference's own training_step by tests/golden/{fs,ls}_train_*.npz) timed on the host cores:
+    n = all physical cores and n = 1 (the reference's default OMP_NUM_THREADS=1, train_dia.py:4-6), bounded sample."""
+    from fs_eend_amd import config as CFG
+    cfg = CFG.load(CFG.LS_EEND_SIMU if flavour == "ls" else CFG.FS_EEND_SIMU)
+    kw = CFG.model_kwargs(cfg)
+    torch.manual_seed(0)
+    if flavour == "ls":
+        from fs_eend_amd.ls_model import OnlineConformerRetentionDADiarization as Model
+        from oracle import train_ls_ref as TR
+        ocfg = dict(n_units=kw["n_units"], n_heads=kw["n_heads"], enc_n_layers=kw["enc_n_layers"], dec_n_layers=kw["dec_n_layers"],
+                    recurrent_chunk_size=kw["recurrent_chunk_size"], conv_delay=kw.get("conv_delay", 9))
+        mk = lambda sd: TR.LsTrainRef(sd, ocfg, warmup=cfg["training"]["warm_steps"], clip=cfg["training"]["grad_clip"])
+    else:
+        from fs_eend_amd.fs_model import OnlineTransformerDADiarization as Model
+        from oracle import train_ref as TR
+        ocfg = dict(n_units=kw["n_units"], n_heads=kw["n_heads"], enc_n_layers=kw["enc_n_layers"], dec_n_layers=kw["dec_n_layers"],
+                    has_mask=kw["has_mask"], mask_delay=kw.get("mask_delay", 0))
+        mk = lambda sd: TR.TrainRef(sd, ocfg, warmup=cfg["training"]["warm_steps"], clip=cfg["training"]["grad_clip"])
+    m = Model(**kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    phys, ncpu = host_cores()
+    cands = [phys, 1] if phys > 1 else [1]
+    t_start, results, samples = time.perf_counter(), {}, {}
+    for ci, th in enumerate(cands):
+        batch = 2 if th > 1 else 1
+        g = torch.Generator().manual_seed(777)
+        feats = [torch.randn(T, 345, generator=g) * 2 - 3 for _ in range(batch)]
+        labels = synthetic_labels([T] * batch, n_spk, 778, "cpu")
         torch.set_num_threads(th)
-        ref = TR.TrainRef(sd, ocfg, warmup=cfg["training"]["warm_steps"], clip=cfg["training"]["grad_clip"])
+        ref = mk(sd)
         ts = []
         for i in range(4):
             t0 = time.perf_counter()
@@ -613,16 +714,18 @@ def cpu_baseline_train(T, n_spk, batch=2, budget_s=25.0):
             dt = time.perf_counter() - t0
             if i > 0:
                 ts.append(dt)
-            if time.perf_counter() - t_start > budget_s * (cands.index(th) + 1) / len(cands):
+            if time.perf_counter() - t_start > budget_s * (ci + 1) / len(cands):
                 if not ts:
                     ts.append(dt)
                 break
         ts.sort()
         results[th] = batch * T / ts[len(ts) // 2]
+        samples[th] = f"B={batch}, {len(ts)} timed step(s)"
     best = max(results, key=results.get)
     return dict(value=results[best], unit="frames/s", cores=best, kind="port", host_physical_cores=phys, host_hw_threads=ncpu,
-                sample=f"oracle TrainRef.step fp32 (dropout off) on host CPU, B={batch} x T={T}, {n_spk} speakers; frames/s by torch "
-                       f"threads: " + ", ".join(f"{k}: {v:.0f}" for k, v in results.items()) +
+                by_threads={str(k): v for k, v in results.items()},
+                sample=f"oracle {'LsTrainRef' if flavour == 'ls' else 'TrainRef'}.step fp32 (dropout off) on host CPU, T={T}, {n_spk} "
+                       f"speakers; " + "; ".join(f"{k} thread(s): {results[k]:.0f} frames/s ({samples[k]})" for k in results) +
                        f"; {time.perf_counter() - t_start:.1f} s of CPU work")
 
 
@@ -641,7 +744,11 @@ def main():
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer: model.test (BASELINE config 2, the headline metric); train: one optimiser step (config 4)")
     ap.add_argument("--speakers", type=int, default=4, help="train mode: speakers per mixture (labels get +2 columns)")
+    ap.add_argument("--flavour", choices=("fs", "ls"), default="fs",
+                    help="train mode: fs = FS-EEND (T=500 chunks), ls = LS-EEND (T=1000 chunks unless --frames is given)")
     args = ap.parse_args()
+    if args.mode == "train" and args.flavour == "ls" and "--frames" not in " ".join(sys.argv):
+        args.frames = 1000                       # data.chunk_size of the LS-EEND yaml
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -677,19 +784,22 @@ def main():
 
     if args.mode == "train":
         from fs_eend_amd.shard import job_throughput
-        eng, dt, loss = time_train(dev, B, T, args.speakers, args.steps, args.warmup, rank, fence)
+        eng, dt, loss = time_train(dev, B, T, args.speakers, args.steps, args.warmup, rank, fence, args.flavour)
+        ls = args.flavour == "ls" 
         value = job_throughput(B * T * args.steps, dt, dev)
         dt = world * B * T * args.steps / value
-        out = {"metric": "training audio frames/sec (T=500 chunks)", "value": value, "unit": "frames/s", "n_gpus": world,
+        out = {"metric": f"training audio frames/sec (T={T} chunks)", "value": value, "unit": "frames/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "dtype_detail": "forward: f16 MFMA linears, bf16 QK^T/PV; backward: bf16 MFMA (gradients), f16/bf16 saved activations; "
                                "fp32 accumulate, residual-gradient stream, LayerNorm statistics, Adam on f32 master weights",
                "data": "synthetic",
-               "config": {"workload": f"FS-EEND training step (conf/spk_onl_tfm_enc_dec_nonautoreg.yaml shapes): {B} utterances/GPU x "
-                                      f"T={T} x 345, {args.speakers}-speaker mixtures (C={args.speakers + 2} label columns), forward + "
-                                      f"BCE/emb-consistency loss + backward + clip 5 + Adam(0.9,0.98,1e-9) x Noam + operand re-layout, "
-                                      f"random init (seed 0)",
+               "config": {"workload": (f"LS-EEND training step (conf/spk_onl_conformer_retention_enc_dec_nonautoreg.yaml shapes: 4 Conformer-"
+                                       f"retention blocks, 2 retention x speaker-attention decoder layers, chunk 500)" if ls else
+                                       f"FS-EEND training step (conf/spk_onl_tfm_enc_dec_nonautoreg.yaml shapes)") +
+                                      f": {B} utterances/GPU x T={T} x 345, {args.speakers}-speaker mixtures (C={args.speakers + 2} label "
+                                      f"columns), forward + BCE/emb-consistency loss + backward + clip 5 + Adam(0.9,0.98,1e-9) x Noam + "
+                                      f"operand re-layout, random init (seed 0)",
                           "batch_per_gpu": B, "global_batch": B * world, "frames": T, "dropout": eng.drop_p,
                           "parallelism": f"dp{world}: one all-reduce of the flat {eng.flat.numel * 4 / 1e6:.1f} MB f32 gradient buffer per step",
                           "launch": "eager ctypes launches"},
@@ -697,7 +807,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_breakdown:
             # dominant kernel: HIP events around every C-ABI call of 2 extra steps (same stream, same inputs).  N = 1 only: a
             # training step contains the gradient all-reduce, a collective every rank would have to enter
-            _, feats, labels = train_setup(dev, B, T, args.speakers, rank)
+            _, feats, labels = train_setup(dev, B, T, args.speakers, rank, args.flavour)
             with TrainCallTimer(T) as tm:
                 for _ in range(2):
                     eng.step(feats, labels, [T] * B)
@@ -713,7 +823,7 @@ def main():
                                    "note": "largest time share among the step's MFMA calls; algorithmic flops 2*M*N*K (GEMM family) "
                                            "or 5*D*T*(T+1) per sequence (attention backward); in-situ HIP events on the launch stream"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_train(T, args.speakers)
+            out["cpu_baseline"] = cpu_baseline_train(T, args.speakers, flavour=args.flavour)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -35,6 +35,17 @@ class RetCore(torch.autograd.Function):
             qq, kk, v2, ot2 = bf(q), bf(k), bf(vv), bf(ot)
             A = bf((ot2 @ v2.transpose(-1, -2)) * causal)
             S = bf((qq @ kk.transpose(-1, -2)) * causal)
+        elif MODE == "f16":
+            beta = 16.0 / ot.abs().amax(dim=(-1, -2), keepdim=True)
+            qq, kk, v2, ot2 = f16(q), f16(k), f16(vv), f16(ot * beta) / beta
+            A = f16((ot2 * beta @ v2.transpose(-1, -2)) * causal) / beta
+            S = f16((qq @ kk.transpose(-1, -2)) * causal)
+        elif MODE == "bf16_demean":
+            qq, kk, ot2 = bf(q), bf(k), bf(ot)
+            v2 = bf(vv - vv.mean(-1, keepdim=True))
+            A = bf((ot2 @ v2.transpose(-1, -2)) * causal)
+            S = bf((qq @ kk.transpose(-1, -2)) * causal)
+            v2 = bf(vv)
         else:
             qq, kk, v2, ot2 = q, k, vv, ot
             A = (ot2 @ v2.transpose(-1, -2)) * causal
@@ -56,7 +67,14 @@ labels = FX.make_labels(meta["lengths"], meta["nspk"], meta["lseed"])
 tr = TL.LsTrainRef(m.state_dict(), meta["cfg"], meta["warm"], meta["clip"], meta["pit"], dtype=torch.float64)
 tot, bce, emb, grads, bn, _, _ = tr.grads([f.double() for f in feats], labels)
 names = meta["param_names"]
+import pickle, os
+if MODE == "exact":
+    pickle.dump({k: (None if g is None else g.clone()) for k, g in grads.items()}, open("/tmp/exact_grads.pkl", "wb"))
+ex = pickle.load(open("/tmp/exact_grads.pkl", "rb"))
 for i, k in enumerate(names):
+    if grads[k] is not None and ("q_proj" in k or "k_proj" in k or "v_proj.weight" in k):
+        print(f"  L2err {float((grads[k]-ex[k]).norm()/ex[k].norm()):.2e}  {k}")
+for i, k in enumerate(names[:0]):
     if "self_attn1" in k and ("q_proj" in k or "k_proj" in k or "v_proj" in k) or "self_attn.q_proj" in k:
         g = grads[k]
         print(f"{k:60s} {float(g.norm()):.4e} ref {arr['grad_norms'][i]:.4e}  rel {float(g.norm())/arr['grad_norms'][i]-1:+.2e}")

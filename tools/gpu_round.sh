@@ -1,31 +1,44 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): GPU tests, smoke, bench, rocprofv3 kernel trace.
+# Runs on the GPU box (via gpurun).  WHAT = space/comma separated subset of: test smoke bench train train_ls prof prof_train_ls
 # Everything judged later is copied from gpurun_out/ into profiles/ by hand.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
-WHAT="${1:-all}"
+R=$PWD
+WHAT="${1:-test smoke bench}"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu_info.txt
 nproc >> gpurun_out/gpu_info.txt
-if [[ "$WHAT" == all || "$WHAT" == *test* ]]; then
-  timeout 900 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+has() { [[ " ${WHAT//,/ } " == *" $1 "* ]]; }
+if has test; then
+  timeout 1800 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-  tail -40 gpurun_out/pytest_gpu.log
+  tail -15 gpurun_out/pytest_gpu.log
 fi
-if [[ "$WHAT" == all || "$WHAT" == *smoke* ]]; then
+if has smoke; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
   tail -3 gpurun_out/smoke.log
 fi
-if [[ "$WHAT" == all || "$WHAT" == *bench* ]]; then
-  timeout 600 python bench.py --steps 20 --warmup 5 ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
-  tail -5 gpurun_out/bench.err; cat gpurun_out/bench.json
+if has bench; then
+  timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+  tail -3 gpurun_out/bench.err; cut -c1-600 gpurun_out/bench.json
 fi
-if [[ "$WHAT" == all || "$WHAT" == *prof* ]]; then
+if has train; then
+  timeout 900 python bench.py --mode train --steps 10 --warmup 3 ${TRAIN_ARGS:-} > gpurun_out/bench_train.json 2> gpurun_out/bench_train.err; echo "bench train rc=$?"
+  tail -3 gpurun_out/bench_train.err; cut -c1-600 gpurun_out/bench_train.json
+fi
+if has train_ls; then
+  timeout 900 python bench.py --mode train --flavour ls --steps 10 --warmup 3 ${TRAIN_ARGS:-} > gpurun_out/bench_train_ls.json 2> gpurun_out/bench_train_ls.err; echo "bench train ls rc=$?"
+  tail -3 gpurun_out/bench_train_ls.err; cut -c1-600 gpurun_out/bench_train_ls.json
+fi
+prof() {   # prof <tag> <bench args...>
+  local tag=$1; shift
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o fs -- \
-      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --graph 0 ${BENCH_ARGS:-}) > gpurun_out/prof_bench.log 2>&1
-  echo "prof rc=$?"; tail -2 gpurun_out/prof_bench.log
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o $tag -- python "$R/bench.py" "$@") > gpurun_out/prof_$tag.log 2>&1
+  echo "prof $tag rc=$?"; tail -2 gpurun_out/prof_$tag.log
   db=$(find gpurun_out/prof -name "*.db" | head -1)
-  [ -n "$db" ] && python tools/rocpd_stats.py "$db" gpurun_out/kernel_stats.csv && head -25 gpurun_out/kernel_stats.csv | cut -c1-200
+  [ -n "$db" ] && python tools/rocpd_stats.py "$db" gpurun_out/${tag}_kernel_stats.csv && head -12 gpurun_out/${tag}_kernel_stats.csv | cut -c1-180
   rm -rf gpurun_out/prof
-fi
+}
+if has prof; then prof fs --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-breakdown --graph 0 ${BENCH_ARGS:-}; fi
+if has prof_train; then prof train --mode train --steps 3 --warmup 2 --no-breakdown --no-cpu-baseline; fi
+if has prof_train_ls; then prof train_ls --mode train --flavour ls --steps 3 --warmup 2 --no-breakdown --no-cpu-baseline; fi
