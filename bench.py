@@ -615,7 +615,7 @@ class TrainCallTimer:
             elif name == "eend_linear_res_scale_ln_train_f16":
                 shape = (int(a[14]), 256, int(a[15]))
             elif name == "eend_retention_bwd_bf16":          # (nseq, H, valid frames, chunk)
-                shape = (int(a[19]), int(a[20]), int(a[23]), int(a[22]))
+                shape = (int(a[18]), int(a[19]), int(a[22]), int(a[21]))
             elif name == "eend_retention_chunk_train_f16":
                 shape = (int(a[12]), int(a[13]), int(a[19]), int(a[15]))
             else:

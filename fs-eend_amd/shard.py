@@ -56,3 +56,29 @@ def all_reduce_mean(buf, group=None):
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     buf.mul_(1.0 / world)
     return buf
+
+
+BN_STATS = 2 * 256 + 1        # per rank: mean[256], M2[256] (sum of squared deviations from that mean), frame count
+
+
+def gather_bn_stats(stats, group=None):
+    """SyncBatchNorm forward exchange (LS-EEND/train_dia_simu.py:167): every rank contributes ONE (mean, M2, n) triple of
+    its conv-module BatchNorm input; returns the (R, 513) table all ranks then merge identically (Chan's parallel
+    variance -- eend_bn_merge_f32).  One all-gather of 2 KB per BatchNorm layer; R = 1 without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return stats.view(1, -1), 1
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * stats.numel(), dtype=stats.dtype, device=stats.device)
+    dist.all_gather_into_tensor(flat, stats.contiguous().view(-1), group=group)
+    return flat.view(world, stats.numel()), world
+
+
+def all_reduce_bn_sums(sums, group=None):
+    """SyncBatchNorm backward exchange: the per-channel sums of d_y and d_y * x_hat become global (in place); the input
+    gradient of every rank then uses the global means, the weight / bias gradients stay local (DDP averages them)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums

@@ -30,6 +30,7 @@ from torch import Tensor
 
 from . import ops
 from .lib import EendHipError
+from .shard import all_reduce_bn_sums, gather_bn_stats
 from .train import (BF16, D, F16, F32, H, I32, WS_FLOATS, TrainStepBase, _Site, _call, drop_step_seed)
 
 ENC_FFA_HID, ENC_FFA_OUT, ENC_RET, ENC_CONV, ENC_FFB_HID, ENC_FFB_OUT = 0, 1, 2, 3, 4, 5
@@ -214,13 +215,6 @@ class LsTrainStep(TrainStepBase):
             self._bufs[key] = b
         return b
 
-    def _world(self):
-        import torch.distributed as dist
-        if self.sync_bn and dist.is_available() and dist.is_initialized():
-            n = dist.get_world_size(self.group)
-            return dist, n
-        return None, 1
-
     def _pit_assign(self, P, ys, ts, n_spk):
         return P.pit_loss_multispk(ys, ts, n_spk)           # train/oln_tfm_enc_dec_spk_pit_on_the_fly.py:92 (Hungarian)
 
@@ -275,7 +269,6 @@ class LsTrainStep(TrainStepBase):
             for b_, l in enumerate(labels):
                 lab[b_, :l.shape[0], :l.shape[1]] = l.to(device=dev, dtype=F32)
         bf.labels = lab
-        dist, world = self._world()
 
         # ---- input projection + LayerNorm (conformer/encoder.py:194-196); pad_sequence(0) + cast in one launch
         ptrs, lens = self._table_for(srcs, T)
@@ -302,11 +295,8 @@ class LsTrainStep(TrainStepBase):
             ops.linear(sv["lnC"].out16, W[f"e{i}.pw1"], self._P(cm + "2.conv.bias"), sv["P"])
             _call("eend_glu_dwconv_f16", sv["P"], self._P(cm + "4.conv.weight"), sv["c16"], B, Tp, Tv, self.kdw)
             _call("eend_bn_batch_stats_f16", sv["c16"], self.ws, WS_FLOATS, bf.bn_stats, B, Tp, Tv)
-            stats, R = bf.bn_stats, 1
-            if world > 1:                                # SyncBatchNorm: one (mean, M2, n) triple per rank, merged exactly
-                stats = torch.empty(world, 2 * D + 1, dtype=F32, device=dev)
-                dist.all_gather_into_tensor(stats, bf.bn_stats, group=self.group)
-                R = world
+            # SyncBatchNorm: one (mean, M2, n) triple per rank, merged exactly (shard.gather_bn_stats; R = 1 without peers)
+            stats, R = (bf.bn_stats.view(1, -1), 1) if not self.sync_bn else gather_bn_stats(bf.bn_stats, self.group)
             bnm = m.enc.encoder.layers[i].sequential[2].module.sequential[5]
             _call("eend_bn_merge_f32", stats, R, sv["bn_mean"], sv["bn_var"], sv["bn_n"], bnm.running_mean, bnm.running_var,
                   self.bn_momentum)
@@ -412,7 +402,6 @@ class LsTrainStep(TrainStepBase):
         ds16, dctx16, dqkv16 = bf.ds16, bf.dctx16, bf.dqkv16
         dr = lambda site: self._drop(bf, site)
         ff_scale = 1.0 / (1.0 - self.drop_p) if bf.drop_base is not None else 1.0
-        dist, world = self._world()
 
         # ---- decoder layers, last to first; bf.g32 = gradient w.r.t. the layer output
         g32 = bf.g32
@@ -468,8 +457,8 @@ class LsTrainStep(TrainStepBase):
             bn_args = (sv["c16"], sv["bn_mean"], sv["bn_var"], bnm.eps, self._P(cm + "5.weight"), self._P(cm + "5.bias"))
             _call("eend_bn_swish_bwd_stats_bf16", dsw, *bn_args, self.ws, WS_FLOATS, bf.bn_sums, self._G(cm + "5.weight"),
                   self._G(cm + "5.bias"), B, Tp, Tv)
-            if world > 1:                                # SyncBatchNorm backward: the two per-channel sums are global
-                dist.all_reduce(bf.bn_sums, group=self.group)
+            if self.sync_bn:                             # SyncBatchNorm backward: the two per-channel sums become global
+                all_reduce_bn_sums(bf.bn_sums, self.group)
             _call("eend_bn_swish_bwd_apply_bf16", dsw, *bn_args, bf.bn_sums, sv["bn_n"], B, Tp, Tv)
             dP = bf.dh16[:Me * 2 * D].view(Me, 2 * D)
             _call("eend_dwconv_glu_bwd_bf16", dsw, sv["P"], self._P(cm + "4.conv.weight"), dP, self.ws, WS_FLOATS,

@@ -243,24 +243,101 @@ class SpeakerDiarization:
         return self._loader("val", 1, False)
 
 
+class ModelCheckpoint:
+    """The checkpoint callback the reference passes to its Trainer (FS-EEND/train_dia.py:118-121: monitor val/obj_metric,
+    save_top_k, save_last; LS-EEND/train_dia_simu.py:131).  Files are named like Lightning's default,
+    `epoch={e}-step={global_step}.ckpt` -- the names `select_epoch_checkpoints` / train_dia.py:166-175 parse -- and hold
+    {"state_dict": {"model.<key>": tensor}, "optimizer_state": ..., "epoch", "global_step"}: enough to resume.
+    save_top_k = -1 keeps every epoch (what checkpoint averaging wants), k > 0 the k best by `monitor`, 0 none."""
+
+    def __init__(self, dirpath, monitor=None, save_top_k=-1, mode="min", save_last=True, **_lightning_only):
+        self.dirpath, self.monitor, self.save_top_k, self.mode, self.save_last = dirpath, monitor, save_top_k, mode, save_last
+        self.kept = []                       # (score, path)
+        self.best_model_path = ""
+
+    def on_epoch_end(self, trainer, module, epoch):
+        import os
+        os.makedirs(self.dirpath, exist_ok=True)
+        ckpt = trainer.checkpoint(module, epoch)
+        if self.save_last:
+            torch.save(ckpt, os.path.join(self.dirpath, "last.ckpt"))
+        if self.save_top_k == 0:
+            return
+        path = os.path.join(self.dirpath, f"epoch={epoch}-step={trainer.global_step}.ckpt")
+        score = module.logged.get(self.monitor) if self.monitor else None
+        score = float(score) if score is not None else float(epoch)
+        if self.mode == "max":
+            score = -score
+        torch.save(ckpt, path)
+        self.kept.append((score, path))
+        if self.save_top_k > 0 and self.monitor:
+            self.kept.sort(key=lambda t: t[0])
+            for _, old in self.kept[self.save_top_k:]:
+                if os.path.exists(old):
+                    os.remove(old)
+            self.kept = self.kept[:self.save_top_k]
+        self.best_model_path = min(self.kept, key=lambda t: t[0])[1]
+
+
 class Trainer:
-    """The slice of pytorch_lightning.Trainer the reference uses (FS-EEND/train_dia.py:145-160,185), one process per GPU."""
+    """The slice of pytorch_lightning.Trainer the reference uses (FS-EEND/train_dia.py:145-160,185; LS-EEND/
+    train_dia_simu.py:159-173), one process per GPU: max_epochs, callbacks (ModelCheckpoint above), strategy "ddp",
+    sync_batchnorm (LS-EEND), accumulate_grad_batches, resume_from_checkpoint, gradient_clip_val,
+    check_val_every_n_epoch, limit_*_batches.  Arguments it does not implement are refused, not ignored."""
+
+    _NO_EFFECT = ("gpus", "devices", "accelerator", "logger", "profiler", "enable_progress_bar", "num_nodes", "deterministic")
 
     def __init__(self, max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=1, check_val_every_n_epoch=1,
                  strategy=None, limit_train_batches=None, limit_val_batches=None, log_every_n_steps=100, callbacks=None,
-                 num_sanity_val_steps=0, **_ignored):
-        if accumulate_grad_batches not in (None, 1):
-            raise NotImplementedError("accumulate_grad_batches > 1 (no shipped config uses it)")
+                 num_sanity_val_steps=0, resume_from_checkpoint=None, sync_batchnorm=None, default_root_dir=None, **kw):
+        unknown = [k for k in kw if k not in self._NO_EFFECT]
+        if unknown:
+            raise TypeError(f"Trainer: unsupported argument(s) {unknown} (not part of the reference's recipe)")
+        if strategy not in (None, "ddp", "ddp_find_unused_parameters_false", "auto"):
+            raise NotImplementedError(f"strategy={strategy!r}: one process per GPU with a flat-gradient all-reduce (ddp) only")
+        self.accum = int(accumulate_grad_batches or 1)
+        if self.accum < 1:
+            raise ValueError("accumulate_grad_batches must be >= 1")
+        self.callbacks = list(callbacks or [])
+        for cb in self.callbacks:
+            if not isinstance(cb, ModelCheckpoint):
+                raise TypeError(f"Trainer: unsupported callback {type(cb).__name__} (fs_eend_amd.trainer.ModelCheckpoint only)")
+        if default_root_dir and not self.callbacks:
+            self.callbacks.append(ModelCheckpoint(default_root_dir))
         self.max_epochs, self.clip, self.val_every = max_epochs, gradient_clip_val, check_val_every_n_epoch
         self.limit_train, self.limit_val, self.log_every = limit_train_batches, limit_val_batches, log_every_n_steps
-        self.strategy = strategy
+        self.strategy, self.resume, self.sync_bn = strategy, resume_from_checkpoint, sync_batchnorm
         self.global_step = 0
+        self.current_epoch = 0
         self.history = []
+
+    @property
+    def checkpoint_callback(self):
+        return self.callbacks[0] if self.callbacks else None
 
     @staticmethod
     def _dist():
         import torch.distributed as dist
         return dist if dist.is_available() and dist.is_initialized() else None
+
+    def checkpoint(self, module, epoch):
+        eng = module._engine()
+        return dict(state_dict={k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
+                    optimizer_state={k: (v.cpu() if isinstance(v, Tensor) else v) for k, v in eng.optimizer_state().items()},
+                    epoch=epoch, global_step=self.global_step)
+
+    def _restore(self, module, path):
+        ckpt = torch.load(path, map_location="cpu")
+        if "state_dict" not in ckpt:                     # a bare state dict (LS-EEND/train_dia_simu.py:196-199 saves those)
+            module.load_state_dict(ckpt)
+            return 0
+        module.load_state_dict(ckpt["state_dict"])
+        eng = module._engine()
+        if ckpt.get("optimizer_state") is not None:
+            eng.load_optimizer_state(ckpt["optimizer_state"])
+        eng.prep_weights()
+        self.global_step = int(ckpt.get("global_step", 0))
+        return int(ckpt.get("epoch", -1)) + 1
 
     def fit(self, module: SpeakerDiarization):
         dist = self._dist()
@@ -268,7 +345,10 @@ class Trainer:
         module.global_rank, module.world_size = rank, world
         if self.clip is not None:
             module.hparams.setdefault("training", {})["grad_clip"] = self.clip
+        if self.sync_bn is not None:
+            module.hparams.setdefault("training", {})["sync_batchnorm"] = bool(self.sync_bn)
         eng = module._engine()
+        first_epoch = self._restore(module, self.resume) if self.resume else 0
         if dist and world > 1:                         # DDP start-up: every rank begins from rank 0's parameters / buffers
             dist.broadcast(eng.flat.params, 0)
             for b in module.model.buffers():
@@ -279,32 +359,54 @@ class Trainer:
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(module.datasets["train"], num_replicas=world, rank=rank,
                                          shuffle=module.hparams["training"].get("shuffle", True))
-        for epoch in range(self.max_epochs):
+        for epoch in range(first_epoch, self.max_epochs):
+            self.current_epoch = epoch
             if sampler is not None:
                 sampler.set_epoch(epoch)
             module.model.train()
+            micro = 0
             for bi, batch in enumerate(module.train_dataloader(sampler)):
                 if self.limit_train is not None and bi >= self.limit_train:
                     break
                 loss = module.training_step(batch, bi)
                 module.backward()
+                eng.accumulate_grads(micro, self.accum)      # no-op for accumulate_grad_batches == 1
+                micro += 1
+                if micro < self.accum:
+                    continue
+                micro = 0
                 lr = module.optimizer_step()
                 self.global_step += 1
                 if self.global_step % self.log_every == 0 or self.global_step == 1:
                     self.history.append(dict(step=self.global_step, loss=float(loss), lr=lr))
+            if micro:                                 # epoch length not a multiple of accumulate_grad_batches: step with what there is
+                _finish_partial(eng, micro, self.accum)
+                module.optimizer_step()
+                self.global_step += 1
             if self.val_every and (epoch + 1) % self.val_every == 0 and "val" in module.datasets:
                 outs = []
+                module.model.eval()
                 for bi, batch in enumerate(module.val_dataloader()):
                     if self.limit_val is not None and bi >= self.limit_val:
                         break
                     outs.append(module.validation_step(batch, bi))
                 if outs:
                     module.validation_epoch_end(outs)
+            if rank == 0:
+                for cb in self.callbacks:
+                    cb.on_epoch_end(self, module, epoch)
         return self
 
     def test(self, module: SpeakerDiarization):
         outs = [module.test_step(b, i) for i, b in enumerate(module.test_dataloader())]
         return module.test_epoch_end(outs) if outs else {}
+
+
+def _finish_partial(eng, done, count):
+    """`done` < `count` micro-batches were accumulated (each scaled 1/count) when the epoch ended: move the running sum
+    into the gradient buffer so the optimiser steps with it (Lightning steps on the last, shorter group too)."""
+    from .train import _call
+    _call("eend_grad_accumulate_f32", eng.flat.grads, eng._gacc, 1.0, 1, eng.flat.numel)
 
 
 def average_checkpoints(state_dicts):

@@ -205,3 +205,69 @@ def test_dropin_binds_next_to_the_reference(flavour, script, model_mod, kept):
             "print('ok')") % (ROOT, os.path.join(ref, script), ref, ref)
     out = _run_py(code)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr + out.stdout
+
+
+def _bn_worker(rank, world, port, q):
+    """SyncBatchNorm exchange of the LS-EEND training step on CPU tensors over gloo: the PRODUCT's host-side exchange
+    (fs_eend_amd.shard.gather_bn_stats / all_reduce_bn_sums) around the oracle's restatement of the device arithmetic."""
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from fs_eend_amd.shard import BN_STATS, all_reduce_bn_sums, gather_bn_stats
+    from oracle import bn_sync_ref as BR
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100)
+    rows = [700, 1300]                                   # ranks own different frame counts (ragged batches)
+    c_all = [torch.randn(r, 256, generator=g) * (1 + i) + 0.3 * i for i, r in enumerate(rows)]
+    ds_all = [torch.randn(r, 256, generator=g) * 1e-3 for r in rows]
+    gamma, beta = 1 + 0.2 * torch.randn(256, generator=g).double(), 0.1 * torch.randn(256, generator=g).double()
+    c, ds = c_all[rank], ds_all[rank]
+    st = BR.local_stats(c).float()
+    assert st.numel() == BN_STATS
+    table, R = gather_bn_stats(st, None)
+    mean, var, n, var_unb = BR.merge(table)
+    sums = BR.bwd_sums(ds, c, mean, var, gamma, beta).float()
+    local_sums = sums.clone()
+    all_reduce_bn_sums(sums, None)
+    dc = BR.bwd_apply(ds, c, mean, var, gamma, beta, sums.double(), n)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, R, mean.numpy(), var.numpy(), var_unb.numpy(), n, dc.numpy(), local_sums.numpy()))     # plain arrays: no shared-memory handles
+
+
+def test_two_rank_sync_batchnorm_exchange_equals_global_batch():
+    """world_size 2: the merged statistics equal those of the concatenated batch, and every rank's input gradient equals
+    the autograd gradient of swish(BatchNorm(c)) over the concatenated batch (torch.nn.SyncBatchNorm semantics); the
+    weight / bias gradients stay rank-local sums (DDP averages them afterwards)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(100)
+    rows = [700, 1300]
+    c_all = [torch.randn(r, 256, generator=g) * (1 + i) + 0.3 * i for i, r in enumerate(rows)]
+    ds_all = [torch.randn(r, 256, generator=g) * 1e-3 for r in rows]
+    gamma, beta = 1 + 0.2 * torch.randn(256, generator=g).double(), 0.1 * torch.randn(256, generator=g).double()
+    cat = torch.cat(c_all).double().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    mu, var = cat.mean(0), cat.var(0, unbiased=False)
+    y = gm * (cat - mu) / torch.sqrt(var + 1e-5) + bt
+    out = y * torch.sigmoid(y)
+    out.backward(torch.cat(ds_all).double())
+    off = 0
+    res = [(r[0], r[1]) + tuple(torch.from_numpy(x) if hasattr(x, "dtype") else x for x in r[2:]) for r in res]
+    for rank, R, mean, v, v_unb, n, dc, local_sums in res:
+        assert R == 2 and n == sum(rows)
+        assert torch.allclose(mean, mu.detach(), atol=1e-6) and torch.allclose(v, var.detach(), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(v_unb, cat.detach().var(0, unbiased=True), rtol=1e-5)
+        assert torch.allclose(dc, cat.grad[off:off + rows[rank]], rtol=1e-4, atol=1e-9)
+        off += rows[rank]
+    # local sums of the two ranks add up to the BatchNorm weight / bias gradients of the global batch
+    tot = res[0][7].double() + res[1][7].double()
+    assert torch.allclose(tot[:256], bt.grad, rtol=1e-4, atol=1e-8) and torch.allclose(tot[256:], gm.grad, rtol=1e-4, atol=1e-8)
