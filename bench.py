@@ -201,6 +201,44 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
                        f"; {time.perf_counter() - t_start:.1f} s of CPU work")
 
 
+def batch_sweep(dev, model, T, C, sizes=(1, 512)):
+    """the same model.test at B in {1, 64, 512} utterances per GPU (64 is the headline line): frames/s and
+    ms/step under hipGraph replay, 5 timed steps each.  B = 1 is the latency end (4 + 2*C sequence-heads cannot fill 256
+    CUs), B = 512 the throughput end (8x the workgroups of the headline batch)."""
+    out = {}
+    for Bs in sizes:
+        try:
+            g = torch.Generator().manual_seed(4242 + Bs)
+            src = [(torch.randn(T, 345, generator=g) * 2 - 3).to(dev) for _ in range(Bs)]
+            il = [T] * Bs
+            model.test(src, il, C)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                model.test(src, il, C)
+            torch.cuda.current_stream().wait_stream(st)
+            with torch.cuda.graph(gr):
+                keep = model.test(src, il, C)
+            for _ in range(2):
+                gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                gr.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out[str(Bs)] = dict(frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3, peak_hbm_bytes=int(torch.cuda.max_memory_allocated(dev)))
+            del gr, keep, src
+            model._ws.clear() if hasattr(model, "_ws") else None
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out[str(Bs)] = dict(error=f"{type(ex).__name__}: {ex}")
+    return out
+
+
 def extras(dev):
     """Side measurements (not the headline metric): LS-EEND chunked batch throughput (BASELINE config 3)
     and frame-by-frame streaming latency / real-time factor of both flavours (config 5 mechanism)."""
@@ -487,6 +525,22 @@ def extras(dev):
         res["fs_eend_streaming_graph"] = dict(workload="1 stream, max_nspks=6, FsStreamSession: K/V caches + device-side history counters "
                                                        "resident in HBM, 3 hipGraph replays per frame (one capture per cache-capacity bucket)",
                                               ms_per_frame=per_g * 1e3, rtf=per_g / 0.1, speedup_vs_eager=per / per_g)
+        # the decode step reads the whole K/V history, so its cost grows with the stream position: measured at the
+        # positions of BASELINE config 5 (one hour = 36 000 frames; K/V caches 4*1 + 2*6 heads-sets x 2 x t x 256 x 2 B)
+        at = {}
+        for pos in (5000, 36000):
+            ses.seek(pos)
+            for t in range(20):
+                ses.push(x[t])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(100):
+                ses.push(x[20 + t % (nfr - 20)])
+            torch.cuda.synchronize()
+            at[str(pos)] = (time.perf_counter() - t0) / 100 * 1e3
+        res["fs_eend_streaming_graph"]["ms_per_frame_at_t"] = at
+        res["fs_eend_streaming_graph"]["rtf_at_t36000"] = at["36000"] * 1e-3 / 0.1
+        res["fs_eend_streaming_graph"]["kv_cache_bytes_at_t36000"] = int(sum(c.numel() * 2 for kv in ses.enc_kv + ses.dec_kv for c in kv))
     except Exception as ex:
         res["fs_eend_streaming_graph"] = dict(error=f"{type(ex).__name__}: {ex}")
     return res
@@ -946,6 +1000,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         out["extras"] = extras(dev)
+        sw = batch_sweep(dev, model, T, C)
+        sw[str(B)] = dict(frames_per_s=value, ms_per_step=dt / args.steps * 1e3)
+        out["extras"]["batch_sweep"] = sw
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, C)

@@ -162,6 +162,42 @@ class _Workspace:
         self.qkv16 = e(Md if not FUSED_SPK else 0, 3 * D, dt=f16)
 
 
+class WorkspaceCache:
+    """Activation workspaces keyed by shape, least-recently-used eviction under a byte budget (EEND_WS_BUDGET_GB, default
+    24): ragged real-world inference walks through many (B, Tp, C) shapes, and dropping every workspace whenever a count is
+    exceeded re-allocates multi-GB slabs per call.  The entry in use is never evicted."""
+
+    def __init__(self, budget_bytes: Optional[int] = None, max_entries: int = 32):
+        import os
+        from collections import OrderedDict
+        self._d = OrderedDict()
+        self.budget = int(float(os.environ.get("EEND_WS_BUDGET_GB", "24")) * 2 ** 30) if budget_bytes is None else budget_bytes
+        self.max_entries = max_entries
+
+    @staticmethod
+    def nbytes(ws) -> int:
+        return sum(t.numel() * t.element_size() for t in vars(ws).values() if isinstance(t, Tensor))
+
+    def get(self, key):
+        ws = self._d.get(key)
+        if ws is not None:
+            self._d.move_to_end(key)
+        return ws
+
+    def put(self, key, ws):
+        self._d[key] = ws
+        total = sum(self.nbytes(w) for w in self._d.values())
+        while len(self._d) > 1 and (total > self.budget or len(self._d) > self.max_entries):
+            _, old = self._d.popitem(last=False)
+            total -= self.nbytes(old)
+
+    def clear(self):
+        self._d.clear()
+
+    def __len__(self):
+        return len(self._d)
+
+
 class OnlineTransformerDADiarization(nn.Module):
     """FS-EEND batch model on MI355X (reference model :10-84)."""
 
@@ -181,7 +217,7 @@ class OnlineTransformerDADiarization(nn.Module):
         self.cnn = nn.Conv1d(n_units, n_units, kernel_size=2 * conv_delay + 1, padding=9)
         self._prep = None
         self._prep_key = None
-        self._ws = {}
+        self._ws = WorkspaceCache()
         self._pc = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
 
@@ -271,13 +307,11 @@ class OnlineTransformerDADiarization(nn.Module):
         key = (str(dev), B, Tp, C)
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 8:
-                self._ws.clear()
             P = self._prep
             F_enc = P["enc.layers"][0]["w1"].shape[0] if P["enc.layers"] else 0
             F_dec = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
             ws = _Workspace(dev, B, Tp, C, self.enc.n_units, F_enc, F_dec, P["Fin_pad"], self.enc.n_heads)
-            self._ws[key] = ws
+            self._ws.put(key, ws)
         return ws
 
     # ------------------------------------------------------------------ the hot path

@@ -395,14 +395,36 @@ class FsStreamSession:
             self._capture()
         self._graphs[i].replay()
 
+    def seek(self, t: int):
+        """Benchmarking aid: continue as if `t` frames had already been pushed -- the K/V caches keep whatever they hold
+        (zeros after construction), only the history counters move, so the per-frame cost at a given stream position
+        (it grows with t: every decode step reads the whole K/V history) can be measured without streaming up to it."""
+        while t + 2 >= self.cap:
+            self._alloc_caches(2 * self.cap, keep=True)
+        self.n_enc, self.n_dec, self.t = t, max(0, t - self.center), t
+        self.t_enc.fill_(self.n_enc)
+        self.t_dec.fill_(self.n_dec)
+
     def _room(self):
         if max(self.n_enc, self.n_dec) + 1 >= self.cap:                   # next capacity bucket: bigger caches, new graphs
             self._alloc_caches(2 * self.cap, keep=True)
+
+    def _check_weights(self):
+        """The captured graphs hold raw pointers into the model's operand copies (model._prepare()): if the weights were
+        refreshed since the capture (load_state_dict, .to(), an optimiser step) those copies are stale or freed -- capture
+        again on the new ones instead of replaying over dead memory."""
+        P = self.m._prep
+        if P is None or (self.t & 255) == 0:
+            P = self.m._prepare()
+        if P is not getattr(self, "_P_captured", None):
+            self._P_captured = P
+            self._graphs = None
 
     @torch.no_grad()
     def push(self, x_t):
         """x_t: features of the next frame ((1,1,in) / (1,in) / (in,)) -> logits (1,1,C) of frame t - conv_delay, or None
         during the first conv_delay frames."""
+        self._check_weights()
         self._room()
         self.x_in.copy_(x_t.reshape(1, 1, -1))
         self._run(0)

@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, PositionalEncoding, _f16, _f32
+from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, PositionalEncoding, WorkspaceCache, _f16, _f32
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -268,7 +268,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         self.cnn = nn.Conv1d(n_units, n_units, kernel_size=2 * conv_delay + 1, padding=conv_delay)
         self._in_size, self._n_heads = in_size, n_heads
         self._prep = self._prep_key = None
-        self._ws, self._pc, self._step_scratch = {}, {}, {}
+        self._ws, self._pc, self._step_scratch = WorkspaceCache(), {}, {}
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
         # back-references for the one-step API (bypass nn.Module registration: no module cycle)
         object.__setattr__(self.enc, "_owner", weakref.ref(self))
@@ -377,13 +377,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         key = (str(dev), B, Tp, C, nc)
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 8:
-                self._ws.clear()
             P = self._prep
             F_enc = P["blocks"][0]["w1a"].shape[0] if P["blocks"] else 0
             F_dec = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
             ws = _Workspace(dev, B, Tp, C, self.n_units, F_enc, F_dec, P["Fin_pad"], self._n_heads, nc)
-            self._ws[key] = ws
+            self._ws.put(key, ws)
         return ws
 
     # ------------------------------------------------------------------ the hot path

@@ -262,9 +262,27 @@ class LsStreamSession:
         else:
             (self._enc, self._conv, self._dec)[i]()
 
+    def _check_weights(self):
+        """The captured graphs hold raw pointers into the model's operand copies: re-capture (keeping the streaming state)
+        when the weights were refreshed since -- load_state_dict, .to(), an optimiser step."""
+        P = self.m._prep
+        if P is None or (self.t & 255) == 0:
+            P = self.m._prepare()
+        if P is not getattr(self, "_P_captured", None):
+            first = getattr(self, "_P_captured", None) is None
+            self._P_captured = P
+            if self._graphs is not None and not first:
+                keep = [t_.clone() for t_ in self._stateful]
+                t = self.t
+                self._capture()
+                for dst, src in zip(self._stateful, keep):
+                    dst.copy_(src)
+                self.t = t
+
     @torch.no_grad()
     def push(self, x_t):
         """x_t (B, 1, in_size) or (B, in_size) features of the next frame -> logits (B, 1, C) of frame t - delay, or None."""
+        self._check_weights()
         self.x_in.copy_(x_t.reshape(self.B, 1, -1))
         self._run(0)
         return self._emit()

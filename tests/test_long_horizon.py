@@ -1,0 +1,117 @@
+"""GPU: long-horizon parity against the REFERENCE's own outputs (oracle/gen_golden_long.py; BASELINE config 5).
+
+  * one hour (T = 36 000, max_nspks = 10) of LS-EEND: `test_chunked` / `test` vs the reference's batch `model.test`
+    (tests/golden/ls_hour_c10.npz) -- 72 retention chunks with the state carried;
+  * the same hour frame by frame through `LsStreamSession` vs the reference's frame-by-frame driver
+    (ls_hour_stream_c10.npz) -- the recurrent form `kv_t = kv_{t-1} sqrt((t-1)/t) + k (x) v / sqrt(t)` over 36 000 steps;
+  * FS-EEND K/V-cache decode to t = 5000 through `FsStreamSession` vs the reference's streaming model and vs its batch
+    test (fs_stream_T5000.npz).
+Bar: per-frame activity logits within 1e-3 of the reference (north_star), measured on the stored rows."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as FX
+from tests.helpers import build_fs_mirror, build_ls_mirror
+
+pytestmark = pytest.mark.gpu
+
+
+def _have(name):
+    return os.path.exists(os.path.join(FX.GOLDEN_DIR, name + ".npz"))
+
+
+def test_ls_one_hour_batch_vs_reference(hip_lib, dev):
+    assert _have("ls_hour_c10")
+    meta, arr = FX.load_case("ls_hour_c10")
+    m = build_ls_mirror(meta).to(dev)
+    T, C = meta["lengths"][0], meta["C"]
+    src = [s.to(dev) for s in FX.make_src([T], meta["in_size"], meta["xseed"])]
+    rows = torch.as_tensor(arr["rows"], device=dev)
+    want = torch.as_tensor(arr["logits"], device=dev)
+    lg, em, _ = m.test_chunked(src, [T], C, return_attractors=False)
+    torch.cuda.synchronize()
+    d = (lg[0][rows] - want).abs()
+    print(f"LS one hour, test_chunked vs reference batch: max |d logit| {float(d.max()):.2e} (first 600 frames {float(d[:600].max()):.2e}, "
+          f"last 600 {float(d[-600:].max()):.2e})")
+    assert float(d.max()) < 1e-3
+    e_want = torch.as_tensor(arr["emb"], device=dev)
+    assert float((em[0][rows[::8]] - e_want).abs().max()) < 3e-3
+    lg2, _, _ = m.test(src, [T], C)
+    assert torch.equal(lg2[0], lg[0])
+
+
+def test_ls_one_hour_streaming_vs_reference_streaming(hip_lib, dev):
+    assert _have("ls_hour_stream_c10")
+    from fs_eend_amd.ls_stream import LsStreamSession
+    meta, arr = FX.load_case("ls_hour_stream_c10")
+    m = build_ls_mirror(meta).to(dev)
+    T, C = meta["lengths"][0], meta["C"]
+    src = FX.make_src([T], meta["in_size"], meta["xseed"])[0].to(dev)
+    sess = LsStreamSession(m, C)
+    keep = {int(r): i for i, r in enumerate(arr["rows"])}
+    got = torch.zeros(len(keep), C, device=dev)
+    n = 0
+    for t in range(T):
+        y = sess.push(src[t])
+        if y is not None:
+            if n in keep:
+                got[keep[n]] = y[0, 0]
+            n += 1
+    for y in sess.flush():
+        if n in keep:
+            got[keep[n]] = y[0, 0]
+        n += 1
+    torch.cuda.synchronize()
+    assert n == meta["frames_out"] == T
+    want = torch.as_tensor(arr["stream_logits"], device=dev)
+    d = (got - want).abs()
+    print(f"LS one hour, LsStreamSession vs reference streaming: max |d logit| {float(d.max()):.2e} (first 600 {float(d[:600].max()):.2e}, "
+          f"last 600 {float(d[-600:].max()):.2e})")
+    assert float(d.max()) < 1e-3
+    # and against the reference's BATCH output of the same hour: the reference's own streaming-vs-batch looseness
+    if _have("ls_hour_c10"):
+        _, barr = FX.load_case("ls_hour_c10")
+        assert np.array_equal(barr["rows"], arr["rows"])
+        ref_gap = float(np.abs(barr["logits"] - arr["stream_logits"]).max())
+        our_gap = float((got - torch.as_tensor(barr["logits"], device=dev)).abs().max())
+        print(f"   streaming vs batch over the hour: reference {ref_gap:.2e}, this build {our_gap:.2e}")
+        assert our_gap < ref_gap + 1e-3
+
+
+def test_fs_streaming_to_5000_frames_vs_reference(hip_lib, dev):
+    assert _have("fs_stream_T5000")
+    from fs_eend_amd.fs_stream import FsStreamSession, StreamingTransformerEDADiarization, copy_params_from_masked_to_streaming
+    meta, arr = FX.load_case("fs_stream_T5000")
+    m = build_fs_mirror(meta).to(dev)
+    sm = StreamingTransformerEDADiarization(in_size=meta["in_size"], **meta["cfg"]).eval().to(dev)
+    copy_params_from_masked_to_streaming(m, sm)
+    T, C = meta["T"], meta["C"]
+    src = FX.make_src([T], meta["in_size"], meta["xseed"])[0].to(dev)
+    sess = FsStreamSession(sm, C, cap=1024)                   # three cache growths on the way to 5000
+    keep = {int(r): i for i, r in enumerate(arr["rows"])}
+    got = torch.zeros(len(keep), C, device=dev)
+    n = 0
+    for t in range(T):
+        y = sess.push(src[t])
+        if y is not None:
+            if n in keep:
+                got[keep[n]] = y[0, 0]
+            n += 1
+    for y in sess.flush():
+        if n in keep:
+            got[keep[n]] = y[0, 0]
+        n += 1
+    torch.cuda.synchronize()
+    assert n == T
+    d = (got - torch.as_tensor(arr["stream_logits"], device=dev)).abs()
+    print(f"FS streaming to t={T}: vs reference streaming max |d logit| {float(d.max()):.2e} (last 600 frames {float(d[-600:].max()):.2e})")
+    assert float(d.max()) < 1e-3
+    # batch path on the same 5000 frames (tiled attention kernel, Tp > 512) vs the reference's batch output
+    lg, _, _ = m.test([src], [T], C)
+    rows = torch.as_tensor(arr["rows"], device=dev)
+    db = (lg[0][rows] - torch.as_tensor(arr["batch_logits"], device=dev)).abs()
+    print(f"FS batch T={T} vs reference batch: max |d logit| {float(db.max()):.2e}")
+    assert float(db.max()) < 1e-3

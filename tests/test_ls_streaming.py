@@ -135,3 +135,55 @@ def test_ls_stream_session(hip_lib, dev, use_graph):
         assert max_abs(ys, want.cpu()) < 3e-4
         assert float(sess.enc_states[0]["scale"][0]) == meta["T"]
         sess.reset()
+
+
+def test_stream_sessions_survive_a_weight_refresh(hip_lib, dev):
+    """the captured graphs point into the model's operand copies; after load_state_dict (which rebuilds them)
+    the sessions must capture again instead of replaying over freed memory -- same weights reloaded mid-stream must not
+    change a single output bit, for both flavours."""
+    import gc
+    from fs_eend_amd.fs_stream import FsStreamSession, StreamingTransformerEDADiarization, copy_params_from_masked_to_streaming
+    from fs_eend_amd.ls_stream import LsStreamSession
+    from tests.helpers import build_fs_mirror
+    meta, _ = FX.load_case("ls_stream_T120")
+    m = build_ls_mirror(meta).to(dev)
+    src = FX.make_src([meta["T"]], meta["in_size"], meta["xseed"])[0].to(dev)
+
+    def run_ls(refresh):
+        s = LsStreamSession(m, meta["C"])
+        out = []
+        for t in range(60):
+            if refresh and t == 30:
+                m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+                gc.collect()
+                torch.cuda.empty_cache()
+                junk = torch.full((64 * 1024 * 1024,), float("nan"), device=dev)      # scribble over whatever was freed
+                del junk
+            y = s.push(src[t])
+            if y is not None:
+                out.append(y)
+        return torch.cat(out)
+
+    assert torch.equal(run_ls(False), run_ls(True))
+    fmeta, _ = FX.load_case("fs_stream_T60")
+    fm = build_fs_mirror(fmeta).to(dev)
+    sm = StreamingTransformerEDADiarization(in_size=fmeta["in_size"], **fmeta["cfg"]).eval().to(dev)
+    copy_params_from_masked_to_streaming(fm, sm)
+    fsrc = FX.make_src([fmeta["T"]], fmeta["in_size"], fmeta["xseed"])[0].to(dev)
+
+    def run_fs(refresh):
+        s = FsStreamSession(sm, fmeta["C"], cap=64)
+        out = []
+        for t in range(50):
+            if refresh and t == 25:
+                sm.load_state_dict({k: v.clone() for k, v in sm.state_dict().items()})
+                gc.collect()
+                torch.cuda.empty_cache()
+                junk = torch.full((64 * 1024 * 1024,), float("nan"), device=dev)
+                del junk
+            y = s.push(fsrc[t])
+            if y is not None:
+                out.append(y)
+        return torch.cat(out)
+
+    assert torch.equal(run_fs(False), run_fs(True))
