@@ -358,6 +358,12 @@ int eend_attn_decode_dev_f16(const void* qkv, void* K_cache, void* V_cache, void
     return eend_launch_attn_decode(qkv, K_cache, V_cache, out_f16, N, H, cap, 0, t_dev, scale, (hipStream_t)stream);
 }
 
+int eend_attn_decode_split_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, float* ws, long ws_floats, int N,
+                               int H, int cap, const int* t_dev, float scale, void* stream) {
+    if (!qkv || !K_cache || !V_cache || !out_f16 || !ws || !t_dev) return EEND_EINVAL;
+    return eend_launch_attn_decode_split(qkv, K_cache, V_cache, out_f16, ws, ws_floats, N, H, cap, t_dev, scale, (hipStream_t)stream);
+}
+
 int eend_counter_add_i32(int* counter, int inc, void* stream) {
     return eend_launch_counter_add(counter, inc, (hipStream_t)stream);
 }

@@ -13,11 +13,18 @@
 // query-block pairs, no barriers).  Q (64 KB per head) makes a round trip through an L2-resident scratch buffer:
 // it is produced feature-split across the waves and consumed query-split, and LDS is full (64 + 64 + 32 KB).
 //
+// Round 3: the kernel is PERSISTENT -- one workgroup per CU walks the (sequence, head) items (item L, L + gridDim.x, ...).
+// The Q scratch is then a per-WORKGROUP 64 KB slot that is rewritten for every item, i.e. it stays in that XCD's L2
+// instead of making a 2 x 100 MB round trip through HBM per decoder launch (r02 PMC: 422 MB per launch against 200 MB
+// algorithmic); the dispatch of a fresh 160 KB-LDS workgroup per item (5.7 us per round in the s_memtime traces) is paid
+// once; and the first X tile of the next item is requested while the current item's flash loop runs.
+//
 // The q rows of W / bias must be pre-multiplied by 1/sqrt(dh) * log2(e) (ops.QSCALE_LOG2), as for the LAZY path of
 // attn_causal_full_kernel.  Block index -> (sequence, head) is XCD-aware: the four heads of a sequence run on the
 // same XCD, so three of the four reads of its X rows are L2 hits.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -55,18 +62,30 @@ void inproj_attn_kernel(const InprojAttnParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int seq, h;
-    {
-        const int L = blockIdx.x;
-        if ((p.nseq & 7) == 0) {                     // XCD = L % 8: the 4 heads of a sequence share an XCD (and its L2)
-            const int xcd = L & 7, slot = L >> 3;
-            seq = (slot >> 2) * 8 + xcd; h = slot & 3;
-        } else {
-            seq = L >> 2; h = L & 3;
-        }
-    }
-    const size_t sh = (size_t)seq * 4 + h;
     const int frow = lane & 15, fkg = lane >> 4;
+    const int nitems = p.nseq * 4;
+    // item -> (sequence, head).  XCD = workgroup id % 8 (hardware round-robin): with nseq % 8 == 0 and a grid that is a
+    // multiple of 8, item L runs on XCD L % 8 and the four heads of a sequence are four consecutive slots of one XCD --
+    // concurrent workgroups sharing an L2, so three of the four reads of the sequence's X rows are L2 hits.
+    const bool xcd_map = (p.nseq & 7) == 0 && ((gridDim.x & 7) == 0 || (int)gridDim.x >= nitems);
+    auto item_of = [&](int L, int& seq_, int& h_) __attribute__((always_inline)) {
+        if (xcd_map) {
+            const int xcd = L & 7, slot = L >> 3;
+            seq_ = (slot >> 2) * 8 + xcd; h_ = slot & 3;
+        } else {
+            seq_ = L >> 2; h_ = L & 3;
+        }
+    };
+    __bf16* __restrict__ Qs = (__bf16*)p.Qs + (size_t)blockIdx.x * p.Tp * 64;      // this workgroup's L2-resident Q slot
+    u32x4 pre[2];                                    // first X tile of the NEXT item, requested during the flash loop
+    bool have_pre = false;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int seq, h;
+    item_of(item, seq, h);
+    int seq_n = 0, h_n = 0;
+    const bool has_next = item + (int)gridDim.x < nitems;
+    if (has_next) item_of(item + gridDim.x, seq_n, h_n);
+    (void)h_n;
 
     // ================================================================== phase 1: K, V^T -> LDS, Q -> scratch
     {
@@ -118,7 +137,6 @@ void inproj_attn_kernel(const InprojAttnParams p) {
         asm volatile("" : "+v"(wkv[0]), "+v"(wkv[1]), "+v"(wkv[2]), "+v"(wkv[3]), "+v"(wkv[4]), "+v"(wkv[5]), "+v"(wkv[6]), "+v"(wkv[7]));
         asm volatile("" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(wq[4]), "+v"(wq[5]), "+v"(wq[6]), "+v"(wq[7]),
                           "+v"(bkv), "+v"(bq));
-        __bf16* __restrict__ Qs = (__bf16*)p.Qs + sh * p.Tp * 64;
         const int jq = wave >> 2;                    // the token fragment this wave projects Q for
         // one projection step on the 32 X rows in buffer xb: K / V^T fragments -> LDS, Q fragment -> scratch
         auto proj_step = [&](int xt, const char* xb) __attribute__((always_inline)) {
@@ -178,7 +196,8 @@ void inproj_attn_kernel(const InprojAttnParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) *(u32x4*)(dst + xdst[i]) = r[i];
         };
-        gload(0, ra);
+        if (have_pre) { ra[0] = pre[0]; ra[1] = pre[1]; }
+        else gload(0, ra);
         lstore(0, ra);
         if (nxt > 1) gload(1, ra);
         __syncthreads();
@@ -212,7 +231,7 @@ void inproj_attn_kernel(const InprojAttnParams p) {
 
     // ================================================================== phase 2: the flash loop (attn_full.hip, LAZY)
     const int lq = lane & 31, hi = lane >> 5;
-    const __bf16* __restrict__ Qg = (const __bf16*)p.Qs + sh * p.Tp * 64;
+    const __bf16* __restrict__ Qg = Qs;
     const int nq = p.Tp / 32;
     const int krow = swap23(lq);
     char* Ow = Xs + wave * OSTG;
@@ -301,8 +320,22 @@ void inproj_attn_kernel(const InprojAttnParams p) {
                 }
             }
     };
+    bool pre_issued = false;
     auto run_pass = [&](int qb) __attribute__((always_inline)) {
         begin_pass(qb);
+#if EEND_AF_REGSTAGE
+        if (has_next && !pre_issued) {
+            // behind this pass's Q fragments in the (in-order) VMEM queue, so nothing in this pass waits for it; the
+            // second pass's Q loads do, ~15 us later
+            const _Float16* __restrict__ Xn = (const _Float16*)p.X + (size_t)seq_n * p.Tp * p.ldx;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + i * 512, row = c >> 5, col = c & 31;
+                pre[i] = *(const u32x4*)(Xn + (size_t)row * p.ldx + col * 8);
+            }
+            pre_issued = true;
+        }
+#endif
         int last_key = qw0 + 31 + p.mask_delay;
         last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
         const int jend = last_key < 0 ? 0 : last_key / KB + 1;
@@ -333,6 +366,9 @@ void inproj_attn_kernel(const InprojAttnParams p) {
     };
     if (has_big) run_pass(qb_big);
     if (has_small) run_pass(qb_small);
+    have_pre = pre_issued;
+    __syncthreads();                                 // every wave is done with K / V^T / the Q slot before the next item
+    }
 }
 
 }  // namespace
@@ -346,6 +382,16 @@ int eend_launch_inproj_attn(const InprojAttnParams& p, hipStream_t stream) {
             return EEND_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(inproj_attn_kernel, dim3(p.nseq * 4), dim3(512), smem, stream, p);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+        n_cu &= ~31;                                 // multiple of 32: a persistent workgroup keeps its head (and its XCD)
+        if (n_cu <= 0) n_cu = 32;
+        if (const char* e = getenv("EEND_AF_PERSIST")) { if (atoi(e) == 0) n_cu = 1 << 30; }     // A/B: one workgroup per item
+    }
+    const int nitems = p.nseq * 4;
+    hipLaunchKernelGGL(inproj_attn_kernel, dim3(nitems < n_cu ? nitems : n_cu), dim3(512), smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -178,6 +178,8 @@ int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const
 int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, int N, int H, int cap, int t, const int* t_dev,
                             float scale, hipStream_t stream);
 int eend_launch_counter_add(int* c, int inc, hipStream_t stream);
+int eend_launch_attn_decode_split(const void* qkv, void* Kc, void* Vc, void* out16, float* part, long part_floats, int N, int H, int cap,
+                                  const int* t_dev, float scale, hipStream_t stream);
 int eend_launch_gather_bn_cast_pad(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w,
                                    const float* bn_b, const float* bn_mean, const float* bn_var, float eps, void* out16,
                                    int B, int T, int Tp, int Fin, int Fpad, int apply_bn, hipStream_t stream);

@@ -158,6 +158,129 @@ void attn_decode_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__
     out[(size_t)n * D + h * 64 + lane] = to_f16_sat(o / l_run);
 }
 
+
+// ---- long histories: the same decode step split over the key axis ("flash decoding").  One wave per (n, h) walks its
+// history serially -- fine for the t <= 1000 the model is trained on, but at the one-hour position of BASELINE config 5
+// (t = 36 000) a frame then costs 86 ms: 64 waves on a 256-CU part, each chasing 36 000 dependent rows.  Here a
+// workgroup owns DEC_R consecutive keys of one (n, h) (its 4 waves take the 64-key chunks round-robin, online softmax
+// per wave, merged through LDS) and writes (max, sum, o[64]) partials; a second tiny kernel merges the partials of a
+// (n, h) and adds the new token.  Grid = (N*H, cap / DEC_R): fixed per cache capacity, so a captured hipGraph stays valid
+// while t (read from device memory) grows; blocks whose key range starts at or beyond t write an empty partial.
+constexpr int DEC_R = 512;
+
+__global__ __launch_bounds__(256)
+void attn_decode_split_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ Kc, _Float16* __restrict__ Vc,
+                              float* __restrict__ part, int N, int H, int cap, int nsplit, const int* __restrict__ t_dev, float scale) {
+    __shared__ float red[4][66];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x, sp = blockIdx.y;
+    const int t = __builtin_amdgcn_readfirstlane(*t_dev);
+    const int n = idx / H, h = idx - n * H;
+    const int D = H * 64;
+    const _Float16* row = qkv + (size_t)n * 3 * D + h * 64;
+    _Float16* Kh = Kc + (size_t)idx * cap * 64;
+    _Float16* Vh = Vc + (size_t)idx * cap * 64;
+    if (sp == 0 && wave == 0 && t < cap) {                    // append the new token's k / v (never read back this step)
+        Kh[(size_t)t * 64 + lane] = row[D + lane];
+        Vh[(size_t)t * 64 + lane] = row[2 * D + lane];
+    }
+    const int k0 = sp * DEC_R;
+    int k1 = k0 + DEC_R;
+    k1 = k1 < t ? k1 : t;
+    float m_run = -INFINITY, l_run = 0.f, o = 0.f;
+    if (k0 < t && t < cap) {
+        float qf[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f16x8 q8 = *(const f16x8*)(row + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[i * 8 + e] = (float)q8[e] * scale;
+        }
+        for (int c0 = k0 + wave * 64; c0 < k1; c0 += 256) {
+            const int key = c0 + lane;
+            float s = -INFINITY;
+            if (key < k1) {
+                const _Float16* kr = Kh + (size_t)key * 64;
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f16x8 k8 = *(const f16x8*)(kr + i * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qf[i * 8 + e], (float)k8[e], acc);
+                }
+                s = acc;
+            }
+            float cm = s;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) cm = wave_xor_max(cm, m);
+            const float m_new = __builtin_fmaxf(m_run, cm);
+            const float alpha = __expf(m_run - m_new);         // exp(-inf) = 0 on the first chunk
+            const float p = __expf(s - m_new);                 // 0 for key >= k1
+            float ps = p;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) ps = wave_xor_add(ps, m);
+            l_run = l_run * alpha + ps;
+            o *= alpha;
+            const int nk = (k1 - c0) < 64 ? (k1 - c0) : 64;
+            for (int j8 = 0; j8 < nk; j8 += 8) {               // 8 independent V rows in flight per step
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = (j8 + jj < nk) ? (float)Vh[(size_t)(c0 + j8 + jj) * 64 + lane] : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) o = __builtin_fmaf(__shfl(p, j8 + jj, 64), v[jj], o);
+            }
+            m_run = m_new;
+        }
+    }
+    red[wave][lane] = o;
+    if (lane == 0) { red[wave][64] = m_run; red[wave][65] = l_run; }
+    __syncthreads();
+    if (wave == 0) {
+        const float m0 = red[0][64], m1 = red[1][64], m2 = red[2][64], m3 = red[3][64];
+        const float M = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3));
+        float L = 0.f, O = 0.f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float mw = red[w][64];
+                const float f = mw > -INFINITY ? __expf(mw - M) : 0.f;
+                L += red[w][65] * f;
+                O += red[w][lane] * f;
+            }
+        }
+        float* pp = part + ((size_t)idx * nsplit + sp) * 66;
+        pp[lane] = O;
+        if (lane == 0) { pp[64] = M; pp[65] = L; }
+    }
+}
+
+__global__ __launch_bounds__(64)
+void attn_decode_merge_kernel(const _Float16* __restrict__ qkv, const float* __restrict__ part, _Float16* __restrict__ out, int N, int H,
+                              int cap, int nsplit, const int* __restrict__ t_dev, float scale) {
+    const int lane = threadIdx.x, idx = blockIdx.x;
+    const int t = __builtin_amdgcn_readfirstlane(*t_dev);
+    if (t >= cap) return;
+    const int n = idx / H, h = idx - n * H;
+    const int D = H * 64;
+    const _Float16* row = qkv + (size_t)n * 3 * D + h * 64;
+    float sn = (float)row[lane] * scale * (float)row[D + lane];            // the new token's own score q . k_new
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) sn = wave_xor_add(sn, m);
+    float M = sn, L = 1.0f, O = (float)row[2 * D + lane];
+    const int ns = (t + DEC_R - 1) / DEC_R;
+    for (int s = 0; s < ns && s < nsplit; ++s) {
+        const float* pp = part + ((size_t)idx * nsplit + s) * 66;
+        const float ms = pp[64], ls = pp[65];
+        if (!(ls > 0.f)) continue;
+        const float Mn = __builtin_fmaxf(M, ms);
+        const float a = __expf(M - Mn), b = __expf(ms - Mn);
+        L = L * a + ls * b;
+        O = O * a + pp[lane] * b;
+        M = Mn;
+    }
+    out[(size_t)n * D + h * 64 + lane] = to_f16_sat(O / L);
+}
+
 __global__ void counter_add_kernel(int* c, int inc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
 }
@@ -169,6 +292,19 @@ int eend_launch_attn_decode(const void* qkv, void* Kc, void* Vc, void* out16, in
     if (N <= 0 || H <= 0 || cap <= 0 || (!t_dev && (t < 0 || t >= cap))) return EEND_EINVAL;
     hipLaunchKernelGGL(attn_decode_kernel, dim3((N * H + 3) / 4), dim3(256), 0, stream, (const _Float16*)qkv, (_Float16*)Kc,
                        (_Float16*)Vc, (_Float16*)out16, N, H, cap, t, t_dev, scale);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_attn_decode_split(const void* qkv, void* Kc, void* Vc, void* out16, float* part, long part_floats, int N, int H, int cap,
+                                  const int* t_dev, float scale, hipStream_t stream) {
+    if (N <= 0 || H <= 0 || cap <= 0 || !t_dev || !part) return EEND_EINVAL;
+    const int nsplit = (cap + DEC_R - 1) / DEC_R;
+    if (nsplit > 65535 || part_floats < (long)N * H * nsplit * 66) return EEND_EINVAL;
+    hipLaunchKernelGGL(attn_decode_split_kernel, dim3(N * H, nsplit), dim3(256), 0, stream, (const _Float16*)qkv, (_Float16*)Kc, (_Float16*)Vc,
+                       part, N, H, cap, nsplit, t_dev, scale);
+    if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
+    hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(N * H), dim3(64), 0, stream, (const _Float16*)qkv, part, (_Float16*)out16, N, H, cap,
+                       nsplit, t_dev, scale);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

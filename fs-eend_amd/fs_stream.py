@@ -314,6 +314,9 @@ class FsStreamSession:
                     a[:, :, :old[2]] = b
         self.cap = cap
         self._graphs = None
+        # long histories: key-split decode kernel (ops.attn_decode_split) and its partial-result scratch
+        self._split = cap >= ops.SPLIT_DECODE_MIN_CAP
+        self._dec_ws = torch.empty(ops.attn_decode_split_ws(max(1, self.C), self.H, cap), dtype=F32, device=self.dev) if self._split else None
 
     def reset(self):
         """Start of a new stream."""
@@ -331,12 +334,18 @@ class FsStreamSession:
             Fi = L["w1"].shape[0]
             ff = self.ff[:Fi].view(1, Fi)
             ops.linear(h16, L["att"][0], L["att"][1], qkv)
-            ops.attn_decode_dev(qkv, kc, vc, o16, 1, H, self.cap, self.t_enc)
+            self._decode(qkv, kc, vc, o16, 1, self.t_enc)
             ops.linear_res_ln(o16, L["att"][2], L["att"][3], h32, L["n1"][0], L["n1"][1], h32, h16, L["n1"][2])
             ops.linear(h16, L["w1"], L["b1"], ff, relu=True)
             ops.linear_res_ln(ff, L["w2"], L["b2"], h32, L["n2"][0], L["n2"][1], h32, h16, L["n2"][2])
         ops.counter_add(self.t_enc, 1)
         self.enc_out.copy_(h32)
+
+    def _decode(self, qkv, kc, vc, o16, N, t_dev):
+        if self._split:
+            ops.attn_decode_split(qkv, kc, vc, o16, self._dec_ws, N, self.H, self.cap, t_dev)
+        else:
+            ops.attn_decode_dev(qkv, kc, vc, o16, N, self.H, self.cap, t_dev)
 
     def _conv(self):
         D, k = self.D, self.k
@@ -356,7 +365,7 @@ class FsStreamSession:
             Fi = L["w1"].shape[0]
             ff = self.ff[:C * Fi].view(C, Fi)
             ops.linear(a16, L["att"][0], L["att"][1], qkv)
-            ops.attn_decode_dev(qkv, kc, vc, o16, C, H, self.cap, self.t_dec)
+            self._decode(qkv, kc, vc, o16, C, self.t_dec)
             ops.linear_res_ln(o16, L["att"][2], L["att"][3], a32, L["n1"][0], L["n1"][1], a32, a16, L["n1"][2])
             ops.linear(a16, L["spk"][0], L["spk"][1], qkv)
             ops.spk_attn(qkv, o16, 1, C, 1, H)

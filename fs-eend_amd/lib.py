@@ -42,6 +42,7 @@ PROTOTYPES = {
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_dev_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
     "eend_counter_add_i32": [_vp, _i, _vp],
+    "eend_attn_decode_split_f16": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _f, _vp],
     "eend_retention_step_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "eend_dwconv_step_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "eend_layernorm_f16": [_vp, _vp, _vp, _f, _vp, _i, _i, _vp],

@@ -297,6 +297,22 @@ def attn_decode_dev(qkv16, k_cache, v_cache, out16, N, H, cap, t_dev):
                                           1.0 / math.sqrt(64.0), _stream()), "eend_attn_decode_dev_f16")
 
 
+SPLIT_DECODE_MIN_CAP = 4096      # cache capacities from here on take the key-split decode kernel
+
+
+def attn_decode_split_ws(N, H, cap):
+    return N * H * ((cap + 511) // 512) * 66
+
+
+def attn_decode_split(qkv16, k_cache, v_cache, out16, ws, N, H, cap, t_dev):
+    """attn_decode_dev with the history split over cap/512 workgroups per (n, h) + a merge kernel (long streams)."""
+    L = _lib.load()
+    _chk(qkv16, F16, "qkv16"); _chk(k_cache, F16, "k_cache"); _chk(v_cache, F16, "v_cache"); _chk(out16, F16, "out16")
+    _chk(t_dev, torch.int32, "t_dev"); _chk(ws, F32, "ws")
+    _lib.check(L.eend_attn_decode_split_f16(_p(qkv16), _p(k_cache), _p(v_cache), _p(out16), _p(ws), ws.numel(), N, H, cap, _p(t_dev),
+                                            1.0 / math.sqrt(64.0), _stream()), "eend_attn_decode_split_f16")
+
+
 def counter_add(counter_i32, inc=1):
     L = _lib.load()
     _chk(counter_i32, torch.int32, "counter")

@@ -264,6 +264,13 @@ int eend_dwconv_bn_swish_f16(const void* x_f16, const float* w, const float* bn_
  * tokens.  out f16 [N][H*64]. */
 int eend_attn_decode_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap,
                          int t, float scale, void* stream);
+/* eend_attn_decode_dev_f16 for long histories (BASELINE config 5: t up to 36 000): the key axis is split over
+ * cap/512 workgroups per (n, h) whose (max, sum, o) partials a second kernel merges with the new token -- the per-frame
+ * cost follows HBM bandwidth instead of one wave's latency chain.  ws: f32 scratch of N*H*ceil(cap/512)*66 floats.
+ * Same results as the single-wave kernel up to fp32 summation order. */
+int eend_attn_decode_split_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, float* ws, long ws_floats, int N,
+                               int H, int cap, const int* t_dev, float scale, void* stream);
+
 /* The same with the token count read from device memory (*t_dev), so that a captured hipGraph of the frame step
  * (FS-EEND/streaming_infer_dia.py's per-frame loop) stays valid while the history grows; *t_dev >= cap makes the
  * launch a no-op.  eend_counter_add_i32: *counter += inc on the stream (the graph's own "t += 1"). */

@@ -1,7 +1,7 @@
 """Long-horizon golden vectors (BASELINE config 5: one hour of audio = 36 000 frames, retention state carried across
 72 chunks; FS-EEND K/V-cache decode far beyond the training chunk) -- runs ONLY in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_long.py ls_batch | ls_stream | fs_stream
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_long.py ls_batch | ls_stream | ls_stream64 | fs_stream
 
 What runs is the imported reference (eval mode, CPU fp32):
   * ls_batch : OnlineConformerRetentionDADiarization.test on 1 x T = 36 000, max_nspks = 10 (LS model :125-147)
@@ -116,6 +116,42 @@ def gen_ls_stream():
           f"-> {os.path.relpath(p)}")
 
 
+def gen_ls_stream64():
+    """The same hour through the ORACLE's frame-by-frame form in float64 (oracle/ls_eend_ref.LsStreamingRef, pinned to the
+    reference's streaming driver by tests/golden/ls_stream_T120.npz): the arbiter for how far apart fp32 implementations
+    of this recurrence may legitimately be after 36 000 steps -- the reference's own fp32 streaming and batch forms
+    differ by ~1e-2 in the logits there (ls_hour_stream_c10 vs ls_hour_c10)."""
+    from oracle import ls_eend_ref as R
+    m, _ = build_ls()
+    T, C = LS_HOUR["T"], LS_HOUR["C"]
+    src = FX.make_src([T], 345, LS_HOUR["xseed"])[0].double()
+    s = R.LsStreamingRef(m.state_dict(), n_heads=4, enc_n_layers=LS_FULL["enc_n_layers"], dec_n_layers=LS_FULL["dec_n_layers"],
+                         conv_kernel_size=LS_FULL["conv_kernel_size"], dtype=torch.float64)
+    idx = set(row_index(T).tolist())
+    kept, n = {}, 0
+    t0 = time.time()
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        for t in range(T):
+            y = s.step(src[t].view(1, 1, -1), C)
+            if y is not None:
+                if n in idx:
+                    kept[n] = y[0, 0].numpy().copy()
+                n += 1
+            if t % 3000 == 0:
+                print(f"  frame {t}/{T}  {time.time() - t0:.0f} s", flush=True)
+        for _ in range(m.delay):
+            y = s.step(None, C)
+            if y is not None:
+                if n in idx:
+                    kept[n] = y[0, 0].numpy().copy()
+                n += 1
+    rows = np.array(sorted(kept), dtype=np.int64)
+    arrays = dict(rows=rows, stream_logits64=np.stack([kept[r] for r in rows]))
+    p = FX.save_case("ls_hour_stream64_c10", ls_meta(m, kind="ls_hour_stream64", frames_out=n, cpu_seconds=time.time() - t0), arrays)
+    print(f"ls_hour_stream64_c10: oracle float64 frame-by-frame over T={T}: {time.time() - t0:.0f} s -> {os.path.relpath(p)}")
+
+
 def gen_fs_stream():
     sys.path.insert(0, os.path.join(REF, "FS-EEND"))
     from nnet.model.onl_tfm_enc_1dcnn_enc_linear_non_autoreg_pos_enc_l2norm import OnlineTransformerDADiarization
@@ -155,4 +191,4 @@ def gen_fs_stream():
 
 
 if __name__ == "__main__":
-    {"ls_batch": gen_ls_batch, "ls_stream": gen_ls_stream, "fs_stream": gen_fs_stream}[sys.argv[1]]()
+    {"ls_batch": gen_ls_batch, "ls_stream": gen_ls_stream, "ls_stream64": gen_ls_stream64, "fs_stream": gen_fs_stream}[sys.argv[1]]()

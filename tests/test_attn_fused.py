@@ -53,9 +53,7 @@ def test_inproj_attn_fused(hip_lib, dev, nseq, Tp, delay, kv_len):
     print(f"fused vs fp32 {e_ref:.2e}; fused vs two-kernel {e_two:.2e}")
     assert torch.isfinite(o).all()
     assert e_ref < 2e-2 and e_two < 1e-2
-    # the scratch buffer holds the projected, pre-scaled q in head layout
-    qh = qs.view(nseq, 4, Tp, 64).float()
-    assert (qh - q).abs().max() < 2e-2 * max(1.0, float(q.abs().max()))
+    # (the scratch buffer is a workspace: one 64 KB Q slot per persistent workgroup, rewritten for every item)
 
 
 @pytest.mark.parametrize("B,T,C", [(1, 37, 1), (3, 130, 3), (5, 500, 6), (2, 512, 10), (8, 257, 4)])

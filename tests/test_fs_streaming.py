@@ -116,3 +116,26 @@ def test_fs_stream_session_matches_eager(hip_lib, dev, use_graph):
         assert ses.cap == 64 and int(ses.t_enc) == meta["T"] and int(ses.t_dec) == meta["T"]
         ses.reset()
     assert max_abs(want[0], arr["stream_logits"]) < 1e-3
+
+
+@pytest.mark.parametrize("N", [1, 6])
+def test_attn_decode_split_matches_single_wave(hip_lib, dev, N):
+    """The key-split decode (long histories) against the single-wave kernel at history lengths around the 512-key split
+    boundaries and far beyond them; both append the new token's k / v at row t."""
+    from fs_eend_amd import ops
+    H, cap = 4, 8192
+    g = torch.Generator().manual_seed(N)
+    kc = (torch.randn(N, H, cap, 64, generator=g) * 0.7).to(F16).to(dev)
+    vc = torch.randn(N, H, cap, 64, generator=g).to(F16).to(dev)
+    ws = torch.empty(ops.attn_decode_split_ws(N, H, cap), dtype=torch.float32, device=dev)
+    for t in (0, 1, 63, 511, 512, 513, 1024, 5000, cap - 1):
+        qkv = torch.randn(N, 768, generator=g).to(F16).to(dev)
+        k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        o1 = torch.empty(N, 256, dtype=F16, device=dev)
+        o2 = torch.full((N, 256), float("nan"), dtype=F16, device=dev)
+        ops.attn_decode(qkv, k1, v1, o1, N, H, cap, t)
+        td = torch.tensor([t], dtype=torch.int32, device=dev)
+        ops.attn_decode_split(qkv, k2, v2, o2, ws, N, H, cap, td)
+        torch.cuda.synchronize()
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)                   # same append
+        assert float((o1.float() - o2.float()).abs().max()) < 2e-3, t
