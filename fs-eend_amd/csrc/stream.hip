@@ -26,8 +26,11 @@ void ret_step_kernel(const _Float16* __restrict__ qkvg, float* __restrict__ kv, 
     const _Float16* row = qkvg + (size_t)n * 4 * D;
     const float ps = scale_in[h];
     const float ns = ps + 1.0f;
-    const float keep = __builtin_sqrtf(ps) / __builtin_sqrtf(ns);
-    const float add = 1.0f / __builtin_sqrtf(ns);
+    // the decay of the old state is applied 36 000 times over an hour of audio: evaluate it in double and round once, so
+    // that the running product of the factors follows sqrt(s/t) to fp32 rounding noise instead of accumulating the bias
+    // of the device's fast f32 sqrt / divide sequences
+    const float keep = (float)__builtin_sqrt((double)ps / (double)ns);
+    const float add = (float)(1.0 / __builtin_sqrt((double)ns));
     const float va = (float)row[2 * D + h * 64 + lane] * add;
     float* st = kv + ((size_t)idx * 64 + lane) * 64;
     float o = 0.f;

@@ -385,28 +385,20 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         return ws
 
     # ------------------------------------------------------------------ the hot path
-    def _run(self, src: Sequence[Tensor], ilens: Sequence[int], C: int):
-        P = self._prepare()
-        dev = self.cnn.weight.device
+    def _encode_span(self, P, ws, part, B, Tc, Tp, states=None, halos=None, carry_in=False):
+        """Conformer-retention encoder (conformer/encoder.py:194-201, :76-113) over one span of Tc frames per sequence
+        (slab rows Tp): `part` = the span's feature tensors.  Result: ws.h16 (f16 encoder output rows).  `states` /
+        `halos` (lists per block, long-form walk): the retention state after the span is written to states[i] (and read
+        from it when carry_in), the conv module's k-1 frames of left context are read from / written to halos[i].
+        The ONE place the block's kernel sequence lives: `test` and `test_chunked` both walk through here."""
         D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
-        srcs = [s.to(device=dev, dtype=torch.float32).contiguous() for s in src]
-        B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
-        Tpad = math.ceil(T / L) * L                        # reference pads to a chunk multiple (:281-283)
-        Tp = ops.frames_pad(Tpad)
-        nc = (Tp + L - 1) // L
-        ws = self._workspace(dev, B, Tp, C, nc)
-        il_key = tuple(min(int(l), T) for l in ilens)
-        if getattr(ws, "il_key", None) != il_key:
-            ws.il = torch.tensor(il_key, dtype=torch.int32, device=dev)
-            ws.il_key = il_key
-        Me, Md = B * Tp, B * C * Tp
-
-        # ---- Conformer-retention encoder (conformer/encoder.py:194-201, :76-113)
-        ops.gather_bn_cast_pad(srcs, None, ws.xin16, T, Tp, 0.0, False)        # pad_sequence(0) (LS model :280) + cast
+        Me = B * Tp
+        ops.gather_bn_cast_pad(part, None, ws.xin16, Tc, Tp, 0.0, False)        # pad_sequence(0) (LS model :280) + cast
         ops.linear_res_ln(ws.xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], ws.h32, ws.h16, P["in.eps"])
         q, k, kt, vt = ws.q[:Me * D], ws.k[:Me * D], ws.kt[:Me * D], ws.vt[:Me * D]
         g, o16 = ws.g[:Me], ws.o16[:Me]
         nb = len(P["blocks"])
+        K1 = self.enc.encoder._conv_kernel_size - 1
         for i, Bk in enumerate(P["blocks"]):
             if i == 0:
                 ops.layernorm_f16(ws.h32, Bk["lna"][0], Bk["lna"][1], ws.x16, Bk["lna"][2])
@@ -422,12 +414,16 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                                           ws.h32, ws.x16, Bk["lnb"][2])
             # x += Retention(LN_b x)                     -> x16 = LN_c(x)
             ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
-            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tpad)
+            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tc,
+                                state_in=states[i] if (states is not None and carry_in) else None,
+                                state_out=states[i] if states is not None else None)
             ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
                                       ws.h32, ws.x16, Bk["lnc"][2])
             # x += ConvModule(x): 1x1 + GLU, causal depthwise + BN + swish, 1x1   -> x16 = LN_d(x)
             ops.linear_glu(ws.x16, Bk["pw1"], Bk["pb1"], ws.glu16)
-            ops.dwconv_bn_swish(ws.glu16, Bk["dw"], Bk["bn"], ws.dw16, B, Tp, Bk["bn_eps"])
+            ops.dwconv_bn_swish(ws.glu16, Bk["dw"], Bk["bn"], ws.dw16, B, Tp, Bk["bn_eps"], halo16=None if halos is None else halos[i])
+            if halos is not None:
+                halos[i] = ws.glu16.view(B, Tp, D)[:, Tc - K1:Tc].clone()       # next span's left context (a copy: glu16 is reused)
             ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
                                       ws.h32, ws.x16, Bk["lnd"][2])
             # x = LN_e(x + fb * FFN(LN_d x))
@@ -442,19 +438,21 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 nx = P["blocks"][i + 1]["lna"]
                 ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
 
-        # ---- truncate / zero re-pad, look-ahead conv, L2 (LS model :80-87)
-        emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)
-        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
-
-        # ---- attractor decoder (LS model :215-220; merge_retnet_layer.py:233-253)
-        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
+    def _decode_span(self, P, ws, emb16, pc, B, Tc, Tp, C, states=None, carry_in=False):
+        """Attractor decoder (LS model :215-220; merge_retnet_layer.py:233-253) over one span: emb16 (B*Tp, D) f16 unit
+        embeddings -> ws.a32 (f32 attractor rows (b, c, t)).  `states`: as in _encode_span, per decoder layer."""
+        D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
+        Md = B * C * Tp
+        ops.convert_fanout(emb16, P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
         q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
         g, o16 = ws.g[:Md], ws.o16[:Md]
-        for Ld in P["dec.layers"]:
+        for j, Ld in enumerate(P["dec.layers"]):
             F = Ld["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
             ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
-            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tpad)
+            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
+                                state_in=states[j] if (states is not None and carry_in) else None,
+                                state_out=states[j] if states is not None else None)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
                 ops.fusion_layer_tail(o16, ws.a32, ws.a16, Ld["out1_w"], Ld["out1_b"], Ld["g11"], Ld["be11"], Ld["eps11"],
                                       Ld["in2_w"], Ld["in2_b"], Ld["out2_w"], Ld["out2_b"], Ld["g21"], Ld["be21"], Ld["eps21"],
@@ -478,6 +476,28 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 ops.linear(ws.a16, Ld["w1"], Ld["b1"], ff, relu=True)
                 ops.linear_res_ln(ff, Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16, Ld["eps22"])
 
+    def _run(self, src: Sequence[Tensor], ilens: Sequence[int], C: int):
+        P = self._prepare()
+        dev = self.cnn.weight.device
+        D, L = self.n_units, self.recurrent_chunk_size
+        srcs = [s.to(device=dev, dtype=torch.float32).contiguous() for s in src]
+        B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
+        Tpad = math.ceil(T / L) * L                        # reference pads to a chunk multiple (:281-283)
+        Tp = ops.frames_pad(Tpad)
+        nc = (Tp + L - 1) // L
+        ws = self._workspace(dev, B, Tp, C, nc)
+        il_key = tuple(min(int(l), T) for l in ilens)
+        if getattr(ws, "il_key", None) != il_key:
+            ws.il = torch.tensor(il_key, dtype=torch.int32, device=dev)
+            ws.il_key = il_key
+        Me = B * Tp
+        # chunks that are pure slab padding (rows Tpad..Tp) are skipped: the span's valid length is Tpad
+        self._encode_span(P, ws, srcs, B, Tpad, Tp)
+
+        # ---- truncate / zero re-pad, look-ahead conv, L2 (LS model :80-87)
+        emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)
+        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+        self._decode_span(P, ws, ws.emb16, self._convert_const(C), B, Tpad, Tp, C)
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
         ops.head_l2dot(emb32, ws.a32, attr, logits, B, T, Tp, C, D)
@@ -495,7 +515,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
 
         chunk_frames must be a multiple of lcm(recurrent_chunk_size, 64) (8000 for the shipped configs): then every
         kernel sees each frame at the same position modulo its tile sizes as in the monolithic call, and the results are
-        BIT-IDENTICAL to `test()` (tests/test_ls_longform.py)."""
+        BIT-IDENTICAL to `test()` (tests/test_ls_longform.py).  Both share _encode_span / _decode_span."""
         P = self._prepare()
         dev = self.cnn.weight.device
         D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
@@ -513,7 +533,6 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         il = torch.tensor([min(int(l), T) for l in ilens], dtype=torch.int32, device=dev)
         enc16 = torch.zeros(B * Tp_full, D, dtype=f16, device=dev)            # encoder output, whole recording
         nb, nd = len(P["blocks"]), len(P["dec.layers"])
-        K1 = self.enc.encoder._conv_kernel_size - 1
         enc_state = [torch.zeros(B, H, 64, 64, dtype=f32, device=dev) for _ in range(nb)]
         enc_halo = [None] * nb
         spans = [(s0, min(s0 + chunk_frames, Tpad)) for s0 in range(0, Tpad, chunk_frames)]
@@ -522,34 +541,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         for s0, s1 in spans:
             Tc = s1 - s0
             Tp = ops.frames_pad(Tc)
-            nc = (Tp + L - 1) // L
-            ws = self._workspace(dev, B, Tp, C, nc)
-            Me = B * Tp
+            ws = self._workspace(dev, B, Tp, C, (Tp + L - 1) // L)
             part = [x[s0:min(s1, x.shape[0])] if x.shape[0] > s0 else x[:0] for x in srcs]     # may be empty: all pad (0)
-            ops.gather_bn_cast_pad(part, None, ws.xin16, Tc, Tp, 0.0, False)
-            ops.linear_res_ln(ws.xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], ws.h32, ws.h16, P["in.eps"])
-            q, k, kt, vt = ws.q[:Me * D], ws.k[:Me * D], ws.kt[:Me * D], ws.vt[:Me * D]
-            g, o16 = ws.g[:Me], ws.o16[:Me]
-            for i, Bk in enumerate(P["blocks"]):
-                if i == 0:
-                    ops.layernorm_f16(ws.h32, Bk["lna"][0], Bk["lna"][1], ws.x16, Bk["lna"][2])
-                ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
-                              ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
-                ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
-                ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tc,
-                                    state_in=enc_state[i] if s0 else None, state_out=enc_state[i])
-                ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
-                                          ws.h32, ws.x16, Bk["lnc"][2])
-                ops.linear_glu(ws.x16, Bk["pw1"], Bk["pb1"], ws.glu16)
-                ops.dwconv_bn_swish(ws.glu16, Bk["dw"], Bk["bn"], ws.dw16, B, Tp, Bk["bn_eps"], halo16=enc_halo[i])
-                enc_halo[i] = ws.glu16.view(B, Tp, D)[:, Tc - K1:Tc].clone()               # next call's left context (a copy: glu16 is reused)
-                ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
-                                          ws.h32, ws.x16, Bk["lnd"][2])
-                ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
-                              ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
-                if i + 1 < nb:
-                    nx = P["blocks"][i + 1]["lna"]
-                    ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
+            self._encode_span(P, ws, part, B, Tc, Tp, states=enc_state, halos=enc_halo, carry_in=s0 > 0)
             enc16.view(B, Tp_full, D)[:, s0:s1] = ws.h16.view(B, Tp, D)[:, :Tc]
 
         # ---- look-ahead conv + L2 norm over the whole recording (one launch; 1.5 KB/frame)
@@ -567,24 +561,12 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             Tc = s1 - s0
             Tv = min(s1, T) - s0                                   # real frames of this super-chunk
             Tp = ops.frames_pad(Tc)
-            nc = (Tp + L - 1) // L
-            ws = self._workspace(dev, B, Tp, C, nc)
-            Md = B * C * Tp
+            ws = self._workspace(dev, B, Tp, C, (Tp + L - 1) // L)
             e16 = torch.zeros(B, Tp, D, dtype=f16, device=dev)
             e32 = torch.zeros(B, Tp, D, dtype=f32, device=dev)
             e16[:, :Tc] = emb16.view(B, Tp_full, D)[:, s0:s1]
             e32[:, :Tc] = emb32.view(B, Tp_full, D)[:, s0:s1]
-            ops.convert_fanout(e16.view(-1, D), P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
-            q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
-            g, o16 = ws.g[:Md], ws.o16[:Md]
-            for j, Ld in enumerate(P["dec.layers"]):
-                ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
-                ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
-                                    state_in=dec_state[j] if s0 else None, state_out=dec_state[j])
-                ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
-                ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
-                ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
-                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
+            self._decode_span(P, ws, e16.view(-1, D), pc, B, Tc, Tp, C, states=dec_state, carry_in=s0 > 0)
             if Tv > 0:
                 direct = B == 1 and return_attractors              # the output slices are contiguous: no staging copy
                 lg = logits[:, s0:s0 + Tv] if direct else torch.empty(B, Tv, C, dtype=f32, device=dev)

@@ -14,7 +14,10 @@ definition:
     (28 + 200 + 28); frame t = padded[t*hop : t*hop + n_fft]; rfft -> 129 bins; 1 + len(y)//hop frames.
   * filters.mel(sr=8000, n_fft=256, n_mels=23): Slaney mel scale (linear below 1 kHz, log above, 200/3 Hz
     per mel), fmin=0, fmax=sr/2, triangular weights, Slaney area normalisation 2/(f[i+2]-f[i]), float32.
-The STFT restatement is cross-checked against torch.stft (built to match librosa) in tests/test_oracle_feature.py;
+The STFT restatement is cross-checked against torch.stft (built to match librosa) and, magnitudes only, against
+scipy.signal.stft; the filterbank equals transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney") -- an
+independently written table that project holds against librosa -- to 1e-9 (tests/test_oracle_feature.py, "unpinned" tests).
+That is two independent sources agreeing, NOT an output of librosa itself: the status stays "parity unpinned".
 everything downstream of the two librosa calls (|.|^2 . mel^T, log10, the mean normalisations, splice,
 subsample, the "drop the last frame when len % hop == 0" rule) follows the reference source line by line.
 """

@@ -61,3 +61,29 @@ def test_silence_hits_the_log_floor():
     out = F.extract_fbank_wave(np.zeros(1600, np.float32))
     assert out.shape == (2, 345)
     assert np.all((out == 0) | (np.abs(out + 10.0) < 2e-6))           # log10(float32(1e-10)) or splice padding
+
+
+def test_unpinned_mel_table_matches_an_independent_librosa_compatible_implementation():
+    """librosa itself is absent (the oracle stays "parity unpinned" for `librosa.filters.mel`); transformers.audio_utils
+    ships an independently written Slaney filterbank that its own test-suite holds against librosa -- a second source."""
+    au = pytest.importorskip("transformers.audio_utils")
+    M2 = au.mel_filter_bank(num_frequency_bins=129, num_mel_filters=23, min_frequency=0.0, max_frequency=4000.0, sampling_rate=8000,
+                            norm="slaney", mel_scale="slaney").T
+    M = F.mel_filterbank(8000, 256, 23)
+    assert M2.shape == M.shape and np.abs(M - M2).max() < 1e-8
+
+
+@pytest.mark.parametrize("n", [8123, 8000, 1601])
+def test_unpinned_stft_power_matches_scipy_signal(n):
+    """Second cross-check of the `librosa.stft` restatement: scipy.signal.stft frames the same samples (boundary padding of
+    win_length/2 = librosa's centred window inside its n_fft/2 padding) and zero-pads each segment at the END, i.e. the
+    same magnitudes with a different linear phase; its 'spectrum' scaling divides by sum(window)."""
+    import scipy.signal as ss
+    g = np.random.default_rng(n)
+    y = (g.standard_normal(n) * 0.1).astype(np.float32)
+    Y = F.stft(y, 200, 80)
+    w = ss.get_window("hann", 200, fftbins=True)
+    _, _, Z = ss.stft(y, fs=8000, window=w, nperseg=200, noverlap=120, nfft=256, boundary="zeros", padded=False)
+    Z = Z.T * w.sum()
+    assert Z.shape[0] >= Y.shape[0]
+    assert np.abs(np.abs(Y) - np.abs(Z[:Y.shape[0]])).max() < 2e-5 * max(1.0, np.abs(Y).max())
