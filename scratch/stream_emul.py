@@ -9,8 +9,9 @@ V = sys.argv[1]
 def hf(x): return x.to(torch.float16).to(x.dtype)
 orig_linear = R.linear
 def lin(x, w, b, q=R._id, role="lin"):
-    ops_f16 = V in ("all", "ops", "ops_out")
-    out_f16 = V in ("all", "out", "ops_out") and role.endswith((".qp", ".kp", ".vp", ".gp"))
+    isret = role.endswith((".qp", ".kp", ".vp", ".gp"))
+    ops_f16 = V in ("all", "ops", "ops_out") or (V == "retproj" and isret) or (V == "nonret" and not isret)
+    out_f16 = V in ("all", "out", "ops_out", "retproj") and isret
     xx, ww = (hf(x), hf(w)) if ops_f16 else (x, w)
     y = xx @ ww.t()
     if b is not None: y = y + b
@@ -18,7 +19,7 @@ def lin(x, w, b, q=R._id, role="lin"):
         return y            # k is scaled after the linear in msr(): round after scaling instead (below)
     return hf(y) if out_f16 else y
 R.linear = lin
-if V in ("all", "out", "ops_out"):
+if V in ("all", "out", "ops_out", "retproj"):
     orig_msr = R.msr
     def msr(x, sd, pfx, H, L, q=R._id, role="ret", state=None):
         # emulate k = f16(k_proj(x) * dk^-0.5) by folding the rounding: patch via a wrapper on retention_step inputs
