@@ -36,6 +36,29 @@ class _FsForward(torch.autograd.Function):
         return (None,) + grads
 
 
+def ls_forward_with_grad(model, src, tgt, ilens):
+    """OnlineConformerRetentionDADiarization.forward (reference LS model :74-122) with autograd support: the same bridge
+    over train_ls.LsTrainStep (train-mode BatchNorm statistics of the conv modules, SyncBatchNorm exchange when a process
+    group is initialised)."""
+    if not model.training:
+        raise EendHipError("gradient-enabled forward needs model.train() (the conv modules' BatchNorm uses batch statistics); "
+                           "use torch.no_grad() for evaluation")
+    eng = getattr(model, "_autograd_engine", None)
+    if eng is None:
+        from .train_ls import LsTrainStep
+        eng = LsTrainStep(model, drop_seed=torch.initial_seed() & 0xFFFFFFFF)
+        object.__setattr__(model, "_autograd_engine", eng)
+    params = [p for _, p in model.named_parameters()]
+    holder = dict(eng=eng, src=src, tgt=tgt, ilens=ilens)
+    logits, emb_loss, emb, attr = _FsForward.apply(holder, *params)
+    n_speakers = [t.shape[1] for t in tgt]
+    # the reference's head sees the length-masked embeddings (LS model :100,:116): rows beyond ilen are sliced off anyway
+    output = [logits[b, :l, :n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
+    embs = [emb[b, :l] for b, l in enumerate(ilens)]
+    attractors = [attr[b, :l, 1:n] for b, (l, n) in enumerate(zip(ilens, n_speakers))]
+    return output, emb_loss, embs, attractors
+
+
 def fs_forward_with_grad(model, src, tgt, ilens):
     """OnlineTransformerDADiarization.forward (reference model :32-65) with autograd support."""
     if not model.training:

@@ -262,6 +262,17 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
     return eend_launch_ret_chunk(p, (hipStream_t)stream);
 }
 
+int eend_retention_proj_step_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* Wqkvg,
+                                 const float* bias, float* qkvg_f32, int N, void* stream) {
+    return eend_launch_ret_proj_step(x, ln_gamma, ln_beta, ln_eps, Wqkvg, bias, qkvg_f32, N, (hipStream_t)stream);
+}
+
+int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, int N,
+                            int H, float gn_eps, void* stream) {
+    if (!qkvg || !kv_state || !scale_in || !scale_out || !out_f16) return EEND_EINVAL;
+    return eend_launch_ret_step_f32in(qkvg, kv_state, scale_in, scale_out, out_f16, N, H, gn_eps, (hipStream_t)stream);
+}
+
 int eend_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out_f16, int M,
                        int D, void* stream) {
     if (!x || !gamma || !beta || !out_f16) return EEND_EINVAL;

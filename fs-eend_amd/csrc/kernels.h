@@ -172,6 +172,10 @@ int eend_launch_head(const float* emb, const float* attr, float* attr_out, float
                      int Tp, int C, int D, hipStream_t stream);
 int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N,
                          int H, float eps, hipStream_t stream);
+int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N, int H, float eps,
+                               hipStream_t stream);
+int eend_launch_ret_proj_step(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
+                              float* out, int N, hipStream_t stream);
 int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const float* bn_w, const float* bn_b,
                             const float* bn_mean, const float* bn_var, float eps, void* out16, int B, int D, int k,
                             hipStream_t stream);

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "eend_counter_add_i32": [_vp, _i, _vp],
     "eend_attn_decode_split_f16": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _f, _vp],
     "eend_retention_step_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "eend_retention_proj_step_f32": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp],
+    "eend_retention_step_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "eend_dwconv_step_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "eend_layernorm_f16": [_vp, _vp, _vp, _f, _vp, _i, _i, _vp],
     "eend_dwconv_bn_swish_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp],

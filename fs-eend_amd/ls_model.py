@@ -221,6 +221,13 @@ def _ret_pack(msr: MultiScaleRetention):
     return _f16(w), _f32(b)
 
 
+def _ret_pack32(msr: MultiScaleRetention):
+    """The same packed projection in f32: operand of the frame-by-frame sessions (eend_retention_proj_step_f32)."""
+    s = msr.scaling
+    w = torch.cat([msr.q_proj.weight, msr.k_proj.weight * s, msr.v_proj.weight, msr.g_proj.weight], dim=0)
+    return _f32(w)
+
+
 class _Workspace:
     def __init__(self, dev, B, Tp, C, D, F_enc, F_dec, Fin_pad, H, nc):
         f16, f32 = torch.float16, torch.float32
@@ -325,7 +332,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 w1a=_f16(ffa[1].linear.weight), b1a=_f32(ffa[1].linear.bias),
                 w2a=_f16(ffa[4].linear.weight), b2a=_f32(ffa[4].linear.bias),
                 lnb=(_f32(ret.layer_norm.weight), _f32(ret.layer_norm.bias), ret.layer_norm.eps),
-                wqkvg=wq, bqkvg=bq, gn_eps=ret.self_attn.group_norm.eps,
+                wqkvg=wq, bqkvg=bq, wqkvg32=_ret_pack32(ret.self_attn), gn_eps=ret.self_attn.group_norm.eps,
                 wo=_f16(ret.self_attn.out_proj.weight), bo=_f32(ret.self_attn.out_proj.bias),
                 lnc=(_f32(cm[0].weight), _f32(cm[0].bias), cm[0].eps),
                 pw1=_f16(inter), pb1=_f32(interb),
@@ -345,7 +352,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         for l in self.dec.layers:
             wq, bq = _ret_pack(l.self_attn1)
             dl.append(dict(
-                wqkvg=wq, bqkvg=bq, gn_eps=l.self_attn1.group_norm.eps,
+                wqkvg=wq, bqkvg=bq, wqkvg32=_ret_pack32(l.self_attn1), gn_eps=l.self_attn1.group_norm.eps,
                 out1_w=_f16(l.self_attn1.out_proj.weight), out1_b=_f32(l.self_attn1.out_proj.bias),
                 in2_w=_f16(l.self_attn2.in_proj_weight), in2_b=_f32(l.self_attn2.in_proj_bias),
                 out2_w=_f16(l.self_attn2.out_proj.weight), out2_b=_f32(l.self_attn2.out_proj.bias),
@@ -588,9 +595,12 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 [attr[b, :l] for b, l in enumerate(ilens)])
 
     def forward(self, src, tgt, ilens):
-        """reference LS model :74-122 (values only; backward kernels are not implemented yet)."""
+        """reference LS model :74-122.  Under torch.no_grad(): values only (eval-mode numerics).  With gradients enabled
+        (the reference's training_step, LS-EEND/train/oln_tfm_enc_dec_on_the_fly.py:78): the HIP training forward runs inside a
+        torch.autograd.Function whose backward is the hand-written HIP backward (autograd.py, train_ls.LsTrainStep)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("fs-eend_amd: backward kernels are not implemented yet; call under torch.no_grad()")
+            from .autograd import ls_forward_with_grad
+            return ls_forward_with_grad(self, src, tgt, ilens)
         n_speakers = [t.shape[1] for t in tgt]
         C = max(n_speakers)
         logits, emb, attr, T, Tp = self._run(src, ilens, C)

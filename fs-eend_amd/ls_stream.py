@@ -12,6 +12,8 @@ driver's (B,D,k-1) f32 tensor, shifted in place.
 """
 from collections import deque
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -35,11 +37,23 @@ def _ret_state(state: dict, N: int, H: int, dev):
     return kv, state["scale"].to(F32).contiguous(), state["_scale_next"]
 
 
-def _ret_step(x16, wqkvg, bqkvg, state, N, H, gn_eps, scratch):
-    qkvg, o16 = scratch["qkvg"][:N], scratch["o16"][:N]
-    ops.linear(x16, wqkvg, bqkvg, qkvg)
+F32_PROJ = os.environ.get("EEND_STREAM_RET_F32", "1") != "0"      # f32 retention projections in the frame steps (A/B switch)
+
+
+def _ret_step(x16, x32, ln, Wd, state, N, H, scratch):
+    """One frame of MultiScaleRetention (retention.py:126-144) on N rows.  The q / k / v / g projections run in full f32 from
+    the f32 residual stream (x32, through LayerNorm `ln` where the block is pre-norm): the recurrence amplifies their
+    rounding with the stream position (see csrc/stream.hip ret_proj_step_kernel)."""
+    o16 = scratch["o16"][:N]
     kv, s_in, s_out = _ret_state(state, N, H, x16.device)
-    ops.retention_step(qkvg, kv, s_in, s_out, o16, N, H, gn_eps)
+    if F32_PROJ:
+        q32 = scratch["qkvg32"][:N]
+        ops.retention_proj_step(x32, ln, Wd["wqkvg32"], Wd["bqkvg"], q32, N)
+        ops.retention_step_f32(q32, kv, s_in, s_out, o16, N, H, Wd["gn_eps"])
+    else:
+        qkvg = scratch["qkvg"][:N]
+        ops.linear(x16, Wd["wqkvg"], Wd["bqkvg"], qkvg)
+        ops.retention_step(qkvg, kv, s_in, s_out, o16, N, H, Wd["gn_eps"])
     if state.get("_static"):
         s_in.copy_(s_out)             # graph-captured sessions: fixed buffers, the new scale is copied back (4 floats)
     else:
@@ -53,7 +67,7 @@ def _scratch(owner, key, N, D, F):
         dev = owner.cnn.weight.device
         e = lambda *s, dt=F16: torch.empty(*s, dtype=dt, device=dev)
         sc = dict(N=N, F=F, xin16=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F16, device=dev),
-                  h32=e(N, D, dt=F32), h16=e(N, D), x16=e(N, D), qkvg=e(N, 4 * D), o16=e(N, D), glu16=e(N, D),
+                  h32=e(N, D, dt=F32), h16=e(N, D), x16=e(N, D), qkvg=e(N, 4 * D), qkvg32=e(N, 4 * D, dt=F32), o16=e(N, D), glu16=e(N, D),
                   dw16=e(N, D), ff16=e(N * F), qkv16=e(N, 3 * D))
         owner._step_scratch[key] = sc
     return sc
@@ -80,7 +94,7 @@ def enc_step(owner, x_t, t, ret_states, conv_caches):
         ff = sc["ff16"][:B * Fi].view(B, Fi)
         ops.linear(x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
         ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1], h32, x16, Bk["lnb"][2])
-        o16 = _ret_step(x16, Bk["wqkvg"], Bk["bqkvg"], ret_states[i], B, H, Bk["gn_eps"], sc)
+        o16 = _ret_step(x16, h32, Bk["lnb"], Bk, ret_states[i], B, H, sc)
         ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], h32, 1.0, Bk["lnc"][0], Bk["lnc"][1], h32, x16, Bk["lnc"][2])
         glu, dw = sc["glu16"][:B], sc["dw16"][:B]
         ops.linear_glu(x16, Bk["pw1"], Bk["pb1"], glu)
@@ -113,7 +127,7 @@ def dec_step(owner, emb_t, t, max_nspks, ret_states):
     for i, Ld in enumerate(P["dec.layers"]):
         Fi = Ld["w1"].shape[0]
         ff = sc["ff16"][:N * Fi].view(N, Fi)
-        o16 = _ret_step(a16, Ld["wqkvg"], Ld["bqkvg"], ret_states[i], N, H, Ld["gn_eps"], sc)
+        o16 = _ret_step(a16, a32, None, Ld, ret_states[i], N, H, sc)
         ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], a32, Ld["g11"], Ld["be11"], a32, a16, Ld["eps11"])
         qkv = sc["qkv16"][:N]
         ops.linear(a16, Ld["in2_w"], Ld["in2_b"], qkv)

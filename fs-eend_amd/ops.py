@@ -269,6 +269,23 @@ def retention_step(qkvg16, kv_state, scale_in, scale_out, out16, N, H, gn_eps=1e
                                          _stream()), "eend_retention_step_f16")
 
 
+def retention_proj_step(x32, ln, w32, b32, qkvg32, N):
+    """qkvg32 (N, 1024) f32 = LayerNorm(x32 (N, 256)) @ w32.T + b32, all f32 (ln = (gamma, beta, eps) or None)."""
+    L = _lib.load()
+    _chk(x32, F32, "x32"); _chk(w32, F32, "w32"); _chk(b32, F32, "b32"); _chk(qkvg32, F32, "qkvg32")
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    _lib.check(L.eend_retention_proj_step_f32(_p(x32), _p(g), _p(b), float(eps), _p(w32), _p(b32), _p(qkvg32), N, _stream()),
+               "eend_retention_proj_step_f32")
+
+
+def retention_step_f32(qkvg32, kv_state, scale_in, scale_out, out16, N, H, gn_eps=1e-6):
+    L = _lib.load()
+    _chk(qkvg32, F32, "qkvg32"); _chk(kv_state, F32, "kv_state"); _chk(scale_in, F32, "scale_in")
+    _chk(scale_out, F32, "scale_out"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_retention_step_f32(_p(qkvg32), _p(kv_state), _p(scale_in), _p(scale_out), _p(out16), N, H, gn_eps, _stream()),
+               "eend_retention_step_f32")
+
+
 def dwconv_step(x16, cache, w, bn, out16, eps=1e-5):
     """x16/out16 f16 (B, D); cache f32 (B, D, k-1) shifted in place; w f32 (D, k)."""
     L = _lib.load()

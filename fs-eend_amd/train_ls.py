@@ -234,10 +234,14 @@ class LsTrainStep(TrainStepBase):
               Tp, self.L, D, D, 1e-6, Tv)
 
     # ------------------------------------------------------------------ forward (saves activations)
-    def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False, dropout: bool = True):
-        """Train-mode model.forward with every activation the backward needs saved, standard_loss + masked
-        emb-consistency loss and their gradients w.r.t. attractors / embeddings.  labels: prepared (T_i, nspk_i+2) tensors
-        (oln_tfm_enc_dec_on_the_fly.py:53-75).  bf.loss = [bce, emb_loss]."""
+    def forward(self, src: Sequence[Tensor], labels: Sequence[Tensor], ilens: Sequence[int], pit: bool = False, dropout: bool = True,
+                fused_loss: bool = True):
+        """Train-mode model.forward with every activation the backward needs saved.  labels: prepared (T_i, nspk_i+2)
+        tensors (oln_tfm_enc_dec_on_the_fly.py:53-75).
+        fused_loss=True : also standard_loss + masked emb-consistency loss and their gradients w.r.t. attractors /
+                          embeddings (bf.loss = [bce, emb_loss]); `backward(bf)` then completes the step.
+        fused_loss=False: stop at the head (bf.logits_full (B,T,C), bf.attr_n (B,T,C,D), bf.loss[1] = emb_loss): the
+                          caller computes its own loss on the logits and passes d loss / d logits to `backward`."""
         m, W, dev, L = self.model, self.W, self.dev, self.L
         srcs = [s.to(device=dev, dtype=F32).contiguous() for s in src]
         B, T = len(srcs), max(int(s.shape[0]) for s in srcs)
@@ -338,6 +342,12 @@ class LsTrainStep(TrainStepBase):
             x16 = sv["s22"].out16
 
         # ---- head + BCE (+ PIT label choice) + masked emb-consistency loss, and their gradients (LS model :89-117)
+        if not fused_loss:
+            bf.logits_full = torch.empty(B, T, C, dtype=F32, device=dev)
+            bf.attr_n = torch.empty(B, T, C, D, dtype=F32, device=dev)
+            ops.head_l2dot(bf.emb32, bf.a32, bf.attr_n, bf.logits_full, B, T, Tp, C, D)
+            bf.loss[1] = ops.emb_consistency(bf.emb32.view(B, Tp, D), lab, T, lens=bf.il, inv_count=bf.inv_sq)
+            return bf
         if pit:
             lab = self._pit_labels(bf, lab, il, ncols)
             bf.labels = lab
@@ -392,11 +402,21 @@ class LsTrainStep(TrainStepBase):
         _call("eend_gemm_bf16", dh, F_, W[f"{wkey}.w1{tag}T"], F_, None, dy, D, M, D, F_)
         self._ln_bwd2(dy, True, site, ln, g32, True, M)
 
-    def backward(self, bf: _LsBuffers):
-        """Gradients of bce + emb_loss w.r.t. every parameter -> self.flat.grads."""
+    def backward(self, bf: _LsBuffers, dlogits: Optional[Tensor] = None, emb_loss_grad: float = 1.0):
+        """Gradients w.r.t. every parameter -> self.flat.grads.  After forward(fused_loss=True): of bce + emb_loss.  After
+        forward(fused_loss=False): of the caller's loss, given dlogits = d loss / d logits (B, T, C) f32 and
+        emb_loss_grad = d loss / d emb_loss."""
         W = self.W
         B, T, Tp, C = bf.shape
         Tv = bf.Tv
+        if dlogits is not None:
+            dl = dlogits.to(device=self.dev, dtype=F32).contiguous()
+            if tuple(dl.shape) != (B, T, C):
+                raise EendHipError(f"backward: dlogits must be ({B}, {T}, {C})")
+            _call("eend_head_bce_f32", bf.emb32, bf.a32, None, None, None, 0.0, dl, None, bf.g32, bf.de32, self.ws, WS_FLOATS,
+                  bf.loss[2:3], B, T, Tp, C)
+            if emb_loss_grad != 0.0:
+                _call("eend_emb_consistency_bwd_f16", bf.emb16, bf.labels, bf.il, float(emb_loss_grad) * bf.inv_sq, bf.de32, B, T, Tp, D, C)
         Me, Md = B * Tp, B * C * Tp
         m = self.model
         ds16, dctx16, dqkv16 = bf.ds16, bf.dctx16, bf.dqkv16

@@ -284,6 +284,16 @@ int eend_counter_add_i32(int* counter, int inc, void* stream);
  * scale_in / scale_out f32 [H] (incremental_state["scale"]; zero state + scale 0 before frame 0). */
 int eend_retention_step_f16(const void* qkvg, float* kv_state, const float* scale_in, float* scale_out,
                             void* out_f16, int N, int H, float gn_eps, void* stream);
+/* Frame-by-frame sessions: the retention projections of one frame in full f32 -- qkvg_f32 [N][1024] =
+ * LayerNorm(x)[N][256] . Wqkvg^T + bias with the packed f32 weight [q; k*dk^-0.5; v; g] (ln_gamma == NULL: no
+ * LayerNorm, the decoder's post-norm stream) -- and the recurrent step on those f32 projections.  The
+ * recurrence amplifies operand rounding with the stream position (retention.py:126-144 normalises a state that grows like
+ * sqrt(t)); f16 projections cost > 1e-3 on the logits late in a one-hour stream, f32 ones keep the reference's fp32
+ * streaming within the 1e-3 bar (tests/test_long_horizon.py). */
+int eend_retention_proj_step_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* Wqkvg,
+                                 const float* bias, float* qkvg_f32, int N, void* stream);
+int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, int N,
+                            int H, float gn_eps, void* stream);
 
 /* One frame of the causal depthwise conv + BatchNorm(eval) + Swish of ConformerConvModule.
  * forward_one_step (conformer/convolution.py:157-163); cache f32 [B][D][k-1] (the driver's

@@ -11,6 +11,9 @@ orig_linear = R.linear
 def lin(x, w, b, q=R._id, role="lin"):
     isret = role.endswith((".qp", ".kp", ".vp", ".gp"))
     ops_f16 = V in ("all", "ops", "ops_out") or (V == "retproj" and isret) or (V == "nonret" and not isret)
+    if V.startswith("nr_") and not isret:
+        skip = {"nr_noop": (".op",), "nr_noff": ("ffa1", "ffa2", "ffb1", "ffb2", "ff1", "ff2"), "nr_encf16": ("dec.",), "nr_decf16": ("enc.", "conv.")}[V]
+        ops_f16 = not any(k in role for k in skip)
     out_f16 = V in ("all", "out", "ops_out", "retproj") and isret
     xx, ww = (hf(x), hf(w)) if ops_f16 else (x, w)
     y = xx @ ww.t()

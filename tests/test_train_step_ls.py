@@ -199,3 +199,32 @@ def test_ls_full_size_step_properties(hip_lib, dev):
     e2, l2 = run(4)
     assert l1 == l2 and torch.equal(e1.flat.params, e2.flat.params)          # fixed summation order: bit-reproducible
     print("LS full-size losses:", [f"{x:.5f}" for x in l1], " peak HBM GB:", torch.cuda.max_memory_allocated() / 2 ** 30)
+
+
+def test_ls_autograd_dropin_matches_reference(hip_lib, dev):
+    """The reference's own LS training recipe on the mirror model: model(feats, labels, ilens) with autograd enabled,
+    torch standard_loss + emb_loss, loss.backward(), clip_grad_norm_ -- the backward that runs is the HIP one."""
+    from fs_eend_amd.trainer import prepare_labels
+    from oracle import train_ref as TR
+    meta, arr = FX.load_case("ls_train_small")
+    m = build_ls_mirror(meta).to(dev).train()
+    feats = [f.to(dev) for f in FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])]
+    raw = [l.to(dev) for l in FX.make_labels(meta["lengths"], meta["nspk"], meta["lseed"])]
+    labels = prepare_labels(raw, meta["lengths"])
+    preds, emb_loss, embs, attrs = m(feats, labels, meta["lengths"])
+    loss = TR.standard_loss(preds, labels) + emb_loss
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(m.parameters(), meta["clip"])
+    want = arr["s0_loss"]
+    assert abs(float(loss) - want[0]) < 1e-4, (float(loss), want[0])
+    assert abs(float(gn) - arr["s0_gradnorm"][0]) < 1e-2 * arr["s0_gradnorm"][0]
+    tot = arr["s0_gradnorm"][0]
+    for i, (k, p) in enumerate(m.named_parameters()):
+        if k in meta["nograd"]:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+            continue
+        ref = arr["grad_norms"][i]
+        assert abs(float(p.grad.double().norm()) - ref) / max(ref, 1e-3 * tot) < 1e-2, k
+    with pytest.raises(Exception):
+        m.eval()
+        m(feats, labels, meta["lengths"])                 # gradient-enabled eval-mode call: refused loudly
