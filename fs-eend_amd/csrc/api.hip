@@ -267,6 +267,11 @@ int eend_retention_proj_step_f32(const float* x, const float* ln_gamma, const fl
     return eend_launch_ret_proj_step(x, ln_gamma, ln_beta, ln_eps, Wqkvg, bias, qkvg_f32, N, (hipStream_t)stream);
 }
 
+int eend_convert_fanout_step_f32(const float* emb_f32, const float* W_f32, int ldw, const float* pc, float* out_f32, void* out_f16,
+                                 int B, int C, void* stream) {
+    return eend_launch_convert_step_f32(emb_f32, W_f32, ldw, pc, out_f32, out_f16, B, C, (hipStream_t)stream);
+}
+
 int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, int N,
                             int H, float gn_eps, void* stream) {
     if (!qkvg || !kv_state || !scale_in || !scale_out || !out_f16) return EEND_EINVAL;

@@ -443,16 +443,16 @@ int eend_retention_chunk_train_f16(const void* Q, const void* K, const void* Kt,
 }
 
 int eend_retention_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* Vt,
-                            const void* dctx_bf16, const void* g_f16, int ldg, const void* rhat_f16, const float* rc_in,
+                            const float* dctx_f32, const void* g_f16, int ldg, const void* rhat_f16, const float* rc_in,
                             void* ot_ws, void* ott_ws, float* kv_ws, float* g_ws, void* St_ws, void* dqkvg_bf16, int ldq,
                             int nseq, int H, int Tp, int L, int T_valid, float sk, void* stream) {
-    if (!Q || !Qt || !K || !Kt || !V || !Vt || !dctx_bf16 || !g_f16 || !rhat_f16 || !rc_in || !ot_ws || !ott_ws || !kv_ws || !g_ws ||
+    if (!Q || !Qt || !K || !Kt || !V || !Vt || !dctx_f32 || !g_f16 || !rhat_f16 || !rc_in || !ot_ws || !ott_ws || !kv_ws || !g_ws ||
         !St_ws || !dqkvg_bf16)
         return EEND_EINVAL;
     if (H != 4 || L <= 0 || T_valid <= 0 || T_valid > Tp || (T_valid % L) != 0 || ldq < 1024 || (ldq & 7)) return EEND_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nc = T_valid / L;
-    int rc = eend_launch_ret_gate_gn_bwd(dctx_bf16, g_f16, ldg, rhat_f16, rc_in, (__bf16*)dqkvg_bf16 + 768, ldq, ot_ws, nseq, Tp, T_valid, st);
+    int rc = eend_launch_ret_gate_gn_bwd(dctx_f32, g_f16, ldg, rhat_f16, rc_in, (__bf16*)dqkvg_bf16 + 768, ldq, ot_ws, nseq, Tp, T_valid, st);
     if (rc != EEND_OK) return rc;
     rc = eend_launch_heads_transpose(ot_ws, 256, ott_ws, nseq, H, Tp, st);
     if (rc != EEND_OK) return rc;

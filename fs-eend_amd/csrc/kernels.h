@@ -174,6 +174,8 @@ int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, flo
                          int H, float eps, hipStream_t stream);
 int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N, int H, float eps,
                                hipStream_t stream);
+int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int C,
+                                 hipStream_t stream);
 int eend_launch_ret_proj_step(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
                               float* out, int N, hipStream_t stream);
 int eend_launch_dwconv_step(const void* x16, float* cache, const float* w, const float* bn_w, const float* bn_b,
@@ -345,5 +347,5 @@ int eend_launch_bn_swish_bwd_apply(void* ds16, const void* c16, const float* mea
                                    const float* beta, const float* sums, const float* n_dev, int nseq, int Tp, int Tv, hipStream_t stream);
 int eend_launch_dwconv_glu_bwd(const void* dc16, const void* P16, const float* w, void* dP16, float* partial, int nseq, int Tp, int Tv,
                                int k, hipStream_t stream);
-int eend_launch_ret_gate_gn_bwd(const void* dctx16, const void* g16, int ldg, const void* rhat16, const float* rc, void* dg16, int ldq,
+int eend_launch_ret_gate_gn_bwd(const float* dctx32, const void* g16, int ldg, const void* rhat16, const float* rc, void* dg16, int ldq,
                                 void* ot16, int nseq, int Tp, int Tv, hipStream_t stream);

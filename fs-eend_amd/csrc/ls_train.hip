@@ -395,10 +395,12 @@ void dwconv_glu_bwd_kernel(const __bf16* __restrict__ dc, const _Float16* __rest
 // Retention gate + per-head LayerNorm backward (retention.py:222-224: out = swish(g) * LN_head(r), eps 1e-6, no affine):
 //   d_rhat = d_out * swish(g);  d_g = d_out * rhat * swish'(g);
 //   d_r = rstd * (d_rhat - mean_head(d_rhat) - rhat * mean_head(d_rhat * rhat));  o~ = c_t * d_r  (rc = rstd * c_t)
-// dctx bf16 [M][256]; g16 f16 [M][ldg]; rhat16 f16 [M][256]; rc f32 [M][4]; dg bf16 [M][ldq] (caller offsets the column);
-// ot bf16 [M][256].  Rows t >= Tv: zeros.  One wave per row, 16 lanes per head.
+// dctx f32 [M][256] (the out-projection's data gradient, kept in f32: the LayerNorm backward below subtracts its two
+// dominant components, so rounding it to bf16 first would be amplified); g16 f16 [M][ldg]; rhat16 f16 [M][256];
+// rc f32 [M][4]; dg bf16 [M][ldq] (caller offsets the column); ot bf16 [M][256].  Rows t >= Tv: zeros.  One wave per
+// row, 16 lanes per head.
 __global__ __launch_bounds__(256)
-void ret_gate_gn_bwd_kernel(const __bf16* __restrict__ dctx, const _Float16* __restrict__ g16, int ldg, const _Float16* __restrict__ rhat16,
+void ret_gate_gn_bwd_kernel(const float* __restrict__ dctx, const _Float16* __restrict__ g16, int ldg, const _Float16* __restrict__ rhat16,
                             const float* __restrict__ rc, __bf16* __restrict__ dg, int ldq, __bf16* __restrict__ ot, long M, int Tp,
                             int Tv) {
     const int lane = threadIdx.x & 63;
@@ -407,8 +409,8 @@ void ret_gate_gn_bwd_kernel(const __bf16* __restrict__ dctx, const _Float16* __r
     const int t = (int)(row % Tp);
     uint2 pg = make_uint2(0u, 0u), po = make_uint2(0u, 0u);
     if (t < Tv) {
-        const uint2 dk = *(const uint2*)(dctx + row * D + lane * 4);
-        const float d[4] = {bf16_lo(dk.x), bf16_hi(dk.x), bf16_lo(dk.y), bf16_hi(dk.y)};
+        const float4 dk = *(const float4*)(dctx + row * D + lane * 4);
+        const float d[4] = {dk.x, dk.y, dk.z, dk.w};
         const f16x4 gv = *(const f16x4*)(g16 + row * ldg + lane * 4);
         const f16x4 rv = *(const f16x4*)(rhat16 + row * D + lane * 4);
         float dr[4], dgv[4], s1 = 0.f, s2 = 0.f;
@@ -565,12 +567,12 @@ int eend_launch_dwconv_glu_bwd(const void* dc16, const void* P16, const float* w
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-int eend_launch_ret_gate_gn_bwd(const void* dctx16, const void* g16, int ldg, const void* rhat16, const float* rc, void* dg16, int ldq,
+int eend_launch_ret_gate_gn_bwd(const float* dctx32, const void* g16, int ldg, const void* rhat16, const float* rc, void* dg16, int ldq,
                                 void* ot16, int nseq, int Tp, int Tv, hipStream_t stream) {
-    if (!dctx16 || !g16 || !rhat16 || !rc || !dg16 || !ot16 || nseq <= 0 || Tp <= 0 || Tv <= 0 || Tv > Tp || (ldg & 3) || (ldq & 3))
+    if (!dctx32 || !g16 || !rhat16 || !rc || !dg16 || !ot16 || nseq <= 0 || Tp <= 0 || Tv <= 0 || Tv > Tp || (ldg & 3) || (ldq & 3))
         return EEND_EINVAL;
     const long M = (long)nseq * Tp;
-    hipLaunchKernelGGL(ret_gate_gn_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, (const __bf16*)dctx16, (const _Float16*)g16,
+    hipLaunchKernelGGL(ret_gate_gn_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, dctx32, (const _Float16*)g16,
                        ldg, (const _Float16*)rhat16, rc, (__bf16*)dg16, ldq, (__bf16*)ot16, M, Tp, Tv);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

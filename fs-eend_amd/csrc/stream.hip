@@ -114,6 +114,30 @@ void ret_proj_step_kernel(const float* __restrict__ x, const float* __restrict__
     }
 }
 
+// Decoder input of one frame in f32 (LS model :229-233, `convert(cat(emb, pe))`, in the split form of DESIGN 3:
+// out[b*C + c] = W[:, :256] emb[b] + pc[c]).  The decoder's retention normalises by a near-zero-mean statistic with
+// eps 1e-6, so the f16 rounding of emb / W here is amplified ~30x at some frames of a long stream (emulated on the
+// oracle: 7.8e-4 in the logits by frame 2000 from this linear alone).  W f32 [256][ldw] (the parameter itself);
+// emb f32 [B][256]; pc f32 [C][256]; out32 f32 / out16 f16 [B*C][256].  A wave owns one output feature.
+__global__ __launch_bounds__(256)
+void convert_step_f32_kernel(const float* __restrict__ emb, const float* __restrict__ W, int ldw, const float* __restrict__ pc,
+                             float* __restrict__ out32, _Float16* __restrict__ out16, int B, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x * 4 + wave;
+    const float4 w = *(const float4*)(W + (size_t)f * ldw + lane * 4);
+    for (int b = 0; b < B; ++b) {
+        const float4 v = *(const float4*)(emb + (size_t)b * 256 + lane * 4);
+        float p = w.x * v.x + w.y * v.y + w.z * v.z + w.w * v.w;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) p = wave_xor_add(p, m);
+        if (lane < C) {
+            const float y = p + pc[(size_t)lane * 256 + f];
+            out32[((size_t)b * C + lane) * 256 + f] = y;
+            out16[((size_t)b * C + lane) * 256 + f] = to_f16_sat(y);
+        }
+    }
+}
+
 // ConformerConvModule.forward_one_step, depthwise part (conformer/convolution.py:157-163):
 // window = [cache (k-1 frames) | x_t]; y = sum_j w[c][j] window[c][j]; BatchNorm(eval); Swish;
 // new cache = window[:, 1:].  x f16 [B][D]; cache f32 [B][D][k-1] (the driver's layout), in place.
@@ -392,6 +416,13 @@ int eend_launch_ret_proj_step(const float* x, const float* gamma, const float* b
                               float* out, int N, hipStream_t stream) {
     if (!x || !W || !bias || !out || N <= 0 || N > 16 * 65535 || (gamma && !beta)) return EEND_EINVAL;
     hipLaunchKernelGGL(ret_proj_step_kernel, dim3(64, (N + 15) / 16), dim3(256), 0, stream, x, gamma, beta, eps, W, bias, out, N);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int C,
+                                 hipStream_t stream) {
+    if (!emb || !W || !pc || !out32 || !out16 || B <= 0 || C <= 0 || C > 64 || ldw < 256 || (ldw & 3)) return EEND_EINVAL;
+    hipLaunchKernelGGL(convert_step_f32_kernel, dim3(64), dim3(256), 0, stream, emb, W, ldw, pc, out32, (_Float16*)out16, B, C);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

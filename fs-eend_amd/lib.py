@@ -46,6 +46,7 @@ PROTOTYPES = {
     "eend_retention_step_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "eend_retention_proj_step_f32": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp],
     "eend_retention_step_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "eend_convert_fanout_step_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "eend_dwconv_step_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "eend_layernorm_f16": [_vp, _vp, _vp, _f, _vp, _i, _i, _vp],
     "eend_dwconv_bn_swish_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _vp],

@@ -121,9 +121,12 @@ def dec_step(owner, emb_t, t, max_nspks, ret_states):
     N = B * C
     F = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
     sc = _scratch(owner, "dec", N, D, F)
-    e16 = emb_t.to(device=dev, dtype=F32).reshape(B, D).to(F16).contiguous()
+    e32 = emb_t.to(device=dev, dtype=F32).reshape(B, D).contiguous()
     a32, a16 = sc["h32"][:N], sc["h16"][:N]
-    ops.convert_fanout(e16, P["convert.w1"], owner._convert_const(C), a32, a16, B, 1, C)
+    if F32_PROJ:
+        ops.convert_fanout_step_f32(e32, P["convert.w32"], owner._convert_const(C), a32, a16, B, C)
+    else:
+        ops.convert_fanout(e32.to(F16), P["convert.w1"], owner._convert_const(C), a32, a16, B, 1, C)
     for i, Ld in enumerate(P["dec.layers"]):
         Fi = Ld["w1"].shape[0]
         ff = sc["ff16"][:N * Fi].view(N, Fi)

@@ -286,6 +286,14 @@ def retention_step_f32(qkvg32, kv_state, scale_in, scale_out, out16, N, H, gn_ep
                "eend_retention_step_f32")
 
 
+def convert_fanout_step_f32(emb32, w32, pc, out32, out16, B, C):
+    """One frame of `convert(cat(emb, pe_c))` in f32: emb32 (B, 256), w32 the (256, 512) convert.weight, pc (C, 256)."""
+    L = _lib.load()
+    _chk(emb32, F32, "emb32"); _chk(w32, F32, "w32"); _chk(pc, F32, "pc"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_convert_fanout_step_f32(_p(emb32), _p(w32), w32.stride(0), _p(pc), _p(out32), _p(out16), B, C, _stream()),
+               "eend_convert_fanout_step_f32")
+
+
 def dwconv_step(x16, cache, w, bn, out16, eps=1e-5):
     """x16/out16 f16 (B, D); cache f32 (B, D, k-1) shifted in place; w f32 (D, k)."""
     L = _lib.load()

@@ -93,6 +93,7 @@ class _LsBuffers:
         self.de32 = e(Me, D, dt=F32)
         self.ds16 = e(Mx, D, dt=BF16)
         self.dctx16 = e(Mx, D, dt=BF16)
+        self.dctx32 = e(Mx, D, dt=F32)
         self.dy16 = e(Mx, D, dt=BF16)
         self.dh16 = e(max(Me * max(F_enc, 2 * D), Md * F_dec), dt=BF16)
         self.dqkvg = e(Mx, 4 * D, dt=BF16)
@@ -371,9 +372,11 @@ class LsTrainStep(TrainStepBase):
         (decoder, post-norm: the input gradient joins g32 directly) or x' = LN(x) (encoder: through the LayerNorm)."""
         W = self.W
         B, T, Tp, C = bf.shape
-        dctx, dq = bf.dctx16[:M], bf.dqkvg[:M]
+        dctx, dq = bf.dctx32[:M], bf.dqkvg[:M]
         self._wgrad(ds16, sv.ctx, M, D, D, pfx + "out_proj.weight")
-        _call("eend_gemm_bf16", ds16, D, W[wkey + ".woT" if wkey[0] == "e" else wkey + ".out1_wT"], D, None, dctx, D, M, D, D)
+        # the out-projection's data gradient stays f32: the per-head LayerNorm backward that consumes it cancels its two
+        # largest components (mean and the component along rhat), which amplifies any rounding applied before it
+        _call("eend_gemm_acc_bf16", ds16, D, W[wkey + ".woT" if wkey[0] == "e" else wkey + ".out1_wT"], D, None, 1.0, dctx, None, M, D)
         _call("eend_retention_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, sv.vt, dctx, sv.g, D, sv.rhat, sv.rc, bf.ot, bf.ott, bf.kv_ws,
               bf.g_ws, bf.st_bwd, dq, 4 * D, nseq, H, Tp, self.L, bf.Tv, 0.125)
         for j, nm in enumerate(("q_proj", "k_proj", "v_proj", "g_proj")):

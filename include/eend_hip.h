@@ -294,6 +294,12 @@ int eend_retention_proj_step_f32(const float* x, const float* ln_gamma, const fl
                                  const float* bias, float* qkvg_f32, int N, void* stream);
 int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, int N,
                             int H, float gn_eps, void* stream);
+/* Frame-by-frame decoder input in f32: out[b*C + c] = W[:, :256] emb[b] + pc[c] (`convert(cat(emb, pe))`, LS model
+ * :229-233; pc from eend_convert_const_f32).  W_f32 is the convert.weight parameter itself ([256][ldw], ldw = 512).
+ * f32 for the same reason as the projections above: the decoder retention amplifies the f16 rounding of this linear ~30x
+ * at some frames of a long stream.  out_f32 / out_f16 [B*C][256]; C <= 64. */
+int eend_convert_fanout_step_f32(const float* emb_f32, const float* W_f32, int ldw, const float* pc, float* out_f32, void* out_f16,
+                                 int B, int C, void* stream);
 
 /* One frame of the causal depthwise conv + BatchNorm(eval) + Swish of ConformerConvModule.
  * forward_one_step (conformer/convolution.py:157-163); cache f32 [B][D][k-1] (the driver's
@@ -579,7 +585,7 @@ int eend_retention_chunk_train_f16(const void* Q, const void* K, const void* Kt,
                                    void* O_f16, void* rhat_f16, float* rc, void* St_ws, float* kv_ws, float* cscale_ws,
                                    float* sexp_ws, int nseq, int H, int Tp, int L, int ldo, int ldg, float gn_eps,
                                    int T_valid, void* stream);
-/* MultiScaleRetention backward from the gradient of its out_proj input (retention.py:196-228, chunk-recurrent form
+/* MultiScaleRetention backward from the gradient of its out_proj input (f32 [nseq*Tp][256]; retention.py:196-228, chunk-recurrent form
  * :146-194): swish gate and per-head LayerNorm backward, then the linear-attention backward with the detached scales,
  *   dq_t = sum_{s<=t} (o~_t.v_s) k_s,  dk_s = sum_{t>=s} (o~_t.v_s) q_t,  dv_s = sum_{t>=s} (q_t.k_s) o~_t,
  * intra-chunk on bf16 MFMA tiles, across chunks through 64x64 prefix / suffix states.  Q..Vt: bf16 head layouts of
@@ -587,7 +593,7 @@ int eend_retention_chunk_train_f16(const void* Q, const void* K, const void* Kt,
  * columns 0 / 256 / 512 / 768.  ot_ws, ott_ws: bf16 scratch [nseq*Tp*256]; kv_ws, g_ws: f32 [nseq*H*nc*4096];
  * St_ws: bf16 [nseq*H*nc*6*4096]. */
 int eend_retention_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* Vt,
-                            const void* dctx_bf16, const void* g_f16, int ldg, const void* rhat_f16, const float* rc,
+                            const float* dctx_f32, const void* g_f16, int ldg, const void* rhat_f16, const float* rc,
                             void* ot_ws, void* ott_ws, float* kv_ws, float* g_ws, void* St_ws, void* dqkvg_bf16, int ldq,
                             int nseq, int H, int Tp, int L, int T_valid, float sk, void* stream);
 

@@ -12,8 +12,10 @@ def lin(x, w, b, q=R._id, role="lin"):
     isret = role.endswith((".qp", ".kp", ".vp", ".gp"))
     ops_f16 = V in ("all", "ops", "ops_out") or (V == "retproj" and isret) or (V == "nonret" and not isret)
     if V.startswith("nr_") and not isret:
-        skip = {"nr_noop": (".op",), "nr_noff": ("ffa1", "ffa2", "ffb1", "ffb2", "ff1", "ff2"), "nr_encf16": ("dec.",), "nr_decf16": ("enc.", "conv.")}[V]
+        skip = {"nr_noop": (".op",), "nr_noff": ("ffa1", "ffa2", "ffb1", "ffb2", "ff1", "ff2"), "nr_encf16": ("dec.",), "nr_decf16": ("enc.", "conv."), "nr_noconvert": ("dec.convert",), "nr_noconvff": ("dec.convert", "dec.ff")}[V]
         ops_f16 = not any(k in role for k in skip)
+    if V.startswith("only:"):
+        ops_f16 = (not isret) and any(k in role for k in V[5:].split(","))
     out_f16 = V in ("all", "out", "ops_out", "retproj") and isret
     xx, ww = (hf(x), hf(w)) if ops_f16 else (x, w)
     y = xx @ ww.t()
@@ -55,6 +57,7 @@ with torch.no_grad():
         if y is not None:
             if n in keep:
                 errs[n] = float(np.abs(y[0, 0].numpy() - truth[keep[n]]).max())
+                if errs[n] > 5e-4: print("  big", n, errs[n], np.abs(truth[keep[n]]).max(), flush=True)
             n += 1
         if t % 6000 == 5999:
             ks = sorted(errs)
