@@ -112,11 +112,16 @@ def msr(x: Tensor, sd: Dict[str, Tensor], pfx: str, H: int, L: int, q=_id, role=
 # ----------------------------------------------------------------------------
 # Conformer encoder (nnet/conformer/*)
 # ----------------------------------------------------------------------------
-def ffn_module(x: Tensor, sd, pfx: str, q=_id, role="ffn") -> Tensor:
-    """FeedForwardModule (feed_forward.py:47-57): LN -> Linear -> Swish -> Linear."""
+def ffn_module(x: Tensor, sd, pfx: str, q=_id, role="ffn", drop=None, site_hid: int = 0, site_out: int = 0) -> Tensor:
+    """FeedForwardModule (feed_forward.py:47-57): LN -> Linear -> Swish -> Dropout -> Linear -> Dropout.  ``drop``
+    (oracle/dropout_ref.HashDropout or None = eval / p = 0) supplies the two masks."""
     h = layer_norm(x, sd[pfx + "sequential.0.weight"], sd[pfx + "sequential.0.bias"])
     h = swish(linear(h, sd[pfx + "sequential.1.linear.weight"], sd[pfx + "sequential.1.linear.bias"], q, role + "1"))
-    return linear(h, sd[pfx + "sequential.4.linear.weight"], sd[pfx + "sequential.4.linear.bias"], q, role + "2")
+    if drop is not None:
+        rows = drop.seq_rows(x.shape[0], x.shape[1], x.device)
+        h = drop.rows(h, site_hid, rows)
+    y = linear(h, sd[pfx + "sequential.4.linear.weight"], sd[pfx + "sequential.4.linear.bias"], q, role + "2")
+    return y if drop is None else drop.rows(y, site_out, rows)
 
 
 def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None, bn_train: Optional[dict] = None):
@@ -159,22 +164,26 @@ def conv_module(x: Tensor, sd, pfx: str, q=_id, cache: Optional[Tensor] = None, 
 
 
 def conformer_block(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: Optional[dict] = None,
-                    conv_cache: Optional[Tensor] = None, bn_train: Optional[dict] = None):
-    """ConformerEncoderBlock (encoder.py:76-123), half-step residual FFNs."""
+                    conv_cache: Optional[Tensor] = None, bn_train: Optional[dict] = None, drop=None, site0: int = 0):
+    """ConformerEncoderBlock (encoder.py:76-123), half-step residual FFNs.  ``drop``: the block's six dropout sites
+    (feed_forward.py:51,53 twice, attention.py:112, convolution.py:148) as site0 + {0 FFN-a hidden, 1 FFN-a out, 2 retention
+    out, 3 conv out, 4 FFN-b hidden, 5 FFN-b out} -- the numbering of fs-eend_amd/train_ls.py."""
     s = pfx + "sequential."
-    x = x + 0.5 * ffn_module(x, sd, s + "0.module.", q, "enc.ffa")
+    rows = None if drop is None else drop.seq_rows(x.shape[0], x.shape[1], x.device)
+    x = x + 0.5 * ffn_module(x, sd, s + "0.module.", q, "enc.ffa", drop, site0 + 0, site0 + 1)
     a = s + "1.module."
     h = layer_norm(x, sd[a + "layer_norm.weight"], sd[a + "layer_norm.bias"])           # attention.py:100,115
-    x = x + msr(h, sd, a + "self_attn.", H, L, q, "enc.ret", ret_state)
+    r = msr(h, sd, a + "self_attn.", H, L, q, "enc.ret", ret_state)
+    x = x + (r if drop is None else drop.rows(r, site0 + 2, rows))
     y, new_cache = conv_module(x, sd, s + "2.module.", q, conv_cache, bn_train)
-    x = x + y
-    x = x + 0.5 * ffn_module(x, sd, s + "3.module.", q, "enc.ffb")
+    x = x + (y if drop is None else drop.rows(y, site0 + 3, rows))
+    x = x + 0.5 * ffn_module(x, sd, s + "3.module.", q, "enc.ffb", drop, site0 + 4, site0 + 5)
     x = layer_norm(x, sd[s + "4.weight"], sd[s + "4.bias"])
     return x, new_cache
 
 
 def encoder(src: Sequence[Tensor], sd, *, H: int, n_layers: int, L: int, q=_id, dtype=torch.float32,
-            taps: Optional[dict] = None, bn_train: Optional[dict] = None) -> Tensor:
+            taps: Optional[dict] = None, bn_train: Optional[dict] = None, drop=None) -> Tensor:
     """EmbeddingEncoderModule.forward (model :279-285) -> ConformerEncoder.forward (encoder.py:194-201)."""
     x = torch.nn.utils.rnn.pad_sequence([s.to(dtype) for s in src], padding_value=0.0, batch_first=True)
     T = x.shape[1]
@@ -184,7 +193,7 @@ def encoder(src: Sequence[Tensor], sd, *, H: int, n_layers: int, L: int, q=_id, 
                q, "enc.in")
     x = layer_norm(x, sd["enc.encoder.layer_norm.weight"], sd["enc.encoder.layer_norm.bias"])
     for i in range(n_layers):
-        x, _ = conformer_block(x, sd, f"enc.encoder.layers.{i}.", H, L, q, bn_train=bn_train)
+        x, _ = conformer_block(x, sd, f"enc.encoder.layers.{i}.", H, L, q, bn_train=bn_train, drop=drop, site0=16 * i)
         if taps is not None:
             taps[f"enc_l{i}"] = x
     return x
@@ -207,32 +216,44 @@ def lookahead_conv_l2(enc_out: Tensor, ilens, sd, L: int, conv_delay: int, q=_id
     return y / torch.linalg.vector_norm(y, dim=-1, keepdim=True)
 
 
-def dec_layer(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: Optional[dict] = None) -> Tensor:
+def dec_layer(x: Tensor, sd, pfx: str, H: int, L: int, q=_id, ret_state: Optional[dict] = None, drop=None,
+              site0: int = 0) -> Tensor:
     """LS TransformerEncoderFusionLayer (modules/merge_retnet_layer.py:233-253 batch,
-    :255-276 one-step): retention over time per speaker slot, MHA over slots, FFN; post-norm."""
+    :255-276 one-step): retention over time per speaker slot, MHA over slots, FFN; post-norm.  ``drop``: dropout11 (:298),
+    self_attn2's probabilities (:82), dropout21 (:307), dropout (:311), dropout2 (:312) as site0 + {1, 2, 3, 4, 5}."""
     B, T, C, D = x.shape
     y = x.transpose(1, 2).reshape(B * C, T, D)
     a = msr(y, sd, pfx + "self_attn1.", H, L, q, "dec.ret", ret_state)
+    if drop is not None:
+        a = drop.rows(a, site0 + drop.SITE_OUT1, drop.seq_rows(B * C, T, x.device))
     y = layer_norm(y + a, sd[pfx + "norm11.weight"], sd[pfx + "norm11.bias"])
     y = y.reshape(B, C, T, D).transpose(1, 2).reshape(B * T, C, D)
     a = mha(y, sd[pfx + "self_attn2.in_proj_weight"], sd[pfx + "self_attn2.in_proj_bias"],
-            sd[pfx + "self_attn2.out_proj.weight"], sd[pfx + "self_attn2.out_proj.bias"], H, None, q, "dec.mha_s")
+            sd[pfx + "self_attn2.out_proj.weight"], sd[pfx + "self_attn2.out_proj.bias"], H, None, q, "dec.mha_s",
+            pdrop=None if drop is None else (lambda p: drop.spk(p, site0 + drop.SITE_SPK, B, T)))
+    rows = None if drop is None else drop.slot_rows(B, T, C, x.device)
+    if drop is not None:
+        a = drop.rows(a, site0 + drop.SITE_OUT2, rows)
     y = layer_norm(y + a, sd[pfx + "norm21.weight"], sd[pfx + "norm21.bias"])
     h = torch.relu(linear(y, sd[pfx + "linear1.weight"], sd[pfx + "linear1.bias"], q, "dec.ff1"))
+    if drop is not None:
+        h = drop.rows(h, site0 + drop.SITE_FF, rows)
     f = linear(h, sd[pfx + "linear2.weight"], sd[pfx + "linear2.bias"], q, "dec.ff2")
+    if drop is not None:
+        f = drop.rows(f, site0 + drop.SITE_FFOUT, rows)
     y = layer_norm(y + f, sd[pfx + "norm22.weight"], sd[pfx + "norm22.bias"])
     return y.reshape(B, T, C, D)
 
 
 def decoder(emb: Tensor, C: int, sd, *, H: int, n_layers: int, L: int, q=_id,
-            ret_states: Optional[List[dict]] = None) -> Tensor:
+            ret_states: Optional[List[dict]] = None, drop=None) -> Tensor:
     """LS MaskedTransformerDecoderModel.forward / forward_one_step (model :215-220,:235-243)."""
     B, T, D = emb.shape
     pe = sd["dec.pos_enc.pe"][0, :C].to(emb.dtype)
     cat = torch.cat([emb[:, :, None, :].expand(B, T, C, D), pe[None, None].expand(B, T, C, D)], dim=-1)
     x = linear(cat, sd["dec.convert.weight"], sd["dec.convert.bias"], q, "dec.convert")
     for i in range(n_layers):
-        x = dec_layer(x, sd, f"dec.layers.{i}.", H, L, q, None if ret_states is None else ret_states[i])
+        x = dec_layer(x, sd, f"dec.layers.{i}.", H, L, q, None if ret_states is None else ret_states[i], drop, 4096 + 16 * i)
     return x
 
 
@@ -253,15 +274,16 @@ def ls_test(src: Sequence[Tensor], ilens: Sequence[int], sd, *, n_heads: int, en
 
 
 def ls_forward(src, tgt, ilens, sd, *, n_heads: int, enc_n_layers: int, dec_n_layers: int, chunk: int = 500,
-               conv_delay: int = 9, q=_id, dtype=torch.float32, bn_train: Optional[dict] = None):
+               conv_delay: int = 9, q=_id, dtype=torch.float32, bn_train: Optional[dict] = None, drop=None):
     """OnlineConformerRetentionDADiarization.forward (model :74-122); eval numerics unless ``bn_train`` is a dict
-    (train mode: the conv modules' BatchNorm uses batch statistics, see conv_module)."""
+    (train mode: the conv modules' BatchNorm uses batch statistics, see conv_module).  Dropout is off unless ``drop`` is an
+    oracle/dropout_ref.HashDropout: the masks are then the HIP path's counter-hash masks, NOT torch's."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     n_speakers = [t.shape[1] for t in tgt]
     C = max(n_speakers)
-    enc_out = encoder(src, sd, H=n_heads, n_layers=enc_n_layers, L=chunk, q=q, dtype=dtype, bn_train=bn_train)
+    enc_out = encoder(src, sd, H=n_heads, n_layers=enc_n_layers, L=chunk, q=q, dtype=dtype, bn_train=bn_train, drop=drop)
     emb = lookahead_conv_l2(enc_out, ilens, sd, chunk, conv_delay, q)
-    attr = decoder(emb, C, sd, H=n_heads, n_layers=dec_n_layers, L=chunk, q=q)
+    attr = decoder(emb, C, sd, H=n_heads, n_layers=dec_n_layers, L=chunk, q=q, drop=drop)
     attr = attr / torch.linalg.vector_norm(attr, dim=-1, keepdim=True)
     seq_len = max(ilens)
     len_mask = torch.nn.utils.rnn.pad_sequence([torch.ones(l, dtype=dtype) for l in ilens], batch_first=True)[..., None]

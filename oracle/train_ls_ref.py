@@ -42,14 +42,15 @@ def pit_permute(logits, labels):
     return [torch.cat([l[:, :1], p, l[:, -1:]], dim=-1) for l, p in zip(labels, perm)]
 
 
-def train_loss(sd: Dict[str, Tensor], feats, labels_raw, cfg: dict, pit: bool = False, bn_train=None, dtype=torch.float32):
+def train_loss(sd: Dict[str, Tensor], feats, labels_raw, cfg: dict, pit: bool = False, bn_train=None, dtype=torch.float32,
+               drop=None):
     """One reference training_step forward: (total, bce, emb_loss, logits, prepared labels)."""
     ilens = [int(f.shape[0]) for f in feats]
     labels = prepare_labels([l.to(dtype) for l in labels_raw], ilens)               # oln_tfm_enc_dec_on_the_fly.py:53-75
     logits, emb_loss, _, _ = R.ls_forward(feats, labels, ilens, sd, n_heads=cfg["n_heads"], enc_n_layers=cfg["enc_n_layers"],
                                           dec_n_layers=cfg["dec_n_layers"], chunk=cfg["recurrent_chunk_size"],
                                           conv_delay=cfg.get("conv_delay", 9), dtype=dtype,
-                                          bn_train=bn_train if bn_train is not None else {})
+                                          bn_train=bn_train if bn_train is not None else {}, drop=drop)
     use = pit_permute(logits, labels) if pit else labels
     bce = standard_loss(logits, use)                                                # loss.py:136-142, label_delay 0
     return bce + emb_loss, bce, emb_loss, logits, use
