@@ -12,6 +12,7 @@ collective (weak scaling: per-GPU batch fixed).
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -63,18 +64,18 @@ def flops_per_launch(name, shape, T):
 
 
 def pmc_traffic(kernel, shape):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json:
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     tags = {("fusion_layer_tail", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 2>(FfnParams)",), "131072"),
             ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
-            ("inproj_attn_causal", (64, 4)): (("inproj_attn_kernel",), "131072"),
-            ("inproj_attn_causal", (384, 4)): (("inproj_attn_kernel",), "786432"),
+            ("inproj_attn_causal", (64, 4)): (("inproj_attn_kernel(InprojAttnParams) #lo",), "131072"),      # persistent launch:
+            ("inproj_attn_causal", (384, 4)): (("inproj_attn_kernel(InprojAttnParams) #hi",), "131072"),     # same grid, two sizes
             ("attn_causal", (64, 4)): (("attn_causal_full_kernel",), "131072"),
             ("attn_causal", (384, 4)): (("attn_causal_full_kernel",), "786432"),
-            ("linear_res_ln", (196608, 256, 256)): (("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4",), "786432")}
+            ("linear_res_ln", (196608, 256, 256)): (("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4", "gemm_f16_kernelIDF16_Li64ELi256ELi1ELi4ELb1ELi0ELi4ELi0E"), "786432")}
     tag = tags.get((kernel, tuple(shape)))
     if tag is None or not os.path.exists(path):
         return None
@@ -82,6 +83,21 @@ def pmc_traffic(kernel, shape):
         if any(t in k for t in tag[0]) and k.endswith("grid=" + tag[1]):
             return v["hbm_bytes"]
     return None
+
+
+def ls_retention_traffic(nseq, H, Tv, L):
+    """PMC HBM bytes of the three retention kernels of one layer (the default LS workload, 160 x T = 2000, only)."""
+    path = os.path.join(ROOT, "profiles", "r03_ls_pmc_traffic.json")
+    if not os.path.exists(path) or (nseq, H, Tv, L) != (160, 4, 2000, 500):
+        return None
+    ks = json.load(open(path))["kernels"]
+    tot = 0.0
+    for name in ("ret_kv_chunk_kernel", "ret_state_scan_kernel", "ret_chunk_full_kernel"):
+        cand = [v["hbm_bytes"] for k, v in ks.items() if name in k]
+        if not cand:
+            return None
+        tot += max(cand)                      # the decoder-layer launch is the larger of the two sizes profiled
+    return tot
 
 
 class OpTimer:
@@ -308,7 +324,9 @@ def extras(dev):
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": r["avg_ms"],
                 "mfma_TFLOPs": r["tflops"], "mfma_frac": None if r["tflops"] is None else r["tflops"] / PEAK_MFMA_TFLOPS,
                 "intensity_flop_per_byte": flops_per_launch("retention_chunk", tuple(r["shape"]), T) / byt,
-                "traffic": None, "traffic_source": "profiles/r03_ls_pmc_* (rocprofv3 --pmc passes) when collected"}
+                "traffic": ls_retention_traffic(nseq_, H_, Tv_, L_),
+                "traffic_source": "profiles/r03_ls_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes): ret_kv_chunk + "
+                                  "ret_state_scan + ret_chunk_full of one decoder layer, bytes per launch"}
     except Exception as ex:
         res["ls_eend_batch"]["roofline"] = dict(error=f"{type(ex).__name__}: {ex}")
 
@@ -432,7 +450,7 @@ def extras(dev):
     # BASELINE config 4: one FS-EEND training step (forward + loss + backward + clip + Adam), 64 x T=500, 4 speakers
     try:
         torch.cuda.reset_peak_memory_stats(dev)
-        eng, dtt, loss = time_train(dev, 64, 500, 4, steps=10, warmup=3)
+        eng, dtt, loss, _f, _l = time_train(dev, 64, 500, 4, steps=10, warmup=3)
         res["fs_eend_train_step"] = dict(workload="FS-EEND training step, 64 utterances x T=500, 4-speaker mixtures (C=6), shipped yaml "
                                                   f"shapes, dropout {eng.drop_p}, Adam x Noam, clip 5; eager launches, 1 GPU",
                                          ms_per_step=dtt / 10 * 1e3, frames_per_s=64 * 500 * 10 / dtt, final_loss=loss,
@@ -610,12 +628,15 @@ def time_train(dev, B, T, n_spk, steps, warmup, rank=0, fence=None, flavour="fs"
     for _ in range(warmup):
         eng.step(feats, labels, ilens)
     (fence or torch.cuda.synchronize)()
+    gc.collect()
+    gc.disable()                      # as timeit does: a generation-2 collection is a 30-40 ms host stall in this process
     t0 = time.perf_counter()
     for _ in range(steps):
         out = eng.step(feats, labels, ilens)
     (fence or torch.cuda.synchronize)()
     dt = time.perf_counter() - t0
-    return eng, dt, float(out["loss"])
+    gc.enable()
+    return eng, dt, float(out["loss"]), feats, labels
 
 
 class TrainCallTimer:
@@ -708,14 +729,18 @@ class TrainCallTimer:
         torch.cuda.synchronize()
         agg = {}
         for name, shape, s, e in self.rec:
-            d = agg.setdefault((name, shape), [0.0, 0])
-            d[0] += s.elapsed_time(e)
-            d[1] += 1
+            agg.setdefault((name, shape), []).append(s.elapsed_time(e))
         out = []
-        for (name, shape), (ms, n) in agg.items():
+        for (name, shape), ts in agg.items():
+            n, ms = len(ts), sum(ts)
             fl = self.flops(name, shape)
-            out.append(dict(call=name, shape=list(shape), launches_per_step=n / steps, avg_ms=ms / n, ms_per_step=ms / steps,
-                            tflops=(fl / (ms / n * 1e-3) / 1e12) if fl else None))
+            row = dict(call=name, shape=list(shape), launches_per_step=n / steps, avg_ms=ms / n, ms_per_step=ms / steps,
+                       tflops=(fl / (ms / n * 1e-3) / 1e12) if fl else None)
+            med = sorted(ts)[n // 2]
+            if max(ts) > 4.0 * med + 0.05:          # an event pair that also covers a host-side stall: say so instead of hiding it
+                row["median_ms"], row["max_ms"] = med, max(ts)
+                print(f"[bench] {name} {shape}: per-launch ms {['%.3f' % t for t in ts]}", file=sys.stderr)
+            out.append(row)
         return sorted(out, key=lambda d: -d["ms_per_step"])
 
 
@@ -838,7 +863,7 @@ def main():
 
     if args.mode == "train":
         from fs_eend_amd.shard import job_throughput
-        eng, dt, loss = time_train(dev, B, T, args.speakers, args.steps, args.warmup, rank, fence, args.flavour)
+        eng, dt, loss, feats, labels = time_train(dev, B, T, args.speakers, args.steps, args.warmup, rank, fence, args.flavour)
         ls = args.flavour == "ls" 
         value = job_throughput(B * T * args.steps, dt, dev)
         dt = world * B * T * args.steps / value
@@ -861,11 +886,13 @@ def main():
         if rank == 0 and world == 1 and not args.no_breakdown:
             # dominant kernel: HIP events around every C-ABI call of 2 extra steps (same stream, same inputs).  N = 1 only: a
             # training step contains the gradient all-reduce, a collective every rank would have to enter
-            _, feats, labels = train_setup(dev, B, T, args.speakers, rank, args.flavour)
+            gc.collect()
+            gc.disable()              # an event pair must not also cover a host-side collection (seen: 36 ms on one random call)
             with TrainCallTimer(T) as tm:
                 for _ in range(2):
                     eng.step(feats, labels, [T] * B)
             calls = tm.summary(2)
+            gc.enable()
             tot = sum(c["ms_per_step"] for c in calls)
             out["breakdown"] = [dict(c, share=c["ms_per_step"] / tot) for c in calls[:16]]
             out["kernel_ms_per_step"] = tot
@@ -944,10 +971,13 @@ def main():
     }
 
     if rank == 0 and not args.no_breakdown:
+        gc.collect()
+        gc.disable()
         with OpTimer(ops, T) as tm:
             for _ in range(3):
                 step()
             ksum = tm.summary()
+        gc.enable()
         tot = sum(k["total_ms"] for k in ksum)
         out["kernel_breakdown"] = [dict(kernel=k["kernel"], shape=k["shape"], launches_per_step=k["launches"] // 3,
                                         avg_ms=round(k["avg_ms"], 4), share=round(k["total_ms"] / tot, 4),
@@ -959,7 +989,7 @@ def main():
                            "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
-                           "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
+                           "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
         fus = [k for k in ksum if k["kernel"] == "inproj_attn_causal" and k["shape"][0] == B]
         if fus:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun).  WHAT = space/comma separated subset of: test smoke bench train train_ls prof prof_train_ls
+# Runs on the GPU box (via gpurun).  WHAT = space/comma separated subset of: test smoke bench train train_ls hour prof prof_train prof_train_ls
 # Everything judged later is copied from gpurun_out/ into profiles/ by hand.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -29,6 +29,9 @@ fi
 if has train_ls; then
   timeout 900 python bench.py --mode train --flavour ls --steps 10 --warmup 3 ${TRAIN_ARGS:-} > gpurun_out/bench_train_ls.json 2> gpurun_out/bench_train_ls.err; echo "bench train ls rc=$?"
   tail -3 gpurun_out/bench_train_ls.err; cut -c1-600 gpurun_out/bench_train_ls.json
+fi
+if has hour; then   # per-window error profile of the one-hour LS stream against the float64 recurrence
+  timeout 600 python tools/ls_hour_profile.py > gpurun_out/ls_hour_stream_profile.txt 2>&1; echo "hour rc=$?"; tail -16 gpurun_out/ls_hour_stream_profile.txt
 fi
 prof() {   # prof <tag> <bench args...>
   local tag=$1; shift

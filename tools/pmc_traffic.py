@@ -16,18 +16,17 @@ def load(path, col):
     return out
 
 
-def main(fetch_csv, write_csv, dst):
+def main(fetch_csv, write_csv, dst, workload="bench.py --steps 2 --graph 0, B=64 T=500 C=6"):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, 0) + w.get(k, 0))):
         fb, wb = 2.0 * f.get(k, 0.0), w.get(k, 0.0)
         kernels[k] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-    note = ("rocprofv3 --pmc, separate passes (FETCH_SIZE alone, WRITE_SIZE alone), bench.py --steps 2 --graph 0, "
-            "B=64 T=500 C=6; per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md; KB -> bytes x1024; "
+    note = ("rocprofv3 --pmc, separate passes (FETCH_SIZE alone, WRITE_SIZE alone), " + workload + "; per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md; KB -> bytes x1024; "
             "'#hi'/'#lo' = the large / small problem size of a persistent kernel (same grid for both)")
     json.dump({"note": note, "kernels": kernels}, open(dst, "w"), indent=1)
     print(f"{len(kernels)} kernels -> {dst}")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])       # optional 4th argument: the workload that was profiled (goes into the note)
