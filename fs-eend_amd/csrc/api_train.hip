@@ -22,14 +22,26 @@ DropSpec drop_spec(const eend_dropout* d) {
     return s;
 }
 
-// split the token axis so that about 512 workgroups run, within the workspace
-int plan_wgrad(long M, int N, int K, long ws_floats, int* nsplit, long* m_per_split) {
+// Output tile and token split of a weight gradient.  Large token counts with 256-aligned shapes take the 256 x 256 tile
+// (one 8-wave workgroup per CU, half the operand bytes per flop: wgrad.hip); the token axis is split so that about one
+// round of workgroups runs (512 for the 128-tile, 256 for the 256-tile), in multiples of 8 so that every XCD owns whole
+// splits, within the workspace.  EEND_WGRAD_TILE=128 forces the small tile (A/B).
+int plan_wgrad(long M, int N, int K, int conv_cin, long ws_floats, int* tile, int* nsplit, long* m_per_split) {
     const long tile_floats = (long)N * K;
     if (tile_floats <= 0 || ws_floats < tile_floats) return EEND_EINVAL;
-    const int ntiles = (N / 128) * (K / 128);
-    long want = (512 + ntiles - 1) / ntiles;
+    static const int force = getenv("EEND_WGRAD_TILE") ? atoi(getenv("EEND_WGRAD_TILE")) : 0;
+    // (a single 256 x 256 output -- N = K = 256 -- keeps the small tile: same speed, half the partials to reduce)
+    const bool big = force != 128 && M >= 131072 && (N % 256) == 0 && (K % 256) == 0 && (long)N * K > 65536 && conv_cin == 0;
+    const int bt = big ? 256 : 128, slots = big ? 256 : 512;
+    *tile = bt;
+    const int ntiles = (N / bt) * (K / bt);
+    long want = (slots + ntiles - 1) / ntiles;
     const long cap = ws_floats / tile_floats;
     if (want > cap) want = cap;
+    if (want >= 8 && (want & 7)) {
+        const long down = want & ~7L, up = down + 8;
+        want = (up <= cap && up * ntiles <= slots) ? up : down;
+    }
     const long steps = (M + 63) / 64;
     if (want > steps) want = steps;
     if (want < 1) want = 1;
@@ -163,7 +175,7 @@ int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f1
     WgradParams p;
     memset(&p, 0, sizeof(p));
     p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.b_is_f16 = x_is_f16 ? 1 : 0;
-    int rc = plan_wgrad(M, N, K, ws_floats, &p.nsplit, &p.m_per_split);
+    int rc = plan_wgrad(M, N, K, 0, ws_floats, &p.tile, &p.nsplit, &p.m_per_split);
     if (rc != EEND_OK) return rc;
     rc = eend_launch_wgrad(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
@@ -179,7 +191,7 @@ int eend_conv1d_wgrad_bf16(const void* dY, const void* X_f16, const int* ilens, 
     memset(&p, 0, sizeof(p));
     p.A = dY; p.B = X_f16; p.partial = ws; p.M = (long)nseq * Tp; p.N = N; p.K = K; p.lda = 256; p.ldb = cin; p.b_is_f16 = 1;
     p.conv = 1; p.conv_cin = cin; p.conv_pad = pad; p.Tp = Tp; p.ilens = ilens;
-    int rc = plan_wgrad(p.M, N, K, ws_floats, &p.nsplit, &p.m_per_split);
+    int rc = plan_wgrad(p.M, N, K, cin, ws_floats, &p.tile, &p.nsplit, &p.m_per_split);
     if (rc != EEND_OK) return rc;
     rc = eend_launch_wgrad(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;

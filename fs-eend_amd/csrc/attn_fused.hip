@@ -28,6 +28,9 @@
 
 namespace {
 
+#ifndef EEND_AF_NT
+#define EEND_AF_NT 0            // 1: X loads and O stores carry the non-temporal hint, so that the streaming traffic does not
+#endif                          //    evict the workgroup's Q slot from L2 between its write (phase 1) and its read (phase 2)
 #ifndef EEND_AF_REGSTAGE
 #define EEND_AF_REGSTAGE 1      // X staging through registers (1) or by LDS-DMA (0: the first form, kept for the A/B)
 #endif
@@ -189,7 +192,13 @@ void inproj_attn_kernel(const InprojAttnParams p) {
         u32x4 ra[2], rb[2];
         auto gload = [&](int xt, u32x4 (&r)[2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) r[i] = *(const u32x4*)(Xg + (size_t)xt * XR * p.ldx + xsrc[i]);
+            for (int i = 0; i < 2; ++i) {
+#if EEND_AF_NT
+                r[i] = __builtin_nontemporal_load((const u32x4*)(Xg + (size_t)xt * XR * p.ldx + xsrc[i]));
+#else
+                r[i] = *(const u32x4*)(Xg + (size_t)xt * XR * p.ldx + xsrc[i]);
+#endif
+            }
         };
         auto lstore = [&](int xt, const u32x4 (&r)[2]) __attribute__((always_inline)) {
             char* dst = Xs + (xt & 1) * XBUF;
@@ -331,7 +340,11 @@ void inproj_attn_kernel(const InprojAttnParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c = tid + i * 512, row = c >> 5, col = c & 31;
+#if EEND_AF_NT
+                pre[i] = __builtin_nontemporal_load((const u32x4*)(Xn + (size_t)row * p.ldx + col * 8));
+#else
                 pre[i] = *(const u32x4*)(Xn + (size_t)row * p.ldx + col * 8);
+#endif
             }
             pre_issued = true;
         }
@@ -359,8 +372,12 @@ void inproj_attn_kernel(const InprojAttnParams p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
-            const uint4 v = *(const uint4*)(Ow + row * 128 + ((ch ^ (row & 7)) << 4));
-            *(uint4*)(Og + (size_t)row * p.ldo + ch * 8) = v;
+            const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((ch ^ (row & 7)) << 4));
+#if EEND_AF_NT
+            __builtin_nontemporal_store(v, (u32x4*)(Og + (size_t)row * p.ldo + ch * 8));
+#else
+            *(u32x4*)(Og + (size_t)row * p.ldo + ch * 8) = v;
+#endif
         }
         __builtin_amdgcn_wave_barrier();
     };

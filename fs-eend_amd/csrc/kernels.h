@@ -257,6 +257,7 @@ struct WgradParams {          // wgrad.hip: partial[s][n][k] = sum_{m in split s
     int N, K, lda, ldb;
     int nsplit;
     long m_per_split;         // multiple of 64
+    int tile;                 // output tile edge: 128 (default) or 256 (N, K, conv_cin multiples of 256)
     int b_is_f16;
     // Conv1d weight gradient: B rows of k-tile (tap, c_in block) are read at frame t + tap - conv_pad (zero outside [0, ilen))
     int conv, conv_cin, conv_pad, Tp;

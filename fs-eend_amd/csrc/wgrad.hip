@@ -20,26 +20,54 @@
 
 namespace {
 
-constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 64;
+#ifndef EEND_WGRAD_PF
+#define EEND_WGRAD_PF 2         // register sets of the global -> LDS staging pipeline (prefetch distance in 64-token steps)
+#endif
+#ifndef EEND_WGRAD_XCD
+#define EEND_WGRAD_XCD 1        // 0: the plain block order (kept for the same-box A/B, tools/ab_variants.sh)
+#endif
+constexpr int TN_BM = 64;
 
-template <bool B_F16, bool CONV>
-__global__ __launch_bounds__(256)
+// BT = output tile edge: 128 (4 waves, 64 KB LDS, two workgroups per CU) or 256 (8 waves, 128 KB LDS, one per CU).
+// The kernel is bound by operand delivery, not by HBM or the MFMA pipe (PMC on [393216, 256, 2048]: FETCH_SIZE = the
+// algorithmic 1.8 GB, MFMA pipe 19 % busy, L2 serving 6.5 GB = every tile's own copy of its dY / X rows at ~7.5 TB/s,
+// ~30 GB/s per CU, for every shape tried), so the lever is bytes per flop: a 256 x 256 tile needs half of them.
+// Measured, same box: 15-18 % faster on the shapes with more than one 256-tile (e.g. [393216, 256, 2048] 866 -> 737 us,
+// 559 TFLOP/s); deeper register prefetch (2 / 3 sets, branch-free loads so that the waits are partial) changed nothing.
+template <bool B_F16, bool CONV, int BT>
+__global__ __launch_bounds__(BT * 2)
 void wgrad_tn_kernel(const WgradParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x (A^T [128][128 B] + B^T [128][128 B]) = 64 KB
+    constexpr int TN_BN = BT, TN_BK = BT;
+    constexpr int HT = BT;                                            // threads staging one operand (BT / 8 feature groups x 8)
+    constexpr int JN = BT / 32;                                       // 16-wide n fragments per wave (wave tile 64 k x BT / 2 n)
+    constexpr int PF = BT == 128 ? EEND_WGRAD_PF : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x (A^T [BT][128 B] + B^T [BT][128 B])
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave >> 1, wn = wave & 1;                          // wave tile: 64 k-rows x 64 n-cols
+    const int wk = wave >> 1, wn = wave & 1;                          // wave tile: 64 k-rows x BT / 2 n-cols
     const int ntk = p.K / TN_BK, ntn = p.N / TN_BN;
-    const int tile = blockIdx.x % (ntk * ntn), split = blockIdx.x / (ntk * ntn);
+    // block -> (output tile, token split).  XCD-aware when the split count allows it: workgroup b runs on XCD b % 8
+    // (hardware round-robin), and ALL output tiles of a token split go to one XCD, so that the split's dY / X rows are
+    // fetched from HBM once and the ntk / ntn-fold re-reads by the other tiles are hits in that XCD's L2 (same-box A/B:
+    // 5-8 % on every shape; the plain b % ntiles order put the four tiles of a [M, 256, 256] split on four XCDs).
+    int tile, split;
+    if (EEND_WGRAD_XCD && (p.nsplit & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        split = (i / (ntk * ntn)) * 8 + xcd;
+        tile = i % (ntk * ntn);
+    } else {
+        tile = blockIdx.x % (ntk * ntn);
+        split = blockIdx.x / (ntk * ntn);
+    }
     const int n0 = (tile / ntk) * TN_BN, k0 = (tile % ntk) * TN_BK;
     const long m_begin = (long)split * p.m_per_split;
     long m_end = m_begin + p.m_per_split;
     if (m_end > p.M) m_end = p.M;
     const int nsteps = m_end > m_begin ? (int)((m_end - m_begin + TN_BM - 1) / TN_BM) : 0;
 
-    // staging role: threads 0..127 transpose the dY tile, 128..255 the X tile; unit = (8 tokens mg, 8 features fc)
-    const bool isB = tid >= 128;
-    const int u = tid & 127, fc = u & 15, mg = u >> 4;
+    // staging role: the first half of the threads transposes the dY tile, the second the X tile; unit = (8 tokens mg, 8 features fc)
+    const bool isB = tid >= HT;
+    const int u = tid & (HT - 1), fc = u & (BT / 8 - 1), mg = u / (BT / 8);
     const unsigned short* src = isB ? (const unsigned short*)p.B + (CONV ? 0 : k0) + fc * 8
                                     : (const unsigned short*)p.A + n0 + fc * 8;
     const int ld = isB ? p.ldb : p.lda;
@@ -50,76 +78,138 @@ void wgrad_tn_kernel(const WgradParams p) {
         conv_shift = tap - p.conv_pad;
     }
 
-    u32x4 reg[8];
-    auto gload = [&](int step) __attribute__((always_inline)) {
+    // PF register sets: the rows of step s are requested PF steps ahead (an MFMA phase is ~0.2 us, a loaded-HBM round trip
+    // ten times that: with one set -- request at s-1, transpose at the end of s-1 -- every step waited for its own loads),
+    // transposed into the LDS buffer one step ahead, consumed at step s.  The loads are branch-free (clamped address +
+    // select) so that the compiler can wait with vmcnt(8 * (PF - 1)) instead of vmcnt(0).
+    u32x4 reg[PF][8];
+    auto gload = [&](int step, u32x4 (&rg)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const long m = m_begin + (long)step * TN_BM + mg * 8 + r;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (m < m_end) {
-                if (CONV && isB) {
-                    const int seq = (int)(m / p.Tp), t = (int)(m - (long)seq * p.Tp);
-                    const int ts = t + conv_shift;
-                    if (ts >= 0 && ts < p.ilens[seq])
-                        v = *(const u32x4*)(src + ((long)seq * p.Tp + ts) * ld + conv_c0);
-                } else {
-                    v = *(const u32x4*)(src + m * ld);
+            if constexpr (CONV) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (m < m_end) {
+                    if (isB) {
+                        const int seq = (int)(m / p.Tp), t = (int)(m - (long)seq * p.Tp);
+                        const int ts = t + conv_shift;
+                        if (ts >= 0 && ts < p.ilens[seq])
+                            v = *(const u32x4*)(src + ((long)seq * p.Tp + ts) * ld + conv_c0);
+                    } else {
+                        v = *(const u32x4*)(src + m * ld);
+                    }
                 }
+                rg[r] = v;
+            } else {
+                const bool ok = m < m_end;
+                const u32x4 v = *(const u32x4*)(src + (ok ? m : m_begin) * ld);
+                rg[r] = ok ? v : u32x4{0u, 0u, 0u, 0u};
             }
-            reg[r] = v;
         }
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-        u32x4 in[8], out[8];
+    auto lstore = [&](int buf, const u32x4 (&rg)[8]) __attribute__((always_inline)) {
+        u32x4 in[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (B_F16 && isB) ? f16x8_to_bf16x8(reg[r]) : reg[r];
-        transpose8x8_b16(in, out);
+        for (int r = 0; r < 8; ++r) in[r] = (B_F16 && isB) ? f16x8_to_bf16x8(rg[r]) : rg[r];
         char* base = smem + buf * (2 * TN_BN * 128) + (isB ? TN_BN * 128 : 0);
+        if constexpr (BT == 256) {
+            // 128 accumulator registers: one transposed row at a time (4 live registers instead of 32), addresses recomputed
+            int fc_ = fc, mg_ = mg;
+            asm volatile("" : "+v"(fc_), "+v"(mg_));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *(u32x4*)(base + swzT(fc * 8 + e, mg)) = out[e];
+            for (int e = 0; e < 8; ++e) {
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned a = in[2 * j][e >> 1], b = in[2 * j + 1][e >> 1];
+                    o[j] = (e & 1) ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16));
+                }
+                *(u32x4*)(base + swzT(fc_ * 8 + e, mg_)) = o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            u32x4 out[8];
+            transpose8x8_b16(in, out);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(u32x4*)(base + swzT(fc * 8 + e, mg)) = out[e];
+        }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][JN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fkg = lane >> 4;
+        for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow_c = lane & 15, fkg_c = lane >> 4;
 
-    if (nsteps > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nsteps) gload(st + 1);
+    auto mma_step = [&](int buf) __attribute__((always_inline)) {
+        int frow = frow_c, fkg = fkg_c;
+        if (BT == 256) asm volatile("" : "+v"(frow), "+v"(fkg));     // 128 accumulator registers: recompute the 24 fragment
+                                                                      // addresses per step instead of keeping them (and spilling)
         const char* at = smem + buf * (2 * TN_BN * 128);              // dY^T: [n][64 m]
         const char* bt = at + TN_BN * 128;                           // X^T : [k][64 m]
+        if constexpr (BT == 256) {
+            // 128 accumulator registers: fragments are fetched in small groups (4 n-fragments, then one k-fragment per 4 MFMAs)
+            // and the groups are fenced, so that at most 20 fragment registers are live
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf16x8 lf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lf[j] = *(const bf16x8*)(at + swzT(wn * 128 + (jh * 4 + j) * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bf16x8 rf = *(const bf16x8*)(bt + swzT(wk * 64 + i * 16 + frow, ks * 4 + fkg));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf, lf[j], acc[i][jh * 4 + j], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 rf[4], lf[4];
+            bf16x8 rf[4], lf[JN];
 #pragma unroll
             for (int i = 0; i < 4; ++i) rf[i] = *(const bf16x8*)(bt + swzT(wk * 64 + i * 16 + frow, ks * 4 + fkg));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lf[j] = *(const bf16x8*)(at + swzT(wn * 64 + j * 16 + frow, ks * 4 + fkg));
+            for (int j = 0; j < JN; ++j) lf[j] = *(const bf16x8*)(at + swzT(wn * (BT / 2) + j * 16 + frow, ks * 4 + fkg));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < JN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[i], lf[j], acc[i][j], 0, 0, 0);
         }
-        if (st + 1 < nsteps) lstore(buf ^ 1);
-        __syncthreads();
+        }
+    };
+    // steps beyond nsteps load nothing (all rows >= m_end select zero) and add zero: the trip count is rounded up to the
+    // unroll factor instead of breaking out of the unrolled body
+#pragma unroll
+    for (int d = 0; d < PF; ++d) gload(d, reg[d]);
+    lstore(0, reg[0]);
+    __syncthreads();
+    constexpr int UN = (PF & 1) ? 2 * PF : PF;                        // register set AND LDS buffer static inside the body
+    for (int st0 = 0; st0 < nsteps; st0 += UN) {
+#pragma unroll
+        for (int dd = 0; dd < UN; ++dd) {
+            const int st = st0 + dd;
+            gload(st + PF, reg[dd % PF]);                             // reg[dd % PF] (step st) went to LDS during step st - 1
+            mma_step(dd & 1);
+            lstore((dd & 1) ^ 1, reg[(dd + 1) % PF]);
+            __syncthreads();
+        }
     }
 
-    // acc[i][j][r]: k = k0 + wk*64 + i*16 + fkg*4 + r (4 consecutive k per lane), n = n0 + wn*64 + j*16 + frow
+    // acc[i][j][r]: k = k0 + wk*64 + i*16 + fkg*4 + r (4 consecutive k per lane), n = n0 + wn*(BT/2) + j*16 + frow
+    const int frow = frow_c, fkg = fkg_c;
     float* __restrict__ out = p.partial + (size_t)split * p.N * p.K;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wk * 64 + i * 16 + fkg * 4, n = n0 + wn * 64 + j * 16 + frow;
+        for (int j = 0; j < JN; ++j) {
+            const int k = k0 + wk * 64 + i * 16 + fkg * 4, n = n0 + wn * (BT / 2) + j * 16 + frow;
             *(f32x4*)(out + (size_t)n * p.K + k) = acc[i][j];
         }
 }
@@ -231,25 +321,30 @@ void conv_wgrad_unpermute_kernel(const float* __restrict__ tmp, float* __restric
 
 int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if (!p.A || !p.B || !p.partial || p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
-    if ((p.N % TN_BN) || (p.K % TN_BK) || (p.lda & 7) || (p.ldb & 7) || p.nsplit <= 0 || p.m_per_split <= 0 ||
-        (p.m_per_split % TN_BM))
+    const int bt = p.tile == 256 ? 256 : 128;
+    if ((p.N % bt) || (p.K % bt) || (p.lda & 7) || (p.ldb & 7) || p.nsplit <= 0 || p.m_per_split <= 0 || (p.m_per_split % TN_BM))
         return EEND_EINVAL;
-    if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % TN_BK) || p.Tp <= 0)) return EEND_EINVAL;
-    const int smem = 2 * 2 * TN_BN * 128;
-    const dim3 grid((unsigned)((p.N / TN_BN) * (p.K / TN_BK) * p.nsplit));
-#define WG_LAUNCH(F16, CV)                                                                                              \
+    if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % bt) || p.Tp <= 0)) return EEND_EINVAL;
+    const int smem = 2 * 2 * bt * 128;
+    const dim3 grid((unsigned)((p.N / bt) * (p.K / bt) * p.nsplit));
+#define WG_LAUNCH(F16, CV, BT)                                                                                          \
     do {                                                                                                                \
         static bool done = false;                                                                                       \
         if (!done) {                                                                                                    \
-            if (hipFuncSetAttribute((const void*)wgrad_tn_kernel<F16, CV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+            if (hipFuncSetAttribute((const void*)wgrad_tn_kernel<F16, CV, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     smem) != hipSuccess)                                                                \
                 return EEND_ELAUNCH;                                                                                    \
             done = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV>), grid, dim3(256), smem, stream, p);                               \
+        hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV, BT>), grid, dim3(BT * 2), smem, stream, p);                        \
     } while (0)
-    if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true); else WG_LAUNCH(false, true); }
-    else { if (p.b_is_f16) WG_LAUNCH(true, false); else WG_LAUNCH(false, false); }
+#define WG_PICK(BT)                                                                                                     \
+    do {                                                                                                                \
+        if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true, BT); else WG_LAUNCH(false, true, BT); }                     \
+        else { if (p.b_is_f16) WG_LAUNCH(true, false, BT); else WG_LAUNCH(false, false, BT); }                          \
+    } while (0)
+    if (bt == 256) WG_PICK(256); else WG_PICK(128);
+#undef WG_PICK
 #undef WG_LAUNCH
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -78,7 +78,9 @@ def test_gemm_acc(T, dev, M, K):
 
 
 @pytest.mark.parametrize("M,N,K,f16", [(1000, 256, 256, True), (4133, 256, 2048, True), (4133, 2048, 256, False), (70, 768, 256, True),
-                                       (50000, 256, 384, True)])
+                                       (50000, 256, 384, True),
+                                       # >= 131072 tokens with 256-aligned shapes: the 256 x 256 output tile (ragged last step)
+                                       (131072 + 37, 256, 512, True), (140000, 512, 256, False), (131072, 256, 256, True)])
 def test_wgrad(T, dev, ws, M, N, K, f16):
     gen = g(dev, M + K)
     dy = (torch.randn(M, N, device=dev, generator=gen) * 1e-5).to(BF16)

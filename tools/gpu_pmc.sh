@@ -5,7 +5,9 @@ mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 ROOT=$PWD
 # PMC_TARGET=fs (default: bench.py, FS-EEND model.test) | ls (tools/ls_prof.py: LS-EEND model.test 16 x T=2000, C=10) | train_ls
+# PMC_TARGET=cmd: profile "$PMC_CMD" (relative to the repo root), outputs tagged ${PMC_TAG:-cmd_}
 case "${PMC_TARGET:-fs}" in
+  cmd) CMD="${PMC_CMD/#python /python $ROOT/}"; TAG=${PMC_TAG:-cmd_} ;;
   ls) CMD="python $ROOT/tools/ls_prof.py 2"; TAG=ls_ ;;
   train_ls) CMD="python $ROOT/bench.py --mode train --flavour ls --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown"; TAG=train_ls_ ;;
   *) CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-breakdown --graph 0 ${BENCH_ARGS:-}"; TAG= ;;
