@@ -272,10 +272,26 @@ int eend_convert_fanout_step_f32(const float* emb_f32, const float* W_f32, int l
     return eend_launch_convert_step_f32(emb_f32, W_f32, ldw, pc, out_f32, out_f16, B, C, (hipStream_t)stream);
 }
 
-int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, int N,
-                            int H, float gn_eps, void* stream) {
-    if (!qkvg || !kv_state || !scale_in || !scale_out || !out_f16) return EEND_EINVAL;
-    return eend_launch_ret_step_f32in(qkvg, kv_state, scale_in, scale_out, out_f16, N, H, gn_eps, (hipStream_t)stream);
+int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, float* out_f32,
+                            int N, int H, float gn_eps, void* stream) {
+    if (!qkvg || !kv_state || !scale_in || !scale_out || (!out_f16 && !out_f32)) return EEND_EINVAL;
+    return eend_launch_ret_step_f32in(qkvg, kv_state, scale_in, scale_out, out_f16, out_f32, N, H, gn_eps, (hipStream_t)stream);
+}
+
+int eend_linear_step_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out_f32, int ldo, int M, int N,
+                         int K, int act, void* stream) {
+    return eend_launch_skinny_plain_f32(A, lda, W, ldw, bias, out_f32, ldo, M, N, K, act, (hipStream_t)stream);
+}
+
+int eend_linear_res_ln_step_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
+                                const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, int M, int K,
+                                void* stream) {
+    if (!gamma || !beta) return EEND_EINVAL;
+    return eend_launch_skinny_res_f32(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 1, (hipStream_t)stream);
+}
+
+int eend_spk_attn_step_f32(const float* qkv, float* out_f32, int B, int C, float scale, void* stream) {
+    return eend_launch_spk_attn_step_f32(qkv, out_f32, B, C, scale, (hipStream_t)stream);
 }
 
 int eend_layernorm_f16(const float* x, const float* gamma, const float* beta, float eps, void* out_f16, int M,

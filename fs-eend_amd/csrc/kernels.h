@@ -172,7 +172,13 @@ int eend_launch_head(const float* emb, const float* attr, float* attr_out, float
                      int Tp, int C, int D, hipStream_t stream);
 int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N,
                          int H, float eps, hipStream_t stream);
-int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N, int H, float eps,
+int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, float* out32, int N,
+                               int H, float eps, hipStream_t stream);
+int eend_launch_spk_attn_step_f32(const float* qkv, float* out, int B, int C, float scale, hipStream_t stream);
+int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out32, int ldo, int M, int N,
+                                 int K, int act, hipStream_t stream);
+int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
+                               const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K, int mode,
                                hipStream_t stream);
 int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int C,
                                  hipStream_t stream);

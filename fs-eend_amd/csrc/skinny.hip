@@ -22,8 +22,8 @@ namespace {
 constexpr int SK_PLAIN = 0, SK_GLU = 1, SK_RES = 2;
 
 struct SkinnyParams {
-    const _Float16* A; int lda;
-    const _Float16* W; int ldw;
+    const void* A; int lda;      // f16 (F32 = false) or f32 (the all-f32 LS decoder frame step)
+    const void* W; int ldw;
     const float* bias;
     int M, N, K;                 // N = output features (GLU: pairs)
     int act;                     // 0 none, 1 relu, 2 swish
@@ -32,21 +32,28 @@ struct SkinnyParams {
     float* out32; _Float16* out16; int ldo;
 };
 
+// 8 consecutive operand elements as floats
+template <bool F32>
+DEV void load8(const void* base, size_t off, float (&v)[8]) {
+    if constexpr (F32) {
+        const float4 a = *(const float4*)((const float*)base + off), b = *(const float4*)((const float*)base + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const f16x8 h = *(const f16x8*)((const _Float16*)base + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    }
+}
+
 DEV float act_apply(float v, int act) {
     if (act == 1) return __builtin_fmaxf(v, 0.f);
     if (act == 2) return v / (1.0f + __expf(-v));
     return v;
 }
 
-DEV float dot8(const f16x8 a, const f16x8 b, float acc) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf((float)a[e], (float)b[e], acc);
-    return acc;
-}
-
 // MB = row bucket (rows >= M are clamped duplicates, never stored); ROWS = weight rows per output (2 for GLU);
 // SPLITK: one workgroup per output, its 4 waves take the 512-wide k chunks round-robin.
-template <int MB, int EPI, bool SPLITK>
+template <int MB, int EPI, bool SPLITK, bool F32>
 __global__ __launch_bounds__(256)
 void skinny_linear_kernel(const SkinnyParams p) {
     constexpr int ROWS = EPI == SK_GLU ? 2 : 1;
@@ -64,15 +71,18 @@ void skinny_linear_kernel(const SkinnyParams p) {
     const int k_first = (SPLITK ? wave : 0) * 512 + lane * 8;
     const int k_step = SPLITK ? 2048 : 512;
     for (int k = k_first; k < p.K; k += k_step) {
-        f16x8 w[ROWS];
+        float w[ROWS][8];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) w[r] = *(const f16x8*)(p.W + (size_t)(nn * ROWS + r) * p.ldw + k);
+        for (int r = 0; r < ROWS; ++r) load8<F32>(p.W, (size_t)(nn * ROWS + r) * p.ldw + k, w[r]);
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             const int mm = m < p.M ? m : p.M - 1;
-            const f16x8 a = *(const f16x8*)(p.A + (size_t)mm * p.lda + k);
+            float a[8];
+            load8<F32>(p.A, (size_t)mm * p.lda + k, a);
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) acc[r][m] = dot8(w[r], a, acc[r][m]);
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r][m] = __builtin_fmaf(w[r][e], a[e], acc[r][m]);
         }
     }
 #pragma unroll
@@ -105,7 +115,8 @@ void skinny_linear_kernel(const SkinnyParams p) {
         if (lane != m || m >= p.M) continue;
         if constexpr (EPI == SK_PLAIN) {
             const float v = act_apply(acc[0][m] + (p.bias ? p.bias[n] : 0.f), p.act);
-            p.out16[(size_t)m * p.ldo + n] = to_f16_sat(v);
+            if (p.out32) p.out32[(size_t)m * p.ldo + n] = v;
+            else p.out16[(size_t)m * p.ldo + n] = to_f16_sat(v);
         } else if constexpr (EPI == SK_GLU) {
             const float a = acc[0][m] + p.bias[2 * n], g = acc[1][m] + p.bias[2 * n + 1];
             p.out16[(size_t)m * p.ldo + n] = to_f16_sat(a / (1.0f + __expf(-g)));
@@ -145,21 +156,21 @@ void skinny_ln_kernel(float* __restrict__ x32, _Float16* __restrict__ out16, con
     }
 }
 
-template <int EPI, bool SPLITK>
+template <int EPI, bool SPLITK, bool F32>
 int launch_bucket(const SkinnyParams& p, hipStream_t stream) {
     const dim3 grid(SPLITK ? p.N : (p.N + 3) / 4), block(256);
-    if (p.M <= 1) hipLaunchKernelGGL((skinny_linear_kernel<1, EPI, SPLITK>), grid, block, 0, stream, p);
-    else if (p.M <= 2) hipLaunchKernelGGL((skinny_linear_kernel<2, EPI, SPLITK>), grid, block, 0, stream, p);
-    else if (p.M <= 4) hipLaunchKernelGGL((skinny_linear_kernel<4, EPI, SPLITK>), grid, block, 0, stream, p);
-    else if (p.M <= 8) hipLaunchKernelGGL((skinny_linear_kernel<8, EPI, SPLITK>), grid, block, 0, stream, p);
-    else if (p.M <= 12) hipLaunchKernelGGL((skinny_linear_kernel<12, EPI, SPLITK>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((skinny_linear_kernel<16, EPI, SPLITK>), grid, block, 0, stream, p);
+    if (p.M <= 1) hipLaunchKernelGGL((skinny_linear_kernel<1, EPI, SPLITK, F32>), grid, block, 0, stream, p);
+    else if (p.M <= 2) hipLaunchKernelGGL((skinny_linear_kernel<2, EPI, SPLITK, F32>), grid, block, 0, stream, p);
+    else if (p.M <= 4) hipLaunchKernelGGL((skinny_linear_kernel<4, EPI, SPLITK, F32>), grid, block, 0, stream, p);
+    else if (p.M <= 8) hipLaunchKernelGGL((skinny_linear_kernel<8, EPI, SPLITK, F32>), grid, block, 0, stream, p);
+    else if (p.M <= 12) hipLaunchKernelGGL((skinny_linear_kernel<12, EPI, SPLITK, F32>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((skinny_linear_kernel<16, EPI, SPLITK, F32>), grid, block, 0, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-template <int EPI>
+template <int EPI, bool F32 = false>
 int launch_skinny(const SkinnyParams& p, hipStream_t stream) {
-    return p.K > 512 ? launch_bucket<EPI, true>(p, stream) : launch_bucket<EPI, false>(p, stream);
+    return p.K > 512 ? launch_bucket<EPI, true, F32>(p, stream) : launch_bucket<EPI, false, F32>(p, stream);
 }
 
 }  // namespace
@@ -171,15 +182,13 @@ bool eend_skinny_ok(const void* A, int lda, const void* W, int ldw, int M, int K
 
 int eend_launch_skinny_plain(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo,
                              int M, int N, int K, int act, hipStream_t stream) {
-    SkinnyParams p{(const _Float16*)A, lda, (const _Float16*)W, ldw, bias, M, N, K, act, 1.0f, nullptr, 0, nullptr,
-                   (_Float16*)out16, ldo};
+    SkinnyParams p{A, lda, W, ldw, bias, M, N, K, act, 1.0f, nullptr, 0, nullptr, (_Float16*)out16, ldo};
     return launch_skinny<SK_PLAIN>(p, stream);
 }
 
 int eend_launch_skinny_glu(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo,
                            int M, int N2, int K, hipStream_t stream) {
-    SkinnyParams p{(const _Float16*)A, lda, (const _Float16*)W, ldw, bias, M, N2 / 2, K, 0, 1.0f, nullptr, 0, nullptr,
-                   (_Float16*)out16, ldo};
+    SkinnyParams p{A, lda, W, ldw, bias, M, N2 / 2, K, 0, 1.0f, nullptr, 0, nullptr, (_Float16*)out16, ldo};
     return launch_skinny<SK_GLU>(p, stream);
 }
 
@@ -189,9 +198,29 @@ int eend_launch_skinny_res(const void* A, int lda, const void* W, int ldw, const
                            const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K,
                            int mode, hipStream_t stream) {
     if (mode != 0 && !out32) return EEND_EINVAL;
-    SkinnyParams p{(const _Float16*)A, lda, (const _Float16*)W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32,
-                   mode == 0 ? (_Float16*)out16 : nullptr, 256};
+    SkinnyParams p{A, lda, W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32, mode == 0 ? (_Float16*)out16 : nullptr, 256};
     int rc = launch_skinny<SK_RES>(p, stream);
+    if (rc != EEND_OK || mode == 0) return rc;
+    hipLaunchKernelGGL(skinny_ln_kernel, dim3(M), dim3(64), 0, stream, out32, (_Float16*)out16, gamma, beta, eps, mode == 1 ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+// The same kernels on f32 activations AND f32 weights (torch nn.Linear layout), f32 out: the LS decoder's frame step.
+int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out32, int ldo, int M, int N,
+                                 int K, int act, hipStream_t stream) {
+    if (!A || !W || !out32 || M < 1 || M > EEND_SKINNY_MAX_M || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
+        return EEND_EINVAL;
+    SkinnyParams p{A, lda, W, ldw, bias, M, N, K, act, 1.0f, nullptr, 0, out32, nullptr, ldo};
+    return launch_skinny<SK_PLAIN, true>(p, stream);
+}
+
+int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
+                               const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K, int mode,
+                               hipStream_t stream) {
+    if (!A || !W || !out32 || M < 1 || M > EEND_SKINNY_MAX_M || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
+        return EEND_EINVAL;
+    SkinnyParams p{A, lda, W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32, mode == 0 ? (_Float16*)out16 : nullptr, 256};
+    int rc = launch_skinny<SK_RES, true>(p, stream);
     if (rc != EEND_OK || mode == 0) return rc;
     hipLaunchKernelGGL(skinny_ln_kernel, dim3(M), dim3(64), 0, stream, out32, (_Float16*)out16, gamma, beta, eps, mode == 1 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

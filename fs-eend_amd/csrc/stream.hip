@@ -20,7 +20,7 @@ namespace {
 template <class QT>
 __global__ __launch_bounds__(256)
 void ret_step_kernel(const QT* __restrict__ qkvg, float* __restrict__ kv, const float* __restrict__ scale_in,
-                     float* __restrict__ scale_out, _Float16* __restrict__ out, int N, int H, float eps) {
+                     float* __restrict__ scale_out, _Float16* __restrict__ out, float* __restrict__ out32, int N, int H, float eps) {
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);       // n*H + h
     if (idx >= N * H) return;
@@ -59,7 +59,9 @@ void ret_step_kernel(const QT* __restrict__ qkvg, float* __restrict__ kv, const 
     for (int m = 1; m < 64; m <<= 1) var = wave_xor_add(var, m);
     const float y = (o - mean) / __builtin_sqrtf(var * (1.0f / 64.0f) + eps);
     const float g = (float)row[3 * D + h * 64 + lane];
-    out[(size_t)n * D + h * 64 + lane] = to_f16_sat(g / (1.0f + __expf(-g)) * y);
+    const float r = g / (1.0f + __expf(-g)) * y;
+    if (out) out[(size_t)n * D + h * 64 + lane] = to_f16_sat(r);
+    if (out32) out32[(size_t)n * D + h * 64 + lane] = r;
     if (n == 0 && lane == 0) scale_out[h] = ns;
 }
 
@@ -136,6 +138,38 @@ void convert_step_f32_kernel(const float* __restrict__ emb, const float* __restr
             out16[((size_t)b * C + lane) * 256 + f] = to_f16_sat(y);
         }
     }
+}
+
+// Speaker-axis attention of one frame in f32 (self_attn2 of the LS decoder layer, merge_retnet_layer.py:300-307, inside
+// the all-f32 decoder frame step): qkv f32 [B*C][768] = [q | k | v] (head h at column h*64), out f32 [B*C][256].
+// One wave per (row, head); lane = head dimension; C <= 16 scores per wave.
+__global__ __launch_bounds__(64)
+void spk_attn_step_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, float scale) {
+    const int lane = threadIdx.x, row = blockIdx.x, h = blockIdx.y;
+    const int b0 = (row / C) * C;
+    const float q = qkv[(size_t)row * 768 + h * 64 + lane] * scale;
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float d = 0.f;
+        if (c < C) {
+            d = q * qkv[(size_t)(b0 + c) * 768 + 256 + h * 64 + lane];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) d = wave_xor_add(d, m);
+            mx = __builtin_fmaxf(mx, d);
+        }
+        sc[c] = d;
+    }
+    float den = 0.f, o = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (c < C) {
+            const float pr = __expf(sc[c] - mx);
+            den += pr;
+            o = __builtin_fmaf(pr, qkv[(size_t)(b0 + c) * 768 + 512 + h * 64 + lane], o);
+        }
+    out[(size_t)row * 256 + h * 64 + lane] = o / den;
 }
 
 // ConformerConvModule.forward_one_step, depthwise part (conformer/convolution.py:157-163):
@@ -400,15 +434,15 @@ int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, flo
                          int H, float eps, hipStream_t stream) {
     if (N <= 0 || H <= 0) return EEND_EINVAL;
     hipLaunchKernelGGL(ret_step_kernel<_Float16>, dim3((N * H + 3) / 4), dim3(256), 0, stream, (const _Float16*)qkvg, kv, scale_in,
-                       scale_out, (_Float16*)out16, N, H, eps);
+                       scale_out, (_Float16*)out16, (float*)nullptr, N, H, eps);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N, int H, float eps,
-                               hipStream_t stream) {
-    if (N <= 0 || H <= 0) return EEND_EINVAL;
+int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, float* out32, int N,
+                               int H, float eps, hipStream_t stream) {
+    if (N <= 0 || H <= 0 || (!out16 && !out32)) return EEND_EINVAL;
     hipLaunchKernelGGL(ret_step_kernel<float>, dim3((N * H + 3) / 4), dim3(256), 0, stream, qkvg, kv, scale_in, scale_out, (_Float16*)out16,
-                       N, H, eps);
+                       out32, N, H, eps);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
@@ -423,6 +457,12 @@ int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, cons
                                  hipStream_t stream) {
     if (!emb || !W || !pc || !out32 || !out16 || B <= 0 || C <= 0 || C > 64 || ldw < 256 || (ldw & 3)) return EEND_EINVAL;
     hipLaunchKernelGGL(convert_step_f32_kernel, dim3(64), dim3(256), 0, stream, emb, W, ldw, pc, out32, (_Float16*)out16, B, C);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_spk_attn_step_f32(const float* qkv, float* out, int B, int C, float scale, hipStream_t stream) {
+    if (!qkv || !out || B <= 0 || C <= 0 || C > 16) return EEND_EINVAL;
+    hipLaunchKernelGGL(spk_attn_step_f32_kernel, dim3(B * C, 4), dim3(64), 0, stream, qkv, out, C, scale);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

@@ -360,7 +360,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
                 g11=_f32(l.norm11.weight), be11=_f32(l.norm11.bias), eps11=l.norm11.eps,
                 g21=_f32(l.norm21.weight), be21=_f32(l.norm21.bias), eps21=l.norm21.eps,
-                g22=_f32(l.norm22.weight), be22=_f32(l.norm22.bias), eps22=l.norm22.eps))
+                g22=_f32(l.norm22.weight), be22=_f32(l.norm22.bias), eps22=l.norm22.eps,
+                # f32 weights of the all-f32 frame step (ls_stream.dec_step: <= 16 rows per frame)
+                out1_w32=_f32(l.self_attn1.out_proj.weight), in2_w32=_f32(l.self_attn2.in_proj_weight),
+                out2_w32=_f32(l.self_attn2.out_proj.weight), w1_32=_f32(l.linear1.weight), w2_32=_f32(l.linear2.weight)))
         P["dec.layers"] = dl
         self._prep, self._prep_key, self._pc = P, key, {}
         return P

@@ -38,9 +38,10 @@ def _ret_state(state: dict, N: int, H: int, dev):
 
 
 F32_PROJ = os.environ.get("EEND_STREAM_RET_F32", "1") != "0"      # f32 retention projections in the frame steps (A/B switch)
+DEC_F32 = os.environ.get("EEND_STREAM_DEC_F32", "1") != "0"       # all-f32 decoder frame step when a frame has <= 16 rows
 
 
-def _ret_step(x16, x32, ln, Wd, state, N, H, scratch):
+def _ret_step(x16, x32, ln, Wd, state, N, H, scratch, out32=None):
     """One frame of MultiScaleRetention (retention.py:126-144) on N rows.  The q / k / v / g projections run in full f32 from
     the f32 residual stream (x32, through LayerNorm `ln` where the block is pre-norm): the recurrence amplifies their
     rounding with the stream position (see csrc/stream.hip ret_proj_step_kernel)."""
@@ -49,7 +50,7 @@ def _ret_step(x16, x32, ln, Wd, state, N, H, scratch):
     if F32_PROJ:
         q32 = scratch["qkvg32"][:N]
         ops.retention_proj_step(x32, ln, Wd["wqkvg32"], Wd["bqkvg"], q32, N)
-        ops.retention_step_f32(q32, kv, s_in, s_out, o16, N, H, Wd["gn_eps"])
+        ops.retention_step_f32(q32, kv, s_in, s_out, o16, N, H, Wd["gn_eps"], out32=out32)
     else:
         qkvg = scratch["qkvg"][:N]
         ops.linear(x16, Wd["wqkvg"], Wd["bqkvg"], qkvg)
@@ -69,6 +70,8 @@ def _scratch(owner, key, N, D, F):
         sc = dict(N=N, F=F, xin16=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F16, device=dev),
                   h32=e(N, D, dt=F32), h16=e(N, D), x16=e(N, D), qkvg=e(N, 4 * D), qkvg32=e(N, 4 * D, dt=F32), o16=e(N, D), glu16=e(N, D),
                   dw16=e(N, D), ff16=e(N * F), qkv16=e(N, 3 * D))
+        if N <= ops.STEP_F32_MAX_ROWS:                # the all-f32 decoder frame step
+            sc.update(o32=e(N, D, dt=F32), qkv32=e(N, 3 * D, dt=F32), ff32=e(N * F, dt=F32))
         owner._step_scratch[key] = sc
     return sc
 
@@ -127,6 +130,21 @@ def dec_step(owner, emb_t, t, max_nspks, ret_states):
         ops.convert_fanout_step_f32(e32, P["convert.w32"], owner._convert_const(C), a32, a16, B, C)
     else:
         ops.convert_fanout(e32.to(F16), P["convert.w1"], owner._convert_const(C), a32, a16, B, 1, C)
+    if F32_PROJ and DEC_F32 and N <= ops.STEP_F32_MAX_ROWS:
+        # one frame x <= 16 slots: the whole layer in f32 (weights included) -- the f16 operand rounding of the linears in
+        # front of the retention's per-head LayerNorm was the heavy tail of the one-hour stream
+        o32, qkv32 = sc["o32"][:N], sc["qkv32"][:N]
+        for i, Ld in enumerate(P["dec.layers"]):
+            Fi = Ld["w1_32"].shape[0]
+            ff32 = sc["ff32"][:N * Fi].view(N, Fi)
+            _ret_step(a16, a32, None, Ld, ret_states[i], N, H, sc, out32=o32)
+            ops.linear_res_ln_step_f32(o32, Ld["out1_w32"], Ld["out1_b"], a32, Ld["g11"], Ld["be11"], a32, Ld["eps11"])
+            ops.linear_step_f32(a32, Ld["in2_w32"], Ld["in2_b"], qkv32)
+            ops.spk_attn_step_f32(qkv32, o32, B, C)
+            ops.linear_res_ln_step_f32(o32, Ld["out2_w32"], Ld["out2_b"], a32, Ld["g21"], Ld["be21"], a32, Ld["eps21"])
+            ops.linear_step_f32(a32, Ld["w1_32"], Ld["b1"], ff32, act=ops.ACT_RELU)
+            ops.linear_res_ln_step_f32(ff32, Ld["w2_32"], Ld["b2"], a32, Ld["g22"], Ld["be22"], a32, Ld["eps22"])
+        return a32.view(B, 1, C, D).clone()
     for i, Ld in enumerate(P["dec.layers"]):
         Fi = Ld["w1"].shape[0]
         ff = sc["ff16"][:N * Fi].view(N, Fi)

@@ -278,12 +278,42 @@ def retention_proj_step(x32, ln, w32, b32, qkvg32, N):
                "eend_retention_proj_step_f32")
 
 
-def retention_step_f32(qkvg32, kv_state, scale_in, scale_out, out16, N, H, gn_eps=1e-6):
+def retention_step_f32(qkvg32, kv_state, scale_in, scale_out, out16, N, H, gn_eps=1e-6, out32=None):
     L = _lib.load()
     _chk(qkvg32, F32, "qkvg32"); _chk(kv_state, F32, "kv_state"); _chk(scale_in, F32, "scale_in")
-    _chk(scale_out, F32, "scale_out"); _chk(out16, F16, "out16")
-    _lib.check(L.eend_retention_step_f32(_p(qkvg32), _p(kv_state), _p(scale_in), _p(scale_out), _p(out16), N, H, gn_eps, _stream()),
-               "eend_retention_step_f32")
+    _chk(scale_out, F32, "scale_out"); _chk(out16, F16, "out16"); _chk(out32, F32, "out32")
+    _lib.check(L.eend_retention_step_f32(_p(qkvg32), _p(kv_state), _p(scale_in), _p(scale_out), _p(out16), _p(out32), N, H, gn_eps,
+                                         _stream()), "eend_retention_step_f32")
+
+
+STEP_F32_MAX_ROWS = 16          # the f32 frame-step linears (skinny.hip) serve one frame x <= 16 slots
+
+
+def linear_step_f32(a32, w32, bias, out32, act=ACT_NONE):
+    """out32 = act(a32 w32^T + bias), everything f32 (the all-f32 LS decoder frame step)."""
+    L = _lib.load()
+    _chk(a32, F32, "a32"); _chk(w32, F32, "w32"); _chk(bias, F32, "bias"); _chk(out32, F32, "out32")
+    M, K = a32.shape
+    _lib.check(L.eend_linear_step_f32(_p(a32), a32.stride(0), _p(w32), w32.stride(0), _p(bias), _p(out32), out32.stride(0), M,
+                                      w32.shape[0], K, act, _stream()), "eend_linear_step_f32")
+
+
+def linear_res_ln_step_f32(a32, w32, bias, res, gamma, beta, out32, eps=1e-5, alpha=1.0, out16=None):
+    """out32 = LayerNorm((a32 w32^T + bias) * alpha + res), f32 operands; out32 may alias res."""
+    L = _lib.load()
+    _chk(a32, F32, "a32"); _chk(w32, F32, "w32"); _chk(bias, F32, "bias"); _chk(res, F32, "res"); _chk(gamma, F32, "gamma")
+    _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = a32.shape
+    if w32.shape[0] != 256:
+        raise _lib.EendHipError("linear_res_ln_step_f32: N must be 256")
+    _lib.check(L.eend_linear_res_ln_step_f32(_p(a32), a32.stride(0), _p(w32), w32.stride(0), _p(bias), _p(res), float(alpha), _p(gamma),
+                                             _p(beta), eps, _p(out32), _p(out16), M, K, _stream()), "eend_linear_res_ln_step_f32")
+
+
+def spk_attn_step_f32(qkv32, out32, B, C):
+    L = _lib.load()
+    _chk(qkv32, F32, "qkv32"); _chk(out32, F32, "out32")
+    _lib.check(L.eend_spk_attn_step_f32(_p(qkv32), _p(out32), B, C, 1.0 / math.sqrt(64.0), _stream()), "eend_spk_attn_step_f32")
 
 
 def convert_fanout_step_f32(emb32, w32, pc, out32, out16, B, C):

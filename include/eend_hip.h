@@ -292,8 +292,19 @@ int eend_retention_step_f16(const void* qkvg, float* kv_state, const float* scal
  * streaming within the 1e-3 bar (tests/test_long_horizon.py). */
 int eend_retention_proj_step_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* Wqkvg,
                                  const float* bias, float* qkvg_f32, int N, void* stream);
-int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, int N,
-                            int H, float gn_eps, void* stream);
+int eend_retention_step_f32(const float* qkvg, float* kv_state, const float* scale_in, float* scale_out, void* out_f16, float* out_f32,
+                            int N, int H, float gn_eps, void* stream);      /* out_f16 and / or out_f32 [N][256] */
+/* The remaining pieces of an all-f32 LS decoder frame step (merge_retnet_layer.py:255-276 with <= 16 rows = one frame x
+ * max_nspks slots): y = act(A W^T + bias) with f32 activations AND f32 weights in torch's nn.Linear layout (act 0 none /
+ * 1 relu / 2 swish; K % 8 == 0, M <= 16); the post-norm join out = LayerNorm((A W^T + bias) * alpha + res) (N = 256; out_f16
+ * optional copy); the speaker-axis attention of the frame on f32 [B*C][768] = [q | k | v] rows (C <= 16).  Why f32: DESIGN
+ * 9a -- the decoder retention's per-head LayerNorm amplifies f16 operand rounding ~30x on isolated frames. */
+int eend_linear_step_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out_f32, int ldo, int M, int N,
+                         int K, int act, void* stream);
+int eend_linear_res_ln_step_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
+                                const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, int M, int K,
+                                void* stream);
+int eend_spk_attn_step_f32(const float* qkv, float* out_f32, int B, int C, float scale, void* stream);
 /* Frame-by-frame decoder input in f32: out[b*C + c] = W[:, :256] emb[b] + pc[c] (`convert(cat(emb, pe))`, LS model
  * :229-233; pc from eend_convert_const_f32).  W_f32 is the convert.weight parameter itself ([256][ldw], ldw = 512).
  * f32 for the same reason as the projections above: the decoder retention amplifies the f16 rounding of this linear ~30x

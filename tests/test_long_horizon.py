@@ -70,33 +70,31 @@ def test_ls_one_hour_streaming_vs_reference_streaming(hip_lib, dev):
     d = (got - want).abs()
     print(f"LS one hour, LsStreamSession vs reference streaming: max |d logit| {float(d.max()):.2e} (first 600 {float(d[:600].max()):.2e}, "
           f"last 600 {float(d[-600:].max()):.2e})")
-    # The recurrence is ill-conditioned at this horizon: the reference's OWN two fp32 forms of it (frame-by-frame vs
-    # chunked batch, same weights, same input) differ by ~1e-2 in the logits after an hour (SURVEY 4 notes the looseness
-    # of its streaming == batch self-checks already at T = 30).  So the bar here is the reference's own spread, and the
-    # arbiter is the float64 evaluation of the same recurrence (ls_hour_stream64_c10, oracle pinned at T = 120):
+    # Streaming is compared with streaming: the reference's OWN two fp32 forms of the recurrence (frame-by-frame vs chunked
+    # batch, same weights, same input) differ by ~1e-2 in the logits after an hour (SURVEY 4 notes the looseness of its
+    # streaming == batch self-checks already at T = 30).  The arbiter between the reference's fp32 streaming and this build
+    # is the float64 evaluation of the same recurrence (ls_hour_stream64_c10, oracle pinned at T = 120):
     _, barr = FX.load_case("ls_hour_c10")
     assert np.array_equal(barr["rows"], arr["rows"])
     ref_gap = float(np.abs(barr["logits"] - arr["stream_logits"]).max())
     our_gap = float((got - torch.as_tensor(barr["logits"], device=dev)).abs().max())
     print(f"   streaming vs batch over the hour: reference {ref_gap:.2e}, this build {our_gap:.2e}")
-    assert float(d[:600].max()) < 1e-3                       # the first minute: the 1e-3 bar holds
-    assert float(d.max()) < max(1e-3, 0.5 * ref_gap) and our_gap < ref_gap + 1e-3
+    # the 1e-3 bar of the batch forms holds on every stored frame of the hour (measured 8.3e-4; 1.2e-3 before the decoder frame
+    # step went all-f32, 2.0e-3 before the retention projections did), and the gap to the batch form stays the reference's own
+    assert float(d.max()) < 1e-3 and our_gap < ref_gap + 1e-3
     if _have("ls_hour_stream64_c10"):
         _, a64 = FX.load_case("ls_hour_stream64_c10")
         assert np.array_equal(a64["rows"], arr["rows"])
         truth = torch.as_tensor(a64["stream_logits64"], device=dev, dtype=torch.float64)
         e_ref = float((want.double() - truth).abs().max())
-        e_our = float((got.double() - truth).abs().max())
         eo = (got.double() - truth).abs().flatten()
-        p999 = float(torch.quantile(eo, 0.999))
+        e_our, p999 = float(eo.max()), float(torch.quantile(eo, 0.999))
         print(f"   against the float64 recurrence: reference fp32 streaming {e_ref:.2e}, this build max {e_our:.2e}, "
-              f"mean {float(eo.mean()):.2e}, 99.9th percentile {p999:.2e}, entries > 1e-3: {int((eo > 1e-3).sum())} of {eo.numel()}")
+              f"mean {float(eo.mean()):.2e}, 99.9th percentile {p999:.2e}")
         # Measured profile (profiles/r03_ls_hour_stream_profile.txt): the error does NOT grow with the stream position -- its
-        # mean is 3-4e-5 in every 3000-frame window of the hour -- but it is heavy-tailed: on a handful of frames the decoder
-        # retention's per-head LayerNorm (eps 1e-6) of a nearly constant vector amplifies the f16 operand rounding of the
-        # linears in front of it ~30x (slots 7-9, the empty speaker slots).  So: no drift (mean), the 1e-3 bar on all but
-        # <= 0.1 % of the logits, and the worst spike well inside the reference's own form-to-form spread.
-        assert float(eo.mean()) < 1e-4 and p999 < 1e-3 and e_our < 0.5 * ref_gap
+        # mean is 3-4e-5 in every 3000-frame window of the hour (the f16 encoder / look-ahead conv operands); what the f16
+        # decoder step added on top was a heavy tail on isolated frames (up to 1.3e-3), gone with the f32 decoder step.
+        assert e_our < 1e-3 and float(eo.mean()) < 1e-4 and p999 < 5e-4
         assert float(eo[-600 * C:].mean()) < 2.0 * float(eo[:600 * C].mean()) + 1e-5      # last minute vs first minute
 
 

@@ -187,3 +187,37 @@ def test_stream_sessions_survive_a_weight_refresh(hip_lib, dev):
         return torch.cat(out)
 
     assert torch.equal(run_fs(False), run_fs(True))
+
+
+@pytest.mark.parametrize("N,C", [(10, 10), (1, 1), (16, 8), (6, 3)])
+def test_f32_frame_step_entries_vs_torch(hip_lib, dev, N, C):
+    from fs_eend_amd import ops
+    """The f32 pieces of the all-f32 decoder frame step (f32 activations AND weights) against plain torch fp32:
+    linear (+ReLU), linear + residual + LayerNorm (K = 256 and the split-K K = 2048 path), speaker-axis attention."""
+    g = torch.Generator().manual_seed(100 + N)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x, w1, b1 = rn(N, 256), rn(2048, 256, sc=0.06), rn(2048, sc=0.1)
+    h = torch.empty(N, 2048, device=dev)
+    ops.linear_step_f32(x, w1, b1, h, act=ops.ACT_RELU)
+    want_h = torch.relu(x.double() @ w1.double().t() + b1.double())
+    assert float((h.double() - want_h).abs().max()) < 2e-6 * float(want_h.abs().max() + 1)
+    w2, b2, res = rn(256, 2048, sc=0.02), rn(256, sc=0.1), rn(N, 256)
+    gam, bet = rn(256, sc=0.3) + 1.0, rn(256, sc=0.1)
+    out = res.clone()
+    o16 = torch.empty(N, 256, dtype=torch.float16, device=dev)
+    ops.linear_res_ln_step_f32(h, w2, b2, out, gam, bet, out, eps=1e-5, alpha=0.5, out16=o16)      # in place on the residual stream
+    pre = (want_h @ w2.double().t() + b2.double()) * 0.5 + res.double()
+    want = torch.nn.functional.layer_norm(pre, (256,), gam.double(), bet.double(), 1e-5)
+    assert float((out.double() - want).abs().max()) < 5e-6 * float(want.abs().max())
+    assert float((o16.double() - want).abs().max()) < 2e-3 * float(want.abs().max())
+    wq, bq = rn(768, 256, sc=0.06), rn(768, sc=0.1)
+    qkv = torch.empty(N, 768, device=dev)
+    ops.linear_step_f32(x, wq, bq, qkv)
+    assert float((qkv.double() - (x.double() @ wq.double().t() + bq.double())).abs().max()) < 1e-5
+    B = N // C
+    att = torch.empty(N, 256, device=dev)
+    ops.spk_attn_step_f32(qkv, att, B, C)
+    q, k, v = (t.double().view(B, C, 4, 64).transpose(1, 2) for t in qkv.split(256, dim=1))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    want_a = (p @ v).transpose(1, 2).reshape(N, 256)
+    assert float((att.double() - want_a).abs().max()) < 1e-5
