@@ -780,6 +780,9 @@ void ffn_fused_kernel(const FfnParams p) {
         // ~60-180 cycles, which hides behind the matrix pipe once MFMAs are in flight.
         auto dma_piece = [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
+#ifdef EEND_FFN_ABLATE
+            if (p.dbg & 4) return;                       // study: no in-loop weight stream (stale slices; results are garbage)
+#endif
             if constexpr (i < 4) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_char*)(smem + V2_W2 + nb * W2_BYTES + (wave * 4 + i) * 1024), 16, vo2[i],
                                                          (c + 1) * FC * 2, 0, 0);

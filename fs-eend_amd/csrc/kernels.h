@@ -232,7 +232,7 @@ struct FfnParams {
     const float* be21;
     float eps21, spk_scale;
     int B, C, Tp;       // M = B*C*Tp, row = (b*C + c)*Tp + t
-    int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read
+    int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read, 4 no in-loop weight DMA
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);
