@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun).  WHAT = space/comma separated subset of: test smoke bench train train_ls hour prof prof_train prof_train_ls
+# Runs on the GPU box (via gpurun).  WHAT = space/comma separated subset of: test smoke bench train train_ls hour rehearse prof prof_train prof_train_ls
 # Everything judged later is copied from gpurun_out/ into profiles/ by hand.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -32,6 +32,16 @@ if has train_ls; then
 fi
 if has hour; then   # per-window error profile of the one-hour LS stream against the float64 recurrence
   timeout 600 python tools/ls_hour_profile.py > gpurun_out/ls_hour_stream_profile.txt 2>&1; echo "hour rc=$?"; tail -16 gpurun_out/ls_hour_stream_profile.txt
+fi
+if has rehearse; then   # the N > 1 code paths with two processes on this one GPU over gloo (no RCCL with a single device)
+  export EEND_DIST_BACKEND=gloo
+  port=29620
+  for what in "infer" "train_fs --mode train --batch 8" "train_ls --mode train --flavour ls --batch 4"; do
+    tag=${what%% *}; extra=${what#$tag}; port=$((port + 1))
+    timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras $extra > gpurun_out/rehearse_$tag.json 2> gpurun_out/rehearse_$tag.err
+    echo "rehearse $tag rc=$?"; cut -c1-260 gpurun_out/rehearse_$tag.json; tail -2 gpurun_out/rehearse_$tag.err
+  done
+  unset EEND_DIST_BACKEND
 fi
 prof() {   # prof <tag> <bench args...>
   local tag=$1; shift
