@@ -290,6 +290,10 @@ int eend_linear_res_ln_step_f32(const float* A, int lda, const float* W, int ldw
     return eend_launch_skinny_res_f32(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 1, (hipStream_t)stream);
 }
 
+int eend_l2norm_rows_f32(const float* x, float* y, int rows, void* stream) {
+    return eend_launch_l2norm_rows_f32(x, y, rows, (hipStream_t)stream);
+}
+
 int eend_spk_attn_step_f32(const float* qkv, float* out_f32, int B, int C, float scale, void* stream) {
     return eend_launch_spk_attn_step_f32(qkv, out_f32, B, C, scale, (hipStream_t)stream);
 }

@@ -175,6 +175,7 @@ int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, flo
 int eend_launch_ret_step_f32in(const float* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, float* out32, int N,
                                int H, float eps, hipStream_t stream);
 int eend_launch_spk_attn_step_f32(const float* qkv, float* out, int B, int C, float scale, hipStream_t stream);
+int eend_launch_l2norm_rows_f32(const float* x, float* y, int rows, hipStream_t stream);
 int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out32, int ldo, int M, int N,
                                  int K, int act, hipStream_t stream);
 int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,

@@ -172,6 +172,18 @@ void spk_attn_step_f32_kernel(const float* __restrict__ qkv, float* __restrict__
     out[(size_t)row * 256 + h * 64 + lane] = o / den;
 }
 
+// y[r] = x[r] / ||x[r]||_2 over 256 features, f32 rows (the embedding normalisation of the f32 frame step; LS model :87, no eps).
+__global__ __launch_bounds__(64)
+void l2norm_rows_f32_kernel(const float* __restrict__ x, float* __restrict__ y) {
+    const int lane = threadIdx.x;
+    const float4 v = *(const float4*)(x + (size_t)blockIdx.x * 256 + lane * 4);
+    float q = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) q = wave_xor_add(q, m);
+    const float r = 1.0f / __builtin_sqrtf(q);
+    *(float4*)(y + (size_t)blockIdx.x * 256 + lane * 4) = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
+}
+
 // ConformerConvModule.forward_one_step, depthwise part (conformer/convolution.py:157-163):
 // window = [cache (k-1 frames) | x_t]; y = sum_j w[c][j] window[c][j]; BatchNorm(eval); Swish;
 // new cache = window[:, 1:].  x f16 [B][D]; cache f32 [B][D][k-1] (the driver's layout), in place.
@@ -457,6 +469,12 @@ int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, cons
                                  hipStream_t stream) {
     if (!emb || !W || !pc || !out32 || !out16 || B <= 0 || C <= 0 || C > 64 || ldw < 256 || (ldw & 3)) return EEND_EINVAL;
     hipLaunchKernelGGL(convert_step_f32_kernel, dim3(64), dim3(256), 0, stream, emb, W, ldw, pc, out32, (_Float16*)out16, B, C);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_l2norm_rows_f32(const float* x, float* y, int rows, hipStream_t stream) {
+    if (!x || !y || rows <= 0) return EEND_EINVAL;
+    hipLaunchKernelGGL(l2norm_rows_f32_kernel, dim3(rows), dim3(64), 0, stream, x, y);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

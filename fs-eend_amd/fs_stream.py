@@ -18,7 +18,12 @@ import torch.nn.functional as F
 from . import ops
 from .fs_model import PositionalEncoding, _f16, _f32
 from .lib import EendHipError
-from .ls_stream import StreamingConv1d  # noqa: F401  (identical ring-buffer conv in both flavours)
+from .ls_stream import StreamingConv1d as _LsStreamingConv1d
+
+
+class StreamingConv1d(_LsStreamingConv1d):
+    """The same ring-buffer conv as the LS flavour's (reference streaming_tfm.py:141-167), f16 MFMA operands."""
+    F32_WINDOW = False
 
 F16, F32 = torch.float16, torch.float32
 
@@ -352,7 +357,7 @@ class FsStreamSession:
         self._shift.copy_(self.win16[:, D:])
         self.win16[:, :(k - 1) * D].copy_(self._shift)
         self.win16[:, (k - 1) * D:].copy_(self.enc_out)                  # f32 -> f16, as StreamingConv1d casts its window
-        wr, bias = self.m.cnn._weights()
+        wr, bias = self.m.cnn._weights()[:2]
         ops.linear_res_scale(self.win16, wr, bias, None, 1.0, self.conv32, None)
         torch.div(self.conv32, torch.linalg.vector_norm(self.conv32, dim=-1, keepdim=True), out=self.e32)   # reference :50
         self.e16.copy_(self.e32)

@@ -347,6 +347,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         cw = self.cnn.weight.detach()
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
         P["cnn.b"], P["cnn.k"], P["cnn.pad"] = _f32(self.cnn.bias), cw.shape[2], self.cnn.padding[0]
+        P["cnn.w32"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float32).contiguous()     # f32 frame steps
         P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
         P["convert.w32"] = self.dec.convert.weight.detach().to(torch.float32).contiguous()     # frame steps (ls_stream.dec_step)
         dl = []

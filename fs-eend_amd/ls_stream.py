@@ -164,6 +164,8 @@ class StreamingConv1d(nn.Module):
     zero left padding.  ``.conv`` holds the parameters (the driver copies model.cnn into it),
     ``.buffer`` / ``.t`` are reset by the driver exactly like the reference's."""
 
+    F32_WINDOW = True       # LS frame steps: f32 window and weights for <= 16 rows (DESIGN 9a); the FS flavour keeps the f16 operands
+
     def __init__(self, in_channels, out_channels, kernel_size=19):
         super().__init__()
         if out_channels != 256 or in_channels % 64:
@@ -181,8 +183,8 @@ class StreamingConv1d(nn.Module):
             w = self.conv.weight.detach()
             if not w.is_cuda:
                 raise EendHipError("StreamingConv1d parameters must live on the GPU: no CPU fallback")
-            self._w = (w.permute(0, 2, 1).reshape(w.shape[0], -1).to(F16).contiguous(),
-                       self.conv.bias.detach().to(F32).contiguous())
+            w2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)
+            self._w = (w2.to(F16).contiguous(), self.conv.bias.detach().to(F32).contiguous(), w2.to(F32).contiguous())
             self._w_key = key
         return self._w
 
@@ -195,10 +197,14 @@ class StreamingConv1d(nn.Module):
         frames = [torch.zeros_like(x_t)] * left + list(self.buffer)
         win = torch.cat(frames, dim=2)                                   # (B, C, k)
         B = win.shape[0]
-        wr, bias = self._weights()
-        win16 = win.permute(0, 2, 1).reshape(B, -1).to(F16).contiguous()  # [b][tap*C + c]
-        out = torch.empty(B, wr.shape[0], dtype=F32, device=win16.device)
-        ops.linear_res_scale(win16, wr, bias, None, 1.0, out, None)
+        wr, bias, w32 = self._weights()
+        out = torch.empty(B, wr.shape[0], dtype=F32, device=win.device)
+        if self.F32_WINDOW and F32_PROJ and DEC_F32 and B <= ops.STEP_F32_MAX_ROWS:       # as LsStreamSession
+            win32 = win.permute(0, 2, 1).reshape(B, -1).to(F32).contiguous()  # [b][tap*C + c]
+            ops.linear_step_f32(win32, w32, bias, out)
+        else:
+            win16 = win.permute(0, 2, 1).reshape(B, -1).to(F16).contiguous()
+            ops.linear_res_scale(win16, wr, bias, None, 1.0, out, None)
         return out.unsqueeze(-1) if self.t >= self.center + 1 else None
 
 
@@ -237,6 +243,12 @@ class LsStreamSession:
         self.enc_out = torch.zeros(batch, 1, D, dtype=F32, device=dev)
         self.win16 = torch.zeros(batch, 64, D, dtype=F16, device=dev)            # frames 0..k-1 = the look-ahead window
         self._shift = torch.zeros(batch, self.k - 1, D, dtype=F16, device=dev)
+        # <= 16 streams: the look-ahead conv and the embedding normalisation in f32 too (window, weights, output): the embedding
+        # is the decoder's input, whose rounding the decoder retention amplifies
+        self.f32_conv = F32_PROJ and DEC_F32 and batch <= ops.STEP_F32_MAX_ROWS
+        self.win32 = torch.zeros(batch, self.k, D, dtype=F32, device=dev)
+        self._shift32 = torch.zeros(batch, self.k - 1, D, dtype=F32, device=dev)
+        self.y32 = torch.zeros(batch, D, dtype=F32, device=dev)
         self.emb32 = torch.zeros(batch * 64, D, dtype=F32, device=dev)
         self.emb16 = torch.zeros(batch * 64, D, dtype=F16, device=dev)
         self.emb_t = torch.zeros(batch, 1, D, dtype=F32, device=dev)
@@ -247,7 +259,7 @@ class LsStreamSession:
         self._graphs = None
         self._stateful = ([s["prev_key_value"] for s in self.enc_states + self.dec_states] +
                           [s[k_] for s in self.enc_states + self.dec_states for k_ in ("scale", "_scale_next")] + self.caches +
-                          [self.win16, self.enc_out])
+                          [self.win16, self.win32, self.enc_out])
         if use_graph:
             self._capture()
 
@@ -258,6 +270,13 @@ class LsStreamSession:
     def _conv(self):
         P = self.m._prepare()
         k = self.k
+        if self.f32_conv:
+            self._shift32.copy_(self.win32[:, 1:k])
+            self.win32[:, :k - 1].copy_(self._shift32)
+            self.win32[:, k - 1:k].copy_(self.enc_out)
+            ops.linear_step_f32(self.win32.view(self.B, k * self.D), P["cnn.w32"], P["cnn.b"], self.y32)
+            ops.l2norm_rows_f32(self.y32, self.emb_t.view(self.B, self.D))
+            return
         self._shift.copy_(self.win16[:, 1:k])
         self.win16[:, :k - 1].copy_(self._shift)
         self.win16[:, k - 1:k].copy_(self.enc_out)                                  # f32 -> f16 (as the batch path's operand)

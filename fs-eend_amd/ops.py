@@ -310,6 +310,14 @@ def linear_res_ln_step_f32(a32, w32, bias, res, gamma, beta, out32, eps=1e-5, al
                                              _p(beta), eps, _p(out32), _p(out16), M, K, _stream()), "eend_linear_res_ln_step_f32")
 
 
+def l2norm_rows_f32(x32, y32):
+    L = _lib.load()
+    _chk(x32, F32, "x32"); _chk(y32, F32, "y32")
+    if x32.shape[-1] != 256:
+        raise _lib.EendHipError("l2norm_rows_f32: rows of 256 features")
+    _lib.check(L.eend_l2norm_rows_f32(_p(x32), _p(y32), x32.numel() // 256, _stream()), "eend_l2norm_rows_f32")
+
+
 def spk_attn_step_f32(qkv32, out32, B, C):
     L = _lib.load()
     _chk(qkv32, F32, "qkv32"); _chk(out32, F32, "out32")

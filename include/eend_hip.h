@@ -305,6 +305,9 @@ int eend_linear_res_ln_step_f32(const float* A, int lda, const float* W, int ldw
                                 const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, int M, int K,
                                 void* stream);
 int eend_spk_attn_step_f32(const float* qkv, float* out_f32, int B, int C, float scale, void* stream);
+/* y[r] = x[r] / ||x[r]||_2, f32 rows of 256 features: the embedding normalisation (LS model :87, no eps) behind the f32
+ * look-ahead conv of a frame step (the conv itself is eend_linear_step_f32 over the flattened 19-frame window). */
+int eend_l2norm_rows_f32(const float* x, float* y, int rows, void* stream);
 /* Frame-by-frame decoder input in f32: out[b*C + c] = W[:, :256] emb[b] + pc[c] (`convert(cat(emb, pe))`, LS model
  * :229-233; pc from eend_convert_const_f32).  W_f32 is the convert.weight parameter itself ([256][ldw], ldw = 512).
  * f32 for the same reason as the projections above: the decoder retention amplifies the f16 rounding of this linear ~30x
