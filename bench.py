@@ -642,7 +642,7 @@ def time_train(dev, B, T, n_spk, steps, warmup, rank=0, fence=None, flavour="fs"
 class TrainCallTimer:
     """Brackets every C-ABI call of the training step (fs_eend_amd.train._call and the ops.* forward wrappers it uses)
     with HIP events on the launch stream, for a few instrumented steps after the timed region."""
-    INT_ARGS = {"eend_wgrad_bf16": (5, 6, 7), "eend_gemm_bf16": (7, 8, 9), "eend_gemm_relu_bwd_bf16": (8, 9, 10),
+    INT_ARGS = {"eend_wgrad_bf16": (5, 6, 7), "eend_wgrad_bias_bf16": (5, 6, 7), "eend_gemm_bf16": (7, 8, 9), "eend_gemm_relu_bwd_bf16": (8, 9, 10),
                 "eend_linear_relu_train_f16": (7, 8, 9)}
     # ops.* forward wrappers the LS step calls directly (not through _call): name -> shape extractor on the positional args
     OPS = {"linear": lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]),
@@ -707,7 +707,7 @@ class TrainCallTimer:
             setattr(self.OPSMOD, k, f)
 
     def flops(self, name, shape):
-        if name in ("eend_wgrad_bf16", "eend_gemm_bf16", "eend_gemm_relu_bwd_bf16", "eend_gemm_acc_bf16",
+        if name in ("eend_wgrad_bf16", "eend_wgrad_bias_bf16", "eend_gemm_bf16", "eend_gemm_relu_bwd_bf16", "eend_gemm_acc_bf16",
                     "eend_linear_relu_train_f16", "eend_linear_res_ln_train_f16", "eend_inproj_heads_train_bf16",
                     "eend_linear_res_scale_ln_train_f16", "ops.linear", "ops.retention_proj", "ops.convert_fanout"):
             M, N, K = shape

@@ -260,6 +260,7 @@ struct WgradParams {          // wgrad.hip: partial[s][n][k] = sum_{m in split s
     const void* A;            // dY, bf16 [M][lda]
     const void* B;            // X, f16 (b_is_f16) or bf16 [M][ldb]
     float* partial;           // f32 [nsplit][N][K]
+    float* bias_partial;      // optional f32 [nsplit][N]: column sums of A per split (the bias gradient on the side)
     long M;
     int N, K, lda, ldb;
     int nsplit;

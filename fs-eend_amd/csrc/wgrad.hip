@@ -34,7 +34,7 @@ constexpr int TN_BM = 64;
 // ~30 GB/s per CU, for every shape tried), so the lever is bytes per flop: a 256 x 256 tile needs half of them.
 // Measured, same box: 15-18 % faster on the shapes with more than one 256-tile (e.g. [393216, 256, 2048] 866 -> 737 us,
 // 559 TFLOP/s); deeper register prefetch (2 / 3 sets, branch-free loads so that the waits are partial) changed nothing.
-template <bool B_F16, bool CONV, int BT>
+template <bool B_F16, bool CONV, int BT, bool BIAS>
 __global__ __launch_bounds__(BT * 2)
 void wgrad_tn_kernel(const WgradParams p) {
     constexpr int TN_BN = BT, TN_BK = BT;
@@ -78,6 +78,12 @@ void wgrad_tn_kernel(const WgradParams p) {
         conv_shift = tap - p.conv_pad;
     }
 
+    // Bias gradient on the side (p.bias_partial): the column sums of dY are accumulated from the staging registers of the dY
+    // stagers -- by the workgroups of k-tile 0 only, every dY element is seen there exactly once -- instead of by a separate
+    // pass over dY (eend_colsum_f32: 3-5 % of a training step, HBM-bound).
+    const bool do_bias = BIAS && (tile % ntk) == 0;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
     // PF register sets: the rows of step s are requested PF steps ahead (an MFMA phase is ~0.2 us, a loaded-HBM round trip
     // ten times that: with one set -- request at s-1, transpose at the end of s-1 -- every step waited for its own loads),
     // transposed into the LDS buffer one step ahead, consumed at step s.  The loads are branch-free (clamped address +
@@ -108,6 +114,16 @@ void wgrad_tn_kernel(const WgradParams p) {
         }
     };
     auto lstore = [&](int buf, const u32x4 (&rg)[8]) __attribute__((always_inline)) {
+        if (do_bias && !isB) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned v = rg[r][j];
+                    cs[2 * j] += bf16_lo(v);
+                    cs[2 * j + 1] += bf16_hi(v);
+                }
+        }
         u32x4 in[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) in[r] = (B_F16 && isB) ? f16x8_to_bf16x8(rg[r]) : rg[r];
@@ -202,6 +218,20 @@ void wgrad_tn_kernel(const WgradParams p) {
         }
     }
 
+    if (do_bias) {                                                    // the loop ended on a barrier: the LDS tiles are free
+        float* red = (float*)smem;                                    // [8 token groups][BT]
+        if (!isB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[mg * BT + fc * 8 + e] = cs[e];
+        }
+        __syncthreads();
+        if (tid < BT) {
+            float t = 0.f;
+#pragma unroll
+            for (int gsum = 0; gsum < 8; ++gsum) t += red[gsum * BT + tid];
+            p.bias_partial[(size_t)split * p.N + n0 + tid] = t;
+        }
+    }
     // acc[i][j][r]: k = k0 + wk*64 + i*16 + fkg*4 + r (4 consecutive k per lane), n = n0 + wn*(BT/2) + j*16 + frow
     const int frow = frow_c, fkg = fkg_c;
     float* __restrict__ out = p.partial + (size_t)split * p.N * p.K;
@@ -327,22 +357,24 @@ int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % bt) || p.Tp <= 0)) return EEND_EINVAL;
     const int smem = 2 * 2 * bt * 128;
     const dim3 grid((unsigned)((p.N / bt) * (p.K / bt) * p.nsplit));
-#define WG_LAUNCH(F16, CV, BT)                                                                                          \
+#define WG_LAUNCH(F16, CV, BT, BS)                                                                                      \
     do {                                                                                                                \
         static bool done = false;                                                                                       \
         if (!done) {                                                                                                    \
-            if (hipFuncSetAttribute((const void*)wgrad_tn_kernel<F16, CV, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            if (hipFuncSetAttribute((const void*)wgrad_tn_kernel<F16, CV, BT, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     smem) != hipSuccess)                                                                \
                 return EEND_ELAUNCH;                                                                                    \
             done = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV, BT>), grid, dim3(BT * 2), smem, stream, p);                        \
+        hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV, BT, BS>), grid, dim3(BT * 2), smem, stream, p);                    \
     } while (0)
 #define WG_PICK(BT)                                                                                                     \
     do {                                                                                                                \
-        if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true, BT); else WG_LAUNCH(false, true, BT); }                     \
-        else { if (p.b_is_f16) WG_LAUNCH(true, false, BT); else WG_LAUNCH(false, false, BT); }                          \
+        if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true, BT, false); else WG_LAUNCH(false, true, BT, false); }       \
+        else if (p.bias_partial) { if (p.b_is_f16) WG_LAUNCH(true, false, BT, (BT == 128)); else WG_LAUNCH(false, false, BT, (BT == 128)); } \
+        else { if (p.b_is_f16) WG_LAUNCH(true, false, BT, false); else WG_LAUNCH(false, false, BT, false); }            \
     } while (0)
+    if (p.bias_partial && (p.conv || bt != 128)) return EEND_EINVAL;      // the column sums ride on the 128-tile kernel only
     if (bt == 256) WG_PICK(256); else WG_PICK(128);
 #undef WG_PICK
 #undef WG_LAUNCH

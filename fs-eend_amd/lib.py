@@ -73,6 +73,7 @@ PROTOTYPES = {
     "eend_gemm_acc_bf16": [_vp, _i, _vp, _i, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_conv1d_dgrad_bf16": [_vp] * 5 + [_i] * 5 + [_vp],
     "eend_wgrad_bf16": [_vp, _i, _vp, _i, _i, _l, _i, _i, _vp, _l, _vp, _i, _i, _f, _i, _vp],
+    "eend_wgrad_bias_bf16": [_vp, _i, _vp, _i, _i, _l, _i, _i, _vp, _l, _vp, _i, _i, _vp, _f, _i, _vp],
     "eend_conv1d_wgrad_bf16": [_vp] * 3 + [_i] * 5 + [_vp, _l, _vp, _vp, _vp],
     "eend_colsum_f32": [_vp, _i, _l, _i, _i, _vp, _l, _vp, _f, _i, _vp],
     "eend_layernorm_bwd_f32": [_vp] * 6 + [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp],

@@ -309,6 +309,11 @@ class TrainStepBase:
         _call("eend_wgrad_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS, g,
               K if ld_out is None else ld_out, K if k_out is None else k_out, scale, 0)
 
+    def _wgrad_bias(self, dy16, x, M, N, K, wname, bname, x_is_f16=True):
+        """Weight gradient AND bias gradient of one linear layer from one pass over dy16 (eend_wgrad_bias_bf16)."""
+        _call("eend_wgrad_bias_bf16", dy16, dy16.stride(0), x, x.stride(0), 1 if x_is_f16 else 0, M, N, K, self.ws, WS_FLOATS,
+              self._G(wname), K, K, self._G(bname), 1.0, 0)
+
     def _ln_bwd(self, g32, site, ln, ds16, M, drop=None, bias=None):
         """`drop`: the spec of the sub-layer output dropout in front of this LayerNorm's residual sum -- the bf16 branch
         gradient ds16 gets the mask, the f32 residual-stream gradient g32 does not.  `bias`: the bias parameter of the
@@ -323,8 +328,7 @@ class TrainStepBase:
         dh = dh16[:M * Fh].view(M, Fh)
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
         _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D, drop_scale)
-        self._bias_grad(dh, M, Fh, p_ + "linear1.bias")
-        self._wgrad(dh, x_in16, M, Fh, D, p_ + "linear1.weight")
+        self._wgrad_bias(dh, x_in16, M, Fh, D, p_ + "linear1.weight", p_ + "linear1.bias")
         _call("eend_gemm_acc_bf16", dh, Fh, W[wkey + ".w1T"], Fh, g32, 1.0, g32, None, M, Fh)
 
     def _pit_labels(self, bf, lab, il, ncols):
@@ -623,8 +627,7 @@ class FsTrainStep(TrainStepBase):
         _call("eend_gemm_bf16", ds16, D, w_outT, D, None, dctx16, D, M, D, D)
         _call("eend_attn_causal_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, dctx16, D, sv.ctx, D, sv.lse, bf.dot_ws, bf.dh_ws, dqkv16,
               3 * D, nseq, H, Tp, delay, kv_len, T, 1.0, 0.125, ops.LN2, drop)
-        self._bias_grad(dqkv16, M, 3 * D, p_in + "_bias")
-        self._wgrad(dqkv16, x_in16, M, 3 * D, D, p_in + "_weight")
+        self._wgrad_bias(dqkv16, x_in16, M, 3 * D, D, p_in + "_weight", p_in + "_bias")
         _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
 
     def backward(self, bf: _Buffers, dlogits: Optional[Tensor] = None, emb_loss_grad: float = 1.0):
@@ -664,8 +667,7 @@ class FsTrainStep(TrainStepBase):
             self._wgrad(dsd, sv["o2"], Md, D, D, p_ + "self_attn2.out_proj.weight")
             _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
             _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125, dr(so + self.SITE_SPK))
-            self._bias_grad(dqkv16[:Md], Md, 3 * D, p_ + "self_attn2.in_proj_bias")
-            self._wgrad(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight")
+            self._wgrad_bias(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight", p_ + "self_attn2.in_proj_bias")
             _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
             # time-axis attention block (:364, :379-385)
             self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + self.SITE_OUT1), p_ + "self_attn1.out_proj.bias")

@@ -381,9 +381,8 @@ class LsTrainStep(TrainStepBase):
               bf.g_ws, bf.st_bwd, dq, 4 * D, nseq, H, Tp, self.L, bf.Tv, 0.125)
         for j, nm in enumerate(("q_proj", "k_proj", "v_proj", "g_proj")):
             blk = dq[:, j * D:(j + 1) * D]
-            _call("eend_colsum_f32", blk, 4 * D, M, D, 1, self.ws, WS_FLOATS, self._G(pfx + nm + ".bias"), 1.0, 0)
-            _call("eend_wgrad_bf16", blk, 4 * D, x_in16, x_in16.stride(0), 1, M, D, D, self.ws, WS_FLOATS, self._G(pfx + nm + ".weight"),
-                  D, D, 1.0, 0)
+            _call("eend_wgrad_bias_bf16", blk, 4 * D, x_in16, x_in16.stride(0), 1, M, D, D, self.ws, WS_FLOATS,
+                  self._G(pfx + nm + ".weight"), D, D, self._G(pfx + nm + ".bias"), 1.0, 0)
         if prenorm_site is None:
             _call("eend_gemm_acc_bf16", dq, 4 * D, W[wkey + ".wqkvgT"], 4 * D, g32, 1.0, g32, None, M, 4 * D)
         else:
@@ -399,8 +398,7 @@ class LsTrainStep(TrainStepBase):
         self._wgrad(ds16, a16, M, D, F_, pfx + "4.linear.weight")
         _call("eend_gemm_bf16", ds16, D, W[f"{wkey}.w2{tag}T"], D, None, dh, F_, M, F_, D)
         _call("eend_swish_bwd_bf16", dh, z16, M, F_, hid_drop)
-        self._bias_grad(dh, M, F_, pfx + "1.linear.bias")
-        self._wgrad(dh, site.out16, M, F_, D, pfx + "1.linear.weight")
+        self._wgrad_bias(dh, site.out16, M, F_, D, pfx + "1.linear.weight", pfx + "1.linear.bias")
         dy = bf.dy16[:M]
         _call("eend_gemm_bf16", dh, F_, W[f"{wkey}.w1{tag}T"], F_, None, dy, D, M, D, F_)
         self._ln_bwd2(dy, True, site, ln, g32, True, M)
@@ -440,8 +438,7 @@ class LsTrainStep(TrainStepBase):
             self._wgrad(dsd, sv["o2"], Md, D, D, p_ + "self_attn2.out_proj.weight")
             _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
             _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125, dr(so + SITE_SPK))
-            self._bias_grad(dqkv16[:Md], Md, 3 * D, p_ + "self_attn2.in_proj_bias")
-            self._wgrad(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight")
+            self._wgrad_bias(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight", p_ + "self_attn2.in_proj_bias")
             _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
             self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + SITE_OUT1), p_ + "self_attn1.out_proj.bias")
             self._ret_bwd(bf, g32, dsd, sv["ret"], x_in16, B * C, Md, f"d{i}", p_ + "self_attn1.")
@@ -486,8 +483,7 @@ class LsTrainStep(TrainStepBase):
             dP = bf.dh16[:Me * 2 * D].view(Me, 2 * D)
             _call("eend_dwconv_glu_bwd_bf16", dsw, sv["P"], self._P(cm + "4.conv.weight"), dP, self.ws, WS_FLOATS,
                   self._G(cm + "4.conv.weight"), B, Tp, Tv, self.kdw)
-            self._bias_grad(dP, Me, 2 * D, cm + "2.conv.bias")
-            self._wgrad(dP, sv["lnC"].out16, Me, 2 * D, D, cm + "2.conv.weight")
+            self._wgrad_bias(dP, sv["lnC"].out16, Me, 2 * D, D, cm + "2.conv.weight", cm + "2.conv.bias")
             dy = bf.dy16[:Me]
             _call("eend_gemm_bf16", dP, 2 * D, W[f"e{i}.pw1T"], 2 * D, None, dy, D, Me, D, 2 * D)
             self._ln_bwd2(dy, True, sv["lnC"], cm + "0", g32, True, Me)

@@ -443,6 +443,11 @@ int eend_conv1d_dgrad_bf16(const void* dY, const void* Wd, const int* src_lens, 
  * X f16 (x_is_f16) or bf16 [M][ldb]; N, K % 128 == 0. */
 int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
                     long ws_floats, float* out, int ld_out, int K_out, float scale, int accumulate, void* stream);
+/* The same with the bias gradient on the side: bias_out[n] = scale * sum_m dY[m][n] (+ bias_out if accumulate), accumulated
+ * from the dY tiles the kernel stages anyway instead of by a separate pass over dY (eend_colsum_f32).  ws needs
+ * nsplit * (N*K + N) floats. */
+int eend_wgrad_bias_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
+                         long ws_floats, float* out, int ld_out, int K_out, float* bias_out, float scale, int accumulate, void* stream);
 /* Conv1d weight gradient into the parameter's own (c_out, c_in, k) layout; tmp: f32 [c_out][k*c_in] scratch. */
 int eend_conv1d_wgrad_bf16(const void* dY, const void* X_f16, const int* ilens, int nseq, int Tp, int cin, int ktaps,
                            int pad, float* ws, long ws_floats, float* tmp, float* out, void* stream);

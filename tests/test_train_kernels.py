@@ -90,6 +90,13 @@ def test_wgrad(T, dev, ws, M, N, K, f16):
     want = dy.float().t() @ x.to(BF16).float()
     assert relnorm(out, want) < 2e-3, relnorm(out, want)
     assert rel(out, want) < 1e-2
+    # the same with the bias gradient on the side (column sums of dy from the staging registers of the k-tile-0 workgroups)
+    out2 = torch.full((N, K), 7.0, dtype=F32, device=dev)
+    bias = torch.full((N,), 3.0, dtype=F32, device=dev)
+    T._call("eend_wgrad_bias_bf16", dy, N, x, K, 1 if f16 else 0, M, N, K, ws, ws.numel(), out2, K, K, bias, 1.0, 0)
+    assert relnorm(out2, want) < 2e-3 and rel(out2, out) < 1e-4        # (a different split plan: not bit-identical to `out`)
+    wantb = dy.double().sum(0)
+    assert float((bias.double() - wantb).abs().max()) < 2e-5 * float(dy.double().abs().sum(0).max()), float((bias.double() - wantb).abs().max())
     # transpose-detecting: an asymmetric case is already covered (N != K); accumulate + narrow destination
     if K == 384:
         dst = torch.ones(N, 345, dtype=F32, device=dev)
