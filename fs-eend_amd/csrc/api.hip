@@ -110,6 +110,15 @@ int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const
     return eend_launch_gemm(p, EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_linear_res16_ln_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_f16,
+                             float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
+                             void* out_f16, int M, int K, void* stream) {
+    if (!A || !W || !res_f16 || !out_f16 || !gamma || !beta) return EEND_EINVAL;
+    GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
+    p.res16 = res_f16; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
+    return eend_launch_gemm(p, EPI_RES_LN, (hipStream_t)stream);
+}
+
 int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ldw, const float* bias,
                                    const float* res, float alpha, const float* gamma, const float* beta, float eps,
                                    float* out_f32, void* out_f16, int M, int K, void* stream) {
@@ -145,6 +154,19 @@ int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const flo
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.Wo = Wo; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
     p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2;
+    p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
+    return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
+int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, const float* bo, const void* res_f16,
+                                     const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
+                                     const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
+                                     float* out_f32, void* out_f16, int M, int F, void* stream) {
+    if (!A || !Wo || !bo || !g1 || !be1 || !res_f16) return EEND_EINVAL;
+    FfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.Wo = Wo; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
+    p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res16 = res_f16; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2;
     p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }

@@ -148,12 +148,14 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
             }
         }
         __syncthreads();
+        if (o32) {                                           // (null: the caller keeps only the f16 stream)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int row = k * 8 + wave;
-            const f32x4 v = *(const f32x4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
-            const long gr = rowmap(row);
-            if (gr >= 0) *(f32x4*)(o32 + (size_t)gr * KD + lane * 4) = v;
+            for (int k = 0; k < 16; ++k) {
+                const int row = k * 8 + wave;
+                const f32x4 v = *(const f32x4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+                const long gr = rowmap(row);
+                if (gr >= 0) *(f32x4*)(o32 + (size_t)gr * KD + lane * 4) = v;
+            }
         }
         __syncthreads();
         // f16 tile -> LDS [128 rows][512 B], 16-B chunk c of row r at chunk c ^ ((r >> 1) & 7)
@@ -414,7 +416,13 @@ void ffn_fused_kernel(const FfnParams p) {
                 for (int i = 0; i < 4; ++i) {
                     const float4 b4 = *(const float4*)(bo + N0 + i * 16);
                     float4 r = make_float4(0, 0, 0, 0);
-                    if (resp && m >= 0) r = *(const float4*)(resp + (size_t)m * KD + N0 + i * 16);
+                    if (m >= 0) {
+                        if (resp) r = *(const float4*)(resp + (size_t)m * KD + N0 + i * 16);
+                        else if (src != 1 && p.res16) {          // (the second out-projection of the layer tail reads its own out32 stream)
+                            const f16x4 h = *(const f16x4*)((const _Float16*)p.res16 + (size_t)m * KD + N0 + i * 16);
+                            r = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                        }
+                    }
                     acc[i][j] = f32x4{r.x + b4.x, r.y + b4.y, r.z + b4.z, r.w + b4.w};
                 }
             }
@@ -914,8 +922,9 @@ extern "C" int eend_debug_ffn_trace(void* dst, void* stream) {
 
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.W1 || !p.W2 || !p.b1 || !p.b2 || !p.gamma ||
-        !p.beta || !p.out32 || !p.out16)
+        !p.beta || !p.out16)
         return EEND_EINVAL;
+    if (!p.out32 && (!p.A || p.Win2 || epi != FFN_EPI_RES_LN)) return EEND_EINVAL;   // f16-only output: the attnout + FFN form only
     if (p.A) {                                               // fused attention out-projection + norm1 producer
         if (!p.Wo || !p.bo || !p.g1 || !p.be1 || (p.lda & 7) || epi != FFN_EPI_RES_LN || act != 1) return EEND_EINVAL;
         if (p.Win2) {                                        // whole second half of a fusion layer

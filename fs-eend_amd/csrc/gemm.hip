@@ -370,7 +370,13 @@ void gemm_f16_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < FR; ++i) {
                 float4 r = make_float4(0, 0, 0, 0);
-                if (!L2K && p.res && ok) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
+                if (!L2K && ok) {
+                    if (p.res) r = *(const float4*)(p.res + (size_t)m * p.ldo + R0 + i * 16);
+                    else if (p.res16) {
+                        const f16x4 h = *(const f16x4*)((const _Float16*)p.res16 + (size_t)m * p.ldo + R0 + i * 16);
+                        r = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                    }
+                }
                 const float s = L2K ? 1.0f : p.alpha;
                 float a0 = acc[i][j][0] + bias4[i].x, a1 = acc[i][j][1] + bias4[i].y, a2 = acc[i][j][2] + bias4[i].z, a3 = acc[i][j][3] + bias4[i].w;
                 if constexpr (EPI == EPI_RES_LN_TRAIN || EPI == EPI_RES_SCALE_LN16_TRAIN) {

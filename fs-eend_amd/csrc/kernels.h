@@ -41,6 +41,8 @@ struct GemmParams {
     void* out16b;       // second half-precision output (K for EPI_QK_HEADS)
     void* out32;        // f32 output or null
     const float* res;   // f32 residual [M][ldo] or null
+    const void* res16;  // ... or the same as f16 (post-norm stacks: the residual IS the previous LayerNorm's output, whose f16
+                        // copy the next MFMA reads anyway; saves the f32 stream's write + read; used when res is null)
     const float* gamma; // LN affine
     const float* beta;
     const float* pc;    // EPI_CONVERT: [C][N] per-speaker-slot constant
@@ -209,6 +211,7 @@ struct FfnParams {
     const void* W2;     // f16 [256][F]
     const float* b2;    // [256]
     const float* res;   // f32 [M][256] or null
+    const void* res16;  // the out-projection residual as f16 [M][256] instead (A != null, used when res is null); out32 may then be null
     const float* gamma; // LN affine [256]
     const float* beta;
     float* out32;       // f32 [M][256]

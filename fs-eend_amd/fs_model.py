@@ -39,6 +39,8 @@ FUSED_TAIL = __import__("os").environ.get("EEND_TAIL_FUSED", "0") == "1"
 # time-axis attention: in-projection + causal attention in one launch per layer, K / V never leave the CU (attn_fused.hip;
 # chunks up to 512 frames).  EEND_ATTN_FUSED=0 keeps the two-kernel path (A/B, and the only path for longer chunks).
 FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
+# f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
+RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
 
 
 class PositionalEncoding(nn.Module):
@@ -337,8 +339,12 @@ class OnlineTransformerDADiarization(nn.Module):
         # ---- embedding encoder (model :162-188)
         # pad_sequence(-1) (model :165) + BatchNorm + cast + slab padding: one gather launch
         ops.gather_bn_cast_pad(srcs, P["bn"], ws.xin16, T, Tp, -1.0, True, P["bn.eps"])
+        # RES16 (default): the stack is post-norm, so the residual of every sub-layer is the previous LayerNorm's output; its
+        # f16 copy (the next MFMA operand anyway) serves as the residual and the f32 stream is only written where something
+        # reads it in f32 (the head).  Oracle emulation: max |d logit| 2.4e-4 -> 2.6e-4.
+        res16 = RES16 and FUSED_FFN and FUSED_ATTNOUT
         ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"],
-                          ws.h32, ws.h16, P["enc.in.eps"])
+                          None if res16 else ws.h32, ws.h16, P["enc.in.eps"])
         q, k, vt = ws.q[:Me * D], ws.k[:Me * D], ws.vt[:Me * D]
         o16 = ws.o16[:Me]
         for L in P["enc.layers"]:
@@ -349,6 +355,10 @@ class OnlineTransformerDADiarization(nn.Module):
             else:
                 ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
                 ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
+            if res16:
+                ops.attnout_ffn_fused_res16(o16, L["out_w"], L["out_b"], ws.h16, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
+                                            L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], None, ws.h16)
+                continue
             if FUSED_FFN and FUSED_ATTNOUT:   # out_proj + norm1 + FFN + norm2 in one launch (x never leaves the CU)
                 ops.attnout_ffn_fused(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
                                       L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], ws.h32, ws.h16)
@@ -369,7 +379,9 @@ class OnlineTransformerDADiarization(nn.Module):
         ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
         q, k, vt = ws.q[:Md * D], ws.k[:Md * D], ws.vt[:Md * D]
         o16 = ws.o16[:Md]
-        for L in P["dec.layers"]:
+        res16 = res16 and FUSED_SPK and not FUSED_TAIL
+        nd = len(P["dec.layers"])
+        for li, L in enumerate(P["dec.layers"]):
             F = L["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
             if FUSED_INPROJ_ATTN and Tp <= 512:
@@ -381,6 +393,16 @@ class OnlineTransformerDADiarization(nn.Module):
                 ops.fusion_layer_tail(o16, ws.a32, ws.a16, L["out1_w"], L["out1_b"], L["g11"], L["be11"], L["eps11"],
                                       L["in2_w"], L["in2_b"], L["out2_w"], L["out2_b"], L["g21"], L["be21"], L["eps21"],
                                       L["w1"], L["b1"], L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], B, C, Tp)
+                continue
+            if res16:
+                if li == 0:    # the first residual is the convert output (not a LayerNorm output): read in f32
+                    ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], None, ws.a16, L["eps11"])
+                else:
+                    ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
+                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)
+                ops.attnout_ffn_fused_res16(o16, L["out2_w"], L["out2_b"], ws.a16, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
+                                            L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32 if li == nd - 1 else None,
+                                            ws.a16)
                 continue
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
             if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)

@@ -21,9 +21,11 @@ PROTOTYPES = {
     "eend_inproj_heads_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_linear_glu_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_linear_res_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_linear_res16_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_linear_res_scale_ln16_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_attnout_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_attnout_ffn_fused_res16_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_inproj_attn_causal_f16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "eend_spk_qkv_attn_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_fusion_layer_tail_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f,

@@ -410,6 +410,34 @@ def gather_bn_cast_pad(src, bn, out16, T, Tp, pad_value, apply_bn=True, eps=1e-5
     return out16
 
 
+def linear_res16_ln(a16, w16, bias, res16, gamma, beta, out32, out16, eps=1e-5, alpha=1.0):
+    """out = LayerNorm((a16 @ w16.T + bias) * alpha + res16) with the residual read from the f16 stream; out32 may be None."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(w16, F16, "w16"); _chk(bias, F32, "bias"); _chk(res16, F16, "res16")
+    _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = a16.shape
+    if w16.shape[0] != 256:
+        raise _lib.EendHipError("linear_res16_ln: N must be 256")
+    _lib.check(L.eend_linear_res16_ln_f16(_p(a16), a16.stride(0), _p(w16), w16.stride(0), _p(bias), _p(res16), float(alpha), _p(gamma),
+                                          _p(beta), eps, _p(out32), _p(out16), M, K, _stream()), "eend_linear_res16_ln_f16")
+
+
+def attnout_ffn_fused_res16(a16, wo, bo, res16, g1, be1, eps1, w1, b1, w2, b2, g2, be2, eps2, out32, out16):
+    """attnout_ffn_fused with the out-projection's residual read from the f16 stream; out32 may be None."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wo, F16, "wo"); _chk(w1, F16, "w1"); _chk(w2, F16, "w2"); _chk(res16, F16, "res16")
+    for n, t in (("bo", bo), ("g1", g1), ("be1", be1), ("b1", b1), ("b2", b2), ("g2", g2), ("be2", be2), ("out32", out32)):
+        _chk(t, F32, n)
+    _chk(out16, F16, "out16")
+    M, K = a16.shape
+    Fh = w1.shape[0]
+    if K != 256 or wo.shape != (256, 256) or w1.shape[1] != 256 or w2.shape != (256, Fh):
+        raise _lib.EendHipError("attnout_ffn_fused_res16: expected d_model 256")
+    _lib.check(L.eend_attnout_ffn_fused_res16_f16(_p(a16), a16.stride(0), _p(wo), _p(bo), _p(res16), _p(g1), _p(be1), eps1, _p(w1),
+                                                  _p(b1), _p(w2), _p(b2), _p(g2), _p(be2), eps2, _p(out32), _p(out16), M, Fh,
+                                                  _stream()), "eend_attnout_ffn_fused_res16_f16")
+
+
 def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, eps2, out32, out16):
     """x = LN1(a16 @ wo.T + bo + res); out = LN2(relu(x @ w1.T + b1) @ w2.T + b2 + x): the attention
     out-projection, both residual adds, both LayerNorms and the FFN of a post-LN layer in one launch."""

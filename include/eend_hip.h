@@ -142,6 +142,18 @@ int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const flo
                                const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
                                float* out_f32, void* out_f16, int M, int F, void* stream);
+/* The two post-norm joins above with the residual taken from the f16 stream: in a post-norm stack (nn.TransformerEncoderLayer,
+ * merge_tfm_encoder.py:356-376) the residual IS the previous LayerNorm's output, whose f16 copy the next MFMA reads anyway, so
+ * the f32 stream's write + read (1 KB per row per sub-layer, the dominant traffic of the HBM-bound out-projection GEMM) can be
+ * dropped; out_f32 may be NULL (only the last layer's output is needed in f32, by the head).  Emulated on the oracle: max
+ * |d logit| 2.4e-4 -> 2.6e-4. */
+int eend_linear_res16_ln_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_f16,
+                             float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
+                             void* out_f16, int M, int K, void* stream);
+int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, const float* bo, const void* res_f16,
+                                     const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
+                                     const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
+                                     float* out_f32, void* out_f16, int M, int F, void* stream);
 
 /* The whole row-local tail of a fusion (attractor decoder) layer in ONE launch, after the time-axis
  * attention / retention core (FS merge_tfm_encoder.py:364-376: out_proj of self_attn1 + norm11, _sa_block2 +

@@ -458,3 +458,33 @@ def test_emb_consistency_loss(hip_lib, dev, B, T, Tp, C, masked):
         want = torch.nn.functional.mse_loss(a, lm)
         got = ops.emb_consistency(emb, lab.contiguous(), T)
     assert abs(got.item() - want.item()) < 1e-6 + 1e-5 * abs(want.item()), (got.item(), want.item())
+
+
+@pytest.mark.parametrize("M", [128, 1000, 4133])
+def test_f16_residual_variants_equal_the_f32_residual_forms(hip_lib, dev, M):
+    """eend_linear_res16_ln_f16 / eend_attnout_ffn_fused_res16_f16 read the residual from the f16 stream: given a residual that is
+    exactly representable in f16 they must reproduce the f32-residual entry points bit for bit, with and without the f32 output."""
+    from fs_eend_amd import ops
+    g = torch.Generator().manual_seed(M)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    a16 = rn(M, 256).half()
+    res16 = rn(M, 256).half()
+    res32 = res16.float()
+    wo, bo = rn(256, 256, sc=0.06).half(), rn(256, sc=0.1)
+    g1, be1 = rn(256, sc=0.2) + 1.0, rn(256, sc=0.1)
+    o32a, o16a = torch.empty(M, 256, device=dev), torch.empty(M, 256, dtype=torch.float16, device=dev)
+    o32b, o16b, o16c = torch.empty_like(o32a), torch.empty_like(o16a), torch.empty_like(o16a)
+    ops.linear_res_ln(a16, wo, bo, res32, g1, be1, o32a, o16a, 1e-5)
+    ops.linear_res16_ln(a16, wo, bo, res16, g1, be1, o32b, o16b, 1e-5)
+    ops.linear_res16_ln(a16, wo, bo, res16, g1, be1, None, o16c, 1e-5)
+    assert torch.equal(o32a, o32b) and torch.equal(o16a, o16b) and torch.equal(o16a, o16c)
+    w1, b1 = rn(2048, 256, sc=0.08).half(), rn(2048, sc=0.3)
+    w2, b2 = rn(256, 2048, sc=0.03).half(), rn(256, sc=0.2)
+    g2, be2 = rn(256, sc=0.2) + 1.0, rn(256, sc=0.1)
+    ops.attnout_ffn_fused(a16, wo, bo, res32, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, o32a, o16a)
+    ops.attnout_ffn_fused_res16(a16, wo, bo, res16, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, o32b, o16b)
+    ops.attnout_ffn_fused_res16(a16, wo, bo, res16, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, None, o16c)
+    assert torch.equal(o32a, o32b) and torch.equal(o16a, o16b) and torch.equal(o16a, o16c)
+    inplace = res16.clone()                      # the model's use: residual and f16 output are the same buffer
+    ops.attnout_ffn_fused_res16(a16, wo, bo, inplace, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, None, inplace)
+    assert torch.equal(inplace, o16a)
