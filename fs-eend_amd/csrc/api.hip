@@ -358,7 +358,7 @@ int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, con
 
 int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
                             int B, int Tp, int C, void* stream) {
-    if (!E || !W1 || !pc || !out_f32 || !out_f16 || B <= 0 || C <= 0 || Tp <= 0) return EEND_EINVAL;
+    if (!E || !W1 || !pc || !out_f16 || B <= 0 || C <= 0 || Tp <= 0) return EEND_EINVAL;     // out_f32 may be NULL (f16 stream only)
     GemmParams p = base_params(E, 256, W1, 256, nullptr, B * Tp, 256, 256);
     p.Tp = Tp; p.C = C; p.pc = pc; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_CONVERT, (hipStream_t)stream);

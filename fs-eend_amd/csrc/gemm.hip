@@ -594,7 +594,7 @@ void gemm_f16_kernel(const GemmParams p) {
                     const int n = R0 + i * 16;
                     const float4 pc = *(const float4*)(p.pc + (size_t)c * p.N + n);
                     const float v0 = acc[i][j][0] + pc.x, v1 = acc[i][j][1] + pc.y, v2 = acc[i][j][2] + pc.z, v3 = acc[i][j][3] + pc.w;
-                    *(float4*)(o32 + row * p.ldo + n) = make_float4(v0, v1, v2, v3);
+                    if (o32) *(float4*)(o32 + row * p.ldo + n) = make_float4(v0, v1, v2, v3);
                     *(f16x4*)(o16 + row * p.ldo + n) = OutCvt<_Float16>::cvt(v0, v1, v2, v3);
                 }
             }

@@ -376,10 +376,10 @@ class OnlineTransformerDADiarization(nn.Module):
         ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
 
         # ---- attractor decoder (model :112-118, merge_tfm_encoder.py:356-376)
-        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), ws.a32, ws.a16, B, Tp, C)
+        res16 = res16 and FUSED_SPK and not FUSED_TAIL
+        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), None if res16 else ws.a32, ws.a16, B, Tp, C)
         q, k, vt = ws.q[:Md * D], ws.k[:Md * D], ws.vt[:Md * D]
         o16 = ws.o16[:Md]
-        res16 = res16 and FUSED_SPK and not FUSED_TAIL
         nd = len(P["dec.layers"])
         for li, L in enumerate(P["dec.layers"]):
             F = L["w1"].shape[0]
@@ -395,10 +395,7 @@ class OnlineTransformerDADiarization(nn.Module):
                                       L["w1"], L["b1"], L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], B, C, Tp)
                 continue
             if res16:
-                if li == 0:    # the first residual is the convert output (not a LayerNorm output): read in f32
-                    ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], None, ws.a16, L["eps11"])
-                else:
-                    ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
+                ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
                 ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)
                 ops.attnout_ffn_fused_res16(o16, L["out2_w"], L["out2_b"], ws.a16, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
                                             L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32 if li == nd - 1 else None,
