@@ -35,28 +35,50 @@ void bn_cast_pad_kernel(const float* __restrict__ x, const float* __restrict__ w
 // (x_ptrs[b] -> f32 [len[b]][Fin]) and supplies the reference's pad value for t >= len[b]
 // (-1 for FS-EEND, model :165; 0 for LS-EEND, model :280): pad_sequence + BatchNorm + cast +
 // slab padding in one launch instead of B small device-to-device copies.
+constexpr int GB_ROWS = 8;      // slab rows per wave: the per-feature BatchNorm scale / shift (a sqrt and a divide each) are
+                                // computed once per wave and reused; a lane owns feature pairs (2l, 2l+1) + 128 j -> 4-byte stores
 __global__ __launch_bounds__(256)
 void gather_bn_cast_pad_kernel(const float* const* __restrict__ x_ptrs, const int* __restrict__ lens, float pad_value,
                                const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
                                const float* __restrict__ var, float eps, _Float16* __restrict__ out, int B, int T, int Tp,
                                int Fin, int Fpad, int apply_bn) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (long)B * Tp) return;
-    const int bb = (int)(row / Tp), t = (int)(row - (long)bb * Tp);
-    _Float16* o = out + row * Fpad;
-    if (t >= T) {
-        for (int k = lane; k < Fpad; k += 64) o[k] = (_Float16)0.f;
-        return;
-    }
-    const float* xi = (t < lens[bb]) ? x_ptrs[bb] + (long)t * Fin : nullptr;
-    for (int k = lane; k < Fpad; k += 64) {
-        float v = 0.f;
-        if (k < Fin) {
-            v = xi ? xi[k] : pad_value;
-            if (apply_bn) v = (v - mean[k]) / __builtin_sqrtf(var[k] + eps) * w[k] + b[k];
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * GB_ROWS;
+    const long nrows = (long)B * Tp;
+    if (row0 >= nrows) return;
+    constexpr int NJ = 4;                               // feature pairs per lane: covers Fpad <= 512
+    float sc[NJ][2], sh[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = 2 * lane + 128 * j + e;
+            sc[j][e] = 1.0f; sh[j][e] = 0.0f;
+            if (apply_bn && k < Fin) {
+                sc[j][e] = w[k] / __builtin_sqrtf(var[k] + eps);
+                sh[j][e] = b[k] - mean[k] * sc[j][e];
+            }
         }
-        o[k] = to_f16_sat(v);
+    for (int r = 0; r < GB_ROWS; ++r) {
+        const long row = row0 + r;
+        if (row >= nrows) return;
+        const int bb = (int)(row / Tp), t = (int)(row - (long)bb * Tp);
+        unsigned* o = (unsigned*)(out + row * Fpad);
+        const float* xi = (t < T && t < lens[bb]) ? x_ptrs[bb] + (long)t * Fin : nullptr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = 2 * lane + 128 * j;
+            if (k >= Fpad) break;
+            float v0 = 0.f, v1 = 0.f;
+            if (t < T) {
+                if (k < Fin) v0 = (xi ? xi[k] : pad_value) * sc[j][0] + sh[j][0];
+                if (k + 1 < Fin) v1 = (xi ? xi[k + 1] : pad_value) * sc[j][1] + sh[j][1];
+            }
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 pk;
+            pk[0] = to_f16_sat(v0); pk[1] = to_f16_sat(v1);
+            o[k >> 1] = __builtin_bit_cast(unsigned, pk);
+        }
     }
 }
 
@@ -256,9 +278,9 @@ int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b
 int eend_launch_gather_bn_cast_pad(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w,
                                    const float* bn_b, const float* bn_mean, const float* bn_var, float eps, void* out16,
                                    int B, int T, int Tp, int Fin, int Fpad, int apply_bn, hipStream_t stream) {
-    if (B <= 0 || T <= 0 || Tp < T || Fin <= 0 || Fpad < Fin) return EEND_EINVAL;
+    if (B <= 0 || T <= 0 || Tp < T || Fin <= 0 || Fpad < Fin || (Fpad & 1) || Fpad > 512) return EEND_EINVAL;
     const long rows = (long)B * Tp;
-    hipLaunchKernelGGL(gather_bn_cast_pad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x_ptrs, lens,
+    hipLaunchKernelGGL(gather_bn_cast_pad_kernel, dim3((unsigned)((rows + 4 * GB_ROWS - 1) / (4 * GB_ROWS))), dim3(256), 0, stream, x_ptrs, lens,
                        pad_value, bn_w, bn_b, bn_mean, bn_var, eps, (_Float16*)out16, B, T, Tp, Fin, Fpad, apply_bn);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
