@@ -384,10 +384,11 @@ int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, co
 }
 
 int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
-                          int B, int C, int Tp, int H, float scale, void* stream) {
-    if (H != 4) return EEND_EINVAL;
+                          int B, int C, int Tp, int T_valid, int H, float scale, void* stream) {
+    if (H != 4 || T_valid < 0 || T_valid > Tp) return EEND_EINVAL;
     SpkFusedParams p;
     p.X = x_f16; p.ldx = ldx; p.W = W_in; p.bias = b_in; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.scale = scale;
+    p.Tv = T_valid > 0 ? T_valid : Tp;
     return eend_launch_spk_qkv_attn(p, (hipStream_t)stream);
 }
 

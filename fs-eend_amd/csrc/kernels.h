@@ -93,6 +93,7 @@ struct SpkFusedParams {
     const float* bias;  // [768]
     void* O;            // f16 [B*C*Tp][256]
     int B, C, Tp, ldx;
+    int Tv;             // frames t < Tv of every slab are computed (rows beyond keep their previous, finite, contents)
     float scale;        // 1/sqrt(dh)
 };
 int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream);

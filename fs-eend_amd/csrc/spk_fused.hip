@@ -56,8 +56,8 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
     constexpr int G = BM / C;                 // frames per tile
     constexpr int ROWS = G * C;               // tile rows in use (local row = c * G + t')
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_per_b = (p.Tp + G - 1) / G;
-    const int ntiles = p.B * tiles_per_b;
+    const int tiles_per_b = (p.Tv + G - 1) / G;          // only the Tv valid frames of a slab: at T = 500, Tp = 512, C = 6 that is
+    const int ntiles = p.B * tiles_per_b;                 // 24 instead of 25 tiles per utterance -- 1536 = 6 x 256 CUs, no 7th round
     const _Float16* __restrict__ X = (const _Float16*)p.X;
     _Float16* __restrict__ O = (_Float16*)p.O;
 
@@ -101,7 +101,7 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
             const int rr = row < ROWS ? row : ROWS - 1;
             const int cs = rr / G, tt = rr - cs * G;
             int t = t0 + tt;
-            t = t < p.Tp ? t : p.Tp - 1;
+            t = t < p.Tv ? t : p.Tv - 1;
             const size_t grow = ((size_t)b * C + cs) * p.Tp + t;
             const u32x4 v = *(const u32x4*)(X + grow * p.ldx + c32 * 8);
             *(u32x4*)(Xst + (c32 >> 3) * (BM * 128) + swz128(row, c32 & 7)) = v;
@@ -161,7 +161,7 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
                 for (int e = 0; e < 8; ++e) o[8 + e] = __builtin_fmaf(pw, (float)v1[e], o[8 + e]);
             }
             const int t = t0 + tq;
-            if (t < p.Tp) {
+            if (t < p.Tv) {
                 f16x8 o0, o1;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o0[e] = to_f16_sat(o[e]); o1[e] = to_f16_sat(o[8 + e]); }
@@ -241,7 +241,7 @@ int launch(const SpkFusedParams& p, hipStream_t stream) {
         return n;
     }();
     constexpr int G = BM / C;
-    const int ntiles = p.B * ((p.Tp + G - 1) / G);
+    const int ntiles = p.B * ((p.Tv + G - 1) / G);
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(NT), SMEM_BYTES, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
@@ -249,7 +249,7 @@ int launch(const SpkFusedParams& p, hipStream_t stream) {
 }  // namespace
 
 int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream) {
-    if (!p.X || !p.W || !p.bias || !p.O || p.B <= 0 || p.Tp <= 0 || (p.ldx & 7)) return EEND_EINVAL;
+    if (!p.X || !p.W || !p.bias || !p.O || p.B <= 0 || p.Tp <= 0 || p.Tv <= 0 || p.Tv > p.Tp || (p.ldx & 7)) return EEND_EINVAL;
     switch (p.C) {
 #define SPK_CASE(n) case n: return launch<n>(p, stream);
         SPK_CASE(1) SPK_CASE(2) SPK_CASE(3) SPK_CASE(4) SPK_CASE(5) SPK_CASE(6) SPK_CASE(7) SPK_CASE(8)

@@ -396,14 +396,14 @@ class OnlineTransformerDADiarization(nn.Module):
                 continue
             if res16:
                 ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
-                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)
+                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
                 ops.attnout_ffn_fused_res16(o16, L["out2_w"], L["out2_b"], ws.a16, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
                                             L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32 if li == nd - 1 else None,
                                             ws.a16)
                 continue
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
             if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
-                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H)
+                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
             else:
                 ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
                 ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)

@@ -27,7 +27,7 @@ PROTOTYPES = {
     "eend_attnout_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_attnout_ffn_fused_res16_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_inproj_attn_causal_f16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    "eend_spk_qkv_attn_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "eend_spk_qkv_attn_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "eend_fusion_layer_tail_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f,
                                    _i, _i, _i, _i, _vp],
     "eend_emb_consistency_f32": [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],

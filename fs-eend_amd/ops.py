@@ -218,14 +218,14 @@ def inproj_attn_causal(x16, w_in, b_in, q_scratch, o16, nseq, H, Tp, mask_delay=
                "eend_inproj_attn_causal_f16")
 
 
-def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4):
+def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4, t_valid=0):
     """Speaker-axis MHA with its in-projection fused: out = MHA_over_slots(x16 @ w_in.T + b_in)."""
     L = _lib.load()
     _chk(x16, F16, "x16"); _chk(w_in, F16, "w_in"); _chk(b_in, F32, "b_in"); _chk(out16, F16, "out16")
     if x16.shape != (B * C * Tp, 256) or w_in.shape != (768, 256) or out16.shape != (B * C * Tp, 256):
         raise _lib.EendHipError("spk_qkv_attn: shape mismatch")
-    _lib.check(L.eend_spk_qkv_attn_f16(_p(x16), x16.stride(0), _p(w_in), _p(b_in), _p(out16), B, C, Tp, H, 0.125, _stream()),
-               "eend_spk_qkv_attn_f16")
+    _lib.check(L.eend_spk_qkv_attn_f16(_p(x16), x16.stride(0), _p(w_in), _p(b_in), _p(out16), B, C, Tp, int(t_valid), H, 0.125,
+                                       _stream()), "eend_spk_qkv_attn_f16")
 
 
 def spk_attn(qkv16, o16, B, C, Tp, H):

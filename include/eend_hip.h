@@ -354,9 +354,10 @@ int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, co
  * frame as eend_spk_attn_f16 (nn.MultiheadAttention self_attn2 of the fusion layers, _sa_block2: FS
  * merge_tfm_encoder.py:388-394; LS merge_retnet_layer.py:301-306).  x f16 [B*C*Tp][ldx] (256 features,
  * row = (b*C + c)*Tp + t), W_in f16 [768][256] (in_proj_weight), b_in f32 [768] -> O f16 [B*C*Tp][256].
- * H = 4, dh = 64. */
+ * H = 4, dh = 64.  T_valid (0 = Tp): only frames t < T_valid of every slab are computed and written -- rows beyond are slab
+ * padding whose O rows keep their previous contents (the model passes the real frame count: one tile round less at T = 500). */
 int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
-                          int B, int C, int Tp, int H, float scale, void* stream);
+                          int B, int C, int Tp, int T_valid, int H, float scale, void* stream);
 
 /* attractors / ||attractors||_2 and logits[b,t,c] = <emb[b,t], attractors[b,t,c]>
  * (FS model :43,:60 / :76,:79; LS model :89,:117).  emb f32 [B][Tp][D], attr f32 [B*C][Tp][D]
