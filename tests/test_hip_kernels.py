@@ -428,6 +428,12 @@ def test_spk_qkv_attn_fused(hip_lib, dev, B, C, Tp):
     s = torch.einsum("bcthd,bethd->bthce", q, k) * 0.125
     want = torch.einsum("bthce,bethd->bcthd", s.softmax(-1), v).reshape(M, 256)
     assert (o.float() - want).abs().max().item() < 3e-3
+    # t_valid: only frames t < Tv of every slab are computed (bit-identical to the full call); rows beyond keep their contents
+    Tv = Tp - 12 if Tp > 64 else Tp - 5
+    o3 = torch.full((M, 256), 7.0, dtype=torch.float16, device=dev)
+    ops.spk_qkv_attn(x, w, bias, o3, B, C, Tp, 4, t_valid=Tv)
+    o3v, ov = o3.view(B * C, Tp, 256), o.view(B * C, Tp, 256)
+    assert torch.equal(o3v[:, :Tv], ov[:, :Tv]) and bool((o3v[:, Tv:] == 7.0).all())
 
 
 @pytest.mark.parametrize("B,T,Tp,C,masked", [(2, 130, 192, 4, False), (3, 64, 64, 3, True), (1, 500, 512, 6, False), (2, 77, 128, 10, True)])
