@@ -465,6 +465,19 @@ def extras(dev):
     except Exception as ex:
         res["fs_eend_train_step"] = dict(error=f"{type(ex).__name__}: {ex}")
 
+    # ... and its LS half: one LS-EEND training step, 64 x T=1000 (two retention chunks), 4 speakers
+    try:
+        torch.cuda.reset_peak_memory_stats(dev)
+        eng, dtt, loss, _f, _l = time_train(dev, 64, 1000, 4, steps=6, warmup=2, flavour="ls")
+        res["ls_eend_train_step"] = dict(workload="LS-EEND training step, 64 utterances x T=1000, 4-speaker mixtures (C=6), shipped yaml "
+                                                  f"shapes, dropout {eng.drop_p}, Adam x Noam, clip 5; eager launches, 1 GPU",
+                                         ms_per_step=dtt / 6 * 1e3, frames_per_s=64 * 1000 * 6 / dtt, final_loss=loss,
+                                         peak_hbm_bytes=int(torch.cuda.max_memory_allocated(dev)))
+        del eng, _f, _l
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        res["ls_eend_train_step"] = dict(error=f"{type(ex).__name__}: {ex}")
+
     # LS-EEND streaming, 8 speakers + 2 slots, O(1) state (LS-EEND/streaming_infer_dia.py:52-97)
     scnn = StreamingConv1d(256, 256, kernel_size=19).to(dev).eval()
     scnn.conv.load_state_dict(ls.cnn.state_dict())

@@ -402,7 +402,13 @@ int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H,
 int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
                         int Tp, int C, int D, void* stream) {
     if (!emb || !attr || !attr_out || !logits) return EEND_EINVAL;
-    return eend_launch_head(emb, attr, attr_out, logits, B, T, Tp, C, D, (hipStream_t)stream);
+    return eend_launch_head(emb, attr, 0, attr_out, logits, B, T, Tp, C, D, (hipStream_t)stream);
+}
+
+int eend_head_l2dot_a16_f32(const float* emb, const void* attr_f16, float* attr_out, float* logits, int B, int T,
+                            int Tp, int C, int D, void* stream) {
+    if (!emb || !attr_f16 || !attr_out || !logits) return EEND_EINVAL;
+    return eend_launch_head(emb, attr_f16, 1, attr_out, logits, B, T, Tp, C, D, (hipStream_t)stream);
 }
 
 int eend_attn_decode_f16(const void* qkv, void* K_cache, void* V_cache, void* out_f16, int N, int H, int cap, int t,

@@ -171,7 +171,7 @@ int eend_launch_spk_attn(const SpkAttnParams& p, hipStream_t stream);
 int eend_launch_bn_cast_pad(const float* x, const float* bn_w, const float* bn_b, const float* bn_mean,
                             const float* bn_var, float eps, void* out16, int B, int T, int Tp, int Fin,
                             int Fpad, int apply_bn, hipStream_t stream);
-int eend_launch_head(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
+int eend_launch_head(const float* emb, const void* attr, int attr_is_f16, float* attr_out, float* logits, int B, int T,
                      int Tp, int C, int D, hipStream_t stream);
 int eend_launch_ret_step(const void* qkvg, float* kv, const float* scale_in, float* scale_out, void* out16, int N,
                          int H, float eps, hipStream_t stream);

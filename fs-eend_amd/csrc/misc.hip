@@ -85,8 +85,16 @@ void gather_bn_cast_pad_kernel(const float* const* __restrict__ x_ptrs, const in
 // attractors /= ||attractors||_2 (FS model :43/:76, no eps) and
 // logits[b,t,c] = <emb[b,t,:], attractors[b,t,c,:]> (FS model :60/:79), one wave per (b,t,c).
 // attr slab rows are ((b*C + c)*Tp + t); outputs are dense (B,T,C,D) / (B,T,C).
+// AT = float, or _Float16 when the decoder's last LayerNorm output is only kept as f16 (FS-EEND f16 residual stream).
+template <class AT>
+DEV float4 load4f(const AT* p) {
+    if constexpr (sizeof(AT) == 4) return *(const float4*)p;
+    else { const f16x4 h = *(const f16x4*)p; return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+}
+
+template <class AT>
 __global__ __launch_bounds__(256)
-void head_kernel(const float* __restrict__ emb, const float* __restrict__ attr, float* __restrict__ attr_out,
+void head_kernel(const float* __restrict__ emb, const AT* __restrict__ attr, float* __restrict__ attr_out,
                  float* __restrict__ logits, int B, int T, int Tp, int C, int D) {
     const int lane = threadIdx.x & 63;
     const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b*T + t)*C + c
@@ -94,13 +102,13 @@ void head_kernel(const float* __restrict__ emb, const float* __restrict__ attr, 
     const int c = (int)(idx % C);
     const long bt = idx / C;
     const int t = (int)(bt % T), b = (int)(bt / T);
-    const float* a = attr + (((long)b * C + c) * Tp + t) * D;
+    const AT* a = attr + (((long)b * C + c) * Tp + t) * D;
     const float* e = emb + ((long)b * Tp + t) * D;
     float ss = 0.f, dot = 0.f;
     float4 av[2];
     int nv = 0;
     for (int k = lane * 4; k < D; k += 256, ++nv) {
-        const float4 x = *(const float4*)(a + k);
+        const float4 x = load4f(a + k);
         const float4 y = *(const float4*)(e + k);
         if (nv < 2) av[nv] = x;
         ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
@@ -112,7 +120,7 @@ void head_kernel(const float* __restrict__ emb, const float* __restrict__ attr, 
     float* ao = attr_out + idx * D;
     nv = 0;
     for (int k = lane * 4; k < D; k += 256, ++nv) {
-        float4 x = (nv < 2) ? av[nv] : *(const float4*)(a + k);
+        float4 x = (nv < 2) ? av[nv] : load4f(a + k);
         x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
         *(float4*)(ao + k) = x;
     }
@@ -285,11 +293,15 @@ int eend_launch_gather_bn_cast_pad(const float* const* x_ptrs, const int* lens, 
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-int eend_launch_head(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
+int eend_launch_head(const float* emb, const void* attr, int attr_is_f16, float* attr_out, float* logits, int B, int T,
                      int Tp, int C, int D, hipStream_t stream) {
     if (B <= 0 || T <= 0 || Tp < T || C <= 0 || D <= 0 || (D & 3)) return EEND_EINVAL;
     const long n = (long)B * T * C;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, emb, attr, attr_out,
-                       logits, B, T, Tp, C, D);
+    if (attr_is_f16)
+        hipLaunchKernelGGL(head_kernel<_Float16>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, emb, (const _Float16*)attr,
+                           attr_out, logits, B, T, Tp, C, D);
+    else
+        hipLaunchKernelGGL(head_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, emb, (const float*)attr, attr_out,
+                           logits, B, T, Tp, C, D);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

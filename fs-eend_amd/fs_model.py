@@ -380,8 +380,7 @@ class OnlineTransformerDADiarization(nn.Module):
         ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), None if res16 else ws.a32, ws.a16, B, Tp, C)
         q, k, vt = ws.q[:Md * D], ws.k[:Md * D], ws.vt[:Md * D]
         o16 = ws.o16[:Md]
-        nd = len(P["dec.layers"])
-        for li, L in enumerate(P["dec.layers"]):
+        for L in P["dec.layers"]:
             F = L["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
             if FUSED_INPROJ_ATTN and Tp <= 512:
@@ -398,8 +397,7 @@ class OnlineTransformerDADiarization(nn.Module):
                 ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
                 ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
                 ops.attnout_ffn_fused_res16(o16, L["out2_w"], L["out2_b"], ws.a16, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
-                                            L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32 if li == nd - 1 else None,
-                                            ws.a16)
+                                            L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], None, ws.a16)
                 continue
             ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
             if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
@@ -422,7 +420,7 @@ class OnlineTransformerDADiarization(nn.Module):
         # ---- attractor L2 norm + embedding . attractor head (model :43,:60)
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
-        ops.head_l2dot(emb32, ws.a32, attr, logits, B, T, Tp, C, D)
+        ops.head_l2dot(emb32, ws.a16 if res16 else ws.a32, attr, logits, B, T, Tp, C, D)
         emb = emb32.view(B, Tp, D)
         return logits, emb, attr, T, Tp
 

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "eend_attn_causal_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "eend_spk_attn_f16": [_vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_head_l2dot_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "eend_head_l2dot_a16_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     # ---- training step
     "eend_linear_res_ln_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "eend_linear_relu_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],

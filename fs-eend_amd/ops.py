@@ -254,10 +254,17 @@ def emb_consistency(emb32, labels, T, lens=None, inv_count=0.0):
     return out[0]
 
 
-def head_l2dot(emb32, attr32, attr_out, logits, B, T, Tp, C, D):
+def head_l2dot(emb32, attr, attr_out, logits, B, T, Tp, C, D):
+    """attr: the un-normalised attractor rows, f32 or f16 (B*C*Tp, D)."""
     L = _lib.load()
-    _chk(emb32, F32, "emb32"); _chk(attr32, F32, "attr32"); _chk(attr_out, F32, "attr_out"); _chk(logits, F32, "logits")
-    _lib.check(L.eend_head_l2dot_f32(_p(emb32), _p(attr32), _p(attr_out), _p(logits), B, T, Tp, C, D, _stream()),
+    _chk(emb32, F32, "emb32"); _chk(attr_out, F32, "attr_out"); _chk(logits, F32, "logits")
+    if attr.dtype == F16:
+        _chk(attr, F16, "attr")
+        _lib.check(L.eend_head_l2dot_a16_f32(_p(emb32), _p(attr), _p(attr_out), _p(logits), B, T, Tp, C, D, _stream()),
+                   "eend_head_l2dot_a16_f32")
+        return
+    _chk(attr, F32, "attr")
+    _lib.check(L.eend_head_l2dot_f32(_p(emb32), _p(attr), _p(attr_out), _p(logits), B, T, Tp, C, D, _stream()),
                "eend_head_l2dot_f32")
 
 

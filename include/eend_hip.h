@@ -364,6 +364,10 @@ int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const fl
  * -> attr_out f32 [B][T][C][D], logits f32 [B][T][C]. */
 int eend_head_l2dot_f32(const float* emb, const float* attr, float* attr_out, float* logits, int B, int T,
                         int Tp, int C, int D, void* stream);
+/* The same reading the un-normalised attractors from the f16 stream (FS-EEND f16 residual mode: the last decoder LayerNorm's
+ * output is then never written in f32). */
+int eend_head_l2dot_a16_f32(const float* emb, const void* attr_f16, float* attr_out, float* logits, int B, int T,
+                            int Tp, int C, int D, void* stream);
 
 
 /* ======================================================================================================
