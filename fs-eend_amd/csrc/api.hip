@@ -312,6 +312,18 @@ int eend_linear_res_ln_step_f32(const float* A, int lda, const float* W, int ldw
     return eend_launch_skinny_res_f32(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 1, (hipStream_t)stream);
 }
 
+int eend_linear_res_scale_ln_step_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
+                                      const float* gamma, const float* beta, float eps, float* out_f32, float* ln_out_f32,
+                                      void* ln_out_f16, int M, int K, void* stream) {
+    if (!gamma || !beta || !out_f32) return EEND_EINVAL;
+    return eend_launch_skinny_res_f32(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, ln_out_f16, M, K, 2, (hipStream_t)stream,
+                                      ln_out_f32);
+}
+
+int eend_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, int M, void* stream) {
+    return eend_launch_layernorm_rows_f32(x, gamma, beta, eps, out_f32, M, (hipStream_t)stream);
+}
+
 int eend_l2norm_rows_f32(const float* x, float* y, int rows, void* stream) {
     return eend_launch_l2norm_rows_f32(x, y, rows, (hipStream_t)stream);
 }

@@ -183,7 +183,8 @@ int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ld
                                  int K, int act, hipStream_t stream);
 int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
                                const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K, int mode,
-                               hipStream_t stream);
+                               hipStream_t stream, float* ln_out32 = nullptr);
+int eend_launch_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float eps, float* out32, int M, hipStream_t stream);
 int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int C,
                                  hipStream_t stream);
 int eend_launch_ret_proj_step(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,

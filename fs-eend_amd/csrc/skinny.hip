@@ -133,7 +133,7 @@ void skinny_linear_kernel(const SkinnyParams p) {
 // normalise_out32: out32 = LN(x) (EPI_RES_LN) -- else out32 keeps the un-normalised stream (EPI_RES_SCALE_LN16).
 __global__ __launch_bounds__(64)
 void skinny_ln_kernel(float* __restrict__ x32, _Float16* __restrict__ out16, const float* __restrict__ gamma,
-                      const float* __restrict__ beta, float eps, int normalise_out32) {
+                      const float* __restrict__ beta, float eps, int normalise_out32, float* __restrict__ ln_out32 = nullptr) {
     const int m = blockIdx.x, lane = threadIdx.x;
     float4 v = *(const float4*)(x32 + (size_t)m * 256 + lane * 4);
     float s = v.x + v.y + v.z + v.w;
@@ -149,6 +149,7 @@ void skinny_ln_kernel(float* __restrict__ x32, _Float16* __restrict__ out16, con
     if (gamma) { g = *(const float4*)(gamma + lane * 4); b = *(const float4*)(beta + lane * 4); }
     const float4 y = make_float4(d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w);
     if (normalise_out32) *(float4*)(x32 + (size_t)m * 256 + lane * 4) = y;
+    if (ln_out32) *(float4*)(ln_out32 + (size_t)m * 256 + lane * 4) = y;          // f32 copy of LN(x) beside the un-normalised stream
     if (out16) {
         f16x4 o;
         o[0] = to_f16_sat(y.x); o[1] = to_f16_sat(y.y); o[2] = to_f16_sat(y.z); o[3] = to_f16_sat(y.w);
@@ -214,14 +215,20 @@ int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ld
     return launch_skinny<SK_PLAIN, true>(p, stream);
 }
 
+int eend_launch_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float eps, float* out32, int M, hipStream_t stream) {
+    if (!x || !gamma || !beta || !out32 || M <= 0) return EEND_EINVAL;
+    hipLaunchKernelGGL(skinny_ln_kernel, dim3(M), dim3(64), 0, stream, (float*)x, (_Float16*)nullptr, gamma, beta, eps, 0, out32);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
 int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
                                const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K, int mode,
-                               hipStream_t stream) {
+                               hipStream_t stream, float* ln_out32) {
     if (!A || !W || !out32 || M < 1 || M > EEND_SKINNY_MAX_M || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
         return EEND_EINVAL;
     SkinnyParams p{A, lda, W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32, mode == 0 ? (_Float16*)out16 : nullptr, 256};
     int rc = launch_skinny<SK_RES, true>(p, stream);
     if (rc != EEND_OK || mode == 0) return rc;
-    hipLaunchKernelGGL(skinny_ln_kernel, dim3(M), dim3(64), 0, stream, out32, (_Float16*)out16, gamma, beta, eps, mode == 1 ? 1 : 0);
+    hipLaunchKernelGGL(skinny_ln_kernel, dim3(M), dim3(64), 0, stream, out32, (_Float16*)out16, gamma, beta, eps, mode == 1 ? 1 : 0, ln_out32);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -51,6 +51,8 @@ PROTOTYPES = {
     "eend_linear_step_f32": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_linear_res_ln_step_f32": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_spk_attn_step_f32": [_vp, _vp, _i, _i, _f, _vp],
+    "eend_linear_res_scale_ln_step_f32": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
+    "eend_layernorm_rows_f32": [_vp, _vp, _vp, _f, _vp, _i, _vp],
     "eend_l2norm_rows_f32": [_vp, _vp, _i, _vp],
     "eend_convert_fanout_step_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "eend_dwconv_step_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],

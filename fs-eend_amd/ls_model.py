@@ -314,6 +314,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         w = torch.zeros(D, Fin_pad, dtype=torch.float16, device=dev)
         w[:, :Fin] = e.input_projection.linear.weight.detach().to(torch.float16)
         P["in.w"], P["in.b"] = w, _f32(e.input_projection.linear.bias)
+        w32 = torch.zeros(D, Fin_pad, dtype=torch.float32, device=dev)            # f32 frame step (ls_stream.enc_step)
+        w32[:, :Fin] = e.input_projection.linear.weight.detach()
+        P["in.w32"] = w32
         P["in.g"], P["in.beta"], P["in.eps"] = _f32(e.layer_norm.weight), _f32(e.layer_norm.bias), e.layer_norm.eps
         P["Fin_pad"] = Fin_pad
         blocks = []
@@ -342,6 +345,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 lnd=(_f32(ffb[0].weight), _f32(ffb[0].bias), ffb[0].eps),
                 w1b=_f16(ffb[1].linear.weight), b1b=_f32(ffb[1].linear.bias),
                 w2b=_f16(ffb[4].linear.weight), b2b=_f32(ffb[4].linear.bias),
+                # f32 half-step FFN weights of the frame step (ls_stream.enc_step)
+                w1a32=_f32(ffa[1].linear.weight), w2a32=_f32(ffa[4].linear.weight),
+                w1b32=_f32(ffb[1].linear.weight), w2b32=_f32(ffb[4].linear.weight),
                 lne=(_f32(ln_e.weight), _f32(ln_e.bias), ln_e.eps)))
         P["blocks"] = blocks
         cw = self.cnn.weight.detach()

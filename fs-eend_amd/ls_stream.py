@@ -70,8 +70,9 @@ def _scratch(owner, key, N, D, F):
         sc = dict(N=N, F=F, xin16=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F16, device=dev),
                   h32=e(N, D, dt=F32), h16=e(N, D), x16=e(N, D), qkvg=e(N, 4 * D), qkvg32=e(N, 4 * D, dt=F32), o16=e(N, D), glu16=e(N, D),
                   dw16=e(N, D), ff16=e(N * F), qkv16=e(N, 3 * D))
-        if N <= ops.STEP_F32_MAX_ROWS:                # the all-f32 decoder frame step
-            sc.update(o32=e(N, D, dt=F32), qkv32=e(N, 3 * D, dt=F32), ff32=e(N * F, dt=F32))
+        if N <= ops.STEP_F32_MAX_ROWS:                # the all-f32 decoder frame step / f32 encoder input projection
+            sc.update(o32=e(N, D, dt=F32), qkv32=e(N, 3 * D, dt=F32), ff32=e(N * F, dt=F32),
+                      xin32=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F32, device=dev))
         owner._step_scratch[key] = sc
     return sc
 
@@ -87,16 +88,33 @@ def enc_step(owner, x_t, t, ret_states, conv_caches):
     F = P["blocks"][0]["w1a"].shape[0] if P["blocks"] else 0
     sc = _scratch(owner, "enc", B, D, F)
     xin16, h32, h16, x16 = sc["xin16"][:B], sc["h32"][:B], sc["h16"][:B], sc["x16"][:B]
-    ops.bn_cast_pad(x, None, xin16, 1, 1, False)
-    ops.linear_res_ln(xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], h32, h16, P["in.eps"])
+    if F32_PROJ and DEC_F32 and B <= ops.STEP_F32_MAX_ROWS:
+        # the input projection in f32: the raw log-mel features are O(10), so their f16 rounding is the largest single operand
+        # error of the encoder step (5e-4 on the worst logit of the one-hour stream, emulated on the oracle)
+        xin32 = sc["xin32"][:B]
+        xin32[:, :x.shape[-1]].copy_(x.view(B, -1))
+        ops.linear_res_ln_step_f32(xin32, P["in.w32"], P["in.b"], None, P["in.g"], P["in.beta"], h32, P["in.eps"], out16=h16)
+    else:
+        ops.bn_cast_pad(x, None, xin16, 1, 1, False)
+        ops.linear_res_ln(xin16, P["in.w"], P["in.b"], None, P["in.g"], P["in.beta"], h32, h16, P["in.eps"])
     nb = len(P["blocks"])
+    f32_ffn = F32_PROJ and DEC_F32 and B <= ops.STEP_F32_MAX_ROWS     # the two half-step FFNs of every block in f32 (weights included)
+    xn32 = sc["o32"][:B] if f32_ffn else None                          # LN(x) in f32: the FFN input
     for i, Bk in enumerate(P["blocks"]):
-        if i == 0:
-            ops.layernorm_f16(h32, Bk["lna"][0], Bk["lna"][1], x16, Bk["lna"][2])
         Fi = Bk["w1a"].shape[0]
-        ff = sc["ff16"][:B * Fi].view(B, Fi)
-        ops.linear(x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
-        ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1], h32, x16, Bk["lnb"][2])
+        if f32_ffn:
+            ff32 = sc["ff32"][:B * Fi].view(B, Fi)
+            if i == 0:
+                ops.layernorm_rows_f32(h32, Bk["lna"][0], Bk["lna"][1], xn32, Bk["lna"][2])
+            ops.linear_step_f32(xn32, Bk["w1a32"], Bk["b1a"], ff32, act=ops.ACT_SWISH)
+            ops.linear_res_scale_ln_step_f32(ff32, Bk["w2a32"], Bk["b2a"], h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1], h32,
+                                             ln_out16=x16, eps=Bk["lnb"][2])
+        else:
+            if i == 0:
+                ops.layernorm_f16(h32, Bk["lna"][0], Bk["lna"][1], x16, Bk["lna"][2])
+            ff = sc["ff16"][:B * Fi].view(B, Fi)
+            ops.linear(x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
+            ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1], h32, x16, Bk["lnb"][2])
         o16 = _ret_step(x16, h32, Bk["lnb"], Bk, ret_states[i], B, H, sc)
         ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], h32, 1.0, Bk["lnc"][0], Bk["lnc"][1], h32, x16, Bk["lnc"][2])
         glu, dw = sc["glu16"][:B], sc["dw16"][:B]
@@ -106,6 +124,15 @@ def enc_step(owner, x_t, t, ret_states, conv_caches):
             raise EendHipError("conv cache must be a contiguous f32 GPU tensor (B, D, k-1)")
         ops.dwconv_step(glu, cache, Bk["dw"], Bk["bn"], dw, Bk["bn_eps"])      # cache shifted in place
         ops.linear_res_scale_ln16(dw, Bk["pw2"], Bk["pb2"], h32, 1.0, Bk["lnd"][0], Bk["lnd"][1], h32, x16, Bk["lnd"][2])
+        if f32_ffn:
+            ops.layernorm_rows_f32(h32, Bk["lnd"][0], Bk["lnd"][1], xn32, Bk["lnd"][2])
+            ops.linear_step_f32(xn32, Bk["w1b32"], Bk["b1b"], ff32, act=ops.ACT_SWISH)
+            ops.linear_res_ln_step_f32(ff32, Bk["w2b32"], Bk["b2b"], h32, Bk["lne"][0], Bk["lne"][1], h32, Bk["lne"][2], alpha=Bk["fb"],
+                                       out16=h16)
+            if i + 1 < nb:
+                nx = P["blocks"][i + 1]["lna"]
+                ops.layernorm_rows_f32(h32, nx[0], nx[1], xn32, nx[2])
+            continue
         ops.linear(x16, Bk["w1b"], Bk["b1b"], ff, act=ops.ACT_SWISH)
         ops.linear_res_ln(ff, Bk["w2b"], Bk["b2b"], h32, Bk["lne"][0], Bk["lne"][1], h32, h16, Bk["lne"][2], alpha=Bk["fb"])
         if i + 1 < nb:

@@ -317,6 +317,29 @@ def linear_res_ln_step_f32(a32, w32, bias, res, gamma, beta, out32, eps=1e-5, al
                                              _p(beta), eps, _p(out32), _p(out16), M, K, _stream()), "eend_linear_res_ln_step_f32")
 
 
+def linear_res_scale_ln_step_f32(a32, w32, bias, res, alpha, gamma, beta, out32, ln_out32=None, ln_out16=None, eps=1e-5):
+    """out32 = (a32 w32^T + bias) * alpha + res (un-normalised stream, may alias res); ln_out32 / ln_out16 = LayerNorm(out32)."""
+    L = _lib.load()
+    for n, t in (("a32", a32), ("w32", w32), ("bias", bias), ("res", res), ("gamma", gamma), ("beta", beta), ("out32", out32), ("ln_out32", ln_out32)):
+        _chk(t, F32, n)
+    _chk(ln_out16, F16, "ln_out16")
+    M, K = a32.shape
+    if w32.shape[0] != 256:
+        raise _lib.EendHipError("linear_res_scale_ln_step_f32: N must be 256")
+    _lib.check(L.eend_linear_res_scale_ln_step_f32(_p(a32), a32.stride(0), _p(w32), w32.stride(0), _p(bias), _p(res), float(alpha),
+                                                   _p(gamma), _p(beta), eps, _p(out32), _p(ln_out32), _p(ln_out16), M, K, _stream()),
+               "eend_linear_res_scale_ln_step_f32")
+
+
+def layernorm_rows_f32(x32, gamma, beta, out32, eps=1e-5):
+    L = _lib.load()
+    _chk(x32, F32, "x32"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32")
+    if x32.shape[-1] != 256:
+        raise _lib.EendHipError("layernorm_rows_f32: rows of 256 features")
+    _lib.check(L.eend_layernorm_rows_f32(_p(x32), _p(gamma), _p(beta), eps, _p(out32), x32.numel() // 256, _stream()),
+               "eend_layernorm_rows_f32")
+
+
 def l2norm_rows_f32(x32, y32):
     L = _lib.load()
     _chk(x32, F32, "x32"); _chk(y32, F32, "y32")

@@ -317,6 +317,13 @@ int eend_linear_res_ln_step_f32(const float* A, int lda, const float* W, int ldw
                                 const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, int M, int K,
                                 void* stream);
 int eend_spk_attn_step_f32(const float* qkv, float* out_f32, int B, int C, float scale, void* stream);
+/* ... and of the Conformer encoder's f32 half-step FFNs (feed_forward.py:47-57 inside the pre-norm blocks of
+ * conformer/encoder.py:76-113): the pre-norm join out_f32 = (A W^T + bias) * alpha + res (the un-normalised stream) with the NEXT
+ * sub-layer's LayerNorm of it as ln_out_f32 and / or ln_out_f16; and a plain row LayerNorm f32 -> f32 (256 features). */
+int eend_linear_res_scale_ln_step_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
+                                      const float* gamma, const float* beta, float eps, float* out_f32, float* ln_out_f32,
+                                      void* ln_out_f16, int M, int K, void* stream);
+int eend_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, int M, void* stream);
 /* y[r] = x[r] / ||x[r]||_2, f32 rows of 256 features: the embedding normalisation (LS model :87, no eps) behind the f32
  * look-ahead conv of a frame step (the conv itself is eend_linear_step_f32 over the flattened 19-frame window). */
 int eend_l2norm_rows_f32(const float* x, float* y, int rows, void* stream);

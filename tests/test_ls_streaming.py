@@ -210,6 +210,16 @@ def test_f32_frame_step_entries_vs_torch(hip_lib, dev, N, C):
     want = torch.nn.functional.layer_norm(pre, (256,), gam.double(), bet.double(), 1e-5)
     assert float((out.double() - want).abs().max()) < 5e-6 * float(want.abs().max())
     assert float((o16.double() - want).abs().max()) < 2e-3 * float(want.abs().max())
+    # pre-norm join: un-normalised stream + LayerNorm of it (f32 and f16 copies); plain row LayerNorm
+    stream = res.clone()
+    ln32, ln16 = torch.empty(N, 256, device=dev), torch.empty(N, 256, dtype=torch.float16, device=dev)
+    ops.linear_res_scale_ln_step_f32(h, w2, b2, stream, 0.5, gam, bet, stream, ln_out32=ln32, ln_out16=ln16, eps=1e-5)
+    assert float((stream.double() - pre).abs().max()) < 5e-6 * float(pre.abs().max())
+    assert float((ln32.double() - want).abs().max()) < 5e-6 * float(want.abs().max())
+    assert float((ln16.double() - want).abs().max()) < 2e-3 * float(want.abs().max())
+    ln_only = torch.empty(N, 256, device=dev)
+    ops.layernorm_rows_f32(stream, gam, bet, ln_only, 1e-5)
+    assert torch.equal(ln_only, ln32)
     wq, bq = rn(768, 256, sc=0.06), rn(768, sc=0.1)
     qkv = torch.empty(N, 768, device=dev)
     ops.linear_step_f32(x, wq, bq, qkv)
