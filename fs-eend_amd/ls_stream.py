@@ -70,9 +70,11 @@ def _scratch(owner, key, N, D, F):
         sc = dict(N=N, F=F, xin16=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F16, device=dev),
                   h32=e(N, D, dt=F32), h16=e(N, D), x16=e(N, D), qkvg=e(N, 4 * D), qkvg32=e(N, 4 * D, dt=F32), o16=e(N, D), glu16=e(N, D),
                   dw16=e(N, D), ff16=e(N * F), qkv16=e(N, 3 * D))
-        if N <= ops.STEP_F32_MAX_ROWS:                # the all-f32 decoder frame step / f32 encoder input projection
-            sc.update(o32=e(N, D, dt=F32), qkv32=e(N, 3 * D, dt=F32), ff32=e(N * F, dt=F32),
-                      xin32=torch.zeros(N, owner._prepare()["Fin_pad"], dtype=F32, device=dev))
+        # buffers of the f32 frame steps (<= 16 rows): always present -- the scratch is cached on the model and a later, smaller
+        # session reuses what a larger one allocated
+        n32 = min(N, ops.STEP_F32_MAX_ROWS)
+        sc.update(o32=e(n32, D, dt=F32), qkv32=e(n32, 3 * D, dt=F32), ff32=e(n32 * F, dt=F32),
+                  xin32=torch.zeros(n32, owner._prepare()["Fin_pad"], dtype=F32, device=dev))
         owner._step_scratch[key] = sc
     return sc
 

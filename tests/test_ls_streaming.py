@@ -231,3 +231,35 @@ def test_f32_frame_step_entries_vs_torch(hip_lib, dev, N, C):
     p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
     want_a = (p @ v).transpose(1, 2).reshape(N, 256)
     assert float((att.double() - want_a).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("nstreams", [3, 20])
+def test_ls_stream_session_several_streams_match_single_streams(hip_lib, dev, nstreams):
+    """A session with several concurrent streams (3: encoder / look-ahead conv in f32, decoder rows 3 x C > 16 -> f16 decoder step;
+    20: everything on the f16 frame steps) gives every stream what a one-stream session (all-f32 frame step) gives it, within the
+    f16-step tolerance, and the streams do not leak into each other (stream 0 is fed the same input in both)."""
+    from fs_eend_amd.ls_stream import LsStreamSession
+    meta, arr = FX.load_case("ls_stream_T120")
+    m = build_ls_mirror(meta).to(dev)
+    C, T = meta["C"], 70
+    g = torch.Generator().manual_seed(nstreams)
+    base = FX.make_src([meta["T"]], meta["in_size"], meta["xseed"])[0][:T]
+    srcs = torch.stack([base] + [base + 0.3 * torch.randn(base.shape, generator=g) for _ in range(nstreams - 1)]).to(dev)   # (S, T, F)
+    multi = LsStreamSession(m, C, batch=nstreams)
+    ys = []
+    for t in range(T):
+        y = multi.push(srcs[:, t])
+        if y is not None:
+            ys.append(y)
+    ys = torch.cat(ys, dim=1)                               # (S, frames, C)
+    for s_ in (0, nstreams - 1):
+        one = LsStreamSession(m, C, batch=1)
+        yo = []
+        for t in range(T):
+            y = one.push(srcs[s_:s_ + 1, t])
+            if y is not None:
+                yo.append(y)
+        yo = torch.cat(yo, dim=1)
+        assert yo.shape[1] == ys.shape[1]
+        assert max_abs(ys[s_], yo[0].cpu()) < 6e-4, (s_, max_abs(ys[s_], yo[0].cpu()))
+    assert max_abs(ys[0], arr["stream_logits"][:ys.shape[1]]) < 1e-3          # stream 0 is the golden input
