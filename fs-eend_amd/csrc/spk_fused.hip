@@ -50,6 +50,20 @@ DEV float quad_allreduce_add(float v) {
     return v;
 }
 
+// Perf-study build (-DEEND_SPK_TRACE, tools/spk_trace.py): s_memtime stamps of the tile phases of thread 0 of every workgroup,
+// read back through eend_debug_spk_trace; never defined in the shipped library.
+#ifdef EEND_SPK_TRACE
+__device__ unsigned long long g_spk_trace[256 * 16 * 12];
+#define SPK_STAMP(k)                                                                                              \
+    do {                                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 256 && (tile - (int)blockIdx.x) / (int)gridDim.x < 16)              \
+            g_spk_trace[((size_t)blockIdx.x * 16 + (tile - (int)blockIdx.x) / (int)gridDim.x) * 12 + (k)] =      \
+                __builtin_amdgcn_s_memtime();                                                                     \
+    } while (0)
+#else
+#define SPK_STAMP(k) do {} while (0)
+#endif
+
 template <int C>
 __global__ __launch_bounds__(NT)
 void spk_qkv_attn_kernel(const SpkFusedParams p) {
@@ -65,6 +79,7 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
         const int b = tile / tiles_per_b, t0 = (tile - b * tiles_per_b) * G;
         if (tile != (int)blockIdx.x)          // the previous tile's LDS reads are retired before anything lands
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SPK_STAMP(0);
         int tid = threadIdx.x;                // laundered per tile: see ffn.hip
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63;
@@ -107,6 +122,7 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
             *(u32x4*)(Xst + (c32 >> 3) * (BM * 128) + swz128(row, c32 & 7)) = v;
         }
         __syncthreads();
+        SPK_STAMP(1);
         f16x8 xf[4][2][2];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -116,6 +132,7 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
                 for (int j = 0; j < 2; ++j)
                     xf[kt][ks][j] = *(const f16x8*)(Xst + kt * (BM * 128) + swz128(gm + j * 16 + frow, ks * 4 + fkg));
         __syncthreads();                      // staging tile is free: it becomes the q / k / v tiles
+        SPK_STAMP(2);
 
         // attention of one head on the three staged tiles
         const int item = tid >> 2, part = tid & 3;                 // 4 threads per (slot, frame): 16 head dims each
@@ -219,10 +236,12 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
                 }
                 __syncthreads();              // tile visible; this slice's weight buffer is free; slice ch+1 has landed
                 if (ch + 2 < 12) dma_w(ch + 2, ch & 1);
+                if (head == 0) SPK_STAMP(3 + sidx);
             });
             attention(head);
             if (head < 3)                     // every thread is done with the q / k / v tiles before they are rewritten
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            SPK_STAMP(6 + head);
         }
     }
 }
@@ -247,6 +266,12 @@ int launch(const SpkFusedParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef EEND_SPK_TRACE
+extern "C" int eend_debug_spk_trace(void* dst, void* stream) {
+    return hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_spk_trace), sizeof(g_spk_trace), 0, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream) {
     if (!p.X || !p.W || !p.bias || !p.O || p.B <= 0 || p.Tp <= 0 || p.Tv <= 0 || p.Tv > p.Tp || (p.ldx & 7)) return EEND_EINVAL;
