@@ -171,6 +171,37 @@ int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, con
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_ffn_stream_elems(int F, int with_wo) { return (int)eend_ffn_stream_nelems(F, with_wo); }
+
+int eend_ffn_stream_pack_f16(const void* Wo, const void* W1, const void* W2, void* stream_out, int F, void* stream) {
+    return eend_launch_ffn_stream_pack(Wo, W1, W2, stream_out, F, Wo ? 1 : 0, (hipStream_t)stream);
+}
+
+int eend_ffn_stream_f16(const void* X, int ldx, const void* wstream, const float* b1, const float* b2,
+                        const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                        float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
+                        void* stream) {
+    FfnStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = X; p.lda = ldx; p.wstream = wstream; p.b1 = b1; p.b2 = b2; p.res32 = res; p.alpha = alpha; p.gamma = gamma;
+    p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
+    return eend_launch_ffn_stream(p, 0, act, residual_stream_unnormalised ? FFN_EPI_RES_SCALE_LN16 : FFN_EPI_RES_LN,
+                                  (hipStream_t)stream);
+}
+
+int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res,
+                                const void* res_f16, const float* g1, const float* be1, float eps1, const float* b1,
+                                const float* b2, const float* g2, const float* be2, float eps2,
+                                float* out_f32, void* out_f16, int M, int F, void* stream) {
+    if ((res != nullptr) == (res_f16 != nullptr)) return EEND_EINVAL;
+    FfnStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.wstream = wstream; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1; p.res32 = res; p.res16 = res_f16;
+    p.b1 = b1; p.b2 = b2; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2; p.out32 = out_f32; p.out16 = out_f16;
+    p.M = M; p.F = F;
+    return eend_launch_ffn_stream(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
 int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
                                const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
                                const void* Win2, const float* bin2,

@@ -241,6 +241,30 @@ struct FfnParams {
     int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read, 4 no in-loop weight DMA
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);
+
+// ffn_stream.hip: the same row-local layer tail on a packed weight stream (4 waves x 48 rows, wave-private hidden units)
+struct FfnStreamParams {
+    const void* A;        // mode 1: attention output f16 [M][lda]; mode 0: X f16 [M][lda]
+    int lda;
+    const void* wstream;  // eend_ffn_stream_pack_f16 output
+    const float* bo;      // mode 1: out-projection bias, LayerNorm1 affine
+    const float* g1;
+    const float* be1;
+    float eps1;
+    const float* res32;   // residual f32 [M][256] (mode 0: required) ...
+    const void* res16;    // ... or, mode 1, f16 [M][256]
+    const float* b1;      // [F]
+    const float* b2;      // [256]
+    const float* gamma;   // final LayerNorm affine
+    const float* beta;
+    float eps, alpha;
+    float* out32;         // may be null in mode 1 / FFN_EPI_RES_LN
+    void* out16;
+    int M, F;
+};
+long eend_ffn_stream_nelems(int F, int with_wo);
+int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
+int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);
 
 enum ProjKind { PROJ_ROWMAJOR = 0, PROJ_HEADS = 1, PROJ_HEADS_T = 2, PROJ_HEADS_BOTH = 3 };

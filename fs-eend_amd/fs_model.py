@@ -39,6 +39,8 @@ FUSED_TAIL = __import__("os").environ.get("EEND_TAIL_FUSED", "0") == "1"
 # time-axis attention: in-projection + causal attention in one launch per layer, K / V never leave the CU (attn_fused.hip;
 # chunks up to 512 frames).  EEND_ATTN_FUSED=0 keeps the two-kernel path (A/B, and the only path for longer chunks).
 FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
+# packed-weight-stream layer-tail kernel (ffn_stream.hip, round 4) in place of ffn.hip's; EEND_FFN_STREAM=0: the round-3 kernel (A/B)
+FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM", "1") != "0"
 # f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
 RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
 
@@ -266,6 +268,10 @@ class OnlineTransformerDADiarization(nn.Module):
                 w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
                 g1=_f32(l.norm1.weight), be1=_f32(l.norm1.bias), eps1=l.norm1.eps,
                 g2=_f32(l.norm2.weight), be2=_f32(l.norm2.bias), eps2=l.norm2.eps))
+        if FFN_STREAM and FUSED_FFN and FUSED_ATTNOUT:
+            for L in layers:
+                if ops.stream_ok(L["w1"].shape[0]):
+                    L["ws"] = ops.ffn_stream_pack(L["out_w"], L["w1"], L["w2"])
         P["enc.layers"] = layers
         cw = self.cnn.weight.detach()                       # (Dout, Din, k)
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
@@ -284,6 +290,10 @@ class OnlineTransformerDADiarization(nn.Module):
                 g11=_f32(l.norm11.weight), be11=_f32(l.norm11.bias), eps11=l.norm11.eps,
                 g21=_f32(l.norm21.weight), be21=_f32(l.norm21.bias), eps21=l.norm21.eps,
                 g22=_f32(l.norm22.weight), be22=_f32(l.norm22.bias), eps22=l.norm22.eps))
+        if FFN_STREAM and FUSED_FFN and FUSED_ATTNOUT:
+            for L in dl:
+                if ops.stream_ok(L["w1"].shape[0]):
+                    L["ws"] = ops.ffn_stream_pack(L["out2_w"], L["w1"], L["w2"])
         P["dec.layers"] = dl
         self._prep, self._prep_key = P, key
         self._pc = {}
@@ -355,6 +365,10 @@ class OnlineTransformerDADiarization(nn.Module):
             else:
                 ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
                 ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
+            if "ws" in L and FUSED_FFN and FUSED_ATTNOUT:   # the same launch on the packed weight stream (ffn_stream.hip)
+                ops.attnout_ffn_stream(o16, L["ws"], L["out_b"], None if res16 else ws.h32, ws.h16 if res16 else None, L["g1"], L["be1"],
+                                       L["eps1"], L["b1"], L["b2"], L["g2"], L["be2"], L["eps2"], None if res16 else ws.h32, ws.h16)
+                continue
             if res16:
                 ops.attnout_ffn_fused_res16(o16, L["out_w"], L["out_b"], ws.h16, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
                                             L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], None, ws.h16)
@@ -396,6 +410,10 @@ class OnlineTransformerDADiarization(nn.Module):
             if res16:
                 ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
                 ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
+                if "ws" in L:
+                    ops.attnout_ffn_stream(o16, L["ws"], L["out2_b"], None, ws.a16, L["g21"], L["be21"], L["eps21"], L["b1"], L["b2"],
+                                           L["g22"], L["be22"], L["eps22"], None, ws.a16)
+                    continue
                 ops.attnout_ffn_fused_res16(o16, L["out2_w"], L["out2_b"], ws.a16, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
                                             L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], None, ws.a16)
                 continue
@@ -405,6 +423,10 @@ class OnlineTransformerDADiarization(nn.Module):
             else:
                 ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
                 ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            if FUSED_FFN and FUSED_ATTNOUT and "ws" in L:
+                ops.attnout_ffn_stream(o16, L["ws"], L["out2_b"], ws.a32, None, L["g21"], L["be21"], L["eps21"], L["b1"], L["b2"],
+                                       L["g22"], L["be22"], L["eps22"], ws.a32, ws.a16)
+                continue
             if FUSED_FFN and FUSED_ATTNOUT:
                 ops.attnout_ffn_fused(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
                                       L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32, ws.a16)

@@ -485,6 +485,60 @@ def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, 
                "eend_attnout_ffn_fused_f16")
 
 
+def ffn_stream_pack(wo, w1, w2):
+    """Pack Wo (or None), W1 [F][256], W2 [256][F] into the MFMA-fragment stream of the stream kernels (once per
+    parameter version).  With wo the stream serves attnout_ffn_stream, without it ffn_stream."""
+    L = _lib.load()
+    _chk(w1, F16, "w1"); _chk(w2, F16, "w2")
+    Fh = w1.shape[0]
+    if w1.shape[1] != 256 or w2.shape != (256, Fh) or Fh % 64 or Fh < 64 or not w1.is_contiguous() or not w2.is_contiguous():
+        raise _lib.EendHipError("ffn_stream_pack: expected contiguous W1 [F][256], W2 [256][F], F a multiple of 64")
+    if wo is not None:
+        _chk(wo, F16, "wo")
+        if wo.shape != (256, 256) or not wo.is_contiguous():
+            raise _lib.EendHipError("ffn_stream_pack: expected contiguous Wo [256][256]")
+    n = L.eend_ffn_stream_elems(Fh, 1 if wo is not None else 0)
+    out = torch.empty(n, dtype=F16, device=w1.device)
+    _lib.check(L.eend_ffn_stream_pack_f16(_p(wo), _p(w1), _p(w2), _p(out), Fh, _stream()), "eend_ffn_stream_pack_f16")
+    return out
+
+
+def stream_ok(Fh):
+    """Whether the packed-stream kernels take this hidden width."""
+    return Fh % 64 == 0 and 64 <= Fh <= 2048
+
+
+def attnout_ffn_stream(a16, wstream, bo, res, res16, g1, be1, eps1, b1, b2, g2, be2, eps2, out32, out16):
+    """attnout_ffn_fused[_res16] on a packed weight stream (ffn_stream_pack(wo, w1, w2)); exactly one of res (f32) / res16."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wstream, F16, "wstream"); _chk(res, F32, "res"); _chk(res16, F16, "res16")
+    for n, t in (("bo", bo), ("g1", g1), ("be1", be1), ("b1", b1), ("b2", b2), ("g2", g2), ("be2", be2), ("out32", out32)):
+        _chk(t, F32, n)
+    _chk(out16, F16, "out16")
+    M, K = a16.shape
+    Fh = b1.shape[0]
+    if K != 256 or wstream.numel() != L.eend_ffn_stream_elems(Fh, 1):
+        raise _lib.EendHipError("attnout_ffn_stream: expected d_model 256 and a stream packed with Wo for this F")
+    _lib.check(L.eend_attnout_ffn_stream_f16(_p(a16), a16.stride(0), _p(wstream), _p(bo), _p(res), _p(res16), _p(g1), _p(be1), eps1,
+                                             _p(b1), _p(b2), _p(g2), _p(be2), eps2, _p(out32), _p(out16), M, Fh, _stream()),
+               "eend_attnout_ffn_stream_f16")
+
+
+def ffn_stream(x16, wstream, b1, b2, res, gamma, beta, out32, out16, act=ACT_RELU, alpha=1.0, eps=1e-5,
+               residual_unnormalised=False):
+    """ffn_fused on a packed weight stream (ffn_stream_pack(None, w1, w2))."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(wstream, F16, "wstream"); _chk(b1, F32, "b1"); _chk(b2, F32, "b2")
+    _chk(res, F32, "res"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    M, K = x16.shape
+    Fh = b1.shape[0]
+    if K != 256 or wstream.numel() != L.eend_ffn_stream_elems(Fh, 0):
+        raise _lib.EendHipError("ffn_stream: expected d_model 256 and a stream packed without Wo for this F")
+    _lib.check(L.eend_ffn_stream_f16(_p(x16), x16.stride(0), _p(wstream), _p(b1), _p(b2), _p(res), float(alpha),
+                                     _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, Fh, act,
+                                     1 if residual_unnormalised else 0, _stream()), "eend_ffn_stream_f16")
+
+
 def fusion_layer_tail(a16, stream32, out16, wo1, bo1, g11, be11, eps11, win2, bin2, wo2, bo2, g21, be21, eps21,
                       w1, b1, w2, b2, g22, be22, eps22, B, C, Tp):
     """Everything of a fusion (decoder) layer after the time-axis attention core, in one launch:

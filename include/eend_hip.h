@@ -155,6 +155,26 @@ int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, con
                                      const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
                                      float* out_f32, void* out_f16, int M, int F, void* stream);
 
+/* Round 4: the same two operators (eend_ffn_fused_f16 / eend_attnout_ffn_fused[_res16]_f16; reference sites as above:
+ * nn.TransformerEncoderLayer of FS model :147, merge_tfm_encoder.py:356-399, LS merge_retnet_layer.py:240-253,
+ * conformer/feed_forward.py:47-57) on a PACKED WEIGHT STREAM.  eend_ffn_stream_pack_f16 re-orders Wo (optional, [256][256]),
+ * W1 ([F][256]) and W2 ([256][F]) once per parameter version into the sequence of 1-KB MFMA fragments the kernel consumes
+ * (eend_ffn_stream_elems(F, with_wo) f16 elements; F a multiple of 64, at most 2048).  With Wo the stream serves eend_attnout_ffn_stream_f16
+ * (the contraction index of W1 follows the register layout LayerNorm1 leaves), without it eend_ffn_stream_f16 (natural order).
+ * The kernel gives one wave 48 token rows end to end: the hidden activations and x stay in its registers, weights flow
+ * through a 4-slot LDS-DMA ring.  Results equal the un-packed entries up to fp32 summation order. */
+int eend_ffn_stream_elems(int F, int with_wo);
+int eend_ffn_stream_pack_f16(const void* Wo, const void* W1, const void* W2, void* stream_out, int F, void* stream);
+int eend_ffn_stream_f16(const void* X, int ldx, const void* wstream, const float* b1, const float* b2,
+                        const float* res, float alpha, const float* gamma, const float* beta, float eps,
+                        float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
+                        void* stream);
+/* res (f32) or res_f16 (f16), exactly one non-null; out_f32 may be NULL */
+int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res,
+                                const void* res_f16, const float* g1, const float* be1, float eps1, const float* b1,
+                                const float* b2, const float* g2, const float* be2, float eps2,
+                                float* out_f32, void* out_f16, int M, int F, void* stream);
+
 /* The whole row-local tail of a fusion (attractor decoder) layer in ONE launch, after the time-axis
  * attention / retention core (FS merge_tfm_encoder.py:364-376: out_proj of self_attn1 + norm11, _sa_block2 +
  * norm21, _ff_block + norm22; LS merge_retnet_layer.py:240-253 likewise with the retention out_proj):

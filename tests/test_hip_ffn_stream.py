@@ -1,0 +1,157 @@
+"""GPU: the packed-weight-stream forms of the fused FFN / out-proj + FFN layer tail (ffn_stream.hip: 4 waves x 48 rows, hidden
+activations wave-private, weights through an LDS-DMA ring) against plain torch fp32 on the same f16-quantised operands and
+against the un-packed kernels of ffn.hip (same operator, different fp32 summation order)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F16, F32 = torch.float16, torch.float32
+
+
+def rnd(shape, dev, seed, dtype=F32, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def test_stream_pack_layout(hip_lib, dev):
+    """The packed stream holds every weight element exactly once, at the documented place, in consumption order:
+    Wo (kc, sl) x 8, W1h(0), { W1h(k), W2h(k-1) } k = 1 .. U-1, W2h(U-1); 16 fragments of [64 lanes][8] per item."""
+    from fs_eend_amd import ops
+    Fh = 128
+    wo = torch.arange(256 * 256, device=dev).remainder(2039).to(F16).view(256, 256).contiguous()
+    w1 = (torch.arange(Fh * 256, device=dev).remainder(2029) + 0.5).to(F16).view(Fh, 256).contiguous()
+    w2 = (torch.arange(256 * Fh, device=dev).remainder(2027) + 0.25).to(F16).view(256, Fh).contiguous()
+    U = Fh // 32
+    lane = torch.arange(64, device=dev)
+    f, g = lane & 15, lane >> 4
+    e = torch.arange(8, device=dev)
+
+    def w1h(k, perm):
+        out = []
+        for p in range(16):
+            s_, hf = p >> 1, p & 1
+            k0 = g[:, None] * 64 + 8 * s_ if perm else s_ * 32 + g[:, None] * 8
+            out.append(w1[(k * 32 + hf * 16 + f)[:, None], k0 + e[None, :]])
+        return torch.stack(out)
+
+    def w2h(k):
+        out = []
+        for i in range(16):
+            n = (f >> 2) * 64 + i * 4 + (f & 3)
+            out.append(w2[n[:, None], k * 32 + (e[None, :] >> 2) * 16 + g[:, None] * 4 + (e[None, :] & 3)])
+        return torch.stack(out)
+
+    for with_wo in (True, False):
+        st = ops.ffn_stream_pack(wo if with_wo else None, w1, w2).view(-1, 16, 64, 8)          # [item][fragment][lane][e]
+        assert st.shape[0] == (8 if with_wo else 0) + 2 * U
+        items = []
+        if with_wo:
+            for kc in range(4):
+                for sl in range(2):
+                    frs = []
+                    for i in range(16):
+                        n = (f >> 2) * 64 + i * 4 + (f & 3)
+                        frs.append(wo[n[:, None], kc * 64 + sl * 32 + g[:, None] * 8 + e[None, :]])
+                    items.append(torch.stack(frs))
+        items.append(w1h(0, with_wo))
+        for k in range(1, U):
+            items += [w1h(k, with_wo), w2h(k - 1)]
+        items.append(w2h(U - 1))
+        assert torch.equal(st, torch.stack(items))
+
+
+@pytest.mark.parametrize("M,Fh,act,alpha,unnorm", [(192, 2048, 1, 1.0, False), (300, 1024, 2, 0.5, True),
+                                                   (1, 256, 1, 1.0, False), (1000, 2048, 1, 1.0, False),
+                                                   (77, 1024, 2, 0.5, False), (50000, 1024, 2, 0.5, True), (191, 64, 1, 1.0, False)])
+def test_ffn_stream(hip_lib, dev, M, Fh, act, alpha, unnorm):
+    from fs_eend_amd import ops
+    x = rnd((M, 256), dev, 1, F16)
+    w1, b1 = rnd((Fh, 256), dev, 2, F16, 0.08), rnd((Fh,), dev, 3) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 4, F16, 0.04), rnd((256,), dev, 5) * 0.3
+    res = rnd((M, 256), dev, 6)
+    g, be = rnd((256,), dev, 7) * 0.2 + 1, rnd((256,), dev, 8) * 0.1
+    ws = ops.ffn_stream_pack(None, w1, w2)
+    o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+    ops.ffn_stream(x, ws, b1, b2, res, g, be, o32, o16, act, alpha, 1e-5, residual_unnormalised=unnorm)
+    h = x.float() @ w1.float().t() + b1
+    h = h.relu() if act == 1 else h * torch.sigmoid(h)
+    h = h.to(F16).float()
+    y = (h @ w2.float().t() + b2) * alpha + res
+    ln = torch.nn.functional.layer_norm(y, (256,), g, be, 1e-5)
+    assert torch.isfinite(o32).all() and torch.isfinite(o16).all()
+    e32 = (o32 - (y if unnorm else ln)).abs().max().item()
+    e16 = (o16.float() - ln).abs().max().item()
+    assert e32 < 2e-3 and e16 < 5e-3, (e32, e16)
+    p32, p16 = torch.empty_like(o32), torch.empty_like(o16)
+    ops.ffn_fused(x, w1, b1, w2, b2, res, g, be, p32, p16, act, alpha, 1e-5, residual_unnormalised=unnorm)
+    assert (o32 - p32).abs().max().item() < 1e-3
+    assert (o16.float() - p16.float()).abs().max().item() < 4e-3
+    # deterministic, and in place as the model calls it (out32 aliases res, out16 aliases x)
+    res2, x2 = res.clone(), x.clone()
+    ops.ffn_stream(x2, ws, b1, b2, res2, g, be, res2, x2, act, alpha, 1e-5, residual_unnormalised=unnorm)
+    assert torch.equal(res2, o32) and torch.equal(x2, o16)
+
+
+@pytest.mark.parametrize("M,Fh,res16,with32", [(192, 2048, True, False), (1000, 2048, True, True), (77, 1024, False, True),
+                                               (40000, 2048, True, False), (40001, 2048, False, True), (1, 64, True, True)])
+def test_attnout_ffn_stream(hip_lib, dev, M, Fh, res16, with32):
+    """out-proj + residual + norm1 + FFN + residual + norm2 on the packed stream == torch fp32 == the un-packed kernel."""
+    from fs_eend_amd import ops
+    a = rnd((M, 256), dev, 21, F16)
+    wo, bo = rnd((256, 256), dev, 22, F16, 0.06), rnd((256,), dev, 23) * 0.2
+    w1, b1 = rnd((Fh, 256), dev, 24, F16, 0.08), rnd((Fh,), dev, 25) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 26, F16, 0.04), rnd((256,), dev, 27) * 0.3
+    res = rnd((M, 256), dev, 28)
+    r16 = res.to(F16)
+    if res16:
+        res = r16.float()
+    g1, be1 = rnd((256,), dev, 29) * 0.2 + 1, rnd((256,), dev, 30) * 0.1
+    g2, be2 = rnd((256,), dev, 31) * 0.2 + 1, rnd((256,), dev, 32) * 0.1
+    ws = ops.ffn_stream_pack(wo, w1, w2)
+    o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev) if with32 else None
+    o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+    ops.attnout_ffn_stream(a, ws, bo, None if res16 else res, r16 if res16 else None, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, o32, o16)
+    x = torch.nn.functional.layer_norm(a.float() @ wo.float().t() + bo + res, (256,), g1, be1, 1e-5)
+    h = (x.to(F16).float() @ w1.float().t() + b1).relu().to(F16).float()
+    want = torch.nn.functional.layer_norm(h @ w2.float().t() + b2 + x, (256,), g2, be2, 1e-5)
+    assert torch.isfinite(o16).all()
+    assert (o16.float() - want).abs().max().item() < 6e-3
+    if with32:
+        assert torch.isfinite(o32).all()
+        assert (o32 - want).abs().max().item() < 3e-3
+    # the un-packed kernel
+    p32, p16 = torch.empty((M, 256), dtype=F32, device=dev), torch.empty_like(o16)
+    if res16:
+        ops.attnout_ffn_fused_res16(a, wo, bo, r16, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, p32, p16)
+    else:
+        ops.attnout_ffn_fused(a, wo, bo, res, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, p32, p16)
+    if with32:
+        assert (o32 - p32).abs().max().item() < 3e-3
+    assert (o16.float() - p16.float()).abs().max().item() < 8e-3
+    # in place, as the model calls it: out16 aliases a (and the f16 residual stream), out32 aliases res; and reproducible
+    a2 = a.clone()
+    if res16:
+        r2 = r16.clone()
+        ops.attnout_ffn_stream(a2, ws, bo, None, r2, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, None, r2)
+        assert torch.equal(r2, o16)
+    else:
+        res2 = res.clone()
+        ops.attnout_ffn_stream(a2, ws, bo, res2, None, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, res2, a2)
+        assert torch.equal(res2, o32) and torch.equal(a2, o16)
+
+
+def test_stream_rejects_bad_arguments(hip_lib, dev):
+    from fs_eend_amd import ops, lib
+    w1, w2 = rnd((192, 256), dev, 1, F16), rnd((256, 192), dev, 2, F16)
+    ws = ops.ffn_stream_pack(None, w1, w2)
+    x = rnd((10, 256), dev, 3, F16)
+    v = torch.zeros(256, device=dev)
+    o32, o16 = torch.empty((10, 256), device=dev), torch.empty((10, 256), dtype=F16, device=dev)
+    with pytest.raises(lib.EendHipError):          # stream packed for another width
+        ops.ffn_stream(x, ws, torch.zeros(128, device=dev), v, o32, v, v, o32, o16)
+    with pytest.raises(lib.EendHipError):          # F not a multiple of 64
+        ops.ffn_stream_pack(None, rnd((96, 256), dev, 4, F16), rnd((256, 96), dev, 5, F16))
+    with pytest.raises(lib.EendHipError):          # both residual forms
+        ops.attnout_ffn_stream(x, ops.ffn_stream_pack(rnd((256, 256), dev, 6, F16), w1, w2), v, o32, o16, v, v, 1e-5,
+                               torch.zeros(192, device=dev), v, v, v, 1e-5, o32, o16)
