@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include <type_traits>
 #include <utility>
+#include <cstdlib>
 
 namespace {
 
@@ -36,9 +37,7 @@ template <int V> using IC = std::integral_constant<int, V>;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 192;            // rows per tile (workgroup)
-constexpr int WM = 48;             // rows per wave
-constexpr int NJ = 3;              // token fragments per wave
+// rows per wave = 16 NJ (NJ token fragments), rows per tile (workgroup) = 64 NJ; NJ = 3 for large M, 2 when that fills more CUs
 constexpr int SLOT = 16384;        // one stream item: 16 fragments of 1 KB
 constexpr int NSLOT = 8;
 constexpr int STAGE = NSLOT * SLOT;    // 4 x 4 KB wave-private output staging (8 rows x 512 B)
@@ -141,10 +140,11 @@ __device__ unsigned long long g_fs_trace[256 * 8 * 10];
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, int ACT, int EPI, bool RES16>
+template <int MODE, int ACT, int EPI, bool RES16, int NJ>
 __global__ __launch_bounds__(256, 1)
 void ffn_stream_kernel(const FfnStreamParams p) {
     constexpr bool PRE = MODE == 1;
+    constexpr int TM = 64 * NJ, WM = 16 * NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int U = p.F >> 5;                               // half-chunks of 32 hidden units
     const int S = (PRE ? 8 : 0) + 2 * U;                  // stream items per tile
@@ -237,7 +237,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
         v = v / (1.0f + __expf(-v));
         return (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
     };
-    auto conv_part = [&](auto PART, f16x8 (&hbo)[NJ]) __attribute__((always_inline)) {          // part = hf * NJ + j  (6 parts)
+    auto conv_part = [&](auto PART, f16x8 (&hbo)[NJ]) __attribute__((always_inline)) {          // part = hf * NJ + j  (2 NJ parts)
         constexpr int hf = decltype(PART)::value / NJ, j = decltype(PART)::value % NJ;
 #pragma unroll
         for (int r = 0; r < 4; ++r) hbo[j][hf * 4 + r] = act_cvt(h[hf][j][r]);
@@ -297,7 +297,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 // the 4 DMA pieces of the item NSLOT-1 ahead, on fragments 0 .. 3
                 if constexpr (pi < 4) dma_piece(sd, IC<pi>{});
                 // activation of the half-chunk held in h (6 fragment parts) on fragments 2, 4, ..., 12
-                if constexpr (kind == 2 && conv && pi >= 2 && pi < 14 && !(pi & 1)) conv_part(IC<(pi - 2) / 2>{}, hbo);
+                if constexpr (kind == 2 && conv && pi >= 2 && pi < 2 + 4 * NJ && !(pi & 1)) conv_part(IC<(pi - 2) / 2>{}, hbo);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -337,7 +337,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     auto touch_rows = [&](const void* base, int row_bytes, int t) __attribute__((always_inline)) {
         if (t < ntiles) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NJ; ++q) {
                 const int idx = q * 64 + lane;
                 int r = t * TM + wave * WM + (idx >> 2);
                 r = r < p.M ? r : p.M - 1;
@@ -457,7 +457,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             step(IC<1>{}, IC<0>{}, Fa{}, T{}, Fa{}, IC<0>{}, nloose > 0, 0, hbA, hbB);
             FS_STAMP(7);
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the hand-written MFMAs' results are read by VALU instructions next
-            sfor<6>([&](auto Q) __attribute__((always_inline)) { conv_part(Q, hbA); });
+            sfor<2 * NJ>([&](auto Q) __attribute__((always_inline)) { conv_part(Q, hbA); });
             FS_STAMP(3);
             step(IC<1>{}, IC<0>{}, Fa{}, T{}, T{}, IC<0>{}, nloose > 1, 1, hbA, hbB);
             for (int k = 2; k < U; k += 2) {                // U is even
@@ -552,22 +552,33 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 }
 
-template <int MODE, int ACT, int EPI, bool RES16>
-int launch(const FfnStreamParams& p, hipStream_t stream) {
+template <int MODE, int ACT, int EPI, bool RES16, int NJ>
+int launch_nj(const FfnStreamParams& p, int ncu, hipStream_t stream) {
     static bool attr_done = false;
-    auto kern = ffn_stream_kernel<MODE, ACT, EPI, RES16>;
+    auto kern = ffn_stream_kernel<MODE, ACT, EPI, RES16, NJ>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
         attr_done = true;
     }
+    const int ntiles = (p.M + 64 * NJ - 1) / (64 * NJ);
+    hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+template <int MODE, int ACT, int EPI, bool RES16>
+int launch(const FfnStreamParams& p, hipStream_t stream) {
     static const int ncu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const int ntiles = (p.M + TM - 1) / TM;
-    hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
-    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+    // 192-row tiles reuse every weight fragment for three MFMAs; when they leave CUs idle in the only (or last of few) rounds,
+    // 128-row tiles finish earlier: compare rounds x rows-per-tile (the time of a tile is close to linear in its rows).
+    const long t3 = (p.M + 191) / 192, t2 = (p.M + 127) / 128;
+    const long c3 = ((t3 + ncu - 1) / ncu) * (3 * 10 + 9), c2 = ((t2 + ncu - 1) / ncu) * (2 * 10 + 9);     // per-tile cost model: rows + fixed part
+    const char* e = getenv("EEND_FS_NJ");
+    const int nj = e ? atoi(e) : (c2 < c3 ? 2 : 3);
+    return nj == 2 ? launch_nj<MODE, ACT, EPI, RES16, 2>(p, ncu, stream) : launch_nj<MODE, ACT, EPI, RES16, 3>(p, ncu, stream);
 }
 
 }  // namespace

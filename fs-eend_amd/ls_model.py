@@ -20,6 +20,12 @@ from torch import Tensor
 
 from . import ops
 from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, PositionalEncoding, WorkspaceCache, _f16, _f32
+
+# The packed-weight-stream layer-tail kernels (ffn_stream.hip) are parity-tested on this model too but measured slower here than
+# ffn.hip's (f32 residual stream + f32 output: 576 KB of row traffic per 192-row tile; Swish on the single wave per SIMD) --
+# 848 vs 829 us for the decoder launch, 71 vs 62 us for a Conformer FFN (profiles/r04_ls_kernel_stats_stream{1,0}.csv): off unless
+# EEND_FFN_STREAM_LS=1.
+FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM_LS", "0") != "0"
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -349,6 +355,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 w1a32=_f32(ffa[1].linear.weight), w2a32=_f32(ffa[4].linear.weight),
                 w1b32=_f32(ffb[1].linear.weight), w2b32=_f32(ffb[4].linear.weight),
                 lne=(_f32(ln_e.weight), _f32(ln_e.bias), ln_e.eps)))
+        if FFN_STREAM and FUSED_FFN:
+            for Bk in blocks:
+                if ops.stream_ok(Bk["w1a"].shape[0]):
+                    Bk["wsa"] = ops.ffn_stream_pack(None, Bk["w1a"], Bk["w2a"])
+                    Bk["wsb"] = ops.ffn_stream_pack(None, Bk["w1b"], Bk["w2b"])
         P["blocks"] = blocks
         cw = self.cnn.weight.detach()
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
@@ -371,6 +382,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 # f32 weights of the all-f32 frame step (ls_stream.dec_step: <= 16 rows per frame)
                 out1_w32=_f32(l.self_attn1.out_proj.weight), in2_w32=_f32(l.self_attn2.in_proj_weight),
                 out2_w32=_f32(l.self_attn2.out_proj.weight), w1_32=_f32(l.linear1.weight), w2_32=_f32(l.linear2.weight)))
+        if FFN_STREAM and FUSED_FFN and FUSED_ATTNOUT:
+            for Ld in dl:
+                if ops.stream_ok(Ld["w1"].shape[0]):
+                    Ld["ws"] = ops.ffn_stream_pack(Ld["out2_w"], Ld["w1"], Ld["w2"])
         P["dec.layers"] = dl
         self._prep, self._prep_key, self._pc = P, key, {}
         return P
@@ -423,7 +438,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             F = Bk["w1a"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
             # x += fa * FFN(LN_a x)                      -> x16 = LN_b(x)
-            if FUSED_FFN:
+            if FUSED_FFN and "wsa" in Bk:
+                ops.ffn_stream(ws.x16, Bk["wsa"], Bk["b1a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
+                               ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
+            elif FUSED_FFN:
                 ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
                               ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
             else:
@@ -445,7 +463,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
                                       ws.h32, ws.x16, Bk["lnd"][2])
             # x = LN_e(x + fb * FFN(LN_d x))
-            if FUSED_FFN:
+            if FUSED_FFN and "wsb" in Bk:
+                ops.ffn_stream(ws.x16, Bk["wsb"], Bk["b1b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
+                               ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
+            elif FUSED_FFN:
                 ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
                               ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
             else:
@@ -482,6 +503,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             else:
                 ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
                 ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+            if FUSED_FFN and FUSED_ATTNOUT and "ws" in Ld:
+                ops.attnout_ffn_stream(o16, Ld["ws"], Ld["out2_b"], ws.a32, None, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["b1"], Ld["b2"],
+                                       Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
+                continue
             if FUSED_FFN and FUSED_ATTNOUT:
                 ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
                                       Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
