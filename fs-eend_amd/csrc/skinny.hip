@@ -61,6 +61,7 @@ void skinny_linear_kernel(const SkinnyParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int m0 = (int)blockIdx.y * MB;               // row group (the f32 frame steps of multi-stream sessions: M > 16 rows)
     const bool live = n < p.N;
     const int nn = live ? n : p.N - 1;
     float acc[ROWS][MB];
@@ -76,7 +77,7 @@ void skinny_linear_kernel(const SkinnyParams p) {
         for (int r = 0; r < ROWS; ++r) load8<F32>(p.W, (size_t)(nn * ROWS + r) * p.ldw + k, w[r]);
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            const int mm = m < p.M ? m : p.M - 1;
+            const int mm = m0 + m < p.M ? m0 + m : p.M - 1;
             float a[8];
             load8<F32>(p.A, (size_t)mm * p.lda + k, a);
 #pragma unroll
@@ -112,19 +113,20 @@ void skinny_linear_kernel(const SkinnyParams p) {
     // lane m finishes row m (every lane holds all the sums after the butterfly)
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-        if (lane != m || m >= p.M) continue;
+        const int row = m0 + m;
+        if (lane != m || row >= p.M) continue;
         if constexpr (EPI == SK_PLAIN) {
             const float v = act_apply(acc[0][m] + (p.bias ? p.bias[n] : 0.f), p.act);
-            if (p.out32) p.out32[(size_t)m * p.ldo + n] = v;
-            else p.out16[(size_t)m * p.ldo + n] = to_f16_sat(v);
+            if (p.out32) p.out32[(size_t)row * p.ldo + n] = v;
+            else p.out16[(size_t)row * p.ldo + n] = to_f16_sat(v);
         } else if constexpr (EPI == SK_GLU) {
             const float a = acc[0][m] + p.bias[2 * n], g = acc[1][m] + p.bias[2 * n + 1];
-            p.out16[(size_t)m * p.ldo + n] = to_f16_sat(a / (1.0f + __expf(-g)));
+            p.out16[(size_t)row * p.ldo + n] = to_f16_sat(a / (1.0f + __expf(-g)));
         } else {
             float v = (acc[0][m] + (p.bias ? p.bias[n] : 0.f)) * p.alpha;
-            if (p.res) v += p.res[(size_t)m * p.ldres + n];
-            if (p.out32) p.out32[(size_t)m * p.ldo + n] = v;
-            if (p.out16) p.out16[(size_t)m * p.ldo + n] = to_f16_sat(v);
+            if (p.res) v += p.res[(size_t)row * p.ldres + n];
+            if (p.out32) p.out32[(size_t)row * p.ldo + n] = v;
+            if (p.out16) p.out16[(size_t)row * p.ldo + n] = to_f16_sat(v);
         }
     }
 }
@@ -159,7 +161,7 @@ void skinny_ln_kernel(float* __restrict__ x32, _Float16* __restrict__ out16, con
 
 template <int EPI, bool SPLITK, bool F32>
 int launch_bucket(const SkinnyParams& p, hipStream_t stream) {
-    const dim3 grid(SPLITK ? p.N : (p.N + 3) / 4), block(256);
+    const dim3 grid(SPLITK ? p.N : (p.N + 3) / 4, p.M > 16 ? (p.M + 15) / 16 : 1), block(256);
     if (p.M <= 1) hipLaunchKernelGGL((skinny_linear_kernel<1, EPI, SPLITK, F32>), grid, block, 0, stream, p);
     else if (p.M <= 2) hipLaunchKernelGGL((skinny_linear_kernel<2, EPI, SPLITK, F32>), grid, block, 0, stream, p);
     else if (p.M <= 4) hipLaunchKernelGGL((skinny_linear_kernel<4, EPI, SPLITK, F32>), grid, block, 0, stream, p);
@@ -209,7 +211,7 @@ int eend_launch_skinny_res(const void* A, int lda, const void* W, int ldw, const
 // The same kernels on f32 activations AND f32 weights (torch nn.Linear layout), f32 out: the LS decoder's frame step.
 int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out32, int ldo, int M, int N,
                                  int K, int act, hipStream_t stream) {
-    if (!A || !W || !out32 || M < 1 || M > EEND_SKINNY_MAX_M || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
+    if (!A || !W || !out32 || M < 1 || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
         return EEND_EINVAL;
     SkinnyParams p{A, lda, W, ldw, bias, M, N, K, act, 1.0f, nullptr, 0, out32, nullptr, ldo};
     return launch_skinny<SK_PLAIN, true>(p, stream);
@@ -224,7 +226,7 @@ int eend_launch_layernorm_rows_f32(const float* x, const float* gamma, const flo
 int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
                                const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K, int mode,
                                hipStream_t stream, float* ln_out32) {
-    if (!A || !W || !out32 || M < 1 || M > EEND_SKINNY_MAX_M || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
+    if (!A || !W || !out32 || M < 1 || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
         return EEND_EINVAL;
     SkinnyParams p{A, lda, W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32, mode == 0 ? (_Float16*)out16 : nullptr, 256};
     int rc = launch_skinny<SK_RES, true>(p, stream);

@@ -293,7 +293,10 @@ def retention_step_f32(qkvg32, kv_state, scale_in, scale_out, out16, N, H, gn_ep
                                          _stream()), "eend_retention_step_f32")
 
 
-STEP_F32_MAX_ROWS = 16          # the f32 frame-step linears (skinny.hip) serve one frame x <= 16 slots
+# The f32 frame-step linears (skinny.hip) serve any number of rows in groups of 16 (round 4: multi-stream sessions take the
+# all-f32 step too -- their f16 step drifted past the 1e-3 bar within an hour).  EEND_STREAM_F32_MAX_ROWS=16
+# restores the round-3 behaviour (f16 MFMA steps above 16 rows per frame) for A/B.
+STEP_F32_MAX_ROWS = int(__import__("os").environ.get("EEND_STREAM_F32_MAX_ROWS", str(1 << 30)))
 
 
 def linear_step_f32(a32, w32, bias, out32, act=ACT_NONE):

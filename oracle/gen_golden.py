@@ -22,6 +22,7 @@ from oracle import fixtures as FX
 
 REF = "/root/reference"
 ROWS = 16          # emb / attractor rows are stored subsampled (every ROWS-th frame)
+ONLY = set(sys.argv[2:])       # optional: generate only the named cases (the others are reproducible bit for bit anyway)
 
 FS_FULL = dict(n_units=256, n_heads=4, enc_n_layers=4, dec_n_layers=2, dropout=0.1, has_mask=True,
                max_seqlen=500, dec_dim_feedforward=2048, mask_delay=0)
@@ -52,6 +53,9 @@ FS_CASES = [
     # 10 speaker slots, single frame-ish edge: T = 1 and T = 65
     dict(name="fs_c10_T65", cfg=fs_cfg(enc_n_layers=1, dec_n_layers=1, dec_dim_feedforward=256),
          lengths=[65, 1], C=10, seed=5, pseed=16, xseed=783),
+    # 12 speaker slots = max_speakers 10 + 2 (the dihard configs of LS-EEND; the largest slot count the kernels dispatch),
+    # full-size model, ragged
+    dict(name="fs_c12_T500", cfg=fs_cfg(), lengths=[500, 317], C=12, seed=8, pseed=19, xseed=787),
 ]
 
 FS_FWD_CASES = [
@@ -84,6 +88,8 @@ def gen_fs():
         return m
 
     for case in FS_CASES:
+        if ONLY and case["name"] not in ONLY:
+            continue
         m = build(case)
         src = FX.make_src(case["lengths"], 345, case["xseed"])
         with torch.no_grad():
@@ -108,6 +114,8 @@ def gen_fs():
         assert err < 2e-6
 
     for case in FS_FWD_CASES:
+        if ONLY and case["name"] not in ONLY:
+            continue
         m = build(case)
         src = FX.make_src(case["lengths"], 345, case["xseed"])
         tgt = FX.make_labels(case["lengths"], case["ncols"], case["lseed"])
@@ -125,6 +133,8 @@ def gen_fs():
         print(f"{case['name']}: emb_loss = {float(loss):.6f} -> {os.path.relpath(p)}")
 
     for case in FS_STREAM_CASES:
+        if ONLY and case["name"] not in ONLY:
+            continue
         m = build(case)
         cfg = dict(case["cfg"])
         sm = StreamingTransformerEDADiarization(in_size=345, **cfg).eval()

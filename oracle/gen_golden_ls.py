@@ -10,6 +10,8 @@ from oracle import fixtures as FX
 REF = "/root/reference"
 ROWS = 16
 
+ONLY = set(sys.argv[2:])       # optional: generate only the named cases
+
 LS_FULL = dict(n_units=256, n_heads=4, enc_n_layers=4, dec_n_layers=2, dropout=0.1, max_seqlen=1000,
                recurrent_chunk_size=500, feed_forward_expansion_factor=4, dec_dim_feedforward=2048,
                conv_expansion_factor=2, conv_kernel_size=16, half_step_residual=True, conv_delay=9)
@@ -36,6 +38,9 @@ LS_CASES = [
          lengths=[200], C=6, seed=23, pseed=34, xseed=804),
     dict(name="ls_T500_c3", cfg=ls_cfg(enc_n_layers=1, dec_n_layers=1, dec_dim_feedforward=256),
          lengths=[500, 499], C=3, seed=24, pseed=35, xseed=805),
+    # 12 slots: conf/spk_onl_conformer_retention_enc_dec_nonautoreg_dihard{2,3}{,_infer}.yaml set max_speakers 10 -> max_nspks 12
+    # (train/oln_tfm_enc_dec.py:35,186); full-size model, two chunks
+    dict(name="ls_c12_T1000", cfg=ls_cfg(), lengths=[1000], C=12, seed=27, pseed=38, xseed=809),
 ]
 
 LS_FWD_CASES = [
@@ -72,6 +77,8 @@ def gen_ls():
                     chunk=cfg["recurrent_chunk_size"], conv_delay=cfg["conv_delay"])
 
     for case in LS_CASES:
+        if ONLY and case["name"] not in ONLY:
+            continue
         m = build(case)
         src = FX.make_src(case["lengths"], 345, case["xseed"])
         with torch.no_grad():
@@ -93,6 +100,8 @@ def gen_ls():
         assert err < 5e-6
 
     for case in LS_FWD_CASES:
+        if ONLY and case["name"] not in ONLY:
+            continue
         m = build(case)
         src = FX.make_src(case["lengths"], 345, case["xseed"])
         tgt = FX.make_labels(case["lengths"], case["ncols"], case["lseed"])
@@ -115,6 +124,8 @@ def gen_ls():
 
     # streaming: drive the reference exactly as LS-EEND/streaming_infer_dia.py:52-97 does
     for case in LS_STREAM_CASES:
+        if ONLY and case["name"] not in ONLY:
+            continue
         m = build(case)
         src = FX.make_src([case["T"]], 345, case["xseed"])[0]
         C = case["C"]

@@ -3,7 +3,8 @@ by the reference itself and (b) the fp32 oracle, plus size-independent propertie
 BASELINE batch size.
 
 Tolerance (stated by BASELINE.json north_star): per-frame activity logits within 1e-3 of the
-reference's fp32 forward.  emb / attractors are unit vectors compared at 2e-3 per component.
+reference's fp32 forward, and (scale-free) a relative RMS logit error below 1 %.  emb / attractors are unit vectors compared
+at 2e-3 per component.
 The linear layers run on f16 MFMA and QK^T / PV on bf16 MFMA, both with fp32 accumulation,
 fp32 residual stream / LayerNorm / softmax statistics.
 """
@@ -46,6 +47,13 @@ def test_fs_test_vs_golden_and_oracle(hip_lib, dev, name):
         assert max_abs(got[1][i], want[1][i]) < VEC_TOL
         assert max_abs(got[2][i], want[2][i]) < VEC_TOL
     print(f"{name}: max |logits - reference| = {worst:.2e}")
+    # secondary, scale-free bar: random-init logits are cosines with std ~0.05, so the absolute 1e-3 bar is ~2 % of a
+    # standard deviation; the relative RMS error over all frames must also stay below 1 % (measured 2-4e-3)
+    num = sum(float(((got[0][i].cpu().double() - torch.as_tensor(arr[f"logits{i}"]).double()) ** 2).sum()) for i in range(len(src)))
+    den = sum(float((torch.as_tensor(arr[f"logits{i}"]).double() ** 2).sum()) for i in range(len(src)))
+    rel_rms = (num / den) ** 0.5
+    print(f"{name}: relative RMS logit error = {rel_rms:.2e}")
+    assert rel_rms < 1e-2, f"{name}: relative RMS logit error {rel_rms:.2e}"
 
 
 def test_fs_forward_vs_golden(hip_lib, dev):

@@ -235,9 +235,9 @@ def test_f32_frame_step_entries_vs_torch(hip_lib, dev, N, C):
 
 @pytest.mark.parametrize("nstreams", [3, 20])
 def test_ls_stream_session_several_streams_match_single_streams(hip_lib, dev, nstreams):
-    """A session with several concurrent streams (3: encoder / look-ahead conv in f32, decoder rows 3 x C > 16 -> f16 decoder step;
-    20: everything on the f16 frame steps) gives every stream what a one-stream session (all-f32 frame step) gives it, within the
-    f16-step tolerance, and the streams do not leak into each other (stream 0 is fed the same input in both)."""
+    """A session with several concurrent streams (3 x C = 30 and 20 x C = 200 rows per frame: several 16-row groups of the
+    all-f32 frame steps, round 4) gives every stream what a one-stream session gives it -- the same f32 arithmetic per row, so
+    to fp32 summation-order level -- and the streams do not leak into each other (stream 0 is fed the same input in both)."""
     from fs_eend_amd.ls_stream import LsStreamSession
     meta, arr = FX.load_case("ls_stream_T120")
     m = build_ls_mirror(meta).to(dev)
@@ -261,5 +261,5 @@ def test_ls_stream_session_several_streams_match_single_streams(hip_lib, dev, ns
                 yo.append(y)
         yo = torch.cat(yo, dim=1)
         assert yo.shape[1] == ys.shape[1]
-        assert max_abs(ys[s_], yo[0].cpu()) < 6e-4, (s_, max_abs(ys[s_], yo[0].cpu()))
+        assert max_abs(ys[s_], yo[0].cpu()) < 1e-4, (s_, max_abs(ys[s_], yo[0].cpu()))
     assert max_abs(ys[0], arr["stream_logits"][:ys.shape[1]]) < 1e-3          # stream 0 is the golden input
