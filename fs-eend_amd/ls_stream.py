@@ -325,6 +325,7 @@ class LsStreamSession:
         self.t = 0
 
     def _capture(self):
+        self._P_captured = self.m._prepare()             # the operand set the recorded graphs point into
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                                                # warm-up: workspaces, operand caches
@@ -352,9 +353,11 @@ class LsStreamSession:
         if P is None or (self.t & 255) == 0:
             P = self.m._prepare()
         if P is not getattr(self, "_P_captured", None):
-            first = getattr(self, "_P_captured", None) is None
-            self._P_captured = P
-            if self._graphs is not None and not first:
+            # (_P_captured is set by _capture() itself, at the time the graphs are recorded: a refresh between construction and
+            # the first push re-captures like any later one -- ADVICE r03)
+            if self._graphs is None:
+                self._P_captured = P
+            else:
                 keep = [t_.clone() for t_ in self._stateful]
                 t = self.t
                 self._capture()

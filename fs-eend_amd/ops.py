@@ -425,6 +425,9 @@ def gather_bn_cast_pad(src, bn, out16, T, Tp, pad_value, apply_bn=True, eps=1e-5
     for s_ in src:
         _chk(s_, F32, "src[i]")
     B, Fin, Fpad = len(src), src[0].shape[1], out16.shape[-1]
+    if Fpad > 512:
+        raise _lib.EendHipError(f"gather_bn_cast_pad: padded feature width {Fpad} > 512 (in_size {Fin}): the gather kernel holds "
+                                "four feature pairs per lane; the shipped configs use in_size 345")
     key = tuple((s_.data_ptr(), s_.shape[0]) for s_ in src)
     tab = _PTR_TABLES.get(key)
     if tab is None:                                            # tiny H2D upload, cached per (pointers, lengths)

@@ -253,6 +253,11 @@ class LsTrainStep(TrainStepBase):
         bf = self._buffers(B, Tp, C)
         Me, Md = B * Tp, B * C * Tp
         il = [min(int(l), T) for l in ilens]
+        if any(int(l) != int(s.shape[0]) for l, s in zip(ilens, srcs)):
+            # the reference pads the decoder and windows the emb-consistency loss by max(ilens) AFTER truncating the embeddings
+            # (LS model :80-84, :100); this step derives both from the feature lengths, which is the same thing only when they agree
+            # -- as they always do in the reference's training_step
+            raise EendHipError("LsTrainStep.forward: ilens must equal the feature lengths (ilens shorter than the features are not supported)")
         key = (tuple(il), tuple(ncols), T)
         if getattr(bf, "len_key", None) != key:              # cached: no H2D copies in the steady state
             bf.il = torch.tensor(il, dtype=I32, device=dev)

@@ -243,6 +243,36 @@ class SpeakerDiarization:
         return self._loader("val", 1, False)
 
 
+class EarlyStopping:
+    """The other callback every reference training script passes (FS-EEND/train_dia.py:111-116, LS-EEND/train_dia_simu.py:127,
+    train_dia_fintun_real.py): EarlyStopping(monitor="val/obj_metric", patience=early_stop_epoch, mode="min").  After each
+    validation the freshly logged metric is compared with the best one so far; `patience` validations without an improvement
+    of more than `min_delta` stop the fit loop (Lightning's semantics; the decision is taken on rank 0 and broadcast)."""
+
+    def __init__(self, monitor="val/obj_metric", patience=3, mode="min", min_delta=0.0, verbose=False, **_lightning_only):
+        if mode not in ("min", "max"):
+            raise ValueError(f"EarlyStopping: mode must be 'min' or 'max', got {mode!r}")
+        self.monitor, self.patience, self.mode, self.min_delta, self.verbose = monitor, int(patience), mode, abs(float(min_delta)), verbose
+        self.best, self.wait, self.stopped_epoch = None, 0, None
+
+    def on_validation_end(self, trainer, module, epoch):
+        """-> True when training should stop."""
+        value = module.logged.get(self.monitor)
+        if value is None:
+            raise RuntimeError(f"EarlyStopping: metric {self.monitor!r} was not logged by validation_epoch_end "
+                               f"(logged: {sorted(module.logged)})")
+        value = float(value)
+        better = self.best is None or (value < self.best - self.min_delta if self.mode == "min" else value > self.best + self.min_delta)
+        if better:
+            self.best, self.wait = value, 0
+            return False
+        self.wait += 1
+        if self.wait >= self.patience:
+            self.stopped_epoch = epoch
+            return True
+        return False
+
+
 class ModelCheckpoint:
     """The checkpoint callback the reference passes to its Trainer (FS-EEND/train_dia.py:118-121: monitor val/obj_metric,
     save_top_k, save_last; LS-EEND/train_dia_simu.py:131).  Files are named like Lightning's default,
@@ -264,10 +294,17 @@ class ModelCheckpoint:
         if self.save_top_k == 0:
             return
         path = os.path.join(self.dirpath, f"epoch={epoch}-step={trainer.global_step}.ckpt")
-        score = module.logged.get(self.monitor) if self.monitor else None
-        score = float(score) if score is not None else float(epoch)
-        if self.mode == "max":
-            score = -score
+        # rank on a metric only if THIS epoch's validation logged it (a stale value of an earlier epoch, or the epoch number of
+        # an epoch without validation, must not beat real scores): missing -> worst possible
+        fresh = self.monitor is not None and getattr(trainer, "validated_epoch", None) == epoch and self.monitor in module.logged
+        if self.monitor is None:
+            score = float(epoch)
+        elif fresh:
+            score = float(module.logged[self.monitor])
+            if self.mode == "max":
+                score = -score
+        else:
+            score = float("inf")
         torch.save(ckpt, path)
         self.kept.append((score, path))
         if self.save_top_k > 0 and self.monitor:
@@ -278,10 +315,17 @@ class ModelCheckpoint:
             self.kept = self.kept[:self.save_top_k]
         self.best_model_path = min(self.kept, key=lambda t: t[0])[1]
 
+    def state_dict(self):
+        return dict(kept=list(self.kept), best_model_path=self.best_model_path)
+
+    def load_state_dict(self, st):
+        self.kept = [tuple(t) for t in st.get("kept", [])]
+        self.best_model_path = st.get("best_model_path", "")
+
 
 class Trainer:
     """The slice of pytorch_lightning.Trainer the reference uses (FS-EEND/train_dia.py:145-160,185; LS-EEND/
-    train_dia_simu.py:159-173), one process per GPU: max_epochs, callbacks (ModelCheckpoint above), strategy "ddp",
+    train_dia_simu.py:159-173), one process per GPU: max_epochs, callbacks (ModelCheckpoint, EarlyStopping above), strategy "ddp",
     sync_batchnorm (LS-EEND), accumulate_grad_batches, resume_from_checkpoint, gradient_clip_val,
     check_val_every_n_epoch, limit_*_batches.  Arguments it does not implement are refused, not ignored."""
 
@@ -300,10 +344,12 @@ class Trainer:
             raise ValueError("accumulate_grad_batches must be >= 1")
         self.callbacks = list(callbacks or [])
         for cb in self.callbacks:
-            if not isinstance(cb, ModelCheckpoint):
-                raise TypeError(f"Trainer: unsupported callback {type(cb).__name__} (fs_eend_amd.trainer.ModelCheckpoint only)")
-        if default_root_dir and not self.callbacks:
+            if not isinstance(cb, (ModelCheckpoint, EarlyStopping)):
+                raise TypeError(f"Trainer: unsupported callback {type(cb).__name__} (fs_eend_amd.trainer.ModelCheckpoint / EarlyStopping only)")
+        if default_root_dir and not any(isinstance(cb, ModelCheckpoint) for cb in self.callbacks):
             self.callbacks.append(ModelCheckpoint(default_root_dir))
+        self.validated_epoch = None
+        self.should_stop = False
         self.max_epochs, self.clip, self.val_every = max_epochs, gradient_clip_val, check_val_every_n_epoch
         self.limit_train, self.limit_val, self.log_every = limit_train_batches, limit_val_batches, log_every_n_steps
         self.strategy, self.resume, self.sync_bn = strategy, resume_from_checkpoint, sync_batchnorm
@@ -313,7 +359,7 @@ class Trainer:
 
     @property
     def checkpoint_callback(self):
-        return self.callbacks[0] if self.callbacks else None
+        return next((cb for cb in self.callbacks if isinstance(cb, ModelCheckpoint)), None)
 
     @staticmethod
     def _dist():
@@ -324,7 +370,8 @@ class Trainer:
         eng = module._engine()
         return dict(state_dict={k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
                     optimizer_state={k: (v.cpu() if isinstance(v, Tensor) else v) for k, v in eng.optimizer_state().items()},
-                    epoch=epoch, global_step=self.global_step)
+                    epoch=epoch, global_step=self.global_step,
+                    callbacks={type(cb).__name__: cb.state_dict() for cb in self.callbacks if hasattr(cb, "state_dict")})
 
     def _restore(self, module, path):
         ckpt = torch.load(path, map_location="cpu")
@@ -337,6 +384,10 @@ class Trainer:
             eng.load_optimizer_state(ckpt["optimizer_state"])
         eng.prep_weights()
         self.global_step = int(ckpt.get("global_step", 0))
+        for cb in self.callbacks:                        # top-k bookkeeping of the run being resumed
+            st = ckpt.get("callbacks", {}).get(type(cb).__name__)
+            if st is not None and hasattr(cb, "load_state_dict"):
+                cb.load_state_dict(st)
         return int(ckpt.get("epoch", -1)) + 1
 
     def fit(self, module: SpeakerDiarization):
@@ -392,9 +443,21 @@ class Trainer:
                     outs.append(module.validation_step(batch, bi))
                 if outs:
                     module.validation_epoch_end(outs)
+                    self.validated_epoch = epoch
+                    stop = False
+                    if rank == 0:
+                        stop = any(cb.on_validation_end(self, module, epoch) for cb in self.callbacks if isinstance(cb, EarlyStopping))
+                    if dist and world > 1:               # every rank leaves the loop in the same epoch
+                        flag = torch.tensor([1 if stop else 0], device=eng.flat.params.device)
+                        dist.broadcast(flag, 0)
+                        stop = bool(int(flag.item()))
+                    self.should_stop = stop
             if rank == 0:
                 for cb in self.callbacks:
-                    cb.on_epoch_end(self, module, epoch)
+                    if isinstance(cb, ModelCheckpoint):
+                        cb.on_epoch_end(self, module, epoch)
+            if self.should_stop:
+                break
         return self
 
     def test(self, module: SpeakerDiarization):
