@@ -171,6 +171,11 @@ int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, con
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_convert_fanout_f32(const float* E_f32, const float* W_f32, int ldw, const float* pc, float* out_f32, void* out_f16,
+                            int B, int Tp, int C, void* stream) {
+    return eend_launch_convert_fanout_f32(E_f32, W_f32, ldw, pc, out_f32, out_f16, B, Tp, C, (hipStream_t)stream);
+}
+
 int eend_ffn_stream_elems(int F, int with_wo) { return (int)eend_ffn_stream_nelems(F, with_wo); }
 
 int eend_ffn_stream_pack_f16(const void* Wo, const void* W1, const void* W2, void* stream_out, int F, void* stream) {

@@ -69,7 +69,8 @@ constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
 #define EEND_FS_PIN 15
 #endif
 #ifndef EEND_FS_XFLATE
-#define EEND_FS_XFLATE 1           // 1: next tile's input rows are touched before the last item and loaded after the epilogue
+#define EEND_FS_XFLATE 1           // next tile's input rows: 0 = loaded fragment by fragment inside the epilogue, 1 = touched before the last
+                                   // two items and loaded after the epilogue, 2 = loaded before the last two items
 #endif
 constexpr int INFL = 4 * (NSLOT - 3);   // this wave's DMA pieces younger than the ones a barrier needs (5 items x 4 pieces)
 
@@ -145,6 +146,10 @@ __global__ __launch_bounds__(256, 1)
 void ffn_stream_kernel(const FfnStreamParams p) {
     constexpr bool PRE = MODE == 1;
     constexpr int TM = 64 * NJ, WM = 16 * NJ;
+    // VMEM operations of a wave that are certainly younger than the DMA pieces the first six barriers after an epilogue wait for:
+    // the INFL pieces in between plus the epilogue's own f16 row stores (8 per token fragment) and, where they are issued in or
+    // behind the epilogue, the next tile's input-row loads (8 per fragment)
+    constexpr int LOOSE = EEND_FS_XFLATE == 2 ? INFL + 8 * NJ : (INFL + 16 * NJ < 63 ? INFL + 16 * NJ : 63);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int U = p.F >> 5;                               // half-chunks of 32 hidden units
     const int S = (PRE ? 8 : 0) + 2 * U;                  // stream items per tile
@@ -254,7 +259,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
         constexpr bool conv = decltype(CONVc)::value;
         constexpr bool cold = decltype(COLDc)::value;    // the previous item did not request this item's first fragments
         constexpr bool pfn = decltype(PFNc)::value;      // request the next item's first fragments (not in front of a VALU phase)
-        if (loose) __builtin_amdgcn_s_waitcnt(0x0F70 | (63 & 15) | ((63 >> 4) << 14));
+        if (loose) __builtin_amdgcn_s_waitcnt(0x0F70 | (LOOSE & 15) | ((LOOSE >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70 | (vw & 15) | ((vw >> 4) << 14));
         __builtin_amdgcn_s_barrier();
         const char* wc = wl + slot * SLOT;
@@ -289,6 +294,8 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(h[hf][j]) : "v"(w), "v"(xf[s_][j]));
                     }
                 } else {
+                    // (hand-written accumulator-tied MFMAs here and in kind 0 were tried to stop hipcc permuting the 192 accumulator
+                    // registers at the phase boundaries: same speed, and their operand hazards are not padded -- builtin kept)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[pi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hb[j], acc[pi][j], 0, 0, 0);
                 }
@@ -461,7 +468,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             FS_STAMP(3);
             step(IC<1>{}, IC<0>{}, Fa{}, T{}, T{}, IC<0>{}, nloose > 1, 1, hbA, hbB);
             for (int k = 2; k < U; k += 2) {                // U is even
-#if EEND_FS_XFLATE && EEND_FS_TOUCH_LEAD > 0
+#if EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD > 0
                 if (k == U - 2 * EEND_FS_TOUCH_LEAD || (U <= 2 * EEND_FS_TOUCH_LEAD && k == 2)) {
                     touch_rows(p.A, p.lda * 2, tile + (int)gridDim.x);
                     if (RES16 && PRE && EEND_FS_TOUCH_RES) touch_rows(p.res16, 512, tile + (int)gridDim.x);
@@ -474,11 +481,16 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             }
             if constexpr (!PRE) loose = false;
             FS_STAMP(4);
-#if EEND_FS_XFLATE && EEND_FS_TOUCH_LEAD == 0
+#if EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0
             touch_rows(p.A, p.lda * 2, tile + (int)gridDim.x);
 #endif
-            step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<(EEND_FS_XFLATE && EEND_FS_TOUCH_LEAD == 0 ? 3 : 0)>{}, false, 0, hbA, hbB);     // W2h(U-2) x hbA, h(U-1) -> hbB
-            step(IC<2>{}, IC<0>{}, Fa{}, Fa{}, Fa{}, IC<(EEND_FS_XFLATE && EEND_FS_TOUCH_LEAD == 0 ? 3 : 0)>{}, false, 0, hbB, hbA);    // W2h(U-1) x hbB
+#if EEND_FS_XFLATE == 2
+            // x is dead: the next tile's input rows are requested here and travel under the last two items and the epilogue
+            if (tile + (int)gridDim.x < ntiles) sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(tile + (int)gridDim.x, J); });
+#endif
+            constexpr int VWL = EEND_FS_XFLATE == 2 ? 8 * NJ : (EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0 ? NJ : 0);
+            step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<VWL>{}, false, 0, hbA, hbB);     // W2h(U-2) x hbA, h(U-1) -> hbB
+            step(IC<2>{}, IC<0>{}, Fa{}, Fa{}, Fa{}, IC<VWL>{}, false, 0, hbB, hbA);    // W2h(U-1) x hbB
             pin_acc(8);
             FS_STAMP(5);
         }
@@ -543,8 +555,10 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
-#if EEND_FS_XFLATE
+#if EEND_FS_XFLATE == 1
         if (ntile < ntiles) { sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); }); if (EEND_FS_RES0 == 0) load_res16(ntile, IC<0>{}); }
+#elif EEND_FS_XFLATE == 2
+        if (ntile < ntiles && EEND_FS_RES0 == 0) load_res16(ntile, IC<0>{});
 #endif
         FS_STAMP(6);
         loose = true;

@@ -265,6 +265,9 @@ struct FfnStreamParams {
 long eend_ffn_stream_nelems(int F, int with_wo);
 int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
 int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream);
+// convert_f32.hip: decoder input in f32 on the exact-f32 MFMA (LS-EEND batch forward)
+int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int Tp,
+                                   int C, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);
 
 enum ProjKind { PROJ_ROWMAJOR = 0, PROJ_HEADS = 1, PROJ_HEADS_T = 2, PROJ_HEADS_BOTH = 3 };

@@ -26,6 +26,8 @@ from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, Positiona
 # 848 vs 829 us for the decoder launch, 71 vs 62 us for a Conformer FFN (profiles/r04_ls_kernel_stats_stream{1,0}.csv): off unless
 # EEND_FFN_STREAM_LS=1.
 FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM_LS", "0") != "0"
+# decoder input linear of the batch forward in f32 (convert_f32.hip); EEND_LS_CONVERT_F32=0: the f16 MFMA form (A/B)
+CONVERT_F32 = __import__("os").environ.get("EEND_LS_CONVERT_F32", "1") != "0"
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -477,12 +479,17 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 nx = P["blocks"][i + 1]["lna"]
                 ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
 
-    def _decode_span(self, P, ws, emb16, pc, B, Tc, Tp, C, states=None, carry_in=False):
+    def _decode_span(self, P, ws, emb16, pc, B, Tc, Tp, C, states=None, carry_in=False, emb32=None):
         """Attractor decoder (LS model :215-220; merge_retnet_layer.py:233-253) over one span: emb16 (B*Tp, D) f16 unit
         embeddings -> ws.a32 (f32 attractor rows (b, c, t)).  `states`: as in _encode_span, per decoder layer."""
         D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
         Md = B * C * Tp
-        ops.convert_fanout(emb16, P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
+        if emb32 is not None and CONVERT_F32:
+            # decoder input in f32 (exact-f32 MFMA): the retention's per-head LayerNorm (eps 1e-6) amplifies the f16 operand rounding
+            # of this linear; at 12 speaker slots the f16 form left the 1e-3 bar (golden ls_c12_T1000: 1.3e-3)
+            ops.convert_fanout_f32(emb32, P["convert.w32"], pc, ws.a32, ws.a16, B, Tp, C)
+        else:
+            ops.convert_fanout(emb16, P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
         q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
         g, o16 = ws.g[:Md], ws.o16[:Md]
         for j, Ld in enumerate(P["dec.layers"]):
@@ -540,7 +547,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         # ---- truncate / zero re-pad, look-ahead conv, L2 (LS model :80-87)
         emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)
         ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
-        self._decode_span(P, ws, ws.emb16, self._convert_const(C), B, Tpad, Tp, C)
+        self._decode_span(P, ws, ws.emb16, self._convert_const(C), B, Tpad, Tp, C, emb32=emb32)
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
         ops.head_l2dot(emb32, ws.a32, attr, logits, B, T, Tp, C, D)
@@ -609,7 +616,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             e32 = torch.zeros(B, Tp, D, dtype=f32, device=dev)
             e16[:, :Tc] = emb16.view(B, Tp_full, D)[:, s0:s1]
             e32[:, :Tc] = emb32.view(B, Tp_full, D)[:, s0:s1]
-            self._decode_span(P, ws, e16.view(-1, D), pc, B, Tc, Tp, C, states=dec_state, carry_in=s0 > 0)
+            self._decode_span(P, ws, e16.view(-1, D), pc, B, Tc, Tp, C, states=dec_state, carry_in=s0 > 0, emb32=e32.view(-1, D))
             if Tv > 0:
                 direct = B == 1 and return_attractors              # the output slices are contiguous: no staging copy
                 lg = logits[:, s0:s0 + Tv] if direct else torch.empty(B, Tv, C, dtype=f32, device=dev)

@@ -194,6 +194,14 @@ def convert_fanout(e16, w1_16, pc, out32, out16, B, Tp, C):
                "eend_convert_fanout_f16")
 
 
+def convert_fanout_f32(e32, w32, pc, out32, out16, B, Tp, C):
+    """convert_fanout with f32 operands (exact-f32 MFMA): e32 (B*Tp, 256) f32, w32 the (256, >= 256) f32 convert.weight."""
+    L = _lib.load()
+    _chk(e32, F32, "e32"); _chk(w32, F32, "w32"); _chk(pc, F32, "pc"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    _lib.check(L.eend_convert_fanout_f32(_p(e32), _p(w32), w32.stride(0), _p(pc), _p(out32), _p(out16), B, Tp, C, _stream()),
+               "eend_convert_fanout_f32")
+
+
 LN2 = math.log(2.0)
 # Multiply the q rows of an in-projection (weight and bias) by QSCALE_LOG2 and call attn_causal with
 # scale=LN2: the scores then leave the QK^T MFMA already scaled and in the log2 domain, which is what the

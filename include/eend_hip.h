@@ -110,6 +110,11 @@ int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, con
  * out f32/f16 [B*C][Tp][256] (decoder slab, sequence index = b*C + c). */
 int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
                             int B, int Tp, int C, void* stream);
+/* The same stage with f32 operands on the exact-f32 MFMA: E_f32 [B][Tp][256], W_f32 = convert.weight ([256][ldw], the first 256
+ * columns are W1).  The LS-EEND batch forward takes it (the decoder retention's per-head LayerNorm, eps 1e-6, amplifies the f16
+ * operand rounding of this linear; with 12 speaker slots the f16 form left the 1e-3 bar).  out_f32 may be NULL. */
+int eend_convert_fanout_f32(const float* E_f32, const float* W_f32, int ldw, const float* pc, float* out_f32, void* out_f16,
+                            int B, int Tp, int C, void* stream);
 
 /* Fused causal MHA core: softmax(mask(Q K^T / sqrt(dh))) V with
  * allowed(i,j) <=> j - i <= mask_delay && j < kv_len evaluated on indices (the (T,T) {0,-inf} tensor
