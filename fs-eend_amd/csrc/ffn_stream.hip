@@ -65,6 +65,12 @@ constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
 #ifndef EEND_FS_TOUCH_RES
 #define EEND_FS_TOUCH_RES 0
 #endif
+#ifndef EEND_FS_STUDY
+#define EEND_FS_STUDY 0
+#endif
+#ifndef EEND_FS_DMA_SPREAD
+#define EEND_FS_DMA_SPREAD 0
+#endif
 #ifndef EEND_FS_PIN
 #define EEND_FS_PIN 15
 #endif
@@ -259,9 +265,13 @@ void ffn_stream_kernel(const FfnStreamParams p) {
         constexpr bool conv = decltype(CONVc)::value;
         constexpr bool cold = decltype(COLDc)::value;    // the previous item did not request this item's first fragments
         constexpr bool pfn = decltype(PFNc)::value;      // request the next item's first fragments (not in front of a VALU phase)
+#if !(EEND_FS_STUDY & 1)      // perf study builds only (results are garbage): 1 = no vmcnt wait, 2 = no barrier, 4 = no activation
         if (loose) __builtin_amdgcn_s_waitcnt(0x0F70 | (LOOSE & 15) | ((LOOSE >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70 | (vw & 15) | ((vw >> 4) << 14));
+#endif
+#if !(EEND_FS_STUDY & 2)
         __builtin_amdgcn_s_barrier();
+#endif
         const char* wc = wl + slot * SLOT;
         const char* wn = wl + ((slot + 1) & (NSLOT - 1)) * SLOT;
         const int sd = (slot + NSLOT - 1) & (NSLOT - 1);
@@ -302,9 +312,15 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 if constexpr (pi + PD < 16) wf[(pi + PD) % NB] = *(const f16x8*)(wc + (pi + PD) * 1024);
                 else if constexpr (pfn) wf[(pi + PD) % NB] = *(const f16x8*)(wn + (pi + PD - 16) * 1024);
                 // the 4 DMA pieces of the item NSLOT-1 ahead, on fragments 0 .. 3
+#if EEND_FS_DMA_SPREAD
+                if constexpr ((pi & 3) == 1) dma_piece(sd, IC<(pi >> 2)>{});      // fragments 1, 5, 9, 13
+#else
                 if constexpr (pi < 4) dma_piece(sd, IC<pi>{});
+#endif
                 // activation of the half-chunk held in h (6 fragment parts) on fragments 2, 4, ..., 12
+#if !(EEND_FS_STUDY & 4)
                 if constexpr (kind == 2 && conv && pi >= 2 && pi < 2 + 4 * NJ && !(pi & 1)) conv_part(IC<(pi - 2) / 2>{}, hbo);
+#endif
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -320,25 +336,6 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
         }
     };
-    // LayerNorm statistics of token fragment j over acc * scale (lane-local sums + two xor shuffles)
-    auto row_stats = [&](auto J, float scale, float eps, float& mean, float& rstd) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-        s = wave_xor_add(s, 16);
-        s = wave_xor_add(s, 32);
-        mean = s * scale * (1.0f / 256);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] * scale - mean; q += d * d; }
-        q = wave_xor_add(q, 16);
-        q = wave_xor_add(q, 32);
-        rstd = 1.0f / __builtin_sqrtf(q * (1.0f / 256) + eps);
-    };
-
     // pull rows of a later tile towards the L2 ahead of their loads: one dword per 128-byte line, values unused.  (3 loads per
     // wave for its 48 rows; the loads complete in order with everything else, so they cost nothing unless waited for.)
     auto touch_rows = [&](const void* base, int row_bytes, int t) __attribute__((always_inline)) {
@@ -403,16 +400,17 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             FS_STAMP(1);
             sfor<NJ>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                // three passes over the accumulator-file copy of the fragment (few live VGPRs; the residual dies in pass 1)
+                // the fragment's 64 values per lane leave the accumulator file once and go back once
+                float v[64];
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if constexpr (RES16) acc[i][j][q] += (float)r8[j][i >> 1][(i & 1) * 4 + q];
-                        else acc[i][j][q] += t4[i][q];
+                        if constexpr (RES16) v[i * 4 + q] = acc[i][j][q] + (float)r8[j][i >> 1][(i & 1) * 4 + q];
+                        else v[i * 4 + q] = acc[i][j][q] + t4[i][q];
                     }
-                    sum += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                    sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
                 }
                 sum = wave_xor_add(sum, 16);
                 sum = wave_xor_add(sum, 32);
@@ -421,20 +419,19 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 if constexpr (j + 1 < NJ) { load_res(IC<j + 1>{}); if constexpr (RES16 && EEND_FS_RES12 == 1) load_res16(tile, IC<j + 1>{}); }   // under passes 2 and 3
                 float sq = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float d = acc[i][j][q] - mean; sq += d * d; }
+                for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
                 sq = wave_xor_add(sq, 16);
                 sq = wave_xor_add(sq, 32);
                 const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const f32x4 gg = vec4(1, i), bb = vec4(2, i), b2 = vec4(3, i);
+                    const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i), b2 = vec4(3, i);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float x = (acc[i][j][q] - mean) * rstd * gg[q] + bb[q];
-                        xf[i >> 1][j][(i & 1) * 4 + q] = to_f16_sat(x);
+                        const float x = __builtin_fmaf(v[i * 4 + q], gg[q], bb[q]);
+                        // (no saturation: |x| <= 16 |gamma| + |beta| after a LayerNorm over 256 features)
+                        xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)x;
                         acc[i][j][q] = x * ralpha + b2[q];
                     }
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // bounds how far the vector reads are hoisted
@@ -504,17 +501,34 @@ void ffn_stream_kernel(const FfnStreamParams p) {
         sfor<NJ>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
             const int rbase = tile * TM + wave * WM + j * 16;
-            float mean, rstd;
-            row_stats(J, p.alpha, p.eps, mean, rstd);
+            // the fragment's 64 values per lane leave the accumulator file once
+            float v[64];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] * p.alpha;
+                sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
+            }
+            sum = wave_xor_add(sum, 16);
+            sum = wave_xor_add(sum, 32);
+            const float mean = sum * (1.0f / 256);
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
+            sq = wave_xor_add(sq, 16);
+            sq = wave_xor_add(sq, 32);
+            const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps);
+            __builtin_amdgcn_sched_barrier(0);
             f16x8 o[8];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const f32x4 gg = vec4(4, i), bb = vec4(5, i);
+                const f32x4 gg = vec4(4, i) * rstd, bb = vec4(5, i);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float y = (acc[i][j][q] * p.alpha - mean) * rstd * gg[q] + bb[q];
-                    o[i >> 1][(i & 1) * 4 + q] = to_f16_sat(y);
-                    if constexpr (EPI == FFN_EPI_RES_LN) acc[i][j][q] = y; else acc[i][j][q] *= p.alpha;
+                    const float y = __builtin_fmaf(v[i * 4 + q], gg[q], bb[q]);
+                    o[i >> 1][(i & 1) * 4 + q] = (_Float16)y;          // (no saturation: a LayerNorm output, |y| <= 16 |gamma| + |beta|)
+                    if constexpr (EPI == FFN_EPI_RES_LN) v[i * 4 + q] = y; else v[i * 4 + q] += mean;       // what out32 receives
                 }
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -539,7 +553,8 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                         if ((frow >> 3) == half) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
-                                *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = acc[fh * 8 + e][j];
+                                *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) =
+                                    f32x4{v[(fh * 8 + e) * 4], v[(fh * 8 + e) * 4 + 1], v[(fh * 8 + e) * 4 + 2], v[(fh * 8 + e) * 4 + 3]};
                         }
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
