@@ -43,7 +43,7 @@ def flops_per_launch(name, shape, T):
         nseq, H = shape
         Tp = (T + 63) // 64 * 64
         return nseq * (2.0 * (H * 64) * T * (T + 1) + 2.0 * T * 768 * 256)
-    if name == "ffn_fused":
+    if name in ("ffn_fused", "ffn_stream"):
         M, F, K = shape
         return 4.0 * M * F * K
     if name == "fusion_layer_tail":    # 2 out-projections + speaker in-projection + the two FFN GEMMs
@@ -51,7 +51,7 @@ def flops_per_launch(name, shape, T):
         return 4.0 * M * F * K + 2.0 * M * K * K * 2 + 2.0 * M * 768 * K
     if name == "spk_qkv_attn":         # the in-projection GEMM (the C x C attention itself is VALU work)
         return 2.0 * shape[0] * 768 * 256
-    if name == "attnout_ffn_fused":    # out-projection (K x K) + the two FFN GEMMs
+    if name in ("attnout_ffn_fused", "attnout_ffn_stream"):    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
     if name == "retention_chunk":      # (nseq, H, valid frames, L): QK^T + PV causal-useful per chunk, + state build and cross term
@@ -64,11 +64,15 @@ def flops_per_launch(name, shape, T):
 
 
 def pmc_traffic(kernel, shape):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json:
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     tags = {("fusion_layer_tail", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 2>(FfnParams)",), "131072"),
+            ("attnout_ffn_stream", (196608, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 3>",), "65536"),
+            ("attnout_ffn_stream", (32768, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 2>",), "65536"),
             ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
             ("inproj_attn_causal", (64, 4)): (("inproj_attn_kernel(InprojAttnParams) #lo",), "131072"),      # persistent launch:
@@ -127,6 +131,10 @@ class OpTimer:
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "attnout_ffn_fused":
                 shape = (a[0].shape[0], a[7].shape[0], a[0].shape[1])
+            elif name == "attnout_ffn_stream":          # (a16, wstream, bo, res, res16, g1, be1, eps1, b1, ...)
+                shape = (a[0].shape[0], a[8].shape[0], a[0].shape[1])
+            elif name == "ffn_stream":                  # (x16, wstream, b1, ...)
+                shape = (a[0].shape[0], a[2].shape[0], a[0].shape[1])
             elif name == "inproj_heads":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "spk_qkv_attn":
@@ -144,7 +152,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
                   "convert_fanout", "attn_causal", "inproj_attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):
@@ -923,7 +931,18 @@ def main():
                                            "or 5*D*T*(T+1) per sequence (attention backward); in-situ HIP events on the launch stream"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_train(T, args.speakers, flavour=args.flavour)
+        else:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_reason"] = ("timed on rank 0 at N = 1 only (the host cores are shared by the ranks of an N > 1 run)" if world > 1
+                                          else "--no-cpu-baseline")
         if world > 1:
+            # data-parallel sanity of the run just timed: after the same number of optimiser steps every rank must hold the same
+            # parameters (one mean all-reduce of the flat gradient per step, identical Adam on every rank)
+            cs = torch.stack([eng.flat.params.double().sum(), eng.flat.params.double().abs().sum()]).to(dev)
+            allcs = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(allcs, cs)
+            out["dp_check"] = {"param_checksums": [[float(v) for v in c.cpu()] for c in allcs],
+                               "identical_on_all_ranks": all(bool(torch.equal(c, allcs[0])) for c in allcs)}
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
@@ -1007,7 +1026,7 @@ def main():
                            "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
-                           "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"}
+                           "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
         fus = [k for k in ksum if k["kernel"] == "inproj_attn_causal" and k["shape"][0] == B]
         if fus:
@@ -1054,6 +1073,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, C)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_reason"] = ("timed on rank 0 at N = 1 only (the host cores are shared by the ranks of an N > 1 run)" if world > 1
+                                      else "--no-cpu-baseline")
 
     if world > 1:
         dist.barrier()

@@ -42,6 +42,7 @@ if has rehearse; then   # the N > 1 code paths with two processes on this one GP
     echo "rehearse $tag rc=$?"; cut -c1-260 gpurun_out/rehearse_$tag.json; tail -2 gpurun_out/rehearse_$tag.err
   done
   unset EEND_DIST_BACKEND
+  python tools/check_rehearse.py gpurun_out/rehearse_infer.json gpurun_out/rehearse_train_fs.json gpurun_out/rehearse_train_ls.json | tee gpurun_out/rehearse_check.txt
 fi
 prof() {   # prof <tag> <bench args...>
   local tag=$1; shift
