@@ -51,6 +51,8 @@ def flops_per_launch(name, shape, T):
         return 4.0 * M * F * K + 2.0 * M * K * K * 2 + 2.0 * M * 768 * K
     if name == "spk_qkv_attn":         # the in-projection GEMM (the C x C attention itself is VALU work)
         return 2.0 * shape[0] * 768 * 256
+    if name == "attnout_spk_stream":   # out-projection + speaker-axis in-projection GEMMs (LayerNorm and attention are VALU work)
+        return 2.0 * shape[0] * (256 + 768) * 256
     if name in ("attnout_ffn_fused", "attnout_ffn_stream"):    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
@@ -137,7 +139,7 @@ class OpTimer:
                 shape = (a[0].shape[0], a[2].shape[0], a[0].shape[1])
             elif name == "inproj_heads":
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
-            elif name == "spk_qkv_attn":
+            elif name in ("spk_qkv_attn", "attnout_spk_stream"):
                 shape = (a[0].shape[0],)
             elif name == "fusion_layer_tail":
                 shape = (a[0].shape[0], a[15].shape[0], 256)
@@ -152,7 +154,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
                   "convert_fanout", "attn_causal", "inproj_attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):

@@ -207,6 +207,24 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
     return eend_launch_ffn_stream(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_spk_stream_elems(void) { return (int)eend_spk_stream_nelems(); }
+
+int eend_spk_stream_ok(int C, int Tp) { return eend_spk_stream_supported(C, Tp); }
+
+int eend_spk_stream_pack_f16(const void* Wo, const void* W_in, void* stream_out, void* stream) {
+    return eend_launch_spk_stream_pack(Wo, W_in, stream_out, (hipStream_t)stream);
+}
+
+int eend_attnout_spk_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const void* res_f16,
+                                const float* g1, const float* be1, float eps1, void* x_f16, const float* b_in, void* O_f16,
+                                int B, int C, int Tp, float scale, void* stream) {
+    SpkStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.wstream = wstream; p.bo = bo; p.res16 = res_f16; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
+    p.x16 = x_f16; p.bin = b_in; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.scale = scale;
+    return eend_launch_spk_stream(p, (hipStream_t)stream);
+}
+
 int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
                                const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
                                const void* Win2, const float* bin2,

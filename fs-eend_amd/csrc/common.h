@@ -30,6 +30,15 @@ DEV _Float16 to_f16_sat(float x) {
 // row) is conflict-free; ds_write_b128 of a contiguous row is conflict-free too.
 DEV int swz128(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
+// Lanes of one wave exchanging data through LDS: the hardware runs a wave's LDS operations in order, so no wait is needed, but
+// the COMPILER reasons per thread -- without this it may reuse an earlier load of the same address (found the hard way: a
+// staging tile read back after other lanes rewrote it).  Generates no instructions.
+DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 DEV float wave_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 DEV float wave_xor_max(float v, int m) { return __builtin_fmaxf(v, __shfl_xor(v, m, 64)); }
 

@@ -538,12 +538,14 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) *(f16x8*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = o[e];
                 }
+                wave_lds_sync();
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
-                    const u32x4 v = *(const u32x4*)(st + rr * 512 + ((cc ^ rr) << 4));
-                    if (rbase + half * 8 + rr < p.M) *(u32x4*)(o16 + (size_t)(rbase + half * 8 + rr) * 256 + cc * 8) = v;
+                    const f16x8 v = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));      // (same type as the writes: no type-based reordering)
+                    if (rbase + half * 8 + rr < p.M) *(f16x8*)(o16 + (size_t)(rbase + half * 8 + rr) * 256 + cc * 8) = v;
                 }
+                wave_lds_sync();
             }
             if (o32) {
 #pragma unroll
@@ -556,6 +558,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                                 *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) =
                                     f32x4{v[(fh * 8 + e) * 4], v[(fh * 8 + e) * 4 + 1], v[(fh * 8 + e) * 4 + 2], v[(fh * 8 + e) * 4 + 3]};
                         }
+                        wave_lds_sync();
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
                             const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
@@ -563,6 +566,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                             if (rbase + half * 8 + rr < p.M)
                                 *(f32x4*)(o32 + (size_t)(rbase + half * 8 + rr) * 256 + (cc >> 3) * 64 + fh * 32 + (cc & 7) * 4) = v;
                         }
+                        wave_lds_sync();
                     }
             }
 #if !EEND_FS_XFLATE

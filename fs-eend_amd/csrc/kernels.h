@@ -265,6 +265,26 @@ struct FfnStreamParams {
 long eend_ffn_stream_nelems(int F, int with_wo);
 int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
 int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream);
+// spk_stream.hip: x1 = LN11(A Wo1^T + bo1 + res16), O = speaker-axis MHA(x1 Win2^T + bin2) in one launch (C in {3, 6, 12})
+struct SpkStreamParams {
+    const void* A;        // time-axis attention output f16 [B*C*Tp][lda], row = (b*C + c)*Tp + t
+    int lda;
+    const void* wstream;  // eend_spk_stream_pack_f16 output
+    const float* bo;      // out-projection bias, LayerNorm11 affine
+    const float* g1;
+    const float* be1;
+    float eps1;
+    const void* res16;    // residual f16 [B*C*Tp][256]
+    void* x16;            // x1 f16 [B*C*Tp][256] (may be res16)
+    const float* bin;     // [768] in-projection bias (q, k, v)
+    void* O;              // attention output f16 [B*C*Tp][256] (may be A when lda == 256)
+    int B, C, Tp;
+    float scale;          // 1/sqrt(dh)
+};
+long eend_spk_stream_nelems();
+int eend_spk_stream_supported(int C, int Tp);
+int eend_launch_spk_stream_pack(const void* Wo, const void* Win, void* out, hipStream_t stream);
+int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream);
 // convert_f32.hip: decoder input in f32 on the exact-f32 MFMA (LS-EEND batch forward)
 int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int Tp,
                                    int C, hipStream_t stream);

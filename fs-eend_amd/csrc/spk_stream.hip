@@ -1,0 +1,423 @@
+// First half of a speaker-fusion decoder layer on a packed weight stream (round 4), one launch instead of two:
+//     x1 = LayerNorm11(A Wo1^T + bo1 + res)                     (time-axis attention out-projection, residual, norm11)
+//     O  = MHA_over_slots(x1 Win2^T + bin2)                     (speaker-axis in-projection + the C x C attention of every frame)
+// Reference sites: FS merge_tfm_encoder.py:356-394 (_sa_block1 tail + norm11, _sa_block2), LS merge_retnet_layer.py:301-306.
+// Replaces eend_linear_res16_ln_f16 + eend_spk_qkv_attn_f16 on the hot path for C in {3, 6, 12}.
+//
+// Same machinery as ffn_stream.hip (one wave per SIMD, 48 token rows per wave, weight fragments streamed by LDS-DMA through an
+// 8-slot ring, one barrier per 16-KB item, LayerNorm output == next GEMM's B operand), with two differences:
+//   * a wave's 48 rows are the C slots of 48/C consecutive frames (row = (b*C + c)*Tp + t), token index = c*G + t', so every
+//     frame's slots sit in ONE wave: in the MFMA output layout (lane = token column, 4 rows per 16-lane group) the keys and
+//     values of the other slots of a lane's frame are in the same lane (other token fragment) or a fixed rotation away inside
+//     the 16-lane row -- DPP row_ror, no LDS, no barrier.  The whole attention is register arithmetic on the projection's
+//     accumulators; q, k, v never exist in memory in any form (and are never rounded to f16).
+//   * the in-projection rows are permuted inside each head (MFMA row rho of feature fragment ff <-> feature (rho>>2)*16 + ff*4
+//     + (rho&3)) so that a lane holds 16 CONSECUTIVE head features of its tokens: the head's output leaves as full 128-byte lines.
+// The key bias is dropped: q . b_k is the same for every key of a query and cancels in the softmax.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int V> using IC = std::integral_constant<int, V>;
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+constexpr int NJ = 3;                // token fragments per wave (48 rows)
+constexpr int SLOT = 16384;          // one stream item: 16 fragments of 1 KB
+constexpr int NSLOT = 8;
+constexpr int STAGE = NSLOT * SLOT;  // 4 x 4 KB wave-private output staging
+constexpr int VECS = STAGE + 4 * 4096;   // f32 vectors: bo, g1, be1 (3 x 256), bin (768)
+constexpr int SMEM = VECS + 6 * 1024;    // 153600
+constexpr int NB = 8;                // weight-fragment registers in rotation
+constexpr int PD = 6;                // fragment prefetch distance
+constexpr int INFL = 4 * (NSLOT - 3);
+constexpr int NITEMS = 8 + 24;       // Wo1: 8 items; in-projection: 4 heads x {q, k, v} x 2 halves of 32 features
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight stream packing, one thread per 16 bytes.  lane = (f = l & 15, g = l >> 4):
+//   items 0..7   Wo (kc = item >> 1, sl = item & 1), fragment i : Wo[(f>>2)*64 + i*4 + (f&3)][kc*64 + sl*32 + g*8 + e]
+//   item 8 + h*6 + t*2 + u (t = 0 q, 1 k, 2 v), fragment p = s*2 + hf :
+//                Win[t*256 + h*64 + (f>>2)*16 + (u*2+hf)*4 + (f&3)][g*64 + 8s + e]
+__global__ void spk_stream_pack_kernel(const _Float16* __restrict__ Wo, const _Float16* __restrict__ Win, _Float16* __restrict__ out) {
+    const long total = (long)NITEMS * (SLOT / 16);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int item = (int)(t >> 10), w = (int)(t & 1023);
+        const int pfrag = w >> 6, l = w & 63, f = l & 15, g = l >> 4;
+        const _Float16* src;
+        if (item < 8) {
+            const int kc = item >> 1, sl = item & 1;
+            src = Wo + (size_t)((f >> 2) * 64 + pfrag * 4 + (f & 3)) * 256 + kc * 64 + sl * 32 + g * 8;
+        } else {
+            const int q = item - 8, h = q / 6, tt = (q % 6) >> 1, u = q & 1;
+            const int s_ = pfrag >> 1, hf = pfrag & 1;
+            src = Win + (size_t)(tt * 256 + h * 64 + (f >> 2) * 16 + (u * 2 + hf) * 4 + (f & 3)) * 256 + g * 64 + 8 * s_;
+        }
+        _Float16* dst = out + t * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = src[e];
+    }
+}
+
+template <int N>
+__device__ __forceinline__ float row_rot(float x) {          // value of the lane N places away inside the 16-lane row
+    if constexpr (N == 0) return x;
+    else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xF, 0xF, false));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// G frames per wave, R = 16/G slots per token fragment, C = 3R slots
+template <int G>
+__global__ __launch_bounds__(256, 1)
+void spk_stream_kernel(const SpkStreamParams p) {
+    constexpr int R = 16 / G, C = 3 * R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TPB = p.Tp / (4 * G);                       // tiles per utterance
+    const int ntiles = p.B * TPB;
+
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int frow = lane & 15, g = lane >> 4;
+    int fo = g * 64;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, NITEMS * SLOT, 0x00020000);
+    int dvo = lane * 16 + wave * 4096;
+    int nxt = 0;
+    int slot = 0;
+
+    auto dma_piece = [&](int sd, auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_char*)(smem + sd * SLOT + wave * 4096 + i * 1024), 16, dvo,
+                                                 nxt * SLOT + i * 1024, 0, 0);
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) { nxt = nxt + 1 == NITEMS ? 0 : nxt + 1; };
+
+    sfor<NSLOT - 1>([&](auto IT) __attribute__((always_inline)) {
+        sfor<4>([&](auto I) __attribute__((always_inline)) { dma_piece(decltype(IT)::value, I); });
+        dma_advance();
+    });
+
+    float* vecs = (float*)(smem + VECS);                  // [0..767]: bo, g1, be1; [768..1535]: bin (q, k, v)
+    {
+        vecs[0 * 256 + tid] = p.bo[tid];
+        vecs[1 * 256 + tid] = p.g1[tid];
+        vecs[2 * 256 + tid] = p.be1[tid];
+        vecs[3 * 256 + tid] = p.bin[tid];
+        vecs[4 * 256 + tid] = p.bin[256 + tid];
+        vecs[5 * 256 + tid] = p.bin[512 + tid];
+    }
+    auto vec4 = [&](int which, int i) __attribute__((always_inline)) { return *(const f32x4*)(vecs + which * 256 + fo + i * 4); };
+
+    const char* wl = smem + lane * 16;
+    f16x8 wf[NB];
+    f32x4 acc[16][NJ];                                    // out-projection accumulators, features fo + i*4 + r
+    f32x4 qkv[12][NJ];                                    // one head: [t*4 + ff], features g*16 + ff*4 + r of the head
+    f16x8 xf[8][NJ];
+
+    // memory row of token (fragment j, column fr) of a tile
+    auto row_tok = [&](int tile, int j, int fr) __attribute__((always_inline)) {
+        const int b = tile / TPB, tt = tile - b * TPB;
+        return (b * C + j * R + fr / G) * p.Tp + tt * (4 * G) + wave * G + (fr % G);
+    };
+    auto load_in_frags = [&](int tile, auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const _Float16* src = (const _Float16*)p.A + (size_t)row_tok(tile, j, frow) * p.lda + g * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xf[s][j] = *(const f16x8*)(src + s * 32);
+    };
+    f16x8 r8[NJ][8];
+    auto load_res16 = [&](int tile, auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const _Float16* src = (const _Float16*)p.res16 + (size_t)row_tok(tile, j, frow) * 256 + fo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r8[j][e] = *(const f16x8*)(src + e * 8);
+    };
+
+    __builtin_amdgcn_s_waitcnt(0x0070 | ((4 * (NSLOT - 2)) & 15) | (((4 * (NSLOT - 2)) >> 4) << 14));   // item 0 has landed; lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    if (blockIdx.x < ntiles) sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(blockIdx.x, J); });
+
+    // One stream item.  KIND 0: acc += Wo(item) x xf[src]; KIND 1: qkv[TU*2 + hf] = Win2 fragments x xf (TU = t*2 + u).
+    // vmcnt(INFL + VWX): the VMEM operations of this wave that are certainly younger than its pieces of the NEXT item.
+    auto step = [&](auto KIND, auto SRCc, auto COLDc, auto PFNc, int wait_sel) __attribute__((always_inline)) {
+        constexpr int kind = decltype(KIND)::value, src = decltype(SRCc)::value;
+        constexpr bool cold = decltype(COLDc)::value, pfn = decltype(PFNc)::value;
+        // wait_sel: 0 = INFL, 1 = INFL + 6 (a head's output stores), 2 = INFL + 24 (first tile: its input loads), 3 = INFL + 30
+        if (wait_sel == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (INFL & 15) | ((INFL >> 4) << 14));
+        else if (wait_sel == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((INFL + 6) & 15) | (((INFL + 6) >> 4) << 14));
+        else if (wait_sel == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((INFL + 24) & 15) | (((INFL + 24) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((INFL + 30) & 15) | (((INFL + 30) >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        const char* wc = wl + slot * SLOT;
+        const char* wn = wl + ((slot + 1) & (NSLOT - 1)) * SLOT;
+        const int sd = (slot + NSLOT - 1) & (NSLOT - 1);
+        if constexpr (cold) {
+            sfor<PD>([&](auto Q) __attribute__((always_inline)) {
+                wf[decltype(Q)::value % NB] = *(const f16x8*)(wc + decltype(Q)::value * 1024);
+            });
+        }
+        sfor<8>([&](auto P2) __attribute__((always_inline)) {
+            sfor<2>([&](auto PH) __attribute__((always_inline)) {
+                constexpr int pi = decltype(P2)::value * 2 + decltype(PH)::value;
+                const f16x8 w = wf[pi % NB];
+                if constexpr (kind == 0) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[pi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[src][j], acc[pi][j], 0, 0, 0);
+                } else {
+                    constexpr int s_ = pi >> 1, hf = pi & 1, idx = src * 2 + hf;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        qkv[idx][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[s_][j], s_ == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : qkv[idx][j], 0, 0, 0);
+                }
+                if constexpr (pi + PD < 16) wf[(pi + PD) % NB] = *(const f16x8*)(wc + (pi + PD) * 1024);
+                else if constexpr (pfn) wf[(pi + PD) % NB] = *(const f16x8*)(wn + (pi + PD - 16) * 1024);
+                if constexpr (pi < 4) dma_piece(sd, IC<pi>{});
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        dma_advance();
+        slot = (slot + 1) & (NSLOT - 1);
+    };
+
+    char* st = smem + STAGE + wave * 4096;
+    bool first = true;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; frow = lane & 15; g = lane >> 4; fo = g * 64;
+        dvo = lane * 16 + wave * 4096;
+        wl = smem + lane * 16;
+        st = smem + STAGE + wave * 4096;
+        const int ntile = tile + (int)gridDim.x;
+        using T = std::true_type;
+        using Fa = std::false_type;
+
+        // ---- x1 = LN11(A Wo1^T + bo1 + res)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 b4 = vec4(0, i);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = b4;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+        const int w0 = first ? 2 : 3;
+        step(IC<0>{}, IC<0>{}, T{}, T{}, w0);
+        step(IC<0>{}, IC<1>{}, Fa{}, T{}, w0);
+        step(IC<0>{}, IC<2>{}, Fa{}, T{}, w0);
+        step(IC<0>{}, IC<3>{}, Fa{}, T{}, w0);
+        step(IC<0>{}, IC<4>{}, Fa{}, T{}, w0);
+        step(IC<0>{}, IC<5>{}, Fa{}, T{}, w0);
+        first = false;
+        step(IC<0>{}, IC<6>{}, Fa{}, T{}, 0);
+        load_res16(tile, IC<0>{});
+        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+        _Float16* x16 = (_Float16*)p.x16;
+        sfor<NJ>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            float v[64];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] + (float)r8[j][i >> 1][(i & 1) * 4 + q];
+                sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
+            }
+            sum = wave_xor_add(sum, 16);
+            sum = wave_xor_add(sum, 32);
+            const float mean = sum * (1.0f / 256);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j + 1 < NJ) load_res16(tile, IC<j + 1>{});
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
+            sq = wave_xor_add(sq, 16);
+            sq = wave_xor_add(sq, 32);
+            const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)__builtin_fmaf(v[i * 4 + q], gg[q], bb[q]);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // x1 rows leave through the staging tile as whole 512-byte rows
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if ((frow >> 3) == half) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) *(f16x8*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = xf[e][j];
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
+                    const f16x8 v4 = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));
+                    *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
+                }
+                wave_lds_sync();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        // ---- per head: q, k, v of the wave's 48 tokens (6 items), then the C x C attention of its frames in registers
+        _Float16* O = (_Float16*)p.O;
+        for (int head = 0; head < 4; ++head) {
+            step(IC<1>{}, IC<0>{}, T{}, T{}, 1);
+            step(IC<1>{}, IC<1>{}, Fa{}, T{}, 1);
+            step(IC<1>{}, IC<2>{}, Fa{}, T{}, 1);
+            step(IC<1>{}, IC<3>{}, Fa{}, T{}, 1);
+            step(IC<1>{}, IC<4>{}, Fa{}, T{}, 1);
+            step(IC<1>{}, IC<5>{}, Fa{}, Fa{}, 1);
+            if (head == 3 && ntile < ntiles)              // x1 is dead: the next tile's input rows travel under the last attention
+                sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); });
+
+            const float* bq = vecs + 3 * 256 + head * 64 + g * 16;
+            float s[NJ][C];
+#pragma unroll
+            for (int a = 0; a < NJ; ++a)
+#pragma unroll
+                for (int c = 0; c < C; ++c) s[a][c] = 0.f;
+            sfor<4>([&](auto FF) __attribute__((always_inline)) {
+                constexpr int ff = decltype(FF)::value;
+                const f32x4 b4 = *(const f32x4*)(bq + ff * 4);
+                f32x4 q[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) q[j] = (qkv[ff][j] + b4) * p.scale;
+                sfor<NJ>([&](auto J2) __attribute__((always_inline)) {
+                    constexpr int j2 = decltype(J2)::value;
+                    const f32x4 k = qkv[4 + ff][j2];
+                    sfor<R>([&](auto D) __attribute__((always_inline)) {
+                        constexpr int d = decltype(D)::value;
+                        f32x4 kr;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) kr[r] = row_rot<d * G>(k[r]);
+#pragma unroll
+                        for (int j1 = 0; j1 < NJ; ++j1)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[j1][j2 * R + d] = __builtin_fmaf(q[j1][r], kr[r], s[j1][j2 * R + d]);
+                    });
+                });
+            });
+#pragma unroll
+            for (int a = 0; a < NJ; ++a) {
+                float mx = -INFINITY, den = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    s[a][c] = wave_xor_add(s[a][c], 16);
+                    s[a][c] = wave_xor_add(s[a][c], 32);
+                    mx = __builtin_fmaxf(mx, s[a][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) { s[a][c] = __expf(s[a][c] - mx); den += s[a][c]; }
+                const float inv = 1.0f / den;
+#pragma unroll
+                for (int c = 0; c < C; ++c) s[a][c] *= inv;
+            }
+            f16x8 of[NJ][2];
+            const float* bv = vecs + 5 * 256 + head * 64 + g * 16;
+            sfor<4>([&](auto FF) __attribute__((always_inline)) {
+                constexpr int ff = decltype(FF)::value;
+                const f32x4 b4 = *(const f32x4*)(bv + ff * 4);
+                f32x4 o[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) o[j] = b4;
+                sfor<NJ>([&](auto J2) __attribute__((always_inline)) {
+                    constexpr int j2 = decltype(J2)::value;
+                    const f32x4 vv = qkv[8 + ff][j2];
+                    sfor<R>([&](auto D) __attribute__((always_inline)) {
+                        constexpr int d = decltype(D)::value;
+                        f32x4 vr;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vr[r] = row_rot<d * G>(vv[r]);
+#pragma unroll
+                        for (int j1 = 0; j1 < NJ; ++j1)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[j1][r] = __builtin_fmaf(s[j1][j2 * R + d], vr[r], o[j1][r]);
+                    });
+                });
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) of[j][ff >> 1][(ff & 1) * 4 + r] = to_f16_sat(o[j][r]);
+            });
+            // the head's 64 features of 16 tokens = 16 full 128-byte lines per token fragment, through a 2-KB staging tile
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                char* sj = st + (j & 1) * 2048;
+                *(f16x8*)(sj + frow * 128 + (((g * 2) ^ (frow & 7)) << 4)) = of[j][0];
+                *(f16x8*)(sj + frow * 128 + (((g * 2 + 1) ^ (frow & 7)) << 4)) = of[j][1];
+                wave_lds_sync();
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int rr = lane >> 3, cc = lane & 7;
+                    const f16x8 v4 = *(const f16x8*)(sj + (half * 8 + rr) * 128 + ((cc ^ rr) << 4));
+                    *(f16x8*)(O + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + head * 64 + cc * 8) = v4;
+                }
+                wave_lds_sync();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int G>
+int launch(const SpkStreamParams& p, hipStream_t stream) {
+    static bool attr_done = false;
+    auto kern = spk_stream_kernel<G>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
+        attr_done = true;
+    }
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int ntiles = p.B * (p.Tp / (4 * G));
+    hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+}  // namespace
+
+long eend_spk_stream_nelems() { return (long)NITEMS * (SLOT / 2); }
+
+int eend_launch_spk_stream_pack(const void* Wo, const void* Win, void* out, hipStream_t stream) {
+    if (!Wo || !Win || !out) return EEND_EINVAL;
+    const long total = eend_spk_stream_nelems() / 8;
+    hipLaunchKernelGGL(spk_stream_pack_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, (const _Float16*)Wo,
+                       (const _Float16*)Win, (_Float16*)out);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_spk_stream_supported(int C, int Tp) {
+    if (C != 3 && C != 6 && C != 12) return 0;
+    return Tp > 0 && Tp % (4 * (48 / C)) == 0;
+}
+
+int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream) {
+    if (!p.A || !p.wstream || !p.bo || !p.g1 || !p.be1 || !p.res16 || !p.x16 || !p.bin || !p.O || p.B <= 0 || (p.lda & 7) ||
+        !eend_spk_stream_supported(p.C, p.Tp))
+        return EEND_EINVAL;
+    switch (p.C) {
+        case 3: return launch<16>(p, stream);
+        case 6: return launch<8>(p, stream);
+        default: return launch<4>(p, stream);
+    }
+}

@@ -43,6 +43,9 @@ FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
 FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM", "1") != "0"
 # f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
 RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
+# the first half of a decoder layer (out-projection + norm11 + speaker-axis in-projection + C x C attention) in one launch on a
+# packed weight stream (spk_stream.hip) where the slot count allows it (C in {3, 6, 12}); 0: linear_res16_ln + spk_qkv_attn
+SPK_STREAM = __import__("os").environ.get("EEND_SPK_STREAM", "1") != "0"
 
 
 class PositionalEncoding(nn.Module):
@@ -294,6 +297,9 @@ class OnlineTransformerDADiarization(nn.Module):
             for L in dl:
                 if ops.stream_ok(L["w1"].shape[0]):
                     L["ws"] = ops.ffn_stream_pack(L["out2_w"], L["w1"], L["w2"])
+        if SPK_STREAM and FUSED_SPK:
+            for L in dl:
+                L["ws1"] = ops.spk_stream_pack(L["out1_w"], L["in2_w"])
         P["dec.layers"] = dl
         self._prep, self._prep_key = P, key
         self._pc = {}
@@ -408,8 +414,12 @@ class OnlineTransformerDADiarization(nn.Module):
                                       L["w1"], L["b1"], L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], B, C, Tp)
                 continue
             if res16:
-                ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
-                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
+                if "ws1" in L and H == 4 and ops.spk_stream_ok(C, Tp):
+                    ops.attnout_spk_stream(o16, L["ws1"], L["out1_b"], ws.a16, L["g11"], L["be11"], L["eps11"], ws.a16, L["in2_b"],
+                                           o16, B, C, Tp)
+                else:
+                    ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
+                    ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
                 if "ws" in L:
                     ops.attnout_ffn_stream(o16, L["ws"], L["out2_b"], None, ws.a16, L["g21"], L["be21"], L["eps21"], L["b1"], L["b2"],
                                            L["g22"], L["be22"], L["eps22"], None, ws.a16)

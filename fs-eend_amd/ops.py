@@ -236,6 +236,37 @@ def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4, t_valid=0):
                                        _stream()), "eend_spk_qkv_attn_f16")
 
 
+def spk_stream_pack(wo16, win16):
+    """Pack Wo1 [256][256] + in_proj_weight [768][256] (f16) into the weight stream of attnout_spk_stream."""
+    L = _lib.load()
+    _chk(wo16, F16, "wo16"); _chk(win16, F16, "win16")
+    if wo16.shape != (256, 256) or win16.shape != (768, 256):
+        raise _lib.EendHipError("spk_stream_pack: expected Wo [256][256] and W_in [768][256]")
+    out = torch.empty(L.eend_spk_stream_elems(), dtype=F16, device=wo16.device)
+    _lib.check(L.eend_spk_stream_pack_f16(_p(wo16), _p(win16), _p(out), _stream()), "eend_spk_stream_pack_f16")
+    return out
+
+
+def spk_stream_ok(C, Tp):
+    return bool(_lib.load().eend_spk_stream_ok(int(C), int(Tp)))
+
+
+def attnout_spk_stream(a16, wstream, bo, res16, g1, be1, eps1, x16, b_in, out16, B, C, Tp):
+    """x16 = LN11(a16 @ Wo1.T + bo + res16); out16 = MHA over the C slots of (x16 @ W_in.T + b_in), one launch.
+    x16 may be res16 and out16 may be a16."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wstream, F16, "wstream"); _chk(res16, F16, "res16"); _chk(x16, F16, "x16"); _chk(out16, F16, "out16")
+    for n, t in (("bo", bo), ("g1", g1), ("be1", be1), ("b_in", b_in)):
+        _chk(t, F32, n)
+    M = B * C * Tp
+    if a16.shape != (M, 256) or res16.shape != (M, 256) or x16.shape != (M, 256) or out16.shape != (M, 256) or b_in.numel() != 768:
+        raise _lib.EendHipError("attnout_spk_stream: shape mismatch")
+    if wstream.numel() != L.eend_spk_stream_elems():
+        raise _lib.EendHipError("attnout_spk_stream: weight stream has the wrong size")
+    _lib.check(L.eend_attnout_spk_stream_f16(_p(a16), a16.stride(0), _p(wstream), _p(bo), _p(res16), _p(g1), _p(be1), eps1, _p(x16),
+                                             _p(b_in), _p(out16), B, C, Tp, 0.125, _stream()), "eend_attnout_spk_stream_f16")
+
+
 def spk_attn(qkv16, o16, B, C, Tp, H):
     L = _lib.load()
     _chk(qkv16, F16, "qkv16"); _chk(o16, F16, "o16")

@@ -180,6 +180,21 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
                                 const float* b2, const float* g2, const float* be2, float eps2,
                                 float* out_f32, void* out_f16, int M, int F, void* stream);
 
+/* First half of a speaker-fusion decoder layer in one launch on a packed weight stream (spk_stream.hip):
+ *   x1 = LayerNorm11(A Wo1^T + bo1 + res)    (out-projection of the time-axis attention, residual, norm11)
+ *   O  = MHA over the C slots of every frame of (x1 W_in^T + b_in)      (self_attn2 of the fusion layers)
+ * i.e. eend_linear_res16_ln_f16 followed by eend_spk_qkv_attn_f16 (FS merge_tfm_encoder.py:356-394; LS
+ * merge_retnet_layer.py:301-306), with q, k, v kept in f32 registers.  Rows are (b*C + c)*Tp + t.  Supported where
+ * eend_spk_stream_ok(C, Tp) != 0 (C in {3, 6, 12}, Tp a multiple of 4*48/C); other shapes return EEND_EINVAL and the caller
+ * uses the two-launch path.  eend_spk_stream_pack_f16 re-orders Wo1 [256][256] and W_in [768][256] (both f16) into the stream
+ * (eend_spk_stream_elems() f16 elements).  x_f16 may be res_f16 and O_f16 may be A (lda == 256): rows are read before written. */
+int eend_spk_stream_elems(void);
+int eend_spk_stream_ok(int C, int Tp);
+int eend_spk_stream_pack_f16(const void* Wo, const void* W_in, void* stream_out, void* stream);
+int eend_attnout_spk_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const void* res_f16,
+                                const float* g1, const float* be1, float eps1, void* x_f16, const float* b_in, void* O_f16,
+                                int B, int C, int Tp, float scale, void* stream);
+
 /* The whole row-local tail of a fusion (attractor decoder) layer in ONE launch, after the time-axis
  * attention / retention core (FS merge_tfm_encoder.py:364-376: out_proj of self_attn1 + norm11, _sa_block2 +
  * norm21, _ff_block + norm22; LS merge_retnet_layer.py:240-253 likewise with the retention out_proj):

@@ -1,0 +1,77 @@
+"""attnout_spk_stream (spk_stream.hip): LN11(A Wo1^T + bo1 + res) + speaker-axis MHA in one launch, against a torch fp32
+restatement of the same operator and against the two-launch path it replaces (linear_res16_ln + spk_qkv_attn)."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module("fs-eend_amd.ops")
+_lib = importlib.import_module("fs-eend_amd.lib")
+
+
+def _inputs(B, C, Tp, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    M = B * C * Tp
+    dev = "cuda"
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    a = r(M, 256).half()
+    res = r(M, 256).half()
+    wo = r(256, 256, sc=1 / 16).half()
+    win = r(768, 256, sc=1 / 8).half()
+    bo = r(256, sc=0.1); g1 = 1 + r(256, sc=0.1); be1 = r(256, sc=0.1); bin_ = r(768, sc=0.3)
+    return a, res, wo, win, bo, g1, be1, bin_
+
+
+def _torch_ref(a, res, wo, win, bo, g1, be1, bin_, B, C, Tp):
+    x = torch.nn.functional.layer_norm(a.float() @ wo.float().T + bo + res.float(), (256,), g1, be1, 1e-5)
+    x16 = x.half()
+    qkv = x16.float() @ win.float().T + bin_
+    q, k, v = qkv.split(256, dim=1)
+    sh = lambda t: t.view(B, C, Tp, 4, 64).permute(0, 2, 3, 1, 4)      # B, Tp, H, C, dh
+    p = torch.softmax(sh(q) @ sh(k).transpose(-1, -2) * 0.125, dim=-1)
+    o = (p @ sh(v)).permute(0, 3, 1, 2, 4).reshape(B * C * Tp, 256)
+    return x, o
+
+
+@pytest.mark.parametrize("B,C,Tp", [(2, 6, 64), (3, 6, 512), (1, 3, 128), (2, 12, 64), (5, 12, 256), (70, 6, 96)])
+def test_attnout_spk_stream_vs_torch(B, C, Tp):
+    a, res, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 11 + C)
+    assert ops.spk_stream_ok(C, Tp)
+    ws = ops.spk_stream_pack(wo, win)
+    x16 = torch.empty_like(res); o16 = torch.empty_like(a)
+    ops.attnout_spk_stream(a, ws, bo, res, g1, be1, 1e-5, x16, bin_, o16, B, C, Tp)
+    torch.cuda.synchronize()
+    xr, orf = _torch_ref(a, res, wo, win, bo, g1, be1, bin_, B, C, Tp)
+    assert torch.isfinite(o16).all() and torch.isfinite(x16).all()
+    assert (x16.float() - xr).abs().max().item() < 2e-2
+    assert (o16.float() - orf).abs().max().item() < 2e-2
+    # the two-launch path it replaces
+    x2 = torch.empty_like(res); o2 = torch.empty_like(a)
+    ops.linear_res16_ln(a, wo, bo, res, g1, be1, None, x2, 1e-5)
+    ops.spk_qkv_attn(x2, win, bin_, o2, B, C, Tp, 4)
+    torch.cuda.synchronize()
+    assert (x16.float() - x2.float()).abs().max().item() < 1e-2
+    assert (o16.float() - o2.float()).abs().max().item() < 2e-2
+
+
+def test_attnout_spk_stream_in_place():
+    B, C, Tp = 4, 6, 128
+    a, res, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 5)
+    ws = ops.spk_stream_pack(wo, win)
+    x16 = torch.empty_like(res); o16 = torch.empty_like(a)
+    ops.attnout_spk_stream(a, ws, bo, res, g1, be1, 1e-5, x16, bin_, o16, B, C, Tp)
+    a2, r2 = a.clone(), res.clone()
+    ops.attnout_spk_stream(a2, ws, bo, r2, g1, be1, 1e-5, r2, bin_, a2, B, C, Tp)      # x over res, O over A
+    torch.cuda.synchronize()
+    assert torch.equal(r2, x16) and torch.equal(a2, o16)
+
+
+def test_attnout_spk_stream_unsupported_shapes():
+    assert not ops.spk_stream_ok(4, 512) and not ops.spk_stream_ok(10, 512) and not ops.spk_stream_ok(6, 500)
+    B, C, Tp = 1, 4, 64
+    a, res, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 3)
+    ws = ops.spk_stream_pack(wo, win)
+    with pytest.raises(_lib.EendHipError):
+        ops.attnout_spk_stream(a, ws, bo, res, g1, be1, 1e-5, torch.empty_like(res), bin_, torch.empty_like(a), B, C, Tp)
