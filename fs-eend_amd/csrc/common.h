@@ -39,6 +39,22 @@ DEV void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sums over lane ^ 16 / lane ^ 32 without an LDS round trip (ds_bpermute costs an exposed ~150-cycle wait in one-wave-per-SIMD
+// kernels): gfx950's permlane swaps exchange the odd 16-lane rows of one register with the even rows of another (16) or the
+// upper half of one with the lower half of another (32); with both registers holding v, their sum is the all-reduce.  By hand:
+// this hipcc maps both results of __builtin_amdgcn_permlane16_swap to the same register.  (s_nop: VALU write -> permlane read.)
+DEV float wave_xor16_add(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+DEV float wave_xor32_add(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+DEV float wave_g_allreduce_add(float v) { return wave_xor32_add(wave_xor16_add(v)); }      // over the four 16-lane rows
+
 DEV float wave_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 DEV float wave_xor_max(float v, int m) { return __builtin_fmaxf(v, __shfl_xor(v, m, 64)); }
 

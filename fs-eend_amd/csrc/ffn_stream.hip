@@ -412,16 +412,14 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                     }
                     sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
                 }
-                sum = wave_xor_add(sum, 16);
-                sum = wave_xor_add(sum, 32);
+                sum = wave_g_allreduce_add(sum);
                 const float mean = sum * (1.0f / 256);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (j + 1 < NJ) { load_res(IC<j + 1>{}); if constexpr (RES16 && EEND_FS_RES12 == 1) load_res16(tile, IC<j + 1>{}); }   // under passes 2 and 3
                 float sq = 0.f;
 #pragma unroll
                 for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
-                sq = wave_xor_add(sq, 16);
-                sq = wave_xor_add(sq, 32);
+                sq = wave_g_allreduce_add(sq);
                 const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -510,14 +508,12 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] * p.alpha;
                 sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
             }
-            sum = wave_xor_add(sum, 16);
-            sum = wave_xor_add(sum, 32);
+            sum = wave_g_allreduce_add(sum);
             const float mean = sum * (1.0f / 256);
             float sq = 0.f;
 #pragma unroll
             for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
-            sq = wave_xor_add(sq, 16);
-            sq = wave_xor_add(sq, 32);
+            sq = wave_g_allreduce_add(sq);
             const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps);
             __builtin_amdgcn_sched_barrier(0);
             f16x8 o[8];

@@ -28,6 +28,7 @@ __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_seq
 template <int V> using IC = std::integral_constant<int, V>;
 
 typedef __attribute__((address_space(3))) char lds_char;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NJ = 3;                // token fragments per wave (48 rows)
 constexpr int SLOT = 16384;          // one stream item: 16 fragments of 1 KB
@@ -38,6 +39,16 @@ constexpr int SMEM = VECS + 6 * 1024;    // 153600
 constexpr int NB = 8;                // weight-fragment registers in rotation
 constexpr int PD = 6;                // fragment prefetch distance
 constexpr int INFL = 4 * (NSLOT - 3);
+#ifndef EEND_SPK_XLATE
+#define EEND_SPK_XLATE 0          // next tile's input rows: 0 = requested before the last head's attention, 1 = after it
+#endif
+#ifndef EEND_SPK_RES
+#define EEND_SPK_RES 0            // where the residual rows are requested (see the tile loop)
+#endif
+#ifndef EEND_SPK_STUDY
+#define EEND_SPK_STUDY 0          // perf-study builds only (results are garbage): 1 no attention math, 2 no x1 stores, 4 no O stores,
+                                  // 8 no score FMAs, 16 no reductions / softmax, 32 no PV FMAs
+#endif
 constexpr int NITEMS = 8 + 24;       // Wo1: 8 items; in-projection: 4 heads x {q, k, v} x 2 halves of 32 features
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -64,6 +75,21 @@ __global__ void spk_stream_pack_kernel(const _Float16* __restrict__ Wo, const _F
         for (int e = 0; e < 8; ++e) dst[e] = src[e];
     }
 }
+
+// Perf-study build (-DEEND_SPK_TRACE, tools/spk_stream_trace.py): s_memtime stamps of the tile phases of wave 0 of every
+// workgroup (first 4 tiles), read back through eend_debug_spk_stream_trace; never defined in the shipped library.
+#ifdef EEND_SPK_TRACE
+__device__ unsigned long long g_spks_trace[256 * 4 * 12];
+#define SPK_STAMP(k) do { ts[k] = __builtin_amdgcn_s_memtime(); } while (0)      /* kept in scalar registers, written at the tile's end */
+#define SPK_STAMP_H(base, head)                                                                                        \
+    do {                                                                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                    \
+        if ((head) == 0) ts[base] = t_; else if ((head) == 1) ts[(base) + 2] = t_; else if ((head) == 2) ts[(base) + 4] = t_; else ts[(base) + 6] = t_; \
+    } while (0)
+#else
+#define SPK_STAMP_H(base, head) do {} while (0)
+#define SPK_STAMP(k) do {} while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ float row_rot(float x) {          // value of the lane N places away inside the 16-lane row
@@ -146,15 +172,14 @@ void spk_stream_kernel(const SpkStreamParams p) {
     if (blockIdx.x < ntiles) sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(blockIdx.x, J); });
 
     // One stream item.  KIND 0: acc += Wo(item) x xf[src]; KIND 1: qkv[TU*2 + hf] = Win2 fragments x xf (TU = t*2 + u).
-    // vmcnt(INFL + VWX): the VMEM operations of this wave that are certainly younger than its pieces of the NEXT item.
-    auto step = [&](auto KIND, auto SRCc, auto COLDc, auto PFNc, int wait_sel) __attribute__((always_inline)) {
-        constexpr int kind = decltype(KIND)::value, src = decltype(SRCc)::value;
+    // vmcnt(INFL + VWX): the VMEM operations of this wave that are certainly younger than its pieces of the NEXT item (those were
+    // requested six items earlier): the INFL pieces of the five items in between plus VWX loads / stores issued since.  Compile-time
+    // (a run-time choice between two s_waitcnt compiles to both); undercounting is safe, it only waits for more.
+    auto step = [&](auto KIND, auto SRCc, auto COLDc, auto PFNc, auto VWXc) __attribute__((always_inline)) {
+        constexpr int kind = decltype(KIND)::value, src = decltype(SRCc)::value, vw = INFL + decltype(VWXc)::value;
         constexpr bool cold = decltype(COLDc)::value, pfn = decltype(PFNc)::value;
-        // wait_sel: 0 = INFL, 1 = INFL + 6 (a head's output stores), 2 = INFL + 24 (first tile: its input loads), 3 = INFL + 30
-        if (wait_sel == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (INFL & 15) | ((INFL >> 4) << 14));
-        else if (wait_sel == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((INFL + 6) & 15) | (((INFL + 6) >> 4) << 14));
-        else if (wait_sel == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((INFL + 24) & 15) | (((INFL + 24) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((INFL + 30) & 15) | (((INFL + 30) >> 4) << 14));
+        static_assert(vw <= 63, "vmcnt is a 6-bit field");
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (vw & 15) | ((vw >> 4) << 14));
         __builtin_amdgcn_s_barrier();
         const char* wc = wl + slot * SLOT;
         const char* wn = wl + ((slot + 1) & (NSLOT - 1)) * SLOT;
@@ -188,7 +213,9 @@ void spk_stream_kernel(const SpkStreamParams p) {
     };
 
     char* st = smem + STAGE + wave * 4096;
-    bool first = true;
+#ifdef EEND_SPK_TRACE
+    int tix = -1;
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63; frow = lane & 15; g = lane >> 4; fo = g * 64;
@@ -196,6 +223,11 @@ void spk_stream_kernel(const SpkStreamParams p) {
         wl = smem + lane * 16;
         st = smem + STAGE + wave * 4096;
         const int ntile = tile + (int)gridDim.x;
+#ifdef EEND_SPK_TRACE
+        ++tix;
+        unsigned long long ts[11];
+#endif
+        SPK_STAMP(0);
         using T = std::true_type;
         using Fa = std::false_type;
 
@@ -210,49 +242,73 @@ void spk_stream_kernel(const SpkStreamParams p) {
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
-        const int w0 = first ? 2 : 3;
-        step(IC<0>{}, IC<0>{}, T{}, T{}, w0);
-        step(IC<0>{}, IC<1>{}, Fa{}, T{}, w0);
-        step(IC<0>{}, IC<2>{}, Fa{}, T{}, w0);
-        step(IC<0>{}, IC<3>{}, Fa{}, T{}, w0);
-        step(IC<0>{}, IC<4>{}, Fa{}, T{}, w0);
-        step(IC<0>{}, IC<5>{}, Fa{}, T{}, w0);
-        first = false;
-        step(IC<0>{}, IC<6>{}, Fa{}, T{}, 0);
+        // items 0..4: the tile's 24 input-row loads are younger than the pieces they wait for (first tile: issued behind the ring
+        // prime; later: behind the previous tile's last item, with 6 output stores on top).  The residual rows are requested
+        // three, two and one item ahead of the LayerNorm that adds them, into registers the consumed input fragments freed.
+        step(IC<0>{}, IC<0>{}, T{}, T{}, IC<24>{});
+        step(IC<0>{}, IC<1>{}, Fa{}, T{}, IC<24>{});
+        step(IC<0>{}, IC<2>{}, Fa{}, T{}, IC<24>{});
+        step(IC<0>{}, IC<3>{}, Fa{}, T{}, IC<24>{});
+        step(IC<0>{}, IC<4>{}, Fa{}, T{}, IC<24>{});
+#if EEND_SPK_RES == 1
         load_res16(tile, IC<0>{});
-        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, 0);
+        step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<32>{});
+        load_res16(tile, IC<1>{});
+        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<16>{});
+        load_res16(tile, IC<2>{});
+        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<24>{});
+#elif EEND_SPK_RES == 3
+        step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<24>{});
+        load_res16(tile, IC<0>{});
+        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<8>{});
+        load_res16(tile, IC<1>{});
+        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<16>{});
+#else
+        step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<24>{});
+        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<0>{});
+        load_res16(tile, IC<0>{});
+        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<8>{});
+#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+        SPK_STAMP(1);
         _Float16* x16 = (_Float16*)p.x16;
         sfor<NJ>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
-            float v[64];
-            float sum = 0.f;
+            // Two passes over the accumulators (AGPR reads are cheap) instead of a 64-value buffer: the buffer next to the residual
+            // rows of this and the next fragment overflowed the register file, and a scratch reload waits for every VMEM
+            // operation in flight (stores, weight DMA).  Statistics: sum and sum of squares in one pass (f32; |x| = O(10)).
+            f32x2 sm = f32x2{0.f, 0.f}, sq2 = f32x2{0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] + (float)r8[j][i >> 1][(i & 1) * 4 + q];
-                sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
+                const f32x4 a4 = acc[i][j];
+                const f32x2 x0 = f32x2{a4[0] + (float)r8[j][i >> 1][(i & 1) * 4 + 0], a4[1] + (float)r8[j][i >> 1][(i & 1) * 4 + 1]};
+                const f32x2 x1 = f32x2{a4[2] + (float)r8[j][i >> 1][(i & 1) * 4 + 2], a4[3] + (float)r8[j][i >> 1][(i & 1) * 4 + 3]};
+                sm += x0 + x1;
+                sq2 = x1 * x1 + (x0 * x0 + sq2);
             }
-            sum = wave_xor_add(sum, 16);
-            sum = wave_xor_add(sum, 32);
+            const float sum = wave_g_allreduce_add(sm[0] + sm[1]);
+            const float sqs = wave_g_allreduce_add(sq2[0] + sq2[1]);
             const float mean = sum * (1.0f / 256);
+            const float var = __builtin_fmaxf(sqs * (1.0f / 256) - mean * mean, 0.f);
+            const float rstd = 1.0f / __builtin_sqrtf(var + p.eps1);
             __builtin_amdgcn_sched_barrier(0);
+#if EEND_SPK_RES == 0
             if constexpr (j + 1 < NJ) load_res16(tile, IC<j + 1>{});
-            float sq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
-            sq = wave_xor_add(sq, 16);
-            sq = wave_xor_add(sq, 32);
-            const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps1);
-            __builtin_amdgcn_sched_barrier(0);
+#elif EEND_SPK_RES == 2
+            if constexpr (j == 0) { load_res16(tile, IC<1>{}); load_res16(tile, IC<2>{}); }
+#elif EEND_SPK_RES == 3
+            if constexpr (j == 0) load_res16(tile, IC<2>{});
+#endif
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i);
+                const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i) - vec4(1, i) * (rstd * mean);
+                const f32x4 a4 = acc[i][j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)__builtin_fmaf(v[i * 4 + q], gg[q], bb[q]);
+                for (int q = 0; q < 4; ++q)
+                    xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)__builtin_fmaf(a4[q] + (float)r8[j][i >> 1][(i & 1) * 4 + q], gg[q], bb[q]);
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             // x1 rows leave through the staging tile as whole 512-byte rows
@@ -267,111 +323,158 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
                     const f16x8 v4 = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));
-                    *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
+                    if (!(EEND_SPK_STUDY & 2)) *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
                 }
                 wave_lds_sync();
             }
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        SPK_STAMP(2);
         // ---- per head: q, k, v of the wave's 48 tokens (6 items), then the C x C attention of its frames in registers
         _Float16* O = (_Float16*)p.O;
-        for (int head = 0; head < 4; ++head) {
-            step(IC<1>{}, IC<0>{}, T{}, T{}, 1);
-            step(IC<1>{}, IC<1>{}, Fa{}, T{}, 1);
-            step(IC<1>{}, IC<2>{}, Fa{}, T{}, 1);
-            step(IC<1>{}, IC<3>{}, Fa{}, T{}, 1);
-            step(IC<1>{}, IC<4>{}, Fa{}, T{}, 1);
-            step(IC<1>{}, IC<5>{}, Fa{}, Fa{}, 1);
-            if (head == 3 && ntile < ntiles)              // x1 is dead: the next tile's input rows travel under the last attention
+        // (the last head is peeled: the next tile's input loads issued there would otherwise look pending at every iteration's top)
+        auto head_body = [&](int head, auto LAST) __attribute__((always_inline)) {
+            step(IC<1>{}, IC<0>{}, T{}, T{}, IC<6>{});
+            step(IC<1>{}, IC<1>{}, Fa{}, T{}, IC<6>{});
+            step(IC<1>{}, IC<2>{}, Fa{}, T{}, IC<6>{});
+            step(IC<1>{}, IC<3>{}, Fa{}, T{}, IC<6>{});
+            step(IC<1>{}, IC<4>{}, Fa{}, T{}, IC<6>{});
+            step(IC<1>{}, IC<5>{}, Fa{}, Fa{}, IC<6>{});
+            SPK_STAMP_H(3, head);
+            if (EEND_SPK_XLATE == 0 && decltype(LAST)::value && ntile < ntiles)              // x1 is dead: the next tile's input rows travel under the last attention
                 sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); });
 
+            // packed f32 arithmetic (v_pk_fma_f32: two FMAs per lane and instruction) on register pairs of the accumulator quads
             const float* bq = vecs + 3 * 256 + head * 64 + g * 16;
-            float s[NJ][C];
+            const float* bv = vecs + 5 * 256 + head * 64 + g * 16;
+            f32x4 bnext = *(const f32x4*)bq;              // bias quads are requested one fragment ahead of their use
+            f32x2 s2[NJ][C];
 #pragma unroll
             for (int a = 0; a < NJ; ++a)
 #pragma unroll
-                for (int c = 0; c < C; ++c) s[a][c] = 0.f;
+                for (int c = 0; c < C; ++c) s2[a][c] = f32x2{0.f, 0.f};
+            f16x8 of[NJ][2];
+#if !(EEND_SPK_STUDY & 1)
             sfor<4>([&](auto FF) __attribute__((always_inline)) {
                 constexpr int ff = decltype(FF)::value;
-                const f32x4 b4 = *(const f32x4*)(bq + ff * 4);
-                f32x4 q[NJ];
+                const f32x4 b4 = bnext;
+                bnext = ff < 3 ? *(const f32x4*)(bq + (ff + 1) * 4) : *(const f32x4*)bv;
+                f32x2 q[NJ][2];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) q[j] = (qkv[ff][j] + b4) * p.scale;
+                for (int j = 0; j < NJ; ++j) {
+                    const f32x4 t = (qkv[ff][j] + b4) * p.scale;
+                    q[j][0] = f32x2{t[0], t[1]}; q[j][1] = f32x2{t[2], t[3]};
+                }
                 sfor<NJ>([&](auto J2) __attribute__((always_inline)) {
                     constexpr int j2 = decltype(J2)::value;
                     const f32x4 k = qkv[4 + ff][j2];
                     sfor<R>([&](auto D) __attribute__((always_inline)) {
                         constexpr int d = decltype(D)::value;
-                        f32x4 kr;
+                        const f32x2 k0 = f32x2{row_rot<d * G>(k[0]), row_rot<d * G>(k[1])};
+                        const f32x2 k1 = f32x2{row_rot<d * G>(k[2]), row_rot<d * G>(k[3])};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) kr[r] = row_rot<d * G>(k[r]);
-#pragma unroll
-                        for (int j1 = 0; j1 < NJ; ++j1)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) s[j1][j2 * R + d] = __builtin_fmaf(q[j1][r], kr[r], s[j1][j2 * R + d]);
+                        for (int j1 = 0; j1 < NJ; ++j1) {
+                            if (EEND_SPK_STUDY & 8) { if (j1 == 0) s2[j1][j2 * R + d] += q[j1][1] + k1 + k0; }
+                            else s2[j1][j2 * R + d] = q[j1][1] * k1 + (q[j1][0] * k0 + s2[j1][j2 * R + d]);
+                        }
                     });
                 });
             });
+            float s[NJ][C];
 #pragma unroll
             for (int a = 0; a < NJ; ++a) {
                 float mx = -INFINITY, den = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    s[a][c] = wave_xor_add(s[a][c], 16);
-                    s[a][c] = wave_xor_add(s[a][c], 32);
+                    s[a][c] = s2[a][c][0] + s2[a][c][1];
+                    if (!(EEND_SPK_STUDY & 16)) s[a][c] = wave_g_allreduce_add(s[a][c]);
                     mx = __builtin_fmaxf(mx, s[a][c]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) { s[a][c] = __expf(s[a][c] - mx); den += s[a][c]; }
-                const float inv = 1.0f / den;
+                for (int c = 0; c < C; ++c) { if (!(EEND_SPK_STUDY & 16)) s[a][c] = __expf(s[a][c] - mx); den += s[a][c]; }
+                const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
                 for (int c = 0; c < C; ++c) s[a][c] *= inv;
             }
-            f16x8 of[NJ][2];
-            const float* bv = vecs + 5 * 256 + head * 64 + g * 16;
             sfor<4>([&](auto FF) __attribute__((always_inline)) {
                 constexpr int ff = decltype(FF)::value;
-                const f32x4 b4 = *(const f32x4*)(bv + ff * 4);
-                f32x4 o[NJ];
+                const f32x4 b4 = bnext;
+                if constexpr (ff < 3) bnext = *(const f32x4*)(bv + (ff + 1) * 4);
+                f32x2 o[NJ][2];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) o[j] = b4;
+                for (int j = 0; j < NJ; ++j) { o[j][0] = f32x2{b4[0], b4[1]}; o[j][1] = f32x2{b4[2], b4[3]}; }
                 sfor<NJ>([&](auto J2) __attribute__((always_inline)) {
                     constexpr int j2 = decltype(J2)::value;
                     const f32x4 vv = qkv[8 + ff][j2];
                     sfor<R>([&](auto D) __attribute__((always_inline)) {
                         constexpr int d = decltype(D)::value;
-                        f32x4 vr;
+                        const f32x2 v0 = f32x2{row_rot<d * G>(vv[0]), row_rot<d * G>(vv[1])};
+                        const f32x2 v1 = f32x2{row_rot<d * G>(vv[2]), row_rot<d * G>(vv[3])};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) vr[r] = row_rot<d * G>(vv[r]);
-#pragma unroll
-                        for (int j1 = 0; j1 < NJ; ++j1)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[j1][r] = __builtin_fmaf(s[j1][j2 * R + d], vr[r], o[j1][r]);
+                        for (int j1 = 0; j1 < NJ; ++j1) {
+                            const f32x2 pw = f32x2{s[j1][j2 * R + d], s[j1][j2 * R + d]};
+                            if (EEND_SPK_STUDY & 32) { if (j1 == 0) { o[j1][0] += pw + v0; o[j1][1] += v1; } }
+                            else {
+                                o[j1][0] = pw * v0 + o[j1][0];
+                                o[j1][1] = pw * v1 + o[j1][1];
+                            }
+                        }
                     });
                 });
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) of[j][ff >> 1][(ff & 1) * 4 + r] = to_f16_sat(o[j][r]);
+                for (int j = 0; j < NJ; ++j) {
+                    of[j][ff >> 1][(ff & 1) * 4 + 0] = to_f16_sat(o[j][0][0]); of[j][ff >> 1][(ff & 1) * 4 + 1] = to_f16_sat(o[j][0][1]);
+                    of[j][ff >> 1][(ff & 1) * 4 + 2] = to_f16_sat(o[j][1][0]); of[j][ff >> 1][(ff & 1) * 4 + 3] = to_f16_sat(o[j][1][1]);
+                }
             });
-            // the head's 64 features of 16 tokens = 16 full 128-byte lines per token fragment, through a 2-KB staging tile
+#else
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                char* sj = st + (j & 1) * 2048;
-                *(f16x8*)(sj + frow * 128 + (((g * 2) ^ (frow & 7)) << 4)) = of[j][0];
-                *(f16x8*)(sj + frow * 128 + (((g * 2 + 1) ^ (frow & 7)) << 4)) = of[j][1];
-                wave_lds_sync();
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int rr = lane >> 3, cc = lane & 7;
-                    const f16x8 v4 = *(const f16x8*)(sj + (half * 8 + rr) * 128 + ((cc ^ rr) << 4));
-                    *(f16x8*)(O + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + head * 64 + cc * 8) = v4;
+                for (int e = 0; e < 8; ++e) { of[j][0][e] = (_Float16)(qkv[0][j][e & 3] + qkv[4][j][e & 3]); of[j][1][e] = (_Float16)qkv[8][j][e & 3]; }
+#endif
+            // the head's 64 features of 16 tokens = 16 full 128-byte lines per token fragment, through the staging tile (2 KB per
+            // fragment: fragments 0 and 1 in one LDS round trip, fragment 2 in a second)
+            auto stage_out = [&](auto J0, auto NF) __attribute__((always_inline)) {
+                constexpr int j0 = decltype(J0)::value, nf = decltype(NF)::value;
+#pragma unroll
+                for (int jj = 0; jj < nf; ++jj) {
+                    char* sj = st + jj * 2048;
+                    *(f16x8*)(sj + frow * 128 + (((g * 2) ^ (frow & 7)) << 4)) = of[j0 + jj][0];
+                    *(f16x8*)(sj + frow * 128 + (((g * 2 + 1) ^ (frow & 7)) << 4)) = of[j0 + jj][1];
                 }
                 wave_lds_sync();
-            }
+                f16x8 v4[nf][2];
+                const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+                for (int jj = 0; jj < nf; ++jj)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) v4[jj][half] = *(const f16x8*)(st + jj * 2048 + (half * 8 + rr) * 128 + ((cc ^ rr) << 4));
+#pragma unroll
+                for (int jj = 0; jj < nf; ++jj)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        if (!(EEND_SPK_STUDY & 4))
+                            *(f16x8*)(O + (size_t)row_tok(tile, j0 + jj, half * 8 + rr) * 256 + head * 64 + cc * 8) = v4[jj][half];
+                wave_lds_sync();
+            };
+            stage_out(IC<0>{}, IC<2>{});
+            stage_out(IC<2>{}, IC<1>{});
+            SPK_STAMP_H(4, head);
             __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int head = 0; head < 3; ++head) head_body(head, Fa{});
+        head_body(3, T{});
+#if EEND_SPK_XLATE == 1
+        if (ntile < ntiles) sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); });
+#endif
+#ifdef EEND_SPK_TRACE
+        if (tix < 4 && threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) g_spks_trace[((size_t)blockIdx.x * 4 + tix) * 12 + k] = ts[k];
         }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -395,6 +498,12 @@ int launch(const SpkStreamParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef EEND_SPK_TRACE
+extern "C" int eend_debug_spk_stream_trace(void* dst, void* stream) {
+    return hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_spks_trace), sizeof(g_spks_trace), 0, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -2;
+}
+#endif
 
 long eend_spk_stream_nelems() { return (long)NITEMS * (SLOT / 2); }
 
