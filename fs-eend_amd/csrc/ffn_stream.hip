@@ -36,6 +36,7 @@ template <int V> using IC = std::integral_constant<int, V>;
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // rows per wave = 16 NJ (NJ token fragments), rows per tile (workgroup) = 64 NJ; NJ = 3 for large M, 2 when that fills more CUs
 constexpr int SLOT = 16384;        // one stream item: 16 fragments of 1 KB
@@ -44,7 +45,8 @@ constexpr int STAGE = NSLOT * SLOT;    // 4 x 4 KB wave-private output staging (
 constexpr int VECS = STAGE + 4 * 4096; // 6 per-feature f32 vectors
 constexpr int B1L = VECS + 6 * 1024;   // b1, up to 2048 hidden units
 constexpr int MAXF = 2048;
-constexpr int SMEM = B1L + MAXF * 4;   // 161792
+constexpr int DUMP = B1L + MAXF * 4;   // 256-byte dump area of the L2-touch loads
+constexpr int SMEM = DUMP + 256;       // 162048
 #ifndef EEND_FS_NB
 #define EEND_FS_NB 8
 #endif
@@ -54,7 +56,7 @@ constexpr int NB = EEND_FS_NB;     // weight-fragment registers in rotation (div
 #endif
 constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
 #ifndef EEND_FS_RES0
-#define EEND_FS_RES0 1            // residual rows of fragment 0: 0 = requested with the tile's input rows, 1 = before the last out-projection item
+#define EEND_FS_RES0 0            // residual rows of fragment 0: 0 = requested with the tile's input rows, 1 = before the last out-projection item
 #endif
 #ifndef EEND_FS_RES12
 #define EEND_FS_RES12 1           // ... of fragments 1, 2: 0 = before the 7th out-projection item, 1 = under the LayerNorm of the previous fragment
@@ -75,7 +77,7 @@ constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
 #define EEND_FS_PIN 15
 #endif
 #ifndef EEND_FS_XFLATE
-#define EEND_FS_XFLATE 1           // next tile's input rows: 0 = loaded fragment by fragment inside the epilogue, 1 = touched before the last
+#define EEND_FS_XFLATE 2           // next tile's input rows: 0 = loaded fragment by fragment inside the epilogue, 1 = touched before the last
                                    // two items and loaded after the epilogue, 2 = loaded before the last two items
 #endif
 constexpr int INFL = 4 * (NSLOT - 3);   // this wave's DMA pieces younger than the ones a barrier needs (5 items x 4 pieces)
@@ -135,13 +137,7 @@ __global__ void ffn_stream_pack_kernel(const _Float16* __restrict__ Wo, const _F
 // every workgroup, read back through eend_debug_fs_trace; never defined in the shipped library.
 #ifdef EEND_FS_TRACE
 __device__ unsigned long long g_fs_trace[256 * 8 * 10];
-#define FS_STAMP(k)                                                                                               \
-    do {                                                                                                          \
-        if (tix < 8) {                                                                                            \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
-            if (threadIdx.x == 0) g_fs_trace[((size_t)blockIdx.x * 8 + tix) * 10 + (k)] = t_;                      \
-        }                                                                                                         \
-    } while (0)
+#define FS_STAMP(k) do { ts[k] = __builtin_amdgcn_s_memtime(); } while (0)       /* kept in scalar registers, written at the tile's end */
 #else
 #define FS_STAMP(k) do {} while (0)
 #endif
@@ -171,6 +167,14 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     int fo = g * 64;                                      // this lane's features: fo + i*4 + r
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, S * SLOT, 0x00020000);
+    // Rows move through raw buffer resources: 32-bit offsets instead of 64-bit pointers (fewer address registers), and the
+    // hardware drops / zero-fills accesses beyond the last row -- no clamps, no per-row branches in the epilogue.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (p.M - 1) * p.lda * 2 + 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR16 = __builtin_amdgcn_make_buffer_rsrc((void*)p.res16, 0, p.res16 ? p.M * 512 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR32 = __builtin_amdgcn_make_buffer_rsrc((void*)p.res32, 0, p.res32 ? p.M * 1024 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO16 = __builtin_amdgcn_make_buffer_rsrc(p.out16, 0, p.M * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO32 = __builtin_amdgcn_make_buffer_rsrc((void*)p.out32, 0, p.out32 ? p.M * 1024 : 0, 0x00020000);
+    auto bload = [&](const __amdgpu_buffer_rsrc_t& r, int off) __attribute__((always_inline)) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
     int dvo = lane * 16 + wave * 4096;                    // this wave moves pieces wave*4 .. wave*4+3 of every item
     int nxt = 0;                                          // next stream item to request (0 .. S-1)
     int slot = 0;                                         // ring slot of the item being consumed
@@ -217,12 +221,9 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     auto row_of = [&](int tile, int j) __attribute__((always_inline)) { return tile * TM + wave * WM + j * 16 + frow; };
     auto load_in_frags = [&](int tile, auto J) __attribute__((always_inline)) {      // xf[s][j] = In[row][s*32 + g*8 ..]
         constexpr int j = decltype(J)::value;
-        const _Float16* __restrict__ A = (const _Float16*)p.A;
-        int r = row_of(tile, j);
-        r = r < p.M ? r : p.M - 1;
-        const _Float16* src = A + (size_t)r * p.lda + g * 8;
+        const int off = row_of(tile, j) * (p.lda * 2) + g * 16;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) xf[s][j] = *(const f16x8*)(src + s * 32);
+        for (int s = 0; s < 8; ++s) xf[s][j] = __builtin_bit_cast(f16x8, bload(rsA, off + s * 64));
     };
 
     // first fragments of slot 0 (legal once every wave's pieces of item 0 have landed); vectors visible
@@ -234,11 +235,9 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     auto load_res16 = [&](int tile, auto J) __attribute__((always_inline)) {
         if constexpr (RES16 && PRE) {
             constexpr int j = decltype(J)::value;
-            int r = row_of(tile, j);
-            r = r < p.M ? r : p.M - 1;
-            const _Float16* src = (const _Float16*)p.res16 + (size_t)r * 256 + fo;
+            const int off = row_of(tile, j) * 512 + fo * 2;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r8[j][e] = *(const f16x8*)(src + e * 8);
+            for (int e = 0; e < 8; ++e) r8[j][e] = __builtin_bit_cast(f16x8, bload(rsR16, off + e * 16));
         }
     };
     if (blockIdx.x < ntiles) { sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(blockIdx.x, J); }); if (EEND_FS_RES0 == 0) load_res16(blockIdx.x, IC<0>{}); }
@@ -336,29 +335,33 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
         }
     };
-    // pull rows of a later tile towards the L2 ahead of their loads: one dword per 128-byte line, values unused.  (3 loads per
-    // wave for its 48 rows; the loads complete in order with everything else, so they cost nothing unless waited for.)
-    auto touch_rows = [&](const void* base, int row_bytes, int t) __attribute__((always_inline)) {
-        if (t < ntiles) {
+    // pull rows of a later tile towards the L2 ahead of their loads: one dword per 128-byte line, by LDS-DMA into a dump area
+    // nobody reads -- no destination register, so nothing ever waits for these loads specifically (a VGPR destination gets "used"
+    // or spilled by the compiler, either of which exposes the HBM round trip; that was the shipped state until the ISA was read).
+    auto touch_rows = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < NJ; ++q) {
-                const int idx = q * 64 + lane;
-                int r = t * TM + wave * WM + (idx >> 2);
-                r = r < p.M ? r : p.M - 1;
-                const unsigned v = *(const unsigned*)((const char*)base + (size_t)r * row_bytes + (idx & 3) * 128);
-                asm volatile("" :: "v"(v));
-            }
+        for (int q = 0; q < NJ; ++q) {
+            const int idx = q * 64 + lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_char*)(smem + DUMP), 4, (t * TM + wave * WM + (idx >> 2)) * (p.lda * 2) + (idx & 3) * 128, 0, 0, 0);
         }
     };
+    auto touch_done = [&]() __attribute__((always_inline)) {};
     bool loose = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float ralpha = 1.0f / p.alpha;
-        asm volatile("" : "+v"(tid));
-        lane = tid & 63; frow = lane & 15; g = lane >> 4; fo = g * 64;
-        dvo = lane * 16 + wave * 4096;
-        wl = smem + lane * 16;
+        float alpha_l = p.alpha;                          // laundered: 1/alpha hoisted out of the tile loop ended up in scratch
+        asm volatile("" : "+s"(alpha_l));
+        float ralpha = 1.0f / alpha_l;
+        // (re-derived at every phase boundary: nothing lane-dependent has to stay live -- or be spilled -- across a phase)
+        auto relaunder = [&]() __attribute__((always_inline)) {
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63; frow = lane & 15; g = lane >> 4; fo = g * 64;
+            dvo = lane * 16 + wave * 4096;
+            wl = smem + lane * 16;
+        };
+        relaunder();
 #ifdef EEND_FS_TRACE
         ++tix;
+        unsigned long long ts[8];
 #endif
         FS_STAMP(0);
         if constexpr (PRE) {
@@ -386,11 +389,9 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             auto load_res = [&](auto J) __attribute__((always_inline)) {
                 if constexpr (!RES16) {
                     constexpr int j = decltype(J)::value;
-                    int r = row_of(tile, j);
-                    r = r < p.M ? r : p.M - 1;
-                    const float* src = p.res32 + (size_t)r * 256 + fo;
+                    const int off = row_of(tile, j) * 1024 + fo * 4;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) t4[i] = *(const f32x4*)(src + i * 4);
+                    for (int i = 0; i < 16; ++i) t4[i] = __builtin_bit_cast(f32x4, bload(rsR32, off + i * 16));
                 }
             };
             load_res(IC<0>{});
@@ -398,58 +399,63 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, Fa{}, IC<(!RES16 ? 16 : (EEND_FS_RES12 == 0 ? 16 : 0) + (EEND_FS_RES0 == 1 ? 8 : 0))>{}, false, 0, hbA, hbB);
             pin_acc(2);
             FS_STAMP(1);
+            relaunder();
+            asm volatile("" : "+s"(alpha_l));
+            ralpha = 1.0f / alpha_l;
             sfor<NJ>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                // the fragment's 64 values per lane leave the accumulator file once and go back once
-                float v[64];
-                float sum = 0.f;
+                // Two passes over the accumulators (AGPR reads are cheap) instead of a 64-value buffer: the buffer next to the
+                // residual rows overflowed the register file, and a scratch reload waits for every VMEM operation in flight.
+                // Statistics in one pass: sum and sum of squares (f32; |x| = O(10)).
+                auto xval = [&](int i, int q) __attribute__((always_inline)) {
+                    if constexpr (RES16) return acc[i][j][q] + (float)r8[j][i >> 1][(i & 1) * 4 + q];
+                    else return acc[i][j][q] + t4[i][q];
+                };
+                f32x2 sm = f32x2{0.f, 0.f}, sq2 = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if constexpr (RES16) v[i * 4 + q] = acc[i][j][q] + (float)r8[j][i >> 1][(i & 1) * 4 + q];
-                        else v[i * 4 + q] = acc[i][j][q] + t4[i][q];
-                    }
-                    sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
+                    const f32x2 x0 = f32x2{xval(i, 0), xval(i, 1)}, x1 = f32x2{xval(i, 2), xval(i, 3)};
+                    sm += x0 + x1;
+                    sq2 = x1 * x1 + (x0 * x0 + sq2);
                 }
-                sum = wave_g_allreduce_add(sum);
+                const float sum = wave_g_allreduce_add(sm[0] + sm[1]);
+                const float sqs = wave_g_allreduce_add(sq2[0] + sq2[1]);
                 const float mean = sum * (1.0f / 256);
+                const float rstd = 1.0f / __builtin_sqrtf(__builtin_fmaxf(sqs * (1.0f / 256) - mean * mean, 0.f) + p.eps1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (j + 1 < NJ) { load_res(IC<j + 1>{}); if constexpr (RES16 && EEND_FS_RES12 == 1) load_res16(tile, IC<j + 1>{}); }   // under passes 2 and 3
-                float sq = 0.f;
-#pragma unroll
-                for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
-                sq = wave_g_allreduce_add(sq);
-                const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps1);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RES16) {
+                    if constexpr (j + 1 < NJ && EEND_FS_RES12 == 1) load_res16(tile, IC<j + 1>{});
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i), b2 = vec4(3, i);
+                    const f32x4 g4 = vec4(1, i), gg = g4 * rstd, bb = vec4(2, i) - g4 * (rstd * mean), b2 = vec4(3, i);
+                    f32x4 xo;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float x = __builtin_fmaf(v[i * 4 + q], gg[q], bb[q]);
+                        const float x = __builtin_fmaf(xval(i, q), gg[q], bb[q]);
                         // (no saturation: |x| <= 16 |gamma| + |beta| after a LayerNorm over 256 features)
                         xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)x;
-                        acc[i][j][q] = x * ralpha + b2[q];
+                        xo[q] = x * ralpha + b2[q];
                     }
+                    acc[i][j] = xo;
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // bounds how far the vector reads are hoisted
                 }
+                if constexpr (!RES16) { if constexpr (j + 1 < NJ) load_res(IC<j + 1>{}); }
             });
         } else {
             // ---- plain FFN: xf already holds X (natural k order); accumulators start at res / alpha + b2
             sfor<NJ>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                int r = row_of(tile, j);
-                r = r < p.M ? r : p.M - 1;
-                const float* src = p.res32 + (size_t)r * 256 + fo;
+                const int off = row_of(tile, j) * 1024 + fo * 4;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i][j] = *(const f32x4*)(src + i * 4) * ralpha + vec4(3, i);
+                for (int i = 0; i < 16; ++i) acc[i][j] = __builtin_bit_cast(f32x4, bload(rsR32, off + i * 16)) * ralpha + vec4(3, i);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
 
         // ---- FFN: item k = { h = W1h(k) x | acc += W2h(k-1) hb(k-1), hb(k) = act(h + b1) }, k = 0 .. U
         FS_STAMP(2);
+        relaunder();
         {
             using T = std::true_type;
             using Fa = std::false_type;
@@ -465,8 +471,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             for (int k = 2; k < U; k += 2) {                // U is even
 #if EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD > 0
                 if (k == U - 2 * EEND_FS_TOUCH_LEAD || (U <= 2 * EEND_FS_TOUCH_LEAD && k == 2)) {
-                    touch_rows(p.A, p.lda * 2, tile + (int)gridDim.x);
-                    if (RES16 && PRE && EEND_FS_TOUCH_RES) touch_rows(p.res16, 512, tile + (int)gridDim.x);
+                    touch_rows(tile + (int)gridDim.x);
                 }
 #endif
                 step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<0>{}, nloose > 2 * k - 2, 0, hbA, hbB);      // W2h(k-2) x hbA, h(k-1) -> hbB
@@ -477,7 +482,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             if constexpr (!PRE) loose = false;
             FS_STAMP(4);
 #if EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0
-            touch_rows(p.A, p.lda * 2, tile + (int)gridDim.x);
+            touch_rows(tile + (int)gridDim.x);
 #endif
 #if EEND_FS_XFLATE == 2
             // x is dead: the next tile's input rows are requested here and travel under the last two items and the epilogue
@@ -492,42 +497,42 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 
         // ---- epilogue, one token fragment at a time: v = acc * alpha; LayerNorm2; rows leave through the wave's 4-KB staging
         // tile as whole rows; the accumulators a fragment frees take the next tile's input rows
+        relaunder();
         char* st = smem + STAGE + wave * 4096;
-        _Float16* __restrict__ o16 = (_Float16*)p.out16;
-        float* __restrict__ o32 = p.out32;
+        const bool o32 = p.out32 != nullptr;
         const int ntile = tile + (int)gridDim.x;
         sfor<NJ>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
             const int rbase = tile * TM + wave * WM + j * 16;
-            // the fragment's 64 values per lane leave the accumulator file once
-            float v[64];
-            float sum = 0.f;
+            // two passes over the accumulators, no 64-value buffer (see LayerNorm1)
+            f32x2 sm = f32x2{0.f, 0.f}, sq2 = f32x2{0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] * p.alpha;
-                sum += (v[i * 4] + v[i * 4 + 1]) + (v[i * 4 + 2] + v[i * 4 + 3]);
+                const f32x4 a4 = acc[i][j] * p.alpha;
+                const f32x2 x0 = f32x2{a4[0], a4[1]}, x1 = f32x2{a4[2], a4[3]};
+                sm += x0 + x1;
+                sq2 = x1 * x1 + (x0 * x0 + sq2);
             }
-            sum = wave_g_allreduce_add(sum);
+            const float sum = wave_g_allreduce_add(sm[0] + sm[1]);
+            const float sqs = wave_g_allreduce_add(sq2[0] + sq2[1]);
             const float mean = sum * (1.0f / 256);
-            float sq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 64; ++e) { v[e] -= mean; sq = __builtin_fmaf(v[e], v[e], sq); }
-            sq = wave_g_allreduce_add(sq);
-            const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 256) + p.eps);
+            const float rstd = 1.0f / __builtin_sqrtf(__builtin_fmaxf(sqs * (1.0f / 256) - mean * mean, 0.f) + p.eps);
             __builtin_amdgcn_sched_barrier(0);
             f16x8 o[8];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const f32x4 gg = vec4(4, i) * rstd, bb = vec4(5, i);
+                const f32x4 g4 = vec4(4, i), gg = g4 * (rstd * p.alpha), bb = vec4(5, i) - g4 * (rstd * mean);
+                const f32x4 a4 = acc[i][j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float y = __builtin_fmaf(v[i * 4 + q], gg[q], bb[q]);
-                    o[i >> 1][(i & 1) * 4 + q] = (_Float16)y;          // (no saturation: a LayerNorm output, |y| <= 16 |gamma| + |beta|)
-                    if constexpr (EPI == FFN_EPI_RES_LN) v[i * 4 + q] = y; else v[i * 4 + q] += mean;       // what out32 receives
-                }
+                for (int q = 0; q < 4; ++q) o[i >> 1][(i & 1) * 4 + q] = (_Float16)__builtin_fmaf(a4[q], gg[q], bb[q]);      // (no saturation: a LayerNorm output)
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            // what out32 receives: the LayerNorm output (RES_LN) or the un-normalised residual stream
+            auto out32_val = [&](int i, int q) __attribute__((always_inline)) {
+                const float a = acc[i][j][q] * p.alpha;
+                if constexpr (EPI == FFN_EPI_RES_LN) return __builtin_fmaf(a - mean, vecs[4 * 256 + fo + i * 4 + q] * rstd, vecs[5 * 256 + fo + i * 4 + q]);
+                else return a;
+            };
 #pragma unroll
             for (int half = 0; half < 2; ++half) {          // token rows 0..7 / 8..15 of the fragment
                 if ((frow >> 3) == half) {
@@ -539,7 +544,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
                     const f16x8 v = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));      // (same type as the writes: no type-based reordering)
-                    if (rbase + half * 8 + rr < p.M) *(f16x8*)(o16 + (size_t)(rbase + half * 8 + rr) * 256 + cc * 8) = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO16, (rbase + half * 8 + rr) * 512 + cc * 16, 0, 0);
                 }
                 wave_lds_sync();
             }
@@ -552,15 +557,15 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
                                 *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) =
-                                    f32x4{v[(fh * 8 + e) * 4], v[(fh * 8 + e) * 4 + 1], v[(fh * 8 + e) * 4 + 2], v[(fh * 8 + e) * 4 + 3]};
+                                    f32x4{out32_val(fh * 8 + e, 0), out32_val(fh * 8 + e, 1), out32_val(fh * 8 + e, 2), out32_val(fh * 8 + e, 3)};
                         }
                         wave_lds_sync();
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
                             const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
                             const f32x4 v = *(const f32x4*)(st + rr * 512 + ((cc ^ rr) << 4));
-                            if (rbase + half * 8 + rr < p.M)
-                                *(f32x4*)(o32 + (size_t)(rbase + half * 8 + rr) * 256 + (cc >> 3) * 64 + fh * 32 + (cc & 7) * 4) = v;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO32,
+                                                                   (rbase + half * 8 + rr) * 1024 + (cc >> 3) * 256 + fh * 128 + (cc & 7) * 16, 0, 0);
                         }
                         wave_lds_sync();
                     }
@@ -575,7 +580,16 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 #elif EEND_FS_XFLATE == 2
         if (ntile < ntiles && EEND_FS_RES0 == 0) load_res16(ntile, IC<0>{});
 #endif
+#if EEND_FS_XFLATE == 1
+        touch_done();
+#endif
         FS_STAMP(6);
+#ifdef EEND_FS_TRACE
+        if (tix < 8 && threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g_fs_trace[((size_t)blockIdx.x * 8 + tix) * 10 + k] = ts[k];
+        }
+#endif
         loose = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
@@ -631,7 +645,7 @@ int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, 
 
 int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream) {
     if (p.M <= 0 || p.F < 64 || (p.F % 64) != 0 || p.F > MAXF || (p.lda & 7) || !p.A || !p.wstream || !p.b1 || !p.b2 || !p.gamma || !p.beta ||
-        !p.out16 || !(p.alpha != 0.f))
+        !p.out16 || !(p.alpha != 0.f) || ((long)p.M + 65536) * 1024 >= (1L << 31) || ((long)p.M + 65536) * p.lda * 2 >= (1L << 31))      // 32-bit buffer offsets (prefetch runs one grid of tiles ahead)
         return EEND_EINVAL;
     if (mode == 1) {
         if (!p.bo || !p.g1 || !p.be1 || act != 1 || epi != FFN_EPI_RES_LN || (!p.res16 && !p.res32)) return EEND_EINVAL;

@@ -2,7 +2,8 @@
 tools/ab_variants.sh build fstrace=-DEEND_FS_TRACE; run with EEND_HIP_LIB=.../libeend_hip_fstrace.so)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fs_eend_amd import lib as _lib, ops
+import importlib
+_lib = importlib.import_module('fs-eend_amd.lib'); ops = importlib.import_module('fs-eend_amd.ops')
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(0)
 def rn(*s, scale=1.0, dt=torch.float32):
@@ -24,7 +25,7 @@ L.eend_debug_fs_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 assert L.eend_debug_fs_trace(tr.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
 raw = tr.view(256, 8, 10).cpu()
-t = raw.double() / 100.0                                  # s_memtime ticks (100 MHz constant clock) -> us
+t = raw.double() / 100.0                                  # s_memtime ticks are shader cycles here (~2.1 GHz): printed numbers are cycles / 100
 nt = M // 192 // 256
 for blk in (0, 255):
     b0 = t[blk, 0, 0]
