@@ -39,7 +39,7 @@ def flops_per_launch(name, shape, T):
     if name == "attn_causal":          # 2*D*T*(T+1) causal-useful flops per sequence, D = H*64
         nseq, H = shape
         return nseq * 2.0 * (H * 64) * T * (T + 1)
-    if name == "inproj_attn_causal":   # packed in-projection (2*Tp*768*256 per sequence) + the causal-useful attention flops
+    if name in ("inproj_attn_causal", "inproj_attn_causal_packed"):   # packed in-projection (2*Tp*768*256 per sequence) + the causal-useful attention flops
         nseq, H = shape
         Tp = (T + 63) // 64 * 64
         return nseq * (2.0 * (H * 64) * T * (T + 1) + 2.0 * T * 768 * 256)
@@ -122,6 +122,8 @@ class OpTimer:
                 shape = (a[4], a[5])
             elif name == "inproj_attn_causal":
                 shape = (a[5], a[6])
+            elif name == "inproj_attn_causal_packed":   # (x16, w_packed, b_in, o16, nseq, H, Tp, ...)
+                shape = (a[4], a[5])
             elif name == "retention_proj":
                 shape = (a[0].shape[0], 1024, 256)
             elif name == "retention_chunk":
@@ -155,7 +157,7 @@ class OpTimer:
 
     def __enter__(self):
         for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
-                  "convert_fanout", "attn_causal", "inproj_attn_causal", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
+                  "convert_fanout", "attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):
                 continue

@@ -449,6 +449,21 @@ int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, co
     return eend_launch_inproj_attn(p, (hipStream_t)stream);
 }
 
+int eend_inproj_attn_packed_elems(void) { return (int)eend_inproj_attn_packed_nelems(); }
+
+int eend_inproj_attn_pack_f16(const void* W_in, void* packed_out, void* stream) {
+    return eend_launch_inproj_attn_pack(W_in, packed_out, (hipStream_t)stream);
+}
+
+int eend_inproj_attn_causal_packed_f16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16,
+                                       int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream) {
+    if (!X_f16 || !W_packed || !b_in || !O_f16 || nseq > 16383) return EEND_EINVAL;
+    InprojAttnParams p;
+    p.X = X_f16; p.ldx = ldx; p.W = W_packed; p.bias = b_in; p.Qs = nullptr; p.O = O_f16;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.mask_delay = mask_delay; p.kv_len = kv_len;
+    return eend_launch_inproj_attn_stream(p, (hipStream_t)stream);
+}
+
 int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
                           int B, int C, int Tp, int T_valid, int H, float scale, void* stream) {
     if (H != 4 || T_valid < 0 || T_valid > Tp) return EEND_EINVAL;

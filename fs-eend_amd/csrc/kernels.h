@@ -147,6 +147,10 @@ struct InprojAttnParams {
     int nseq, H, Tp, ldo, mask_delay, kv_len;
 };
 int eend_launch_inproj_attn(const InprojAttnParams& p, hipStream_t stream);
+// attn_stream.hip: the same operator with token-owning waves and fragment-packed weights (Tp = 512); p.W = packed weights, p.Qs unused
+long eend_inproj_attn_packed_nelems();
+int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream);
+int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream);
 
 // skinny.hip: linear layers with M <= EEND_SKINNY_MAX_M rows (the frame-by-frame streaming steps); same epilogue
 // semantics as the gemm.hip epilogues they replace.  EEND_SKINNY=0 in the environment keeps the tiled GEMM (A/B).

@@ -43,6 +43,8 @@ FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
 FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM", "1") != "0"
 # f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
 RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
+# time-axis attention with token-owning waves, packed in-projection weights and Q kept in registers (attn_stream.hip; Tp = 512 only)
+ATTN_STREAM = __import__("os").environ.get("EEND_ATTN_STREAM", "1") != "0"
 # the first half of a decoder layer (out-projection + norm11 + speaker-axis in-projection + C x C attention) in one launch on a
 # packed weight stream (spk_stream.hip) where the slot count allows it (C in {3, 6, 12}); 0: linear_res16_ln + spk_qkv_attn
 SPK_STREAM = __import__("os").environ.get("EEND_SPK_STREAM", "1") != "0"
@@ -275,6 +277,9 @@ class OnlineTransformerDADiarization(nn.Module):
             for L in layers:
                 if ops.stream_ok(L["w1"].shape[0]):
                     L["ws"] = ops.ffn_stream_pack(L["out_w"], L["w1"], L["w2"])
+        if ATTN_STREAM and FUSED_INPROJ_ATTN and enc.n_heads == 4:
+            for L in layers:
+                L["in_wp"] = ops.inproj_attn_pack(L["in_w"])
         P["enc.layers"] = layers
         cw = self.cnn.weight.detach()                       # (Dout, Din, k)
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
@@ -300,6 +305,9 @@ class OnlineTransformerDADiarization(nn.Module):
         if SPK_STREAM and FUSED_SPK:
             for L in dl:
                 L["ws1"] = ops.spk_stream_pack(L["out1_w"], L["in2_w"])
+        if ATTN_STREAM and FUSED_INPROJ_ATTN and enc.n_heads == 4:
+            for L in dl:
+                L["in1_wp"] = ops.inproj_attn_pack(L["in1_w"])
         P["dec.layers"] = dl
         self._prep, self._prep_key = P, key
         self._pc = {}
@@ -366,7 +374,9 @@ class OnlineTransformerDADiarization(nn.Module):
         for L in P["enc.layers"]:
             F = L["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
-            if FUSED_INPROJ_ATTN and Tp <= 512:
+            if FUSED_INPROJ_ATTN and Tp == 512 and "in_wp" in L:
+                ops.inproj_attn_causal_packed(ws.h16, L["in_wp"], L["in_b"], o16, B, H, Tp, delay_e, kv_e)
+            elif FUSED_INPROJ_ATTN and Tp <= 512:
                 ops.inproj_attn_causal(ws.h16, L["in_w"], L["in_b"], q, o16, B, H, Tp, delay_e, kv_e)
             else:
                 ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
@@ -403,7 +413,9 @@ class OnlineTransformerDADiarization(nn.Module):
         for L in P["dec.layers"]:
             F = L["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
-            if FUSED_INPROJ_ATTN and Tp <= 512:
+            if FUSED_INPROJ_ATTN and Tp == 512 and "in1_wp" in L:
+                ops.inproj_attn_causal_packed(ws.a16, L["in1_wp"], L["in1_b"], o16, B * C, H, Tp, self.dec.mask_delay, T)
+            elif FUSED_INPROJ_ATTN and Tp <= 512:
                 ops.inproj_attn_causal(ws.a16, L["in1_w"], L["in1_b"], q, o16, B * C, H, Tp, self.dec.mask_delay, T)
             else:
                 ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)

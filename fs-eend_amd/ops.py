@@ -226,6 +226,28 @@ def inproj_attn_causal(x16, w_in, b_in, q_scratch, o16, nseq, H, Tp, mask_delay=
                "eend_inproj_attn_causal_f16")
 
 
+def inproj_attn_pack(w_in):
+    """Pack in_proj_weight f16 [768][256] (q rows pre-scaled by QSCALE_LOG2) for inproj_attn_causal_packed."""
+    L = _lib.load()
+    _chk(w_in, F16, "w_in")
+    if w_in.shape != (768, 256):
+        raise _lib.EendHipError("inproj_attn_pack: expected in_proj_weight [768][256]")
+    out = torch.empty(L.eend_inproj_attn_packed_elems(), dtype=F16, device=w_in.device)
+    _lib.check(L.eend_inproj_attn_pack_f16(_p(w_in), _p(out), _stream()), "eend_inproj_attn_pack_f16")
+    return out
+
+
+def inproj_attn_causal_packed(x16, w_packed, b_in, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
+    """inproj_attn_causal on packed weights (attn_stream.hip; Tp = 512, H = 4): no Q scratch, Q stays in registers."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(w_packed, F16, "w_packed"); _chk(b_in, F32, "b_in"); _chk(o16, F16, "o16")
+    if w_packed.numel() != L.eend_inproj_attn_packed_elems() or b_in.numel() != 768 or x16.shape[0] < nseq * Tp or o16.shape[0] < nseq * Tp:
+        raise _lib.EendHipError("inproj_attn_causal_packed: shape mismatch")
+    _lib.check(L.eend_inproj_attn_causal_packed_f16(_p(x16), x16.stride(0), _p(w_packed), _p(b_in), _p(o16), nseq, H, Tp,
+                                                    o16.stride(0), mask_delay, Tp if kv_len is None else kv_len, _stream()),
+               "eend_inproj_attn_causal_packed_f16")
+
+
 def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4, t_valid=0):
     """Speaker-axis MHA with its in-projection fused: out = MHA_over_slots(x16 @ w_in.T + b_in)."""
     L = _lib.load()

@@ -396,6 +396,17 @@ int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H,
 int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, const float* b_in, void* Q_scratch_bf16,
                                 void* O_f16, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
 
+/* The same operator with the in-projection weights pre-packed in MFMA fragment order (attn_stream.hip): a wave keeps the X rows
+ * of the 64 tokens whose queries it runs in registers, the head's 96 KB of weights arrive by LDS-DMA, Q never leaves the wave --
+ * no Q scratch buffer.  eend_inproj_attn_pack_f16 re-orders W_in f16 [768][256] (q rows pre-scaled as above) into
+ * eend_inproj_attn_packed_elems() f16 elements, once per parameter version.  Tp must be 512 (EEND_EINVAL otherwise: the
+ * caller keeps eend_inproj_attn_causal_f16 for other chunk lengths); H = 4.  The key bias is not applied (it cancels in the
+ * softmax); b_in is the same [768] vector. */
+int eend_inproj_attn_packed_elems(void);
+int eend_inproj_attn_pack_f16(const void* W_in, void* packed_out, void* stream);
+int eend_inproj_attn_causal_packed_f16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16,
+                                       int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
+
 /* In-projection + attention core of the speaker-axis self-attention in one launch (the [M][768] qkv
  * tensor never reaches HBM): qkv = x W_in^T + b_in, then the unmasked MHA over the C (<= 12) slots of each
  * frame as eend_spk_attn_f16 (nn.MultiheadAttention self_attn2 of the fusion layers, _sa_block2: FS

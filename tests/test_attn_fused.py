@@ -56,6 +56,44 @@ def test_inproj_attn_fused(hip_lib, dev, nseq, Tp, delay, kv_len):
     # (the scratch buffer is a workspace: one 64 KB Q slot per persistent workgroup, rewritten for every item)
 
 
+@pytest.mark.parametrize("nseq,delay,kv_len", [(1, 0, 512), (8, 0, 500), (5, 3, 470), (40, 0, 500), (2, 1000, 512), (300, 0, 500)])
+def test_inproj_attn_packed(hip_lib, dev, nseq, delay, kv_len):
+    """attn_stream.hip (token-owning waves, packed weights, Q in registers) against fp32 torch and against attn_fused.hip."""
+    from fs_eend_amd import ops
+    Tp = 512
+    x, w, b = _case(dev, nseq, Tp, nseq * 11 + delay)
+    wp = ops.inproj_attn_pack(w)
+    o = torch.full((nseq * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.inproj_attn_causal_packed(x, wp, b, o, nseq, 4, Tp, delay, kv_len)
+    qs = torch.empty(nseq * Tp * 256, dtype=BF16, device=dev)
+    o1 = torch.empty_like(o)
+    ops.inproj_attn_causal(x, w, b, qs, o1, nseq, 4, Tp, delay, kv_len)
+    assert torch.isfinite(o).all()
+    e_old = (o.float() - o1.float()).abs().max().item()
+    if nseq <= 40:
+        y = x.float() @ w.float().t() + b
+        q, k, v = (y[:, i * 256:(i + 1) * 256].view(nseq, Tp, 4, 64).transpose(1, 2) for i in range(3))
+        s = (q @ k.transpose(-1, -2)) * math.log(2.0)
+        i = torch.arange(Tp, device=dev)[:, None]
+        j = torch.arange(Tp, device=dev)[None, :]
+        ok = ((j - i) <= delay) & (j < kv_len)
+        want = (torch.softmax(s.masked_fill(~ok, float("-inf")), -1) @ v).transpose(1, 2).reshape(nseq * Tp, 256)
+        e_ref = (o.float() - want).abs().max().item()
+        e_ref_old = (o1.float() - want).abs().max().item()
+        print(f"packed vs fp32 {e_ref:.2e} (attn_fused vs fp32 {e_ref_old:.2e}); packed vs attn_fused {e_old:.2e}")
+        assert e_ref < 2e-2
+    # two different bf16 roundings of K (here without the key bias, which cancels in the softmax) and of Q
+    assert e_old < 3e-2
+
+
+def test_inproj_attn_packed_rejects_other_lengths(hip_lib, dev):
+    from fs_eend_amd import ops, lib as _lib
+    x, w, b = _case(dev, 2, 256, 1)
+    wp = ops.inproj_attn_pack(w)
+    with pytest.raises(_lib.EendHipError):
+        ops.inproj_attn_causal_packed(x, wp, b, torch.empty_like(x), 2, 4, 256, 0, 256)
+
+
 @pytest.mark.parametrize("B,T,C", [(1, 37, 1), (3, 130, 3), (5, 500, 6), (2, 512, 10), (8, 257, 4)])
 def test_model_fused_vs_two_kernel_path(hip_lib, dev, B, T, C):
     """model.test through the fused in-projection + attention kernel == through inproj_heads + attn_causal (the path
