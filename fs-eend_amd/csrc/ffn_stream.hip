@@ -67,6 +67,9 @@ constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
 #ifndef EEND_FS_TOUCH_RES
 #define EEND_FS_TOUCH_RES 0
 #endif
+#ifndef EEND_FS_ILV
+#define EEND_FS_ILV 0              // 1: activation VALU instructions interleaved one per MFMA (sched_group_barrier); measured: no difference
+#endif
 #ifndef EEND_FS_STUDY
 #define EEND_FS_STUDY 0
 #endif
@@ -321,6 +324,18 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 if constexpr (kind == 2 && conv && pi >= 2 && pi < 2 + 4 * NJ && !(pi & 1)) conv_part(IC<(pi - 2) / 2>{}, hbo);
 #endif
             });
+#if EEND_FS_ILV
+            // a pair that carries an activation part (4 clamps + 2 packs): one VALU instruction behind each of its 2 NJ MFMAs.  Left
+            // to the scheduler the six follow the MFMAs in a block, and the matrix pipe idles while they issue (the pipe takes a
+            // new MFMA every 16 cycles, a VALU instruction occupies the wave's issue slot for 4).
+            if constexpr (kind == 2 && conv && decltype(P2)::value >= 1 && decltype(P2)::value < 1 + 2 * NJ) {
+#pragma unroll
+                for (int q = 0; q < 2 * NJ; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         dma_advance();
