@@ -59,7 +59,8 @@ constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
 #define EEND_FS_RES0 0            // residual rows of fragment 0: 0 = requested with the tile's input rows, 1 = before the last out-projection item
 #endif
 #ifndef EEND_FS_RES12
-#define EEND_FS_RES12 1           // ... of fragments 1, 2: 0 = before the 7th out-projection item, 1 = under the LayerNorm of the previous fragment
+#define EEND_FS_RES12 2           // ... of fragments 1, 2: 0 = before the 7th out-projection item, 1 = under the LayerNorm of the previous fragment,
+                                  // 2 = both behind the first pass of fragment 0's LayerNorm (whole-step timing: -0.7 % against 1)
 #endif
 #ifndef EEND_FS_TOUCH_LEAD
 #define EEND_FS_TOUCH_LEAD 0      // touch the next tile's input rows this many hidden-unit pairs (1.6 us each) before the loop ends; 0: before the last two items
@@ -353,13 +354,14 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     // pull rows of a later tile towards the L2 ahead of their loads: one dword per 128-byte line, by LDS-DMA into a dump area
     // nobody reads -- no destination register, so nothing ever waits for these loads specifically (a VGPR destination gets "used"
     // or spilled by the compiler, either of which exposes the HBM round trip; that was the shipped state until the ISA was read).
-    auto touch_rows = [&](int t) __attribute__((always_inline)) {
+    auto touch_rows_of = [&](const __amdgpu_buffer_rsrc_t& r, int row_bytes, int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NJ; ++q) {
             const int idx = q * 64 + lane;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_char*)(smem + DUMP), 4, (t * TM + wave * WM + (idx >> 2)) * (p.lda * 2) + (idx & 3) * 128, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_char*)(smem + DUMP), 4, (t * TM + wave * WM + (idx >> 2)) * row_bytes + (idx & 3) * 128, 0, 0, 0);
         }
     };
+    auto touch_rows = [&](int t) __attribute__((always_inline)) { touch_rows_of(rsA, p.lda * 2, t); };
     auto touch_done = [&]() __attribute__((always_inline)) {};
     bool loose = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -440,6 +442,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (RES16) {
                     if constexpr (j + 1 < NJ && EEND_FS_RES12 == 1) load_res16(tile, IC<j + 1>{});
+                    if constexpr (j == 0 && EEND_FS_RES12 == 2) { load_res16(tile, IC<1>{}); if constexpr (NJ > 2) load_res16(tile, IC<2>{}); }
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -501,9 +504,11 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 #endif
 #if EEND_FS_XFLATE == 2
             // x is dead: the next tile's input rows are requested here and travel under the last two items and the epilogue
-            if (tile + (int)gridDim.x < ntiles) sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(tile + (int)gridDim.x, J); });
+            // (unconditionally -- rows beyond M read as zeros -- so that the wait counts below hold on the last tile too)
+            sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(tile + (int)gridDim.x, J); });
+            if constexpr (RES16 && PRE && EEND_FS_TOUCH_RES) touch_rows_of(rsR16, 512, tile + (int)gridDim.x);      // its residual rows towards L2
 #endif
-            constexpr int VWL = EEND_FS_XFLATE == 2 ? 8 * NJ : (EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0 ? NJ : 0);
+            constexpr int VWL = EEND_FS_XFLATE == 2 ? 8 * NJ + (RES16 && PRE && EEND_FS_TOUCH_RES ? NJ : 0) : (EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0 ? NJ : 0);
             step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<VWL>{}, false, 0, hbA, hbB);     // W2h(U-2) x hbA, h(U-1) -> hbB
             step(IC<2>{}, IC<0>{}, Fa{}, Fa{}, Fa{}, IC<VWL>{}, false, 0, hbB, hbA);    // W2h(U-1) x hbB
             pin_acc(8);
