@@ -159,7 +159,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
                   "convert_fanout", "attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):

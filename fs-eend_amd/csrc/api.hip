@@ -207,6 +207,20 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
     return eend_launch_ffn_stream(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_encoder_input_ok(int Fin, int Tp, int ldw) { return eend_encin_supported(Fin, Tp, ldw); }
+
+int eend_encoder_input_f16(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w, const float* bn_b,
+                           const float* bn_mean, const float* bn_var, float bn_eps, const void* W_f16, int ldw, const float* bias,
+                           const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, int B, int T, int Tp,
+                           int Fin, void* stream) {
+    EncInParams p;
+    memset(&p, 0, sizeof(p));
+    p.x_ptrs = x_ptrs; p.lens = lens; p.pad_value = pad_value; p.bn_w = bn_w; p.bn_b = bn_b; p.bn_mean = bn_mean; p.bn_var = bn_var;
+    p.bn_eps = bn_eps; p.W = W_f16; p.ldw = ldw; p.bias = bias; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32;
+    p.out16 = out_f16; p.B = B; p.T = T; p.Tp = Tp; p.Fin = Fin;
+    return eend_launch_encin(p, (hipStream_t)stream);
+}
+
 int eend_spk_stream_elems(void) { return (int)eend_spk_stream_nelems(); }
 
 int eend_spk_stream_ok(int C, int Tp) { return eend_spk_stream_supported(C, Tp); }

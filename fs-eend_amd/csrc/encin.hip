@@ -1,0 +1,276 @@
+// Encoder input in one launch (round 4): pad_sequence + BatchNorm(eval) + cast, the input projection (in_size -> 256) and its
+// LayerNorm -- eend_gather_bn_cast_pad_f16 followed by eend_linear_res_ln_f16 (FS model :162-170: pad_sequence(-1), self.bn,
+// enc.encoder, enc.encoder_norm).  The pair moved 44 MB of f32 features into a 25 MB f16 copy and read that back through a
+// generic K = 384 GEMM: 83 us for 6 GFLOP and 85 MB.  Here the features are read ONCE, as they lie in memory:
+//   * a tile = 16 consecutive frames of one utterance = one contiguous, 16-byte aligned block of 16 x in_size floats; it arrives by
+//     LDS-DMA (1-KB pieces, five buffers: four tiles are in flight while one is computed -- with one in flight the stream was
+//     latency-bound at 1 TB/s); frames beyond the utterance's length
+//     are zero-filled by the buffer bounds check, so nothing is read past an allocation;
+//   * the weights are STATIONARY: a wave owns 64 of the 256 output features and holds their [64][K] slice in registers as MFMA A
+//     fragments (NK x 4 fragments, 176 VGPRs at K = 352) for the whole launch -- no weight traffic after the prologue;
+//   * the B fragments of the tile's 32 frames are built once from the staged floats (pad value, BatchNorm scale / shift from an LDS
+//     table, saturating cast; each wave a quarter of the k-steps) and shared through LDS as lane-linear 1-KB images; 8 NK MFMAs per wave;
+//   * LayerNorm over the 256 features: wave-local partial sums (permlane reductions), one exchange through LDS, rows leave through
+//     a shared staging tile as whole 512-byte rows.
+// HBM-bound: 1380 B in + 512 B out per frame.  Supported: 320 < in_size <= 384 (NK = 11 or 12 k-steps of 32), Tp a multiple of 16,
+// 16-byte aligned utterance pointers; anything else returns EEND_EINVAL and the caller keeps the two-launch path.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ROWS = 16;                  // frames per tile (one MFMA token fragment)
+constexpr int NBUF = 5;                   // staging buffers: the tile being computed + 4 in flight (the stream is latency-bound otherwise)
+constexpr int XB = 24 * 1024;             // one staging buffer: 16 x 384 floats (24 pieces of 1 KB)
+constexpr int L_X = 0;
+constexpr int L_OUT = NBUF * XB;          // [16 rows][512 B] f16 output tile
+constexpr int L_STAT = L_OUT + ROWS * 512;             // [4 waves][16 rows] (sum, sum of squares)
+constexpr int L_TAB = L_STAT + 4 * ROWS * 8;           // sc[384], sh[384], bias[256], gamma[256], beta[256]
+constexpr int L_FR = L_TAB + (2 * 384 + 3 * 256) * 4;  // 12 fragment images of 1 KB
+constexpr int SMEM = L_FR + 12 * 1024;                 // 150016
+
+// Scalar reads of the (host-written, kernel-constant) pointer / length tables.  Left to the compiler they become vector loads (the
+// kernel also stores, so it will not use the scalar cache on its own) followed by vmcnt(0) -- a wait for the previous tile's stores.
+__device__ __forceinline__ unsigned long long sload64(const void* base, int byte_off) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
+    return v;
+}
+__device__ __forceinline__ int sload32(const void* base, int byte_off) {
+    int v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
+    return v;
+}
+
+#ifdef EEND_ENCIN_TRACE
+__device__ unsigned long long g_encin_trace[256 * 8 * 8];
+#define EI_STAMP(k) do { ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EI_STAMP(k) do {} while (0)
+#endif
+
+template <int NK>
+__global__ __launch_bounds__(256, 1)
+void encin_kernel(const EncInParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, g = lane >> 4;
+    const int TPB = p.Tp / ROWS;
+    const int ntiles = p.B * TPB;
+    const int rowbytes = p.Fin * 4;
+    const int npieces = (ROWS * rowbytes + 1023) >> 10;    // <= 48
+    float* sc = (float*)(smem + L_TAB);
+    float* sh = sc + 384;
+    float* vb = sh + 384;                 // bias, gamma, beta
+
+    // this wave's pieces of tile t -> staging buffer t & 1
+    auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+        // (uniform indices forced into scalar registers; tiles beyond the last get a zero-length resource: same number of requests
+        // per iteration -- the counted wait below relies on it -- and no memory traffic)
+        const bool in = t < ntiles;
+        const int tt = in ? t : 0;
+        const int b = __builtin_amdgcn_readfirstlane(tt / TPB), t0 = (tt - b * TPB) * ROWS;
+        const float* base = (const float*)sload64(p.x_ptrs, b * 8);
+        int len = sload32(p.lens, b * 4);
+        len = len < p.T ? len : p.T;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, in ? len * rowbytes : 0, 0x00020000);
+        for (int pc = wave; pc < npieces; pc += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_char*)(smem + L_X + buf * XB + pc * 1024), 16, lane * 16, t0 * rowbytes + pc * 1024, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) dma_tile(blockIdx.x + i * gridDim.x, i);
+
+    // tables; the wave's weight slice as A fragments: w[ks][nf] = W[64 wave + nf*16 + frow][ks*32 + g*8 .. +8]
+    for (int k = tid; k < 384; k += 256) {
+        float s_ = 0.f, h_ = 0.f;
+        if (k < p.Fin) {
+            s_ = p.bn_w[k] / __builtin_sqrtf(p.bn_var[k] + p.bn_eps);
+            h_ = p.bn_b[k] - p.bn_mean[k] * s_;
+        }
+        sc[k] = s_; sh[k] = h_;
+    }
+    vb[tid] = p.bias[tid]; vb[256 + tid] = p.gamma[tid]; vb[512 + tid] = p.beta[tid];
+    f16x8 w[NK][4];
+    {
+        const _Float16* W = (const _Float16*)p.W;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const _Float16* src = W + (size_t)(64 * wave + nf * 16 + frow) * p.ldw + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) w[ks][nf] = *(const f16x8*)(src + ks * 32);
+        }
+    }
+
+#ifdef EEND_ENCIN_TRACE
+    int tix = 0;
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+#endif
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef EEND_ENCIN_TRACE
+        unsigned long long ts[8];
+        ts[7] = tstart;
+#endif
+        EI_STAMP(0);
+        const int b = __builtin_amdgcn_readfirstlane(tile / TPB), t0 = (tile - b * TPB) * ROWS;
+        int len = sload32(p.lens, b * 4);
+        len = len < p.T ? len : p.T;
+        // this tile has landed (all waves' pieces), and every wave is done with the buffer of the previous tile and with the output
+        // tile.  Younger than its pieces in this wave's (in-order) VMEM queue: the requests of the next three tiles (>= 5 pieces each;
+        // before the first tile: the 44 weight loads) and the row stores of the last four (2 each): at least 23 operations
+        asm volatile("s_waitcnt vmcnt(23) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        EI_STAMP(1);
+        dma_tile(tile + (NBUF - 1) * (int)gridDim.x, buf == 0 ? NBUF - 1 : buf - 1);
+        EI_STAMP(2);
+
+        // the tile's B fragments are built ONCE (wave w: k-steps w, w + 4, w + 8) and shared through LDS as 1-KB lane-linear images
+        const char* xb = smem + L_X + buf * XB;
+        char* fr = smem + L_FR;
+#pragma unroll
+        for (int i = 0; i < (NK + 3) / 4; ++i) {
+            const int ks = wave + 4 * i;
+            if (ks < NK) {
+                const int k0 = ks * 32 + g * 8;
+                const f32x4 s0 = *(const f32x4*)(sc + k0), s1 = *(const f32x4*)(sc + k0 + 4);
+                const f32x4 h0 = *(const f32x4*)(sh + k0), h1 = *(const f32x4*)(sh + k0 + 4);
+                // all 16 staged floats first, unconditionally (pinned: left alone, the compiler sinks each read into the branch of
+                // its select and waits for it there), then the selects as arithmetic
+                float raw[8];
+                const float* src = (const float*)(xb + frow * rowbytes) + k0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[e] = src[e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(raw[e]));
+                const int t = t0 + frow;
+                const bool real = t < len, live = t < p.T;
+                f16x8 xf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = real ? raw[e] : p.pad_value;            // (beyond the row / the buffer: masked below, never multiplied)
+                    v = __builtin_fmaf(v, e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
+                    v = live ? v : 0.f;
+                    v = (k0 + e < p.Fin) ? v : 0.f;
+                    xf[e] = to_f16_sat(v);
+                }
+                *(f16x8*)(fr + ks * 1024 + lane * 16) = xf;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        EI_STAMP(3);
+        f32x4 acc[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[nf] = *(const f32x4*)(vb + 64 * wave + nf * 16 + g * 4);
+        sfor<NK>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+            const f16x8 xf = *(const f16x8*)(fr + ks * 1024 + lane * 16);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][nf], xf, acc[nf], 0, 0, 0);
+        });
+
+        EI_STAMP(4);
+        // LayerNorm over the 256 features: lane holds features 64 wave + nf*16 + g*4 + r of token frow
+        float* stat = (float*)(smem + L_STAT);
+        {
+            f32x2 sm = f32x2{0.f, 0.f}, sq = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const f32x2 x0 = f32x2{acc[nf][0], acc[nf][1]}, x1 = f32x2{acc[nf][2], acc[nf][3]};
+                sm += x0 + x1;
+                sq = x1 * x1 + (x0 * x0 + sq);
+            }
+            const float s1 = wave_g_allreduce_add(sm[0] + sm[1]);
+            const float s2 = wave_g_allreduce_add(sq[0] + sq[1]);
+            if (g == 0) *(f32x2*)(stat + (wave * ROWS + frow) * 2) = f32x2{s1, s2};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        char* ot = smem + L_OUT;
+        {
+            const int r = frow;
+            f32x2 tot = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) tot += *(const f32x2*)(stat + (ww * ROWS + r) * 2);
+            const float mean = tot[0] * (1.0f / 256);
+            const float rstd = 1.0f / __builtin_sqrtf(__builtin_fmaxf(tot[1] * (1.0f / 256) - mean * mean, 0.f) + p.eps);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int f0 = 64 * wave + nf * 16 + g * 4;
+                const f32x4 gg = *(const f32x4*)(vb + 256 + f0) * rstd, bb = *(const f32x4*)(vb + 512 + f0);
+                f32x4 y;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[q] = __builtin_fmaf(acc[nf][q] - mean, gg[q], bb[q]);
+                f16x4 o;
+                o[0] = (_Float16)y[0]; o[1] = (_Float16)y[1]; o[2] = (_Float16)y[2]; o[3] = (_Float16)y[3];      // a LayerNorm output: no saturation needed
+                const int chunk = 8 * wave + nf * 2 + (g >> 1);
+                *(f16x4*)(ot + r * 512 + ((chunk ^ (r & 7)) << 4) + (g & 1) * 8) = o;
+                if (p.out32) *(f32x4*)(p.out32 + ((size_t)b * p.Tp + t0 + r) * 256 + f0) = y;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            _Float16* o16 = (_Float16*)p.out16 + ((size_t)b * p.Tp + t0) * 256;
+            const int r = tid >> 4;                        // 16 rows x 16 threads, 2 chunks each
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = (tid & 15) + 16 * i;
+                const f16x8 v = *(const f16x8*)(ot + r * 512 + ((c ^ (r & 7)) << 4));
+                *(f16x8*)(o16 + (size_t)r * 256 + c * 8) = v;
+            }
+        }
+        EI_STAMP(5);
+#ifdef EEND_ENCIN_TRACE
+        if (tix < 8 && threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g_encin_trace[((size_t)blockIdx.x * 8 + tix) * 8 + k] = ts[k];
+        }
+        ++tix;
+#endif
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
+}
+
+template <int NK>
+int launch(const EncInParams& p, hipStream_t stream) {
+    static bool attr_done = false;
+    auto kern = encin_kernel<NK>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
+        attr_done = true;
+    }
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int ntiles = p.B * (p.Tp / ROWS);
+    hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+}  // namespace
+
+#ifdef EEND_ENCIN_TRACE
+extern "C" int eend_debug_encin_trace(void* dst, void* stream) {
+    return hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_encin_trace), sizeof(g_encin_trace), 0, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -2;
+}
+#endif
+
+int eend_encin_supported(int Fin, int Tp, int ldw) { return Fin > 320 && Fin <= 384 && Tp > 0 && (Tp % ROWS) == 0 && ldw >= (Fin + 31) / 32 * 32 && (ldw & 7) == 0; }
+
+int eend_launch_encin(const EncInParams& p, hipStream_t stream) {
+    if (!p.x_ptrs || !p.lens || !p.bn_w || !p.bn_b || !p.bn_mean || !p.bn_var || !p.W || !p.bias || !p.gamma || !p.beta || !p.out16 ||
+        p.B <= 0 || p.T <= 0 || p.T > p.Tp || !eend_encin_supported(p.Fin, p.Tp, p.ldw) || (long)p.T * p.Fin * 4 >= (1L << 31))
+        return EEND_EINVAL;
+    return p.Fin <= 352 ? launch<11>(p, stream) : launch<12>(p, stream);
+}

@@ -289,6 +289,23 @@ long eend_spk_stream_nelems();
 int eend_spk_stream_supported(int C, int Tp);
 int eend_launch_spk_stream_pack(const void* Wo, const void* Win, void* out, hipStream_t stream);
 int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream);
+// encin.hip: pad_sequence + BatchNorm + cast + input projection + LayerNorm of the encoder input in one launch
+struct EncInParams {
+    const float* const* x_ptrs;   // device table of B utterance pointers, each (len_b, Fin) f32, 16-byte aligned
+    const int* lens;              // device, [B]
+    float pad_value;
+    const float *bn_w, *bn_b, *bn_mean, *bn_var;
+    float bn_eps;
+    const void* W;                // f16 [256][ldw], columns >= Fin zero
+    int ldw;
+    const float *bias, *gamma, *beta;
+    float eps;
+    float* out32;                 // optional f32 [B*Tp][256]
+    void* out16;                  // f16 [B*Tp][256]
+    int B, T, Tp, Fin;
+};
+int eend_encin_supported(int Fin, int Tp, int ldw);
+int eend_launch_encin(const EncInParams& p, hipStream_t stream);
 // convert_f32.hip: decoder input in f32 on the exact-f32 MFMA (LS-EEND batch forward)
 int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int Tp,
                                    int C, hipStream_t stream);

@@ -43,6 +43,8 @@ FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
 FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM", "1") != "0"
 # f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
 RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
+# encoder input (pad_sequence + BatchNorm + projection + LayerNorm) in one launch (encin.hip; 320 < in_size <= 384)
+ENCIN_FUSED = __import__("os").environ.get("EEND_ENCIN_FUSED", "1") != "0"
 # time-axis attention with token-owning waves, packed in-projection weights and Q kept in registers (attn_stream.hip; Tp = 512 only)
 ATTN_STREAM = __import__("os").environ.get("EEND_ATTN_STREAM", "1") != "0"
 # the first half of a decoder layer (out-projection + norm11 + speaker-axis in-projection + C x C attention) in one launch on a
@@ -362,13 +364,19 @@ class OnlineTransformerDADiarization(nn.Module):
 
         # ---- embedding encoder (model :162-188)
         # pad_sequence(-1) (model :165) + BatchNorm + cast + slab padding: one gather launch
-        ops.gather_bn_cast_pad(srcs, P["bn"], ws.xin16, T, Tp, -1.0, True, P["bn.eps"])
+        res16 = RES16 and FUSED_FFN and FUSED_ATTNOUT
+        encin = ENCIN_FUSED and ops.encoder_input_ok(srcs, Tp, P["enc.in.w"])
+        if encin:      # gather + BatchNorm + input projection + LayerNorm in one launch, the f32 features read once (encin.hip)
+            ops.encoder_input(srcs, P["bn"], P["enc.in.w"], P["enc.in.b"], P["enc.in.g"], P["enc.in.beta"], None if res16 else ws.h32,
+                              ws.h16, T, Tp, -1.0, P["bn.eps"], P["enc.in.eps"])
+        else:
+            ops.gather_bn_cast_pad(srcs, P["bn"], ws.xin16, T, Tp, -1.0, True, P["bn.eps"])
         # RES16 (default): the stack is post-norm, so the residual of every sub-layer is the previous LayerNorm's output; its
         # f16 copy (the next MFMA operand anyway) serves as the residual and the f32 stream is only written where something
         # reads it in f32 (the head).  Oracle emulation: max |d logit| 2.4e-4 -> 2.6e-4.
-        res16 = RES16 and FUSED_FFN and FUSED_ATTNOUT
-        ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"],
-                          None if res16 else ws.h32, ws.h16, P["enc.in.eps"])
+        if not encin:
+            ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"],
+                              None if res16 else ws.h32, ws.h16, P["enc.in.eps"])
         q, k, vt = ws.q[:Me * D], ws.k[:Me * D], ws.vt[:Me * D]
         o16 = ws.o16[:Me]
         for L in P["enc.layers"]:

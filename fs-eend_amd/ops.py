@@ -489,15 +489,7 @@ def gather_bn_cast_pad(src, bn, out16, T, Tp, pad_value, apply_bn=True, eps=1e-5
     if Fpad > 512:
         raise _lib.EendHipError(f"gather_bn_cast_pad: padded feature width {Fpad} > 512 (in_size {Fin}): the gather kernel holds "
                                 "four feature pairs per lane; the shipped configs use in_size 345")
-    key = tuple((s_.data_ptr(), s_.shape[0]) for s_ in src)
-    tab = _PTR_TABLES.get(key)
-    if tab is None:                                            # tiny H2D upload, cached per (pointers, lengths)
-        if len(_PTR_TABLES) > 64:
-            _PTR_TABLES.clear()
-        dev = out16.device
-        tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
-               torch.tensor([min(k[1], T) for k in key], dtype=torch.int32, device=dev))
-        _PTR_TABLES[key] = tab
+    tab = _ptr_table(src, T, out16.device)
     w = b = m = v = None
     if apply_bn:
         w, b, m, v = bn
@@ -505,6 +497,44 @@ def gather_bn_cast_pad(src, bn, out16, T, Tp, pad_value, apply_bn=True, eps=1e-5
                                              _p(out16), B, T, Tp, Fin, Fpad, 1 if apply_bn else 0, _stream()),
                "eend_gather_bn_cast_pad_f16")
     return out16
+
+
+def _ptr_table(src, T, dev):
+    key = tuple((s_.data_ptr(), s_.shape[0]) for s_ in src)
+    tab = _PTR_TABLES.get(key)
+    if tab is None:                                            # tiny H2D upload, cached per (pointers, lengths)
+        if len(_PTR_TABLES) > 64:
+            _PTR_TABLES.clear()
+        tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
+               torch.tensor([min(k[1], T) for k in key], dtype=torch.int32, device=dev))
+        _PTR_TABLES[key] = tab
+    return tab
+
+
+def encoder_input_ok(src, Tp, w16):
+    """True where encoder_input covers the shapes (else the caller runs gather_bn_cast_pad + linear_res_ln)."""
+    Fin = src[0].shape[1]
+    return (bool(_lib.load().eend_encoder_input_ok(int(Fin), int(Tp), int(w16.stride(0)))) and w16.shape[0] == 256
+            and all(s_.is_contiguous() and s_.data_ptr() % 16 == 0 and s_.shape[1] == Fin for s_ in src))
+
+
+def encoder_input(src, bn, w16, bias, gamma, beta, out32, out16, T, Tp, pad_value, bn_eps=1e-5, eps=1e-5):
+    """out = LayerNorm(BN(pad_sequence(src, pad_value)) @ w16.T + bias) in one launch (encin.hip): src list of B f32 GPU tensors
+    (T_i, Fin); w16 f16 (256, >= ceil32(Fin)) zero-padded; out16 f16 (B*Tp, 256), out32 optional."""
+    L = _lib.load()
+    _chk(w16, F16, "w16"); _chk(out16, F16, "out16"); _chk(out32, F32, "out32")
+    for n, t in (("bias", bias), ("gamma", gamma), ("beta", beta)) + tuple(("bn", t) for t in bn):
+        _chk(t, F32, n)
+    for s_ in src:
+        _chk(s_, F32, "src[i]")
+    B, Fin = len(src), src[0].shape[1]
+    if out16.shape != (B * Tp, 256) or not encoder_input_ok(src, Tp, w16):
+        raise _lib.EendHipError("encoder_input: unsupported shapes (see eend_encoder_input_ok)")
+    tab = _ptr_table(src, T, out16.device)
+    w, b, m, v = bn
+    _lib.check(L.eend_encoder_input_f16(_p(tab[0]), _p(tab[1]), float(pad_value), _p(w), _p(b), _p(m), _p(v), bn_eps, _p(w16), w16.stride(0),
+                                        _p(bias), _p(gamma), _p(beta), eps, _p(out32), _p(out16), B, T, Tp, Fin, _stream()),
+               "eend_encoder_input_f16")
 
 
 def linear_res16_ln(a16, w16, bias, res16, gamma, beta, out32, out16, eps=1e-5, alpha=1.0):

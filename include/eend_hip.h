@@ -49,6 +49,19 @@ int eend_gather_bn_cast_pad_f16(const void* const* x_ptrs, const int* lens, floa
                                 const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,
                                 int Fpad, int apply_bn, void* stream);
 
+/* Encoder input in ONE launch (encin.hip): pad_sequence(pad_value) + BatchNorm(eval) + cast, the input projection
+ * (in_size -> 256) and its LayerNorm, i.e. eend_gather_bn_cast_pad_f16 followed by eend_linear_res_ln_f16 without a residual
+ * (FS model :162-170: pad_sequence(-1), self.bn, enc.encoder, enc.encoder_norm) -- the f32 features are read once, the f16 copy
+ * never exists.  x_ptrs: device table of B pointers to (len_b, Fin) f32 rows (16-byte aligned), lens[b] frames valid (frames
+ * len_b <= t < T take pad_value through the BatchNorm, frames T <= t < Tp are zero before the projection, exactly as the pair);
+ * W f16 [256][ldw] with columns >= Fin zero; out_f16 [B*Tp][256], out_f32 optional.  Supported where
+ * eend_encoder_input_ok(Fin, Tp, ldw) != 0 (320 < Fin <= 384, Tp a multiple of 32); EEND_EINVAL otherwise. */
+int eend_encoder_input_ok(int Fin, int Tp, int ldw);
+int eend_encoder_input_f16(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w, const float* bn_b,
+                           const float* bn_mean, const float* bn_var, float bn_eps, const void* W_f16, int ldw, const float* bias,
+                           const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, int B, int T, int Tp,
+                           int Fin, void* stream);
+
 /* out = act(A W^T + bias), f16 in / f16 out, f32 accumulate; act: 0 none, 1 ReLU, 2 Swish.
  * torch.nn.Linear call sites: FFN linear1+ReLU of nn.TransformerEncoderLayer (FS model :147) and of
  * the fusion layer (FS-EEND/nnet/modules/merge_tfm_encoder.py:397-399), packed in-proj of the speaker
