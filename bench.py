@@ -59,7 +59,7 @@ def flops_per_launch(name, shape, T):
     if name == "retention_chunk":      # (nseq, H, valid frames, L): QK^T + PV causal-useful per chunk, + state build and cross term
         nseq, H, Tv, L = shape
         return nseq * H * (Tv // L) * (2 * 64.0 * L * (L + 1) + 2 * 2.0 * L * 64 * 64)
-    if name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16", "retention_proj", "inproj_heads", "convert_fanout", "conv1d_l2norm"):
+    if name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16", "retention_proj", "inproj_heads", "convert_fanout", "conv1d_l2norm", "conv1d_l2norm_stream"):
         M, N, K = shape
         return 2.0 * M * N * K
     return 0.0
@@ -152,6 +152,8 @@ class OpTimer:
                 shape = (a[0].shape[0], 256, 256)
             elif name == "conv1d_l2norm":
                 shape = (a[0].shape[0], 256, a[1].shape[1])
+            elif name == "conv1d_l2norm_stream":        # (x16, wstream, bias, ilens, out32, out16, nseq, Tp, ktaps, pad)
+                shape = (a[0].shape[0], 256, a[8] * 256)
             else:
                 shape = ()
             self.rec.append((name, shape, s, e))
@@ -159,7 +161,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm", "conv1d_l2norm_stream",
                   "convert_fanout", "attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):

@@ -207,6 +207,23 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
     return eend_launch_ffn_stream(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_conv_stream_elems(int ktaps) { return (int)eend_conv_stream_nelems(ktaps); }
+
+int eend_conv_stream_ok(int cin, int ktaps, int pad) { return eend_conv_stream_supported(cin, ktaps, pad); }
+
+int eend_conv_stream_pack_f16(const void* Wr, void* stream_out, int ktaps, void* stream) {
+    return eend_launch_conv_stream_pack(Wr, stream_out, ktaps, (hipStream_t)stream);
+}
+
+int eend_conv1d_l2norm_stream_f16(const void* X, const void* wstream, const float* bias, const int* ilens, float* out_f32,
+                                  void* out_f16, int nseq, int Tp, int ktaps, int pad, void* stream) {
+    ConvStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = X; p.wstream = wstream; p.bias = bias; p.ilens = ilens; p.out32 = out_f32; p.out16 = out_f16; p.nseq = nseq; p.Tp = Tp;
+    p.ktaps = ktaps; p.pad = pad;
+    return eend_launch_conv_stream(p, (hipStream_t)stream);
+}
+
 int eend_encoder_input_ok(int Fin, int Tp, int ldw) { return eend_encin_supported(Fin, Tp, ldw); }
 
 int eend_encoder_input_f16(const float* const* x_ptrs, const int* lens, float pad_value, const float* bn_w, const float* bn_b,

@@ -289,6 +289,21 @@ long eend_spk_stream_nelems();
 int eend_spk_stream_supported(int C, int Tp);
 int eend_launch_spk_stream_pack(const void* Wo, const void* Win, void* out, hipStream_t stream);
 int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream);
+// conv_stream.hip: look-ahead Conv1d(256 -> 256) + bias + L2 norm on a packed weight stream
+struct ConvStreamParams {
+    const void* X;        // f16 [nseq][Tp][256]
+    const void* wstream;  // eend_conv_stream_pack_f16 output
+    const float* bias;    // [256]
+    const int* ilens;     // [nseq]: frames >= ilens[seq] read as zero
+    float* out32;         // f32 [nseq*Tp][256]
+    void* out16;          // f16 [nseq*Tp][256]
+    float* inv_norm;      // optional [nseq*Tp]
+    int nseq, Tp, ktaps, pad;
+};
+long eend_conv_stream_nelems(int ktaps);
+int eend_conv_stream_supported(int cin, int ktaps, int pad);
+int eend_launch_conv_stream_pack(const void* Wr, void* out, int ktaps, hipStream_t stream);
+int eend_launch_conv_stream(const ConvStreamParams& p, hipStream_t stream);
 // encin.hip: pad_sequence + BatchNorm + cast + input projection + LayerNorm of the encoder input in one launch
 struct EncInParams {
     const float* const* x_ptrs;   // device table of B utterance pointers, each (len_b, Fin) f32, 16-byte aligned

@@ -43,6 +43,8 @@ FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
 FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM", "1") != "0"
 # f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
 RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
+# look-ahead conv + L2 norm on a packed weight stream (conv_stream.hip; 256 channels)
+CONV_STREAM = __import__("os").environ.get("EEND_CONV_STREAM", "1") != "0"
 # encoder input (pad_sequence + BatchNorm + projection + LayerNorm) in one launch (encin.hip; 320 < in_size <= 384)
 ENCIN_FUSED = __import__("os").environ.get("EEND_ENCIN_FUSED", "1") != "0"
 # time-axis attention with token-owning waves, packed in-projection weights and Q kept in registers (attn_stream.hip; Tp = 512 only)
@@ -287,6 +289,8 @@ class OnlineTransformerDADiarization(nn.Module):
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
         P["cnn.b"] = _f32(self.cnn.bias)
         P["cnn.k"], P["cnn.pad"] = cw.shape[2], self.cnn.padding[0]
+        if CONV_STREAM and ops.conv_stream_ok(cw.shape[1], cw.shape[2], self.cnn.padding[0]) and cw.shape[0] == 256:
+            P["cnn.ws"] = ops.conv_stream_pack(P["cnn.w"], cw.shape[2])
         D = enc.n_units
         P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
         dl = []
@@ -411,7 +415,10 @@ class OnlineTransformerDADiarization(nn.Module):
 
         # ---- truncate to ilen / zero re-pad, look-ahead conv, L2 norm (model :38-41)
         emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)       # returned to the caller (views, no copies)
-        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+        if "cnn.ws" in P:        # the same operator on the packed weight stream (conv_stream.hip)
+            ops.conv1d_l2norm_stream(ws.h16, P["cnn.ws"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, P["cnn.k"], P["cnn.pad"])
+        else:
+            ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
 
         # ---- attractor decoder (model :112-118, merge_tfm_encoder.py:356-376)
         res16 = res16 and FUSED_SPK and not FUSED_TAIL

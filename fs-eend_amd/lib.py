@@ -30,6 +30,10 @@ PROTOTYPES = {
     "eend_ffn_stream_elems": [_i, _i],
     "eend_ffn_stream_pack_f16": [_vp, _vp, _vp, _vp, _i, _vp],
     "eend_ffn_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
+    "eend_conv_stream_elems": [_i],
+    "eend_conv_stream_ok": [_i, _i, _i],
+    "eend_conv_stream_pack_f16": [_vp, _vp, _i, _vp],
+    "eend_conv1d_l2norm_stream_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_encoder_input_ok": [_i, _i, _i],
     "eend_encoder_input_f16": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_inproj_attn_packed_elems": [],

@@ -187,6 +187,33 @@ def conv1d_l2norm(x16, wr16, bias, ilens_i32, out32, out16, nseq, Tp, cin, ktaps
                                         Tp, cin, ktaps, pad, _stream()), "eend_conv1d_l2norm_f16")
 
 
+def conv_stream_ok(cin, ktaps, pad):
+    return bool(_lib.load().eend_conv_stream_ok(int(cin), int(ktaps), int(pad)))
+
+
+def conv_stream_pack(wr16, ktaps):
+    """Pack the tap-major conv weight Wr f16 [256][ktaps*256] into the weight stream of conv1d_l2norm_stream."""
+    L = _lib.load()
+    _chk(wr16, F16, "wr16")
+    if wr16.shape != (256, ktaps * 256):
+        raise _lib.EendHipError("conv_stream_pack: expected Wr [256][ktaps*256]")
+    out = torch.empty(L.eend_conv_stream_elems(int(ktaps)), dtype=F16, device=wr16.device)
+    _lib.check(L.eend_conv_stream_pack_f16(_p(wr16), _p(out), int(ktaps), _stream()), "eend_conv_stream_pack_f16")
+    return out
+
+
+def conv1d_l2norm_stream(x16, wstream, bias, ilens_i32, out32, out16, nseq, Tp, ktaps, pad):
+    """conv1d_l2norm on the packed weight stream (conv_stream.hip; cin = 256)."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(wstream, F16, "wstream"); _chk(bias, F32, "bias"); _chk(ilens_i32, torch.int32, "ilens")
+    _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
+    if x16.shape != (nseq * Tp, 256) or out32.shape != (nseq * Tp, 256) or out16.shape != (nseq * Tp, 256) or \
+            wstream.numel() != L.eend_conv_stream_elems(int(ktaps)):
+        raise _lib.EendHipError("conv1d_l2norm_stream: shape mismatch")
+    _lib.check(L.eend_conv1d_l2norm_stream_f16(_p(x16), _p(wstream), _p(bias), _p(ilens_i32), _p(out32), _p(out16), nseq, Tp, ktaps, pad,
+                                               _stream()), "eend_conv1d_l2norm_stream_f16")
+
+
 def convert_fanout(e16, w1_16, pc, out32, out16, B, Tp, C):
     L = _lib.load()
     _chk(e16, F16, "e16"); _chk(w1_16, F16, "w1"); _chk(pc, F32, "pc"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")

@@ -117,6 +117,16 @@ int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, con
                            float* out_f32, void* out_f16, int nseq, int Tp, int cin, int ktaps, int pad,
                            void* stream);
 
+/* The same operator on a packed weight stream (conv_stream.hip; cin = 256, ktaps <= 24): the tile's input rows are staged once in
+ * LDS and every tap reads them shifted, the weights -- re-ordered once per parameter version by eend_conv_stream_pack_f16 from the
+ * same Wr [256][ktaps*256] into eend_conv_stream_elems(ktaps) f16 elements -- flow through an LDS-DMA ring.  EEND_EINVAL where
+ * eend_conv_stream_ok(cin, ktaps, pad) == 0 (the caller keeps eend_conv1d_l2norm_f16). */
+int eend_conv_stream_elems(int ktaps);
+int eend_conv_stream_ok(int cin, int ktaps, int pad);
+int eend_conv_stream_pack_f16(const void* Wr, void* stream_out, int ktaps, void* stream);
+int eend_conv1d_l2norm_stream_f16(const void* X, const void* wstream, const float* bias, const int* ilens, float* out_f32,
+                                  void* out_f16, int nseq, int Tp, int ktaps, int pad, void* stream);
+
 /* attr0[(b,c)][t][:] = W1 emb[b][t][:] + pc[c][:], the factored form of
  * convert(cat(emb, pe[c])) (FS model :113-114, LS model :216-217): W1 = convert.weight[:, :D],
  * pc[c] = convert.weight[:, D:] pe[c] + convert.bias.  E f16 [B][Tp][256] ->
