@@ -1,14 +1,16 @@
 // Look-ahead Conv1d(256 -> 256, ktaps, padding) + bias + L2 normalisation on a packed weight stream (round 4): the operator of
 // eend_conv1d_l2norm_f16 (FS model :38-41 / LS model :80-87; frames >= ilens[seq] read as zero) with the decomposition of
 // ffn_stream.hip instead of the generic implicit GEMM (119 us for 81 GFLOP = 0.27 of the f16 peak):
-//   * one workgroup per CU, one wave per SIMD; a tile = 128 consecutive frames of one sequence, a wave owns 32 of them and all 256
-//     output features (128 accumulator registers);
+//   * one workgroup per CU, one wave per SIMD; a tile = 128 consecutive frames of one sequence; a wave owns 64 of them and 128 of the
+//     256 output features (128 accumulator registers): per 16-KB weight item a wave reads 8 weight and 4 input fragments for 32 MFMAs,
+//     48 KB of LDS reads per item for the workgroup (with 32 frames x 256 features per wave it was 72 KB and LDS-read-bound);
 //   * the tile's input rows (128 + ktaps - 1, halo included) are staged ONCE in LDS by LDS-DMA (chunk index XORed with the row via
 //     the per-lane source address; rows outside [0, min(ilen, Tp)) are zero-filled by the buffer bounds check); the B fragment of
 //     tap tau is the same tile read tau rows further down -- no im2col, no re-read;
 //   * the weights, pre-packed per (tap, 32-wide channel block) in MFMA fragment order (eend_conv_stream_pack_f16), flow by LDS-DMA
 //     through a 5-slot ring, one barrier per 16-KB item (32 MFMAs per wave), continuously across tiles;
-//   * bias, sum of squares (wave-local), x / ||x||; f32 and f16 rows leave through a staging tile as whole rows.
+//   * bias, sum of squares (wave-local + one exchange with the wave holding the other half of the features), x / ||x||; f32 and f16
+//     half rows (256 / 512 contiguous bytes) leave through a staging tile as full 128-byte lines.
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
@@ -26,8 +28,15 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NJ = 2;                // token fragments per wave (32 rows); 128-row tiles
-constexpr int TM = 64 * NJ, WM = 16 * NJ;
+#ifndef EEND_CS_PIN
+#define EEND_CS_PIN 0           // 1: accumulators and fragment registers pinned per item (clean steady loop, but measured 6 % slower)
+#endif
+#ifndef EEND_CS_STUDY
+#define EEND_CS_STUDY 0
+#endif
+constexpr int NR = 4;                // token fragments per wave (64 rows)
+constexpr int NF = 8;                // feature fragments per wave (128 features)
+constexpr int TM = 128, WM = 64;     // rows per tile / per wave
 constexpr int SLOT = 16384;          // one stream item: 16 fragments of 1 KB = the weights of one (tap, 32-channel block)
 constexpr int NSLOT = 5;
 constexpr int MAXTAPS = 24;
@@ -35,17 +44,19 @@ constexpr int XROWS = TM + MAXTAPS;  // staged input rows (halo included), 512 B
 constexpr int L_RING = 0;
 constexpr int L_X = NSLOT * SLOT;                 // 81920
 constexpr int L_VEC = L_X + XROWS * 512;          // bias
-constexpr int SMEM = L_VEC + 1024;                // 160768
-constexpr int NB = 8, PD = 6;
+constexpr int L_SS = L_VEC + 1024;                // [2 row groups][64 rows][2 halves] partial sums of squares
+constexpr int SMEM = L_SS + 1024;                 // 161792
+constexpr int NB = 8, PD = 4;
 constexpr int INFL = 4 * (NSLOT - 3);             // this wave's pieces younger than the ones a barrier needs (2 items x 4)
 
-// weight stream: item q = tau*8 + kc, fragment i, lane (f = l & 15, g = l >> 4): Wr[(f>>2)*64 + i*4 + (f&3)][tau*256 + kc*32 + g*8 + e]
+// weight stream: item q = tau*8 + kc, fragment i, lane (f = l & 15, g = l >> 4): Wr[n(i,f)][tau*256 + kc*32 + g*8 + e] with
+// n(i,f) = (i>>3)*128 + (f>>2)*32 + (i&7)*4 + (f&3): fragments 0..7 / 8..15 are the two feature halves, a lane's 32 features contiguous
 __global__ void conv_stream_pack_kernel(const _Float16* __restrict__ Wr, _Float16* __restrict__ out, int ktaps) {
     const long total = (long)ktaps * 8 * 1024;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int item = (int)(t >> 10), w = (int)(t & 1023), i = w >> 6, l = w & 63, f = l & 15, g = l >> 4;
         const int tau = item >> 3, kc = item & 7;
-        const _Float16* src = Wr + (size_t)((f >> 2) * 64 + i * 4 + (f & 3)) * (ktaps * 256) + tau * 256 + kc * 32 + g * 8;
+        const _Float16* src = Wr + (size_t)((i >> 3) * 128 + (f >> 2) * 32 + (i & 7) * 4 + (f & 3)) * (ktaps * 256) + tau * 256 + kc * 32 + g * 8;
         _Float16* dst = out + t * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dst[e] = src[e];
@@ -95,8 +106,9 @@ void conv_stream_kernel(const ConvStreamParams p) {
         }
     };
 
+    const int rg = wave >> 1, nh = wave & 1;             // row group (64 rows), feature half (128 features)
     f16x8 wf[NB];
-    f32x4 acc[16][NJ];
+    f32x4 acc[NF][NR];
     bool cold = true;                                     // the fragment rotation is empty (first item of the launch only)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" : "+v"(tid));
@@ -108,51 +120,69 @@ void conv_stream_kernel(const ConvStreamParams p) {
         // the rows and item 0 have landed: everything this wave requested so far (the ring keeps streaming behind it)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f32x4 b4 = *(const f32x4*)(vb + g * 64 + i * 4);
+        for (int i = 0; i < NF; ++i) {
+            const f32x4 b4 = *(const f32x4*)(vb + nh * 128 + g * 32 + i * 4);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = b4;
+            for (int j = 0; j < NR; ++j) acc[i][j] = b4;
         }
         const char* xl = smem + L_X;
-        auto read_x = [&](int q, f16x8 (&xo)[NJ]) __attribute__((always_inline)) {
+        auto read_x = [&](int q, f16x8 (&xo)[NR]) __attribute__((always_inline)) {
             const int tau = q >> 3, kc = q & 7;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int r = wave * WM + j * 16 + frow + tau;
+            for (int j = 0; j < NR; ++j) {
+                const int r = rg * WM + j * 16 + frow + tau;
                 xo[j] = *(const f16x8*)(xl + r * 512 + (((kc * 4 + g) ^ (r & 7)) << 4));
             }
         };
-        f16x8 xf[NJ], xn[NJ];
+        f16x8 xf[NR], xn[NR];
         read_x(0, xf);
         for (int q = 0; q < S; ++q) {
             // this wave's pieces of the NEXT item have landed (2 younger items x 4 pieces may stay in flight) -- so behind the barrier
             // every wave's have, and its first fragments can be requested under this item's last MFMAs
             if (q > 0) {
+#if !(EEND_CS_STUDY & 1)      // perf-study builds only (results are garbage): 1 = no counted wait, 2 = no barrier, 4 = no weight DMA, 8 = no weight fragment reads, 16 = no input fragment reads
                 __builtin_amdgcn_s_waitcnt(0x0F70 | INFL);
+#endif
+#if !(EEND_CS_STUDY & 2)
                 __builtin_amdgcn_s_barrier();
+#endif
             }
-            const char* wc = smem + L_RING + slot * SLOT + lane * 16;
-            const char* wn = smem + L_RING + (slot + 1 == NSLOT ? 0 : slot + 1) * SLOT + lane * 16;
+            // accumulators pinned to the accumulator file, the fragment rotation to the vector file, once per item: left alone the
+            // compiler renames them around the loop (124 v_accvgpr_mov per item, each waiting for the MFMA that wrote its source)
+#if EEND_CS_PIN
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) asm volatile("" : "+a"(acc[i][j]));
+#pragma unroll
+            for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(wf[k]));
+#endif
+            const char* wc = smem + L_RING + slot * SLOT + nh * (NF * 1024) + lane * 16;
+            const char* wn = smem + L_RING + (slot + 1 == NSLOT ? 0 : slot + 1) * SLOT + nh * (NF * 1024) + lane * 16;
             const int sd = slot == 0 ? NSLOT - 1 : slot - 1;
             if (cold) {
                 sfor<PD>([&](auto Q) __attribute__((always_inline)) { wf[decltype(Q)::value % NB] = *(const f16x8*)(wc + decltype(Q)::value * 1024); });
                 cold = false;
             }
-            sfor<8>([&](auto P2) __attribute__((always_inline)) {
-                sfor<2>([&](auto PH) __attribute__((always_inline)) {
-                    constexpr int pi = decltype(P2)::value * 2 + decltype(PH)::value;
-                    const f16x8 w = wf[pi % NB];
+            sfor<NF>([&](auto PI) __attribute__((always_inline)) {
+                constexpr int pi = decltype(PI)::value;
+                const f16x8 w = wf[pi % NB];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[pi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[j], acc[pi][j], 0, 0, 0);
-                    if constexpr (pi + PD < 16) wf[(pi + PD) % NB] = *(const f16x8*)(wc + (pi + PD) * 1024);
-                    else wf[(pi + PD) % NB] = *(const f16x8*)(wn + (pi + PD - 16) * 1024);
-                    if constexpr (pi < 4) dma_piece(sd, IC<pi>{});      // the item NSLOT-1 ahead -> the slot every wave finished before this barrier
-                    if constexpr (pi == 6) { if (q + 1 < S) read_x(q + 1, xn); }
-                });
+                for (int j = 0; j < NR; ++j) acc[pi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[j], acc[pi][j], 0, 0, 0);
+#if !(EEND_CS_STUDY & 8)
+                if constexpr (pi + PD < NF) wf[(pi + PD) % NB] = *(const f16x8*)(wc + (pi + PD) * 1024);
+                else wf[(pi + PD) % NB] = *(const f16x8*)(wn + (pi + PD - NF) * 1024);
+#endif
+#if !(EEND_CS_STUDY & 4)
+                if constexpr (pi < 4) dma_piece(sd, IC<pi>{});
+#endif      // the item NSLOT-1 ahead -> the slot every wave finished before this barrier
+#if !(EEND_CS_STUDY & 16)
+                if constexpr (pi == 2) { if (q + 1 < S) read_x(q + 1, xn); }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xf[j] = xn[j];
+            for (int j = 0; j < NR; ++j) xf[j] = xn[j];
             dma_advance();
             slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
@@ -160,56 +190,61 @@ void conv_stream_kernel(const ConvStreamParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         asm volatile("" : "+v"(tid));
         lane = tid & 63; frow = lane & 15; g = lane >> 4;
-        char* st = smem + L_X + wave * 8192;              // 8 rows x 1 KB (f32) / 8 rows x 512 B (f16)
-        const int tlim = p.Tp - t0;                       // rows of this tile inside the sequence
-        sfor<NJ>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
+        // sum of squares: this wave's 128 features, then the other half's through LDS
+        float* ssl = (float*)(smem + L_SS);
+        float ss[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
             f32x2 sq2 = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NF; ++i) {
                 const f32x2 x0 = f32x2{acc[i][j][0], acc[i][j][1]}, x1 = f32x2{acc[i][j][2], acc[i][j][3]};
                 sq2 = x1 * x1 + (x0 * x0 + sq2);
             }
-            const float ss = wave_g_allreduce_add(sq2[0] + sq2[1]);
-            const float rinv = 1.0f / __builtin_sqrtf(ss);
-            if (p.inv_norm) { const int rr = wave * WM + j * 16 + frow; if (g == 0 && rr < tlim) p.inv_norm[(size_t)seq * p.Tp + t0 + rr] = rinv; }
+            ss[j] = wave_g_allreduce_add(sq2[0] + sq2[1]);
+            if (g == 0) ssl[(rg * WM + j * 16 + frow) * 2 + nh] = ss[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        char* st = smem + L_X + wave * 4096;              // 8 rows x 512 B (f32 half rows) / 8 rows x 256 B (f16 half rows)
+        const int tlim = p.Tp - t0;                       // rows of this tile inside the sequence
+        sfor<NR>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            const float rinv = 1.0f / __builtin_sqrtf(ss[j] + ssl[(rg * WM + j * 16 + frow) * 2 + (nh ^ 1)]);
+            if (p.inv_norm) { const int rr = rg * WM + j * 16 + frow; if (g == 0 && nh == 0 && rr < tlim) p.inv_norm[(size_t)seq * p.Tp + t0 + rr] = rinv; }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {          // token rows 0..7 / 8..15 of the fragment
-                const int rb = wave * WM + j * 16 + half * 8;
-                // f16 rows
+                const int rb = rg * WM + j * 16 + half * 8;
+                // f16 half rows: the lane's 32 features = 4 chunks of 16 B at chunk g*4 + e of a 256-byte row
                 if ((frow >> 3) == half) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 4; ++e) {
                         f16x8 o;
 #pragma unroll
                         for (int q = 0; q < 8; ++q) o[q] = to_f16_sat(acc[e * 2 + (q >> 2)][j][q & 3] * rinv);
-                        *(f16x8*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = o;
+                        *(f16x8*)(st + (frow & 7) * 256 + (((g * 4 + e) ^ (frow & 7)) << 4)) = o;
                     }
                 }
                 wave_lds_sync();
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
-                    const f16x8 v = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));
-                    if (rb + rr < tlim) *(f16x8*)((_Float16*)p.out16 + ((size_t)seq * p.Tp + t0 + rb + rr) * 256 + cc * 8) = v;
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int rr = lane >> 3, cc = (lane & 7) + 8 * ps;
+                    const f16x8 v = *(const f16x8*)(st + rr * 256 + ((cc ^ rr) << 4));
+                    if (rb + rr < tlim) *(f16x8*)((_Float16*)p.out16 + ((size_t)seq * p.Tp + t0 + rb + rr) * 256 + nh * 128 + cc * 8) = v;
                 }
                 wave_lds_sync();
-                // f32 rows, features g*64 + 0..31 / 32..63
+                // f32 half rows: 8 chunks of 16 B at chunk g*8 + e of a 512-byte row
+                if ((frow >> 3) == half) {
 #pragma unroll
-                for (int fh = 0; fh < 2; ++fh) {
-                    if ((frow >> 3) == half) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = acc[fh * 8 + e][j] * rinv;
-                    }
-                    wave_lds_sync();
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
-                        const f32x4 v = *(const f32x4*)(st + rr * 512 + ((cc ^ rr) << 4));
-                        if (rb + rr < tlim) *(f32x4*)(p.out32 + ((size_t)seq * p.Tp + t0 + rb + rr) * 256 + (cc >> 3) * 64 + fh * 32 + (cc & 7) * 4) = v;
-                    }
-                    wave_lds_sync();
+                    for (int e = 0; e < 8; ++e) *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = acc[e][j] * rinv;
                 }
+                wave_lds_sync();
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rr = lane >> 3, cc = (lane & 7) + 8 * ps;
+                    const f32x4 v = *(const f32x4*)(st + rr * 512 + ((cc ^ rr) << 4));
+                    if (rb + rr < tlim) *(f32x4*)(p.out32 + ((size_t)seq * p.Tp + t0 + rb + rr) * 256 + nh * 128 + cc * 4) = v;
+                }
+                wave_lds_sync();
             }
         });
     }
