@@ -78,6 +78,7 @@ def pmc_traffic(kernel, shape):
             ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
             ("attnout_spk_stream", (196608,)): (("spk_stream_kernel<8>",), "65536"),
+            ("conv1d_l2norm_stream", (32768, 256, 4864)): (("conv_stream_kernel",), "65536"),
             ("inproj_attn_causal_packed", (64, 4)): (("inproj_attn_stream_kernel(InprojAttnParams) #lo",), "131072"),
             ("inproj_attn_causal_packed", (384, 4)): (("inproj_attn_stream_kernel(InprojAttnParams) #hi",), "131072"),
             ("inproj_attn_causal", (64, 4)): (("inproj_attn_kernel(InprojAttnParams) #lo",), "131072"),      # persistent launch:
