@@ -456,6 +456,9 @@ int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, con
 int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
                             int B, int Tp, int C, void* stream) {
     if (!E || !W1 || !pc || !out_f16 || B <= 0 || C <= 0 || Tp <= 0) return EEND_EINVAL;     // out_f32 may be NULL (f16 stream only)
+    static const bool gemm_path = [] { const char* e = getenv("EEND_CONVERT_GEMM"); return e && atoi(e) != 0; }();      // A/B: the round-1 GEMM epilogue
+    if (!gemm_path && C <= 32 && (long)B * Tp * 512 < (1L << 31))
+        return eend_launch_convert_fanout_rows(E, W1, pc, out_f32, out_f16, B, Tp, C, (hipStream_t)stream);
     GemmParams p = base_params(E, 256, W1, 256, nullptr, B * Tp, 256, 256);
     p.Tp = Tp; p.C = C; p.pc = pc; p.out32 = out_f32; p.out16 = out_f16;
     return eend_launch_gemm(p, EPI_CONVERT, (hipStream_t)stream);

@@ -289,6 +289,9 @@ long eend_spk_stream_nelems();
 int eend_spk_stream_supported(int C, int Tp);
 int eend_launch_spk_stream_pack(const void* Wo, const void* Win, void* out, hipStream_t stream);
 int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream);
+// convert_rows.hip: the decoder input fan-out as a store-shaped kernel (weights stationary)
+int eend_launch_convert_fanout_rows(const void* E, const void* W1, const float* pc, float* out32, void* out16, int B, int Tp, int C,
+                                    hipStream_t stream);
 // conv_stream.hip: look-ahead Conv1d(256 -> 256) + bias + L2 norm on a packed weight stream
 struct ConvStreamParams {
     const void* X;        // f16 [nseq][Tp][256]
