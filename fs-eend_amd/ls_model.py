@@ -28,6 +28,7 @@ from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, Positiona
 FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM_LS", "0") != "0"
 # decoder input linear of the batch forward in f32 (convert_f32.hip); EEND_LS_CONVERT_F32=0: the f16 MFMA form (A/B)
 CONVERT_F32 = __import__("os").environ.get("EEND_LS_CONVERT_F32", "1") != "0"
+CONV_STREAM = __import__("os").environ.get("EEND_CONV_STREAM", "1") != "0"
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -366,6 +367,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         cw = self.cnn.weight.detach()
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
         P["cnn.b"], P["cnn.k"], P["cnn.pad"] = _f32(self.cnn.bias), cw.shape[2], self.cnn.padding[0]
+        if CONV_STREAM and cw.shape[0] == 256 and ops.conv_stream_ok(cw.shape[1], cw.shape[2], self.cnn.padding[0]):
+            P["cnn.ws"] = ops.conv_stream_pack(P["cnn.w"], cw.shape[2])      # the look-ahead conv on the packed weight stream (conv_stream.hip)
         P["cnn.w32"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float32).contiguous()     # f32 frame steps
         P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
         P["convert.w32"] = self.dec.convert.weight.detach().to(torch.float32).contiguous()     # frame steps (ls_stream.dec_step)
@@ -546,7 +549,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
 
         # ---- truncate / zero re-pad, look-ahead conv, L2 (LS model :80-87)
         emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)
-        ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
+        if "cnn.ws" in P:
+            ops.conv1d_l2norm_stream(ws.h16, P["cnn.ws"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, P["cnn.k"], P["cnn.pad"])
+        else:
+            ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], ws.il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
         self._decode_span(P, ws, ws.emb16, self._convert_const(C), B, Tpad, Tp, C, emb32=emb32)
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
@@ -599,7 +605,10 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         # ---- look-ahead conv + L2 norm over the whole recording (one launch; 1.5 KB/frame)
         emb32 = torch.empty(B * Tp_full, D, dtype=f32, device=dev)
         emb16 = torch.empty(B * Tp_full, D, dtype=f16, device=dev)
-        ops.conv1d_l2norm(enc16, P["cnn.w"], P["cnn.b"], il, emb32, emb16, B, Tp_full, D, P["cnn.k"], P["cnn.pad"])
+        if "cnn.ws" in P:
+            ops.conv1d_l2norm_stream(enc16, P["cnn.ws"], P["cnn.b"], il, emb32, emb16, B, Tp_full, P["cnn.k"], P["cnn.pad"])
+        else:
+            ops.conv1d_l2norm(enc16, P["cnn.w"], P["cnn.b"], il, emb32, emb16, B, Tp_full, D, P["cnn.k"], P["cnn.pad"])
         del enc16
 
         # ---- pass 2: attractor decoder + head, super-chunk by super-chunk
