@@ -91,3 +91,23 @@ def test_state_dict_contract():
               "cnn.weight", "dec.pos_enc.pe", "dec.encoder.weight", "enc.bn.running_mean"):
         assert k in sd
     assert sd["dec.pos_enc.pe"].shape == (1, 5000, 256) and sd["cnn.weight"].shape == (256, 256, 19)
+
+
+def test_packed_stream_shape_predicates(hip_lib):
+    """The pure shape predicates / stream sizes of the round-4 packed-weight entries (host arithmetic only, no launch): each packed
+    form covers a stated set of shapes and reports everything else as unsupported, so that the caller keeps the unpacked entry."""
+    L = hip_lib
+    # layer tail: F/32 pairs of 16-KB items (+ 8 out-projection items)
+    assert L.eend_ffn_stream_elems(2048, 1) == (8 + 2 * 64) * 8192 and L.eend_ffn_stream_elems(1024, 0) == 2 * 32 * 8192
+    # decoder layer head: 8 out-projection + 24 in-projection items; slots 3 / 6 / 12 with Tp a multiple of 4 * 48 / C
+    assert L.eend_spk_stream_elems() == 32 * 8192
+    assert [c for c in range(1, 13) if L.eend_spk_stream_ok(c, 512)] == [3, 6, 12]
+    assert L.eend_spk_stream_ok(6, 480) and not L.eend_spk_stream_ok(6, 500) and not L.eend_spk_stream_ok(3, 96)
+    # time-axis attention: 4 heads x 6 items
+    assert L.eend_inproj_attn_packed_elems() == 4 * 6 * 8192
+    # look-ahead conv: 8 items per tap; 256 channels, up to 24 taps
+    assert L.eend_conv_stream_elems(19) == 19 * 8 * 8192
+    assert L.eend_conv_stream_ok(256, 19, 9) and not L.eend_conv_stream_ok(256, 25, 9) and not L.eend_conv_stream_ok(128, 19, 9)
+    # encoder input: 320 < in_size <= 384, Tp a multiple of 16, padded weight rows
+    assert L.eend_encoder_input_ok(345, 512, 384) and L.eend_encoder_input_ok(384, 64, 384)
+    assert not L.eend_encoder_input_ok(320, 512, 320) and not L.eend_encoder_input_ok(345, 500, 384) and not L.eend_encoder_input_ok(345, 512, 345)
