@@ -2,7 +2,8 @@
 //     x1 = LayerNorm11(A Wo1^T + bo1 + res)                     (time-axis attention out-projection, residual, norm11)
 //     O  = MHA_over_slots(x1 Win2^T + bin2)                     (speaker-axis in-projection + the C x C attention of every frame)
 // Reference sites: FS merge_tfm_encoder.py:356-394 (_sa_block1 tail + norm11, _sa_block2), LS merge_retnet_layer.py:301-306.
-// Replaces eend_linear_res16_ln_f16 + eend_spk_qkv_attn_f16 on the hot path for C in {3, 6, 12}.
+// Replaces eend_linear_res16_ln_f16 + eend_spk_qkv_attn_f16 on the hot path for every slot count C <= 12 (3 / 6 / 12 fill the tiling
+// exactly; the others leave phantom slot positions that are masked and never stored).
 //
 // Same machinery as ffn_stream.hip (one wave per SIMD, 48 token rows per wave, weight fragments streamed by LDS-DMA through an
 // 8-slot ring, one barrier per 16-KB item, LayerNorm output == next GEMM's B operand), with two differences:
@@ -98,11 +99,15 @@ __device__ __forceinline__ float row_rot(float x) {          // value of the lan
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// G frames per wave, R = 16/G slots per token fragment, C = 3R slots
-template <int G>
+// G frames per wave, R = 16/G slot positions per token fragment, C = 3R positions of which the first CC hold the model's slots.
+// CC < C: the phantom positions read the last slot's rows (any valid rows do), are masked as keys (a -1e30 score bias that is rotated
+// with the keys, so it always describes the lane it came from) and are never stored.
+template <int G, int CC>
 __global__ __launch_bounds__(256, 1)
 void spk_stream_kernel(const SpkStreamParams p) {
     constexpr int R = 16 / G, C = 3 * R;
+    constexpr bool FULL = CC == C;
+    static_assert(CC >= 1 && CC <= C, "slot count beyond the positions of this tiling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TPB = p.Tp / (4 * G);                       // tiles per utterance
     const int ntiles = p.B * TPB;
@@ -149,9 +154,12 @@ void spk_stream_kernel(const SpkStreamParams p) {
     f16x8 xf[8][NJ];
 
     // memory row of token (fragment j, column fr) of a tile
+    auto slot_of = [&](int j, int fr) __attribute__((always_inline)) { return j * R + fr / G; };
     auto row_tok = [&](int tile, int j, int fr) __attribute__((always_inline)) {
         const int b = tile / TPB, tt = tile - b * TPB;
-        return (b * C + j * R + fr / G) * p.Tp + tt * (4 * G) + wave * G + (fr % G);
+        int c = slot_of(j, fr);
+        if constexpr (!FULL) c = c < CC ? c : CC - 1;
+        return (b * CC + c) * p.Tp + tt * (4 * G) + wave * G + (fr % G);
     };
     auto load_in_frags = [&](int tile, auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
@@ -323,7 +331,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
                     const f16x8 v4 = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));
-                    if (!(EEND_SPK_STUDY & 2)) *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
+                    if (!(EEND_SPK_STUDY & 2) && (FULL || slot_of(j, half * 8 + rr) < CC)) *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
                 }
                 wave_lds_sync();
             }
@@ -334,6 +342,15 @@ void spk_stream_kernel(const SpkStreamParams p) {
         // ---- per head: q, k, v of the wave's 48 tokens (6 items), then the C x C attention of its frames in registers
         _Float16* O = (_Float16*)p.O;
         // (the last head is peeled: the next tile's input loads issued there would otherwise look pending at every iteration's top)
+        // score bias of the key each (fragment, rotation) delivers to this lane: 0 for a real slot, -1e30 for a phantom position
+        float kbias[FULL ? 1 : C];
+        if constexpr (!FULL) {
+            sfor<NJ>([&](auto J2) __attribute__((always_inline)) {
+                constexpr int j2 = decltype(J2)::value;
+                const float own = slot_of(j2, frow) < CC ? 0.f : -1e30f;
+                sfor<R>([&](auto D) __attribute__((always_inline)) { kbias[j2 * R + decltype(D)::value] = row_rot<decltype(D)::value * G>(own); });
+            });
+        }
         auto head_body = [&](int head, auto LAST) __attribute__((always_inline)) {
             step(IC<1>{}, IC<0>{}, T{}, T{}, IC<6>{});
             step(IC<1>{}, IC<1>{}, Fa{}, T{}, IC<6>{});
@@ -388,6 +405,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     s[a][c] = s2[a][c][0] + s2[a][c][1];
+                    if constexpr (!FULL) s[a][c] += kbias[c];
                     if (!(EEND_SPK_STUDY & 16)) s[a][c] = wave_g_allreduce_add(s[a][c]);
                     mx = __builtin_fmaxf(mx, s[a][c]);
                 }
@@ -455,7 +473,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 for (int jj = 0; jj < nf; ++jj)
 #pragma unroll
                     for (int half = 0; half < 2; ++half)
-                        if (!(EEND_SPK_STUDY & 4))
+                        if (!(EEND_SPK_STUDY & 4) && (FULL || slot_of(j0 + jj, half * 8 + rr) < CC))
                             *(f16x8*)(O + (size_t)row_tok(tile, j0 + jj, half * 8 + rr) * 256 + head * 64 + cc * 8) = v4[jj][half];
                 wave_lds_sync();
             };
@@ -479,10 +497,10 @@ void spk_stream_kernel(const SpkStreamParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int G>
+template <int G, int CC>
 int launch(const SpkStreamParams& p, hipStream_t stream) {
     static bool attr_done = false;
-    auto kern = spk_stream_kernel<G>;
+    auto kern = spk_stream_kernel<G, CC>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
         attr_done = true;
@@ -496,6 +514,8 @@ int launch(const SpkStreamParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
+
+constexpr int frames_per_wave(int C) { return C <= 3 ? 16 : C <= 6 ? 8 : 4; }
 
 }  // namespace
 
@@ -516,8 +536,8 @@ int eend_launch_spk_stream_pack(const void* Wo, const void* Win, void* out, hipS
 }
 
 int eend_spk_stream_supported(int C, int Tp) {
-    if (C != 3 && C != 6 && C != 12) return 0;
-    return Tp > 0 && Tp % (4 * (48 / C)) == 0;
+    if (C < 1 || C > 12) return 0;
+    return Tp > 0 && Tp % (4 * frames_per_wave(C)) == 0;
 }
 
 int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream) {
@@ -525,8 +545,10 @@ int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream) {
         !eend_spk_stream_supported(p.C, p.Tp))
         return EEND_EINVAL;
     switch (p.C) {
-        case 3: return launch<16>(p, stream);
-        case 6: return launch<8>(p, stream);
-        default: return launch<4>(p, stream);
+#define SPK_CASE(n) case n: return launch<frames_per_wave(n), n>(p, stream);
+        SPK_CASE(1) SPK_CASE(2) SPK_CASE(3) SPK_CASE(4) SPK_CASE(5) SPK_CASE(6) SPK_CASE(7) SPK_CASE(8) SPK_CASE(9) SPK_CASE(10)
+        SPK_CASE(11) SPK_CASE(12)
+#undef SPK_CASE
+        default: return EEND_EINVAL;
     }
 }

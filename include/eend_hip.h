@@ -208,8 +208,8 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
  *   O  = MHA over the C slots of every frame of (x1 W_in^T + b_in)      (self_attn2 of the fusion layers)
  * i.e. eend_linear_res16_ln_f16 followed by eend_spk_qkv_attn_f16 (FS merge_tfm_encoder.py:356-394; LS
  * merge_retnet_layer.py:301-306), with q, k, v kept in f32 registers.  Rows are (b*C + c)*Tp + t.  Supported where
- * eend_spk_stream_ok(C, Tp) != 0 (C in {3, 6, 12}, Tp a multiple of 4*48/C); other shapes return EEND_EINVAL and the caller
- * uses the two-launch path.  eend_spk_stream_pack_f16 re-orders Wo1 [256][256] and W_in [768][256] (both f16) into the stream
+ * eend_spk_stream_ok(C, Tp) != 0 (1 <= C <= 12, Tp a multiple of 64 / 32 / 16 for C <= 3 / 6 / 12); other shapes return EEND_EINVAL and
+ * the caller uses the two-launch path.  eend_spk_stream_pack_f16 re-orders Wo1 [256][256] and W_in [768][256] (both f16) into the stream
  * (eend_spk_stream_elems() f16 elements).  x_f16 may be res_f16 and O_f16 may be A (lda == 256): rows are read before written. */
 int eend_spk_stream_elems(void);
 int eend_spk_stream_ok(int C, int Tp);

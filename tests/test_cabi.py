@@ -99,10 +99,10 @@ def test_packed_stream_shape_predicates(hip_lib):
     L = hip_lib
     # layer tail: F/32 pairs of 16-KB items (+ 8 out-projection items)
     assert L.eend_ffn_stream_elems(2048, 1) == (8 + 2 * 64) * 8192 and L.eend_ffn_stream_elems(1024, 0) == 2 * 32 * 8192
-    # decoder layer head: 8 out-projection + 24 in-projection items; slots 3 / 6 / 12 with Tp a multiple of 4 * 48 / C
+    # decoder layer head: 8 out-projection + 24 in-projection items; 1..12 slots, Tp a multiple of 64 / 32 / 16 frames (C <= 3 / 6 / 12)
     assert L.eend_spk_stream_elems() == 32 * 8192
-    assert [c for c in range(1, 13) if L.eend_spk_stream_ok(c, 512)] == [3, 6, 12]
-    assert L.eend_spk_stream_ok(6, 480) and not L.eend_spk_stream_ok(6, 500) and not L.eend_spk_stream_ok(3, 96)
+    assert [c for c in range(0, 14) if L.eend_spk_stream_ok(c, 512)] == list(range(1, 13))
+    assert L.eend_spk_stream_ok(6, 480) and not L.eend_spk_stream_ok(6, 500) and not L.eend_spk_stream_ok(3, 96) and L.eend_spk_stream_ok(10, 80)
     # time-axis attention: 4 heads x 6 items
     assert L.eend_inproj_attn_packed_elems() == 4 * 6 * 8192
     # look-ahead conv: 8 items per tap; 256 channels, up to 24 taps

@@ -35,7 +35,9 @@ def _torch_ref(a, res, wo, win, bo, g1, be1, bin_, B, C, Tp):
     return x, o
 
 
-@pytest.mark.parametrize("B,C,Tp", [(2, 6, 64), (3, 6, 512), (1, 3, 128), (2, 12, 64), (5, 12, 256), (70, 6, 96)])
+@pytest.mark.parametrize("B,C,Tp", [(2, 6, 64), (3, 6, 512), (1, 3, 128), (2, 12, 64), (5, 12, 256), (70, 6, 96),
+                                    # slot counts that leave phantom positions in the tiling (masked keys, rows never stored)
+                                    (2, 1, 64), (2, 2, 128), (3, 4, 64), (2, 5, 96), (2, 7, 64), (2, 8, 64), (1, 9, 128), (3, 10, 512), (2, 11, 64)])
 def test_attnout_spk_stream_vs_torch(B, C, Tp):
     a, res, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 11 + C)
     assert ops.spk_stream_ok(C, Tp)
@@ -69,8 +71,8 @@ def test_attnout_spk_stream_in_place():
 
 
 def test_attnout_spk_stream_unsupported_shapes():
-    assert not ops.spk_stream_ok(4, 512) and not ops.spk_stream_ok(10, 512) and not ops.spk_stream_ok(6, 500)
-    B, C, Tp = 1, 4, 64
+    assert not ops.spk_stream_ok(13, 512) and not ops.spk_stream_ok(0, 512) and not ops.spk_stream_ok(6, 500) and not ops.spk_stream_ok(3, 96)
+    B, C, Tp = 1, 6, 80
     a, res, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 3)
     ws = ops.spk_stream_pack(wo, win)
     with pytest.raises(_lib.EendHipError):
