@@ -25,7 +25,6 @@ __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_seq
 template <int V> using IC = std::integral_constant<int, V>;
 
 typedef __attribute__((address_space(3))) char lds_char;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef EEND_CS_PIN

@@ -362,7 +362,6 @@ void ffn_stream_kernel(const FfnStreamParams p) {
         }
     };
     auto touch_rows = [&](int t) __attribute__((always_inline)) { touch_rows_of(rsA, p.lda * 2, t); };
-    auto touch_done = [&]() __attribute__((always_inline)) {};
     bool loose = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         float alpha_l = p.alpha;                          // laundered: 1/alpha hoisted out of the tile loop ended up in scratch
@@ -600,9 +599,6 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 #elif EEND_FS_XFLATE == 2
         if (ntile < ntiles && EEND_FS_RES0 == 0) load_res16(ntile, IC<0>{});
 #endif
-#if EEND_FS_XFLATE == 1
-        touch_done();
-#endif
         FS_STAMP(6);
 #ifdef EEND_FS_TRACE
         if (tix < 8 && threadIdx.x == 0) {
@@ -669,7 +665,6 @@ int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi,
         return EEND_EINVAL;
     if (mode == 1) {
         if (!p.bo || !p.g1 || !p.be1 || act != 1 || epi != FFN_EPI_RES_LN || (!p.res16 && !p.res32)) return EEND_EINVAL;
-        if (!p.res16 && !p.out32 && false) return EEND_EINVAL;
         return p.res16 ? launch<1, 1, FFN_EPI_RES_LN, true>(p, stream) : launch<1, 1, FFN_EPI_RES_LN, false>(p, stream);
     }
     if (!p.res32) return EEND_EINVAL;
