@@ -148,13 +148,13 @@ int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, 
 int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const float* bo, const float* res,
                                const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
-                               float* out_f32, void* out_f16, int M, int F, void* stream) {
+                               float* out_f32, void* out_f16, void* out_lo_f16, int M, int F, void* stream) {
     if (!A || !Wo || !bo || !g1 || !be1) return EEND_EINVAL;
     FfnParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.Wo = Wo; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
     p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2;
-    p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
+    p.out32 = out_f32; p.out16 = out_f16; p.out16lo = out_lo_f16; p.M = M; p.F = F;
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
@@ -172,8 +172,8 @@ int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, con
 }
 
 int eend_convert_fanout_f32(const float* E_f32, const float* W_f32, int ldw, const float* pc, float* out_f32, void* out_f16,
-                            int B, int Tp, int C, void* stream) {
-    return eend_launch_convert_fanout_f32(E_f32, W_f32, ldw, pc, out_f32, out_f16, B, Tp, C, (hipStream_t)stream);
+                            void* out_lo_f16, int B, int Tp, int C, void* stream) {
+    return eend_launch_convert_fanout_f32(E_f32, W_f32, ldw, pc, out_f32, out_f16, out_lo_f16, B, Tp, C, (hipStream_t)stream);
 }
 
 int eend_ffn_stream_elems(int F, int with_wo) { return (int)eend_ffn_stream_nelems(F, with_wo); }
@@ -367,6 +367,38 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
     if (rc != EEND_OK) return rc;
     if (use_full) return eend_launch_ret_chunk_full(p, (hipStream_t)stream);
     return eend_launch_ret_chunk(p, (hipStream_t)stream);
+}
+
+int eend_retention_stream_elems(void) { return (int)eend_ret_stream_packed_nelems(); }
+
+int eend_retention_stream_ok(int L, int Tp, int ldx, int ldo) { return eend_ret_stream_ok(L, Tp, ldx, ldo) ? 1 : 0; }
+
+int eend_retention_stream_pack_f16(const float* Wqkvg_f32, void* packed_out, void* stream) {
+    return eend_launch_ret_stream_pack(Wqkvg_f32, packed_out, (hipStream_t)stream);
+}
+
+int eend_retention_stream_f16(const void* X_f16, int ldx, const void* Xlo_f16, const void* W_packed, const float* bias, void* O_f16, int ldo,
+                              void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq, int Tp, int L, float gn_eps,
+                              int T_valid, const float* state_in, float* state_out, void* stream) {
+    if (!X_f16 || !W_packed || !bias || !O_f16 || !St_ws || !kv_ws || !cscale_ws || !sexp_ws || L <= 0 || nseq <= 0 || nseq > 65535)
+        return EEND_EINVAL;
+    if (!eend_ret_stream_ok(L, Tp, ldx, ldo)) return EEND_EINVAL;
+    const int Tv = (T_valid > 0 && T_valid < Tp) ? T_valid : Tp;
+    const int nc = (Tv + L - 1) / L;
+    RetStreamParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = X_f16; q.ldx = ldx; q.Xlo = Xlo_f16; q.W = W_packed; q.bias = bias; q.O = O_f16; q.ldo = ldo;
+    q.St = St_ws; q.cscale = cscale_ws; q.sexp = sexp_ws; q.kv_ws = kv_ws;
+    q.nseq = nseq; q.Tp = Tp; q.L = L; q.nc = nc; q.nkv = state_out ? nc : nc - 1; q.gn_eps = gn_eps; q.has_state_in = state_in ? 1 : 0;
+    int rc = eend_launch_ret_stream(q, true, (hipStream_t)stream);           // pass 1: chunk K^T V products
+    if (rc != EEND_OK) return rc;
+    RetParams p;
+    memset(&p, 0, sizeof(p));
+    p.St = St_ws; p.cscale = cscale_ws; p.sexp = sexp_ws; p.kv_ws = kv_ws;
+    p.nseq = nseq; p.H = 4; p.Tp = Tp; p.L = L; p.nc = nc; p.gn_eps = gn_eps; p.state_in = state_in; p.state_out = state_out;
+    rc = eend_launch_ret_state_scan_only(p, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_ret_stream(q, false, (hipStream_t)stream);             // pass 2: the rows
 }
 
 int eend_retention_proj_step_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* Wqkvg,

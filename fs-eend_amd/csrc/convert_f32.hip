@@ -17,7 +17,7 @@ namespace {
 
 __global__ __launch_bounds__(256)
 void convert_fanout_f32_kernel(const float* __restrict__ emb, const float* __restrict__ W, int ldw, const float* __restrict__ pc,
-                               float* __restrict__ out32, _Float16* __restrict__ out16, int B, int Tp, int C) {
+                               float* __restrict__ out32, _Float16* __restrict__ out16, _Float16* __restrict__ out16lo, int B, int Tp, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = (float*)smem;                            // [64 rows][256 + 4] (padded against bank conflicts of the fragment reads)
     constexpr int LD = 260;
@@ -70,14 +70,20 @@ void convert_fanout_f32_kernel(const float* __restrict__ emb, const float* __res
             f16x4 h;
             h[0] = to_f16_sat(v.x); h[1] = to_f16_sat(v.y); h[2] = to_f16_sat(v.z); h[3] = to_f16_sat(v.w);
             *(f16x4*)(out16 + o) = h;
+            if (out16lo) {                                  // the f16 remainder of the f32 row: the retention's query path reads hi + lo
+                f16x4 l;
+                l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+                l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+                *(f16x4*)(out16lo + o) = l;
+            }
         }
     }
 }
 
 }  // namespace
 
-int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int Tp,
-                                   int C, hipStream_t stream) {
+int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, void* out16lo,
+                                   int B, int Tp, int C, hipStream_t stream) {
     if (!emb || !W || !pc || !out16 || B <= 0 || Tp <= 0 || C <= 0 || ldw < 256) return EEND_EINVAL;
     static bool attr_done = false;
     constexpr int smem_bytes = 64 * 260 * 4;
@@ -88,6 +94,6 @@ int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, co
     }
     const long M = (long)B * Tp;
     hipLaunchKernelGGL(convert_fanout_f32_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), smem_bytes, stream, emb, W, ldw, pc, out32,
-                       (_Float16*)out16, B, Tp, C);
+                       (_Float16*)out16, (_Float16*)out16lo, B, Tp, C);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -127,7 +127,7 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
     _Float16* __restrict__ o16 = (_Float16*)p.out16;
     {
         const int lane = frow + fkg * 16;
-        f16x4 h16[4][4];
+        f16x4 h16[4][4], l16[4][4];
         // fp32 tile -> LDS [128 rows][1 KB], 16-B chunk c of row r at chunk c ^ (r & 7)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -143,6 +143,8 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
                 v[3] = (acc[i][j][3] - mean[j]) * rstd[j] * g.w + be.w;
                 h16[i][j][0] = to_f16_sat(v[0]); h16[i][j][1] = to_f16_sat(v[1]);
                 h16[i][j][2] = to_f16_sat(v[2]); h16[i][j][3] = to_f16_sat(v[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) l16[i][j][r] = (_Float16)(v[r] - (float)h16[i][j][r]);
                 *(f32x4*)(smem + row * 1024 + (((n >> 2) ^ (row & 7)) << 4)) =
                     EPI == FFN_EPI_RES_SCALE_LN16 ? acc[i][j] : v;       // LS: the residual stream stays un-normalised
             }
@@ -175,6 +177,27 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
             const u32x4 v = *(const u32x4*)(smem + row * 512 + ((c ^ ((row >> 1) & 7)) << 4));
             const long gr = rowmap(row);
             if (gr >= 0) *(u32x4*)(o16 + (size_t)gr * KD + c * 8) = v;
+        }
+        if (p.out16lo) {                                     // the f16 remainder tile, same way
+            _Float16* __restrict__ o16l = (_Float16*)p.out16lo;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = N0 + i * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = g2m + j * 16 + frow;
+                    *(f16x4*)(smem + row * 512 + (((n >> 3) ^ ((row >> 1) & 7)) << 4) + ((n >> 2) & 1) * 8) = l16[i][j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = (k * 8 + wave) * 2 + (lane >> 5), c = lane & 31;
+                const u32x4 v = *(const u32x4*)(smem + row * 512 + ((c ^ ((row >> 1) & 7)) << 4));
+                const long gr = rowmap(row);
+                if (gr >= 0) *(u32x4*)(o16l + (size_t)gr * KD + c * 8) = v;
+            }
         }
     }
 }

@@ -222,6 +222,7 @@ struct FfnParams {
     const float* beta;
     float* out32;       // f32 [M][256]
     void* out16;        // f16 [M][256]
+    void* out16lo;      // optional f16 [M][256]: f16(v - f16(v)) of what out16 holds (the next retention's query path, ret_stream.hip)
     float alpha, eps;
     int M, F, ldx;
     // optional fused producer (null A = off): X = LayerNorm1(A Wo^T + bo + res), which also becomes the residual
@@ -325,8 +326,8 @@ struct EncInParams {
 int eend_encin_supported(int Fin, int Tp, int ldw);
 int eend_launch_encin(const EncInParams& p, hipStream_t stream);
 // convert_f32.hip: decoder input in f32 on the exact-f32 MFMA (LS-EEND batch forward)
-int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int Tp,
-                                   int C, hipStream_t stream);
+int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, void* out16lo,
+                                   int B, int Tp, int C, hipStream_t stream);
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream);
 
 enum ProjKind { PROJ_ROWMAJOR = 0, PROJ_HEADS = 1, PROJ_HEADS_T = 2, PROJ_HEADS_BOTH = 3 };
@@ -343,6 +344,28 @@ struct ProjParams {       // proj.hip: up to four 256-feature output groups
 };
 int eend_launch_proj_xres(const ProjParams& p, hipStream_t stream);
 int eend_launch_ret_chunk_full(const RetParams& p, hipStream_t stream);
+
+// ret_stream.hip (round 5): the retention with its q / k / v / g projections fused on chip (pass 1: chunk K^T V products, pass 2: rows)
+struct RetStreamParams {
+    const void* X; int ldx;      // f16 [nseq*Tp][ldx]: the retention's input rows (256 model dims)
+    const void* Xlo;             // optional f16 rows, same layout: f16(x - f16(x)) of the f32 residual stream (query path only)
+    const void* W;               // packed weight stream (eend_launch_ret_stream_pack)
+    const float* bias;           // [1024]: q, k * dk^-0.5, v, g
+    void* O; int ldo;            // f16 [nseq*Tp][ldo]: gated, normalised retention rows (input of the out-projection)
+    const void* St;              // scan outputs (retention.hip): hi/lo state before each chunk, cross_scale, prescale exponent
+    const float* cscale;
+    const float* sexp;
+    float* kv_ws;                // pass 1: [nseq][4][nc][64][64] f32 chunk products
+    int nseq, Tp, L, nc;
+    int nkv;                     // pass 1: chunks 0 .. nkv-1
+    float gn_eps;
+    int has_state_in;            // a state is carried into chunk 0 (long-form walk)
+};
+long eend_ret_stream_packed_nelems();
+bool eend_ret_stream_ok(int L, int Tp, int ldx, int ldo);
+int eend_launch_ret_stream_pack(const float* W, void* out, hipStream_t stream);
+int eend_launch_ret_stream(const RetStreamParams& p, bool kv, hipStream_t stream);
+int eend_launch_ret_state_scan_only(const RetParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------
 // training step (backward kernels, optimiser)

@@ -373,6 +373,15 @@ int eend_launch_ret_state_scan(const RetParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
+// the prefix scan alone (ret_stream.hip's pass 1 has filled kv_ws)
+int eend_launch_ret_state_scan_only(const RetParams& p, hipStream_t stream) {
+    if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc < 1 || p.nc > (p.Tp + p.L - 1) / p.L ||
+        !p.kv_ws || !p.St || !p.cscale || !p.sexp)
+        return EEND_EINVAL;
+    hipLaunchKernelGGL(ret_state_scan_kernel, dim3(p.H, p.nseq), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
 int eend_launch_ret_chunk(const RetParams& p, hipStream_t stream) {
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || p.L <= 0 || p.nc < 1 || p.nc > (p.Tp + p.L - 1) / p.L ||
         (p.ldo & 3) || (p.ldg & 3))

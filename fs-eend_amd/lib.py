@@ -24,9 +24,9 @@ PROTOTYPES = {
     "eend_linear_res16_ln_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_linear_res_scale_ln16_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
-    "eend_attnout_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "eend_attnout_ffn_fused_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "eend_attnout_ffn_fused_res16_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
-    "eend_convert_fanout_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "eend_convert_fanout_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "eend_ffn_stream_elems": [_i, _i],
     "eend_ffn_stream_pack_f16": [_vp, _vp, _vp, _vp, _i, _vp],
     "eend_ffn_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -59,6 +59,10 @@ PROTOTYPES = {
     "eend_pit_assign_i32": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "eend_retention_proj_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_retention_chunk_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
+    "eend_retention_stream_elems": [],
+    "eend_retention_stream_ok": [_i, _i, _i, _i],
+    "eend_retention_stream_pack_f16": [_vp, _vp, _vp],
+    "eend_retention_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "eend_attn_decode_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "eend_attn_decode_dev_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
     "eend_counter_add_i32": [_vp, _i, _vp],

@@ -29,6 +29,10 @@ FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM_LS", "0") != "0"
 # decoder input linear of the batch forward in f32 (convert_f32.hip); EEND_LS_CONVERT_F32=0: the f16 MFMA form (A/B)
 CONVERT_F32 = __import__("os").environ.get("EEND_LS_CONVERT_F32", "1") != "0"
 CONV_STREAM = __import__("os").environ.get("EEND_CONV_STREAM", "1") != "0"
+# the retention with its projections fused on chip (ret_stream.hip); EEND_RET_STREAM=0: retention_proj + retention_chunk (A/B)
+RET_STREAM = __import__("os").environ.get("EEND_RET_STREAM", "1") != "0"
+# ... with the f16 remainder of the decoder's f32 residual stream as the query path's second operand; 0: hi rows only
+RET_XLO = __import__("os").environ.get("EEND_RET_XLO", "1") != "0"
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -253,6 +257,7 @@ class _Workspace:
         self.ff16 = e(max(Me * F_enc, Md * F_dec) if not FUSED_FFN else 0, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
         self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
+        self.a16lo = e(Md if (RET_STREAM and RET_XLO) else 0, D, dt=f16)     # f16 remainder of a32's rows (query path of ret_stream.hip)
         self.qkv16 = e(Md if not FUSED_SPK else 0, 3 * D, dt=f16)
         nseq = max(B, B * C)
         self.st = e(nseq * H * nc * 2 * 4096, dt=f16)
@@ -358,6 +363,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 w1a32=_f32(ffa[1].linear.weight), w2a32=_f32(ffa[4].linear.weight),
                 w1b32=_f32(ffb[1].linear.weight), w2b32=_f32(ffb[4].linear.weight),
                 lne=(_f32(ln_e.weight), _f32(ln_e.bias), ln_e.eps)))
+        if RET_STREAM:
+            for Bk in blocks:
+                Bk["wrs"] = ops.retention_stream_pack(Bk["wqkvg32"])
         if FFN_STREAM and FUSED_FFN:
             for Bk in blocks:
                 if ops.stream_ok(Bk["w1a"].shape[0]):
@@ -391,6 +399,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             for Ld in dl:
                 if ops.stream_ok(Ld["w1"].shape[0]):
                     Ld["ws"] = ops.ffn_stream_pack(Ld["out2_w"], Ld["w1"], Ld["w2"])
+        if RET_STREAM:
+            for Ld in dl:
+                Ld["wrs"] = ops.retention_stream_pack(Ld["wqkvg32"])
         P["dec.layers"] = dl
         self._prep, self._prep_key, self._pc = P, key, {}
         return P
@@ -454,10 +465,15 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], ws.h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1],
                                           ws.h32, ws.x16, Bk["lnb"][2])
             # x += Retention(LN_b x)                     -> x16 = LN_c(x)
-            ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
-            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tc,
-                                state_in=states[i] if (states is not None and carry_in) else None,
-                                state_out=states[i] if states is not None else None)
+            if "wrs" in Bk and H == 4 and ops.retention_stream_ok(L, Tp):      # projections + retention in one operator (ret_stream.hip)
+                ops.retention_stream(ws.x16, None, Bk["wrs"], Bk["bqkvg"], o16, ws.st, ws.cscale, ws.sexp, B, Tp, L, Bk["gn_eps"], t_valid=Tc,
+                                     state_in=states[i] if (states is not None and carry_in) else None,
+                                     state_out=states[i] if states is not None else None)
+            else:
+                ops.retention_proj(ws.x16, Bk["wqkvg"], Bk["bqkvg"], q, k, kt, vt, g, B, Tp, H)
+                ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B, H, Tp, L, Bk["gn_eps"], t_valid=Tc,
+                                    state_in=states[i] if (states is not None and carry_in) else None,
+                                    state_out=states[i] if states is not None else None)
             ops.linear_res_scale_ln16(o16, Bk["wo"], Bk["bo"], ws.h32, 1.0, Bk["lnc"][0], Bk["lnc"][1],
                                       ws.h32, ws.x16, Bk["lnc"][2])
             # x += ConvModule(x): 1x1 + GLU, causal depthwise + BN + swish, 1x1   -> x16 = LN_d(x)
@@ -487,10 +503,14 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         embeddings -> ws.a32 (f32 attractor rows (b, c, t)).  `states`: as in _encode_span, per decoder layer."""
         D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
         Md = B * C * Tp
+        # the retention's query path reads the decoder rows as a hi / lo f16 pair (ret_stream.hip; DESIGN 4): the producers of the
+        # layer inputs -- the f32 decoder-input linear and the un-streamed layer tail -- write the remainder next to the f16 copy
+        plain_tail = FUSED_FFN and FUSED_ATTNOUT and not (FUSED_SPK and FUSED_TAIL) and not any("ws" in Ld for Ld in P["dec.layers"])
+        xlo = RET_STREAM and RET_XLO and emb32 is not None and CONVERT_F32 and plain_tail and ws.a16lo.numel() > 0
         if emb32 is not None and CONVERT_F32:
             # decoder input in f32 (exact-f32 MFMA): the retention's per-head LayerNorm (eps 1e-6) amplifies the f16 operand rounding
             # of this linear; at 12 speaker slots the f16 form left the 1e-3 bar (golden ls_c12_T1000: 1.3e-3)
-            ops.convert_fanout_f32(emb32, P["convert.w32"], pc, ws.a32, ws.a16, B, Tp, C)
+            ops.convert_fanout_f32(emb32, P["convert.w32"], pc, ws.a32, ws.a16, B, Tp, C, out16lo=ws.a16lo if xlo else None)
         else:
             ops.convert_fanout(emb16, P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
         q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
@@ -498,10 +518,15 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         for j, Ld in enumerate(P["dec.layers"]):
             F = Ld["w1"].shape[0]
             ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
-            ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
-            ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
-                                state_in=states[j] if (states is not None and carry_in) else None,
-                                state_out=states[j] if states is not None else None)
+            if "wrs" in Ld and H == 4 and ops.retention_stream_ok(L, Tp):
+                ops.retention_stream(ws.a16, ws.a16lo if xlo else None, Ld["wrs"], Ld["bqkvg"], o16, ws.st, ws.cscale, ws.sexp, B * C, Tp, L,
+                                     Ld["gn_eps"], t_valid=Tc, state_in=states[j] if (states is not None and carry_in) else None,
+                                     state_out=states[j] if states is not None else None)
+            else:
+                ops.retention_proj(ws.a16, Ld["wqkvg"], Ld["bqkvg"], q, k, kt, vt, g, B * C, Tp, H)
+                ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
+                                    state_in=states[j] if (states is not None and carry_in) else None,
+                                    state_out=states[j] if states is not None else None)
             if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
                 ops.fusion_layer_tail(o16, ws.a32, ws.a16, Ld["out1_w"], Ld["out1_b"], Ld["g11"], Ld["be11"], Ld["eps11"],
                                       Ld["in2_w"], Ld["in2_b"], Ld["out2_w"], Ld["out2_b"], Ld["g21"], Ld["be21"], Ld["eps21"],
@@ -519,7 +544,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 continue
             if FUSED_FFN and FUSED_ATTNOUT:
                 ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
-                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
+                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16,
+                                      out16lo=ws.a16lo if (xlo and j + 1 < len(P["dec.layers"])) else None)
                 continue
             ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], ws.a32, ws.a16, Ld["eps21"])
             if FUSED_FFN:

@@ -134,6 +134,49 @@ def retention_chunk(q, k, kt, vt, g, o16, st_ws, cscale_ws, sexp_ws, nseq, H, Tp
                                           gn_eps, int(t_valid), _p(state_in), _p(state_out), _stream()), "eend_retention_chunk_f16")
 
 
+def retention_stream_ok(L, Tp, ldx=256, ldo=256):
+    return bool(_lib.load().eend_retention_stream_ok(int(L), int(Tp), int(ldx), int(ldo)))
+
+
+def retention_stream_pack(wqkvg32):
+    """Pack the f32 [q; k * dk^-0.5; v; g] rows (1024, 256) into the weight stream of retention_stream (hi / lo parts of the q rows)."""
+    L = _lib.load()
+    _chk(wqkvg32, F32, "wqkvg32")
+    if wqkvg32.shape != (1024, 256):
+        raise _lib.EendHipError("retention_stream_pack: expected the packed projection [1024][256]")
+    out = torch.empty(L.eend_retention_stream_elems(), dtype=F16, device=wqkvg32.device)
+    _lib.check(L.eend_retention_stream_pack_f16(_p(wqkvg32), _p(out), _stream()), "eend_retention_stream_pack_f16")
+    return out
+
+
+def retention_stream(x16, xlo16, wstream, bias, o16, st_ws, cscale_ws, sexp_ws, nseq, Tp, chunk, gn_eps=1e-6, t_valid=0,
+                     state_in=None, state_out=None):
+    """o16 = swish(g) * LN_head(retention(q, k, v)) with q / k / v / g projected on chip from the rows x16 (ret_stream.hip); xlo16
+    (optional): the f16 remainder of the f32 stream behind x16 (query path precision).  H = 4."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(xlo16, F16, "xlo16"); _chk(wstream, F16, "wstream"); _chk(bias, F32, "bias"); _chk(o16, F16, "o16")
+    _chk(st_ws, F16, "st_ws"); _chk(cscale_ws, F32, "cscale_ws"); _chk(sexp_ws, F32, "sexp_ws")
+    _chk(state_in, F32, "state_in"); _chk(state_out, F32, "state_out")
+    H = 4
+    if x16.shape != (nseq * Tp, 256) or o16.shape[0] < nseq * Tp or bias.numel() != 1024 or wstream.numel() != L.eend_retention_stream_elems() or \
+            (xlo16 is not None and (xlo16.shape != x16.shape or xlo16.stride(0) != x16.stride(0))):
+        raise _lib.EendHipError("retention_stream: shape mismatch")
+    for st_ in (state_in, state_out):
+        if st_ is not None and st_.numel() < nseq * H * 4096:
+            raise _lib.EendHipError("retention_stream: carried state must be (nseq, H, 64, 64) f32")
+    nc = (Tp + chunk - 1) // chunk
+    if st_ws.numel() < nseq * H * nc * 2 * 4096 or cscale_ws.numel() < nseq * H * nc or sexp_ws.numel() < nseq * H * nc:
+        raise _lib.EendHipError("retention_stream: workspace too small")
+    need = nseq * H * nc * 4096
+    kv_ws = _KV_WS.get(str(x16.device))
+    if kv_ws is None or kv_ws.numel() < need:                  # f32 per-chunk K^T V workspace, grown on demand
+        kv_ws = torch.empty(need, dtype=F32, device=x16.device)
+        _KV_WS[str(x16.device)] = kv_ws
+    _lib.check(L.eend_retention_stream_f16(_p(x16), x16.stride(0), _p(xlo16), _p(wstream), _p(bias), _p(o16), o16.stride(0), _p(st_ws),
+                                           _p(kv_ws), _p(cscale_ws), _p(sexp_ws), nseq, Tp, chunk, gn_eps, int(t_valid), _p(state_in),
+                                           _p(state_out), _stream()), "eend_retention_stream_f16")
+
+
 def layernorm_f16(x32, gamma, beta, out16, eps=1e-5):
     L = _lib.load()
     _chk(x32, F32, "x32"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(out16, F16, "out16")
@@ -221,11 +264,12 @@ def convert_fanout(e16, w1_16, pc, out32, out16, B, Tp, C):
                "eend_convert_fanout_f16")
 
 
-def convert_fanout_f32(e32, w32, pc, out32, out16, B, Tp, C):
-    """convert_fanout with f32 operands (exact-f32 MFMA): e32 (B*Tp, 256) f32, w32 the (256, >= 256) f32 convert.weight."""
+def convert_fanout_f32(e32, w32, pc, out32, out16, B, Tp, C, out16lo=None):
+    """convert_fanout with f32 operands (exact-f32 MFMA): e32 (B*Tp, 256) f32, w32 the (256, >= 256) f32 convert.weight; out16lo
+    (optional): the f16 remainder of the f32 rows."""
     L = _lib.load()
-    _chk(e32, F32, "e32"); _chk(w32, F32, "w32"); _chk(pc, F32, "pc"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16")
-    _lib.check(L.eend_convert_fanout_f32(_p(e32), _p(w32), w32.stride(0), _p(pc), _p(out32), _p(out16), B, Tp, C, _stream()),
+    _chk(e32, F32, "e32"); _chk(w32, F32, "w32"); _chk(pc, F32, "pc"); _chk(out32, F32, "out32"); _chk(out16, F16, "out16"); _chk(out16lo, F16, "out16lo")
+    _lib.check(L.eend_convert_fanout_f32(_p(e32), _p(w32), w32.stride(0), _p(pc), _p(out32), _p(out16), _p(out16lo), B, Tp, C, _stream()),
                "eend_convert_fanout_f32")
 
 
@@ -592,20 +636,20 @@ def attnout_ffn_fused_res16(a16, wo, bo, res16, g1, be1, eps1, w1, b1, w2, b2, g
                                                   _stream()), "eend_attnout_ffn_fused_res16_f16")
 
 
-def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, eps2, out32, out16):
+def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, eps2, out32, out16, out16lo=None):
     """x = LN1(a16 @ wo.T + bo + res); out = LN2(relu(x @ w1.T + b1) @ w2.T + b2 + x): the attention
     out-projection, both residual adds, both LayerNorms and the FFN of a post-LN layer in one launch."""
     L = _lib.load()
     _chk(a16, F16, "a16"); _chk(wo, F16, "wo"); _chk(w1, F16, "w1"); _chk(w2, F16, "w2")
     for n, t in (("bo", bo), ("res", res), ("g1", g1), ("be1", be1), ("b1", b1), ("b2", b2), ("g2", g2), ("be2", be2), ("out32", out32)):
         _chk(t, F32, n)
-    _chk(out16, F16, "out16")
+    _chk(out16, F16, "out16"); _chk(out16lo, F16, "out16lo")
     M, K = a16.shape
     Fh = w1.shape[0]
     if K != 256 or wo.shape != (256, 256) or w1.shape[1] != 256 or w2.shape != (256, Fh):
         raise _lib.EendHipError("attnout_ffn_fused: expected d_model 256")
     _lib.check(L.eend_attnout_ffn_fused_f16(_p(a16), a16.stride(0), _p(wo), _p(bo), _p(res), _p(g1), _p(be1), eps1, _p(w1), _p(b1),
-                                            _p(w2), _p(b2), _p(g2), _p(be2), eps2, _p(out32), _p(out16), M, Fh, _stream()),
+                                            _p(w2), _p(b2), _p(g2), _p(be2), eps2, _p(out32), _p(out16), _p(out16lo), M, Fh, _stream()),
                "eend_attnout_ffn_fused_f16")
 
 

@@ -135,9 +135,10 @@ int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, floa
                             int B, int Tp, int C, void* stream);
 /* The same stage with f32 operands on the exact-f32 MFMA: E_f32 [B][Tp][256], W_f32 = convert.weight ([256][ldw], the first 256
  * columns are W1).  The LS-EEND batch forward takes it (the decoder retention's per-head LayerNorm, eps 1e-6, amplifies the f16
- * operand rounding of this linear; with 12 speaker slots the f16 form left the 1e-3 bar).  out_f32 may be NULL. */
+ * operand rounding of this linear; with 12 speaker slots the f16 form left the 1e-3 bar).  out_f32 may be NULL.  out_lo_f16 (optional,
+ * same layout as out_f16): f16(v - f16(v)), the remainder the retention's query path reads next to out_f16 (eend_retention_stream_f16). */
 int eend_convert_fanout_f32(const float* E_f32, const float* W_f32, int ldw, const float* pc, float* out_f32, void* out_f16,
-                            int B, int Tp, int C, void* stream);
+                            void* out_lo_f16, int B, int Tp, int C, void* stream);
 
 /* Fused causal MHA core: softmax(mask(Q K^T / sqrt(dh))) V with
  * allowed(i,j) <=> j - i <= mask_delay && j < kv_len evaluated on indices (the (T,T) {0,-inf} tensor
@@ -165,11 +166,12 @@ int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, 
  * the second half of the fusion layers (out_proj of self_attn2 + norm21, _ff_block + norm22: FS
  * merge_tfm_encoder.py:371-376,397-399; LS merge_retnet_layer.py:248-253,309-311).  x never leaves the CU.
  * A f16 [M][lda] (attention output), Wo f16 [256][256], res f32 [M][256] (stream before the attention
- * sub-layer; may alias out_f32), out_f32 f32 [M][256], out_f16 f16 [M][256] (may alias A). */
+ * sub-layer; may alias out_f32), out_f32 f32 [M][256], out_f16 f16 [M][256] (may alias A); out_lo_f16 (optional, f16 [M][256]):
+ * f16(out - f16(out)), the remainder next to out_f16 (the next layer's retention reads both: eend_retention_stream_f16). */
 int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const float* bo, const float* res,
                                const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
-                               float* out_f32, void* out_f16, int M, int F, void* stream);
+                               float* out_f32, void* out_f16, void* out_lo_f16, int M, int F, void* stream);
 /* The two post-norm joins above with the residual taken from the f16 stream: in a post-norm stack (nn.TransformerEncoderLayer,
  * merge_tfm_encoder.py:356-376) the residual IS the previous LayerNorm's output, whose f16 copy the next MFMA reads anyway, so
  * the f32 stream's write + read (1 KB per row per sub-layer, the dominant traffic of the HBM-bound out-projection GEMM) can be
@@ -319,6 +321,23 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
                              void* O_f16, void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq,
                              int H, int Tp, int L, int ldo, int ldg, float gn_eps, int T_valid,
                              const float* state_in, float* state_out, void* stream);
+
+/* The same operator with its four projections fused on chip (ret_stream.hip, round 5): replaces eend_retention_proj_f16 +
+ * eend_retention_chunk_f16 (`MultiScaleRetention.forward`, LS-EEND/nnet/modules/retention.py:196-228, called from
+ * conformer/attention.py and merge_retnet_layer.py:233-253): q / k / k^T / v^T / g never exist in HBM.  X f16 [nseq*Tp][ldx]: the
+ * retention's input rows; Xlo (optional, same layout): f16(x - f16(x)) of the f32 stream the rows were rounded from -- with it the
+ * QUERY projection carries ~22 significand bits (three f16 MFMA products); the query is a hi/lo f16 pair in the score and cross-chunk
+ * products either way.  W_packed: eend_retention_stream_pack_f16 of the f32 [q; k * dk^-0.5; v; g] rows ([1024][256]) into
+ * eend_retention_stream_elems() f16 elements (hi and lo parts of the q rows), once per parameter version; bias f32 [1024] likewise.
+ * H = 4, dh = 64, L <= 512 (eend_retention_stream_ok; the caller keeps the two-call form otherwise).  Workspaces, T_valid,
+ * state_in / state_out: as eend_retention_chunk_f16.  Three launches: chunk K^T V products (projecting K, V on the fly), prefix scan,
+ * rows. */
+int eend_retention_stream_elems(void);
+int eend_retention_stream_ok(int L, int Tp, int ldx, int ldo);
+int eend_retention_stream_pack_f16(const float* Wqkvg_f32, void* packed_out, void* stream);
+int eend_retention_stream_f16(const void* X_f16, int ldx, const void* Xlo_f16, const void* W_packed, const float* bias, void* O_f16, int ldo,
+                              void* St_ws, float* kv_ws, float* cscale_ws, float* sexp_ws, int nseq, int Tp, int L, float gn_eps,
+                              int T_valid, const float* state_in, float* state_out, void* stream);
 
 /* Stand-alone LayerNorm f32 [M][D] -> f16 (D <= 1024): second of two back-to-back LayerNorms
  * (conformer/encoder.py:110 then feed_forward.py:48; encoder.py:196 then feed_forward.py:48). */

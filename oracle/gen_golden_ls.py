@@ -41,6 +41,10 @@ LS_CASES = [
     # 12 slots: conf/spk_onl_conformer_retention_enc_dec_nonautoreg_dihard{2,3}{,_infer}.yaml set max_speakers 10 -> max_nspks 12
     # (train/oln_tfm_enc_dec.py:35,186); full-size model, two chunks
     dict(name="ls_c12_T1000", cfg=ls_cfg(), lengths=[1000], C=12, seed=27, pseed=38, xseed=809),
+    # round 5: further random initialisations at the largest slot counts (the margin of the one C = 12 seed was 10 %)
+    dict(name="ls_c12_T1000_s2", cfg=ls_cfg(), lengths=[1000], C=12, seed=41, pseed=42, xseed=811),
+    dict(name="ls_c12_T1000_s3", cfg=ls_cfg(), lengths=[1000], C=12, seed=43, pseed=44, xseed=812),
+    dict(name="ls_c10_T1500_s2", cfg=ls_cfg(), lengths=[1500, 1100], C=10, seed=45, pseed=46, xseed=813),
 ]
 
 LS_FWD_CASES = [

@@ -30,7 +30,7 @@ def wrap(name, fn):
     def w(*a, **k):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); r = fn(*a, **k); e.record()
-        shp = tuple(a[0].shape) if hasattr(a[0], "shape") else (len(a[0]),)
+        shp = tuple(a[0].shape) if hasattr(a[0], "shape") else ((len(a[0]),) if hasattr(a[0], "__len__") else ())
         rec.append((name, shp, s, e)); return r
     return w
 for n in NAMES:
