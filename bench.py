@@ -278,6 +278,45 @@ def batch_sweep(dev, model, T, C, sizes=(1, 512)):
     return out
 
 
+def length_sweep(dev, model, C, lengths=(300, 500, 1000, 2000), frames_per_step=32000):
+    """The same model.test at other chunk lengths (about the same number of frames per step): the packed-weight attention kernel
+    (attn_stream.hip) covers the padded length 512 only -- every other length runs the round-2/3 attention kernels (attn_fused.hip
+    for Tp <= 512, the tiled kernel beyond), so the T = 500 headline does not transfer."""
+    out = {}
+    for T in lengths:
+        Bs = max(1, frames_per_step // T)
+        Tp = (T + 63) // 64 * 64
+        try:
+            g = torch.Generator().manual_seed(977 + T)
+            src = [(torch.randn(T, 345, generator=g) * 2 - 3).to(dev) for _ in range(Bs)]
+            il = [T] * Bs
+            model.test(src, il, C)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                model.test(src, il, C)
+            torch.cuda.current_stream().wait_stream(st)
+            with torch.cuda.graph(gr):
+                keep = model.test(src, il, C)
+            for _ in range(2):
+                gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                gr.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out[str(T)] = dict(batch=Bs, padded_frames=Tp, frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3,
+                               attention_kernel="attn_stream.hip (packed weights)" if Tp == 512 else ("attn_fused.hip" if Tp <= 512 else "proj.hip + attn.hip (tiled)"))
+            del gr, keep, src
+        except Exception as e:                                   # noqa: BLE001
+            out[str(T)] = dict(error=str(e)[:200])
+    return out
+
+
 def extras(dev):
     """Side measurements (not the headline metric): LS-EEND chunked batch throughput (BASELINE config 3)
     and frame-by-frame streaming latency / real-time factor of both flavours (config 5 mechanism)."""
@@ -847,8 +886,8 @@ def cpu_baseline_train(T, n_spk, budget_s=30.0, flavour="fs"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--slots", type=int, default=6, help="speaker slots C = data.max_speakers + 2")
@@ -1038,27 +1077,37 @@ def main():
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
                            "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
-        fus = [k for k in ksum if k["kernel"] == "inproj_attn_causal" and k["shape"][0] == B]
+        # the encoder's time-axis attention launch (nseq = B): the packed-weight form at Tp = 512 (attn_stream.hip), else attn_fused.hip
+        fus = [k for k in ksum if k["kernel"] in ("inproj_attn_causal_packed", "inproj_attn_causal") and k["shape"][0] == B]
+        dec = [k for k in ksum if k["kernel"] in ("inproj_attn_causal_packed", "inproj_attn_causal") and k["shape"][0] == B * C]
         if fus:
             # the encoder's time-axis attention as it runs now: in-projection + QK^T / PV in one kernel, K and V on chip.
             # flops: the packed in-projection (2*Tp*768*256 per sequence, executed on the padded rows) + the causal-useful
             # attention flops 2*D*T*(T+1); `attention_only_*` prices the kernel's WHOLE time against the attention flops
             # alone (the figure comparable with the stand-alone kernel of round 1).
             a = fus[0]
-            fl = flops_per_launch("inproj_attn_causal", tuple(a["shape"]), T)
+            fl = flops_per_launch(a["kernel"], tuple(a["shape"]), T)
             fl_att = flops_per_launch("attn_causal", tuple(a["shape"]), T)
             Tp_ = (T + 63) // 64 * 64
             byt = a["shape"][0] * (Tp_ * 256 * 2 * 2.0 + 2 * Tp_ * 256 * 2.0)   # X read once + O written once (+ Q scratch round trip, L2)
             tf = fl / (a["avg_ms"] * 1e-3) / 1e12
             out["roofline_attention"] = {
-                "kernel": f"encoder inproj_attn_causal (in-projection + causal MHA fused) nseq={a['shape'][0]} H=4 T={T}", "bound": "mfma",
+                "kernel": f"encoder {a['kernel']} (in-projection + causal MHA fused) nseq={a['shape'][0]} H=4 T={T}", "bound": "mfma",
                 "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS,
-                "traffic": pmc_traffic("inproj_attn_causal", a["shape"]), "avg_launch_ms": a["avg_ms"], "mfma_TFLOPs": tf,
+                "traffic": pmc_traffic(a["kernel"], a["shape"]), "avg_launch_ms": a["avg_ms"], "mfma_TFLOPs": tf,
                 "mfma_frac": tf / PEAK_MFMA_TFLOPS,
                 "attention_only_TFLOPs": fl_att / (a["avg_ms"] * 1e-3) / 1e12,
                 "attention_only_mfma_frac": fl_att / (a["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                 "algorithmic_hbm_GBps": byt / (a["avg_ms"] * 1e-3) / 1e9,
                 "intensity_flop_per_byte": fl / byt, "ridge_flop_per_byte": PEAK_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS}
+            if dec:        # the decoder's time-axis launch of the same kernel (nseq = B * C): the larger share of the step
+                d = dec[0]
+                fld, flad = flops_per_launch(d["kernel"], tuple(d["shape"]), T), flops_per_launch("attn_causal", tuple(d["shape"]), T)
+                out["roofline_attention"]["decoder_launch"] = {
+                    "kernel": f"{d['kernel']} nseq={d['shape'][0]}", "avg_launch_ms": d["avg_ms"],
+                    "mfma_frac": fld / (d["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                    "attention_only_mfma_frac": flad / (d["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                    "traffic": pmc_traffic(d["kernel"], d["shape"])}
         elif att:
             a = att[0]
             fl = flops_per_launch("attn_causal", tuple(a["shape"]), T)
@@ -1080,6 +1129,7 @@ def main():
         sw = batch_sweep(dev, model, T, C)
         sw[str(B)] = dict(frames_per_s=value, ms_per_step=dt / args.steps * 1e3)
         out["extras"]["batch_sweep"] = sw
+        out["extras"]["length_sweep"] = length_sweep(dev, model, C)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, C)

@@ -182,6 +182,42 @@ int eend_ffn_stream_pack_f16(const void* Wo, const void* W1, const void* W2, voi
     return eend_launch_ffn_stream_pack(Wo, W1, W2, stream_out, F, Wo ? 1 : 0, (hipStream_t)stream);
 }
 
+// The stream kernels address rows with 32-bit buffer offsets (and prefetch one grid of tiles ahead): a launch takes at most
+// eend_ffn_stream_max_rows(lda) rows.  Larger batches are served in several launches over row ranges (rows are independent; the range
+// size is a multiple of both tile sizes, so every row sits at the same tile position as in one launch).  ADVICE r04: the un-chunked
+// entry returned EEND_EINVAL beyond ~2.03 M rows (B = 512, C = 12, Tp = 512) where the kernels it replaced had no limit.
+int eend_ffn_stream_max_rows(int lda) {
+    const long row_bytes = (long)(lda > 512 ? lda : 512) * 2;       // widest row the kernel addresses: f32 residual / output rows are 1 KB
+    long m = ((1L << 31) - 1) / row_bytes - 65536 - 1;
+    const char* e = getenv("EEND_FFN_STREAM_MAX_ROWS");              // tests: exercise the multi-launch path at small sizes
+    if (e && atol(e) > 0 && atol(e) < m) m = atol(e);
+    m = m / 384 * 384;
+    return m > 0 ? (int)m : 0;
+}
+
+static int ffn_stream_chunked(FfnStreamParams p, int mode, int act, int epi, hipStream_t stream) {
+    const int cap = eend_ffn_stream_max_rows(p.lda);
+    if (cap <= 0 || p.M <= 0) return EEND_EINVAL;
+    const char* A = (const char*)p.A;
+    const char* r16 = (const char*)p.res16;
+    const float* r32 = p.res32;
+    float* o32 = p.out32;
+    char* o16 = (char*)p.out16;
+    const int M = p.M;
+    for (int m0 = 0; m0 < M; m0 += cap) {
+        FfnStreamParams q = p;
+        q.M = M - m0 < cap ? M - m0 : cap;
+        q.A = A + (size_t)m0 * p.lda * 2;
+        q.res16 = r16 ? r16 + (size_t)m0 * 512 : nullptr;
+        q.res32 = r32 ? r32 + (size_t)m0 * 256 : nullptr;
+        q.out32 = o32 ? o32 + (size_t)m0 * 256 : nullptr;
+        q.out16 = o16 + (size_t)m0 * 512;
+        const int rc = eend_launch_ffn_stream(q, mode, act, epi, stream);
+        if (rc != EEND_OK) return rc;
+    }
+    return EEND_OK;
+}
+
 int eend_ffn_stream_f16(const void* X, int ldx, const void* wstream, const float* b1, const float* b2,
                         const float* res, float alpha, const float* gamma, const float* beta, float eps,
                         float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
@@ -190,8 +226,7 @@ int eend_ffn_stream_f16(const void* X, int ldx, const void* wstream, const float
     memset(&p, 0, sizeof(p));
     p.A = X; p.lda = ldx; p.wstream = wstream; p.b1 = b1; p.b2 = b2; p.res32 = res; p.alpha = alpha; p.gamma = gamma;
     p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F;
-    return eend_launch_ffn_stream(p, 0, act, residual_stream_unnormalised ? FFN_EPI_RES_SCALE_LN16 : FFN_EPI_RES_LN,
-                                  (hipStream_t)stream);
+    return ffn_stream_chunked(p, 0, act, residual_stream_unnormalised ? FFN_EPI_RES_SCALE_LN16 : FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
 int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res,
@@ -204,7 +239,7 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
     p.A = A; p.lda = lda; p.wstream = wstream; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1; p.res32 = res; p.res16 = res_f16;
     p.b1 = b1; p.b2 = b2; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2; p.out32 = out_f32; p.out16 = out_f16;
     p.M = M; p.F = F;
-    return eend_launch_ffn_stream(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
+    return ffn_stream_chunked(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
 int eend_conv_stream_elems(int ktaps) { return (int)eend_conv_stream_nelems(ktaps); }

@@ -396,20 +396,10 @@ int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream) {
 // p.W = the packed weights (eend_launch_inproj_attn_pack); p.Qs unused
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream) {
     if (p.Tp != TP || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O) return EEND_EINVAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)inproj_attn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-        n_cu &= ~31;                                 // multiple of 32: a persistent workgroup keeps its head (and its XCD)
-        if (n_cu <= 0) n_cu = 32;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel, SMEM)) return EEND_ELAUNCH;
+    int n_cu = eend_cu_count() & ~31;                // multiple of 32: a persistent workgroup keeps its head (and its XCD)
+    if (n_cu <= 0) n_cu = 32;
     const int nitems = p.nseq * 4;
     hipLaunchKernelGGL(inproj_attn_stream_kernel, dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

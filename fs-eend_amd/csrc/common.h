@@ -99,3 +99,32 @@ DEV bool drop_keep(const DropSpec d, unsigned a, unsigned b) {
 DEV float drop_apply(const DropSpec d, float v, unsigned a, unsigned b) {
     return d.thresh24 == 0 ? v : (drop_keep(d, a, b) ? v * d.scale : 0.f);
 }
+
+// ---- host-side launch helpers: per-device, thread-safe caches (function-local `static bool attr_done` / `static int ncu` were
+// neither -- harmless with one process per GPU, wrong the day one process drives two devices or two host threads race on first use).
+#include <atomic>
+struct EendOncePerDevice {                       // bit d = "done on device d" (devices >= 32 simply redo the call every time)
+    std::atomic<unsigned> mask{0};
+};
+inline int eend_current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device)
+inline bool eend_set_dynamic_lds(EendOncePerDevice& once, const void* kern, int bytes) {
+    const int dev = eend_current_device();
+    if (dev >= 0 && dev < 32 && (once.mask.load(std::memory_order_acquire) >> dev & 1u)) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32) once.mask.fetch_or(1u << dev, std::memory_order_release);
+    return true;
+}
+// compute units of the current device (cached per device)
+inline int eend_cu_count() {
+    static std::atomic<int> cus[32];
+    const int dev = eend_current_device();
+    int n = (dev >= 0 && dev < 32) ? cus[dev].load(std::memory_order_relaxed) : 0;
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < 32) cus[dev].store(n, std::memory_order_relaxed);
+    return n;
+}

@@ -266,16 +266,9 @@ int eend_launch_conv_stream(const ConvStreamParams& p, hipStream_t stream) {
     if (!p.X || !p.wstream || !p.bias || !p.ilens || !p.out32 || !p.out16 || p.nseq <= 0 || p.Tp <= 0 || !eend_conv_stream_supported(256, p.ktaps, p.pad) ||
         (long)p.Tp * 512 >= (1L << 31))
         return EEND_EINVAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)conv_stream_kernel, SMEM)) return EEND_ELAUNCH;
+    const int ncu = eend_cu_count();
     const int ntiles = p.nseq * ((p.Tp + TM - 1) / TM);
     hipLaunchKernelGGL(conv_stream_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

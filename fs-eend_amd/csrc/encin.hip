@@ -242,17 +242,10 @@ void encin_kernel(const EncInParams p) {
 
 template <int NK>
 int launch(const EncInParams& p, hipStream_t stream) {
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     auto kern = encin_kernel<NK>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    if (!eend_set_dynamic_lds(attr_once, (const void*)kern, SMEM)) return EEND_ELAUNCH;
+    const int ncu = eend_cu_count();
     const int ntiles = p.B * (p.Tp / ROWS);
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

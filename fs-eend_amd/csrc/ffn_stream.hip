@@ -613,12 +613,9 @@ void ffn_stream_kernel(const FfnStreamParams p) {
 
 template <int MODE, int ACT, int EPI, bool RES16, int NJ>
 int launch_nj(const FfnStreamParams& p, int ncu, hipStream_t stream) {
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     auto kern = ffn_stream_kernel<MODE, ACT, EPI, RES16, NJ>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    if (!eend_set_dynamic_lds(attr_once, (const void*)kern, SMEM)) return EEND_ELAUNCH;
     const int ntiles = (p.M + 64 * NJ - 1) / (64 * NJ);
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
@@ -626,11 +623,7 @@ int launch_nj(const FfnStreamParams& p, int ncu, hipStream_t stream) {
 
 template <int MODE, int ACT, int EPI, bool RES16>
 int launch(const FfnStreamParams& p, hipStream_t stream) {
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    const int ncu = eend_cu_count();
     // 192-row tiles reuse every weight fragment for three MFMAs; when they leave CUs idle in the only (or last of few) rounds,
     // 128-row tiles finish earlier: compare rounds x rows-per-tile (the time of a tile is close to linear in its rows).
     const long t3 = (p.M + 191) / 192, t2 = (p.M + 127) / 128;

@@ -208,8 +208,9 @@ void ret_stream_kernel(const RetStreamParams p) {
     // the wave's first two token fragments, requested BEFORE the barrier that ends the previous item: a wave that has finished its
     // block has its rows in flight while it waits for the others.  (Requested a phase earlier -- under the previous item's epilogue --
     // their 64 registers spill into the ingest path: measured +20 %.)
-    u32x4 xq_r[2][8];
+    u32x4 xq_r[2][8], xo_r1[2][8];
     request_rows(p.X, seq, f0 + tq0, xq_r);
+    if constexpr (KV_ONLY) request_rows(p.X, seq, f0 + to0, xo_r1);      // pass 1: all four fragments (nothing else is live there)
 
     const size_t sh = (size_t)seq * 4 + h;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + (size_t)h * NITEM * WITEM), 0,
@@ -254,7 +255,7 @@ void ret_stream_kernel(const RetStreamParams p) {
 
     f16x8 xq[2][8], xo[2][8];
     // the xq rows are older than everything issued in this item
-    if (KV_ONLY) __builtin_amdgcn_s_waitcnt(0x0F70 | (12 & 15) | ((12 >> 4) << 14));                     // bv 4 + DMA 8
+    if (KV_ONLY) __builtin_amdgcn_s_waitcnt(0x0F70 | (28 & 15) | ((28 >> 4) << 14));                     // xo 16 + biases 4 + DMA 8
     else if (has_lo) __builtin_amdgcn_s_waitcnt(0x0F70 | (32 & 15) | ((32 >> 4) << 14));                 // bv 4 + xlo 16 + DMA 12
     else __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));                             // bv 4 + DMA 12
     to_frags(xq_r, xq);
@@ -456,11 +457,9 @@ void ret_stream_kernel(const RetStreamParams p) {
         }
         RS_STAMP(14);
     } else {
-        // pass 1: fragments 2, 3 = the chunk's upper half
-        u32x4 xo_r[2][8];
-        request_rows(p.X, seq, f0 + to0, xo_r);
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
-        to_frags(xo_r, xo);
+        // pass 1: fragments 2, 3 = the chunk's upper half (biases 4 + DMA 8 are younger)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 12);
+        to_frags(xo_r1, xo);
     }
 
     // ================================================================== K, V^T -> LDS
@@ -724,15 +723,8 @@ void ret_stream_kernel(const RetStreamParams p) {
 }
 
 int n_cu_cached() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-        n_cu &= ~31;                                 // multiple of 32: a persistent workgroup keeps its head (and its XCD)
-        if (n_cu <= 0) n_cu = 32;
-    }
-    return n_cu;
+    int n_cu = eend_cu_count() & ~31;                // multiple of 32: a persistent workgroup keeps its head (and its XCD)
+    return n_cu > 0 ? n_cu : 32;
 }
 
 }  // namespace
@@ -762,12 +754,9 @@ int eend_launch_ret_stream(const RetStreamParams& p, bool kv, hipStream_t stream
         if (!p.kv_ws || p.nkv < 0 || p.nkv > p.nc) return EEND_EINVAL;
         if (p.nkv == 0) return EEND_OK;
     } else if (!p.O || !p.St || !p.cscale || !p.sexp) return EEND_EINVAL;
-    static bool attr_done[2] = {false, false};
+    static EendOncePerDevice attr_once[2];
     const void* kern = kv ? (const void*)ret_stream_kernel<true> : (const void*)ret_stream_kernel<false>;
-    if (!attr_done[kv]) {
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
-        attr_done[kv] = true;
-    }
+    if (!eend_set_dynamic_lds(attr_once[kv], kern, SMEM)) return EEND_ELAUNCH;
     int nunits;
     if (kv) nunits = p.nkv * p.nseq;
     else {

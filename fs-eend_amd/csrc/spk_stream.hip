@@ -499,17 +499,10 @@ void spk_stream_kernel(const SpkStreamParams p) {
 
 template <int G, int CC>
 int launch(const SpkStreamParams& p, hipStream_t stream) {
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     auto kern = spk_stream_kernel<G, CC>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    if (!eend_set_dynamic_lds(attr_once, (const void*)kern, SMEM)) return EEND_ELAUNCH;
+    const int ncu = eend_cu_count();
     const int ntiles = p.B * (p.Tp / (4 * G));
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

@@ -50,7 +50,11 @@ ENCIN_FUSED = __import__("os").environ.get("EEND_ENCIN_FUSED", "1") != "0"
 # time-axis attention with token-owning waves, packed in-projection weights and Q kept in registers (attn_stream.hip; Tp = 512 only)
 ATTN_STREAM = __import__("os").environ.get("EEND_ATTN_STREAM", "1") != "0"
 # the first half of a decoder layer (out-projection + norm11 + speaker-axis in-projection + C x C attention) in one launch on a
-# packed weight stream (spk_stream.hip) where the slot count allows it (C in {3, 6, 12}); 0: linear_res16_ln + spk_qkv_attn
+# packed weight stream (spk_stream.hip), any slot count C = 1 .. 12 (3 / 6 / 12 fill the tiling, the others run with phantom slots);
+# 0: linear_res16_ln + spk_qkv_attn.  Unlike spk_qkv_attn it takes no T_valid: the slab's padded frames [T, Tp) are computed too (finite
+# don't-care rows, masked as keys and dropped by the head) -- 2.4 % of the rows at T = 500 / Tp = 512, the bench configuration; for
+# lengths far below their padded length (T = 260, Tp = 320: 19 %) that is work the two-launch path skipped (kept deliberately:
+# a per-tile T_valid test costs the packed kernel its tile-uniform control flow).
 SPK_STREAM = __import__("os").environ.get("EEND_SPK_STREAM", "1") != "0"
 
 

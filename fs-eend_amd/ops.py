@@ -671,6 +671,11 @@ def ffn_stream_pack(wo, w1, w2):
     return out
 
 
+def ffn_stream_max_rows(lda=256):
+    """Rows one launch of the packed-stream layer-tail kernels takes; larger M is served in several launches inside the C ABI."""
+    return int(_lib.load().eend_ffn_stream_max_rows(int(lda)))
+
+
 def stream_ok(Fh):
     """Whether the packed-stream kernels take this hidden width."""
     return Fh % 64 == 0 and 64 <= Fh <= 2048

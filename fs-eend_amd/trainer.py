@@ -262,6 +262,9 @@ class EarlyStopping:
             raise RuntimeError(f"EarlyStopping: metric {self.monitor!r} was not logged by validation_epoch_end "
                                f"(logged: {sorted(module.logged)})")
         value = float(value)
+        if value != value or value in (float("inf"), float("-inf")):      # Lightning's check_finite default: a NaN / inf metric stops the run
+            self.stopped_epoch = epoch
+            return True
         better = self.best is None or (value < self.best - self.min_delta if self.mode == "min" else value > self.best + self.min_delta)
         if better:
             self.best, self.wait = value, 0
@@ -271,6 +274,13 @@ class EarlyStopping:
             self.stopped_epoch = epoch
             return True
         return False
+
+
+    def state_dict(self):
+        return dict(best=self.best, wait=self.wait, stopped_epoch=self.stopped_epoch)
+
+    def load_state_dict(self, st):
+        self.best, self.wait, self.stopped_epoch = st.get("best"), int(st.get("wait", 0)), st.get("stopped_epoch")
 
 
 class ModelCheckpoint:
@@ -288,10 +298,9 @@ class ModelCheckpoint:
     def on_epoch_end(self, trainer, module, epoch):
         import os
         os.makedirs(self.dirpath, exist_ok=True)
-        ckpt = trainer.checkpoint(module, epoch)
-        if self.save_last:
-            torch.save(ckpt, os.path.join(self.dirpath, "last.ckpt"))
         if self.save_top_k == 0:
+            if self.save_last:
+                torch.save(trainer.checkpoint(module, epoch), os.path.join(self.dirpath, "last.ckpt"))
             return
         path = os.path.join(self.dirpath, f"epoch={epoch}-step={trainer.global_step}.ckpt")
         # rank on a metric only if THIS epoch's validation logged it (a stale value of an earlier epoch, or the epoch number of
@@ -305,15 +314,23 @@ class ModelCheckpoint:
                 score = -score
         else:
             score = float("inf")
-        torch.save(ckpt, path)
+        # bookkeeping first, files second: the callback state stored INSIDE this epoch's checkpoint (and last.ckpt) must already list this
+        # epoch -- otherwise a resumed run never prunes the newest file and best_model_path lags one epoch
         self.kept.append((score, path))
+        pruned = []
         if self.save_top_k > 0 and self.monitor:
             self.kept.sort(key=lambda t: t[0])
-            for _, old in self.kept[self.save_top_k:]:
-                if os.path.exists(old):
-                    os.remove(old)
+            pruned = [old for _, old in self.kept[self.save_top_k:]]
             self.kept = self.kept[:self.save_top_k]
         self.best_model_path = min(self.kept, key=lambda t: t[0])[1]
+        ckpt = trainer.checkpoint(module, epoch)
+        if path not in pruned:
+            torch.save(ckpt, path)
+        if self.save_last:
+            torch.save(ckpt, os.path.join(self.dirpath, "last.ckpt"))
+        for old in pruned:
+            if os.path.exists(old):
+                os.remove(old)
 
     def state_dict(self):
         return dict(kept=list(self.kept), best_model_path=self.best_model_path)
@@ -371,7 +388,7 @@ class Trainer:
         return dict(state_dict={k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
                     optimizer_state={k: (v.cpu() if isinstance(v, Tensor) else v) for k, v in eng.optimizer_state().items()},
                     epoch=epoch, global_step=self.global_step,
-                    callbacks={type(cb).__name__: cb.state_dict() for cb in self.callbacks if hasattr(cb, "state_dict")})
+                    callbacks={f"{i}:{type(cb).__name__}": cb.state_dict() for i, cb in enumerate(self.callbacks) if hasattr(cb, "state_dict")})
 
     def _restore(self, module, path):
         ckpt = torch.load(path, map_location="cpu")
@@ -384,8 +401,9 @@ class Trainer:
             eng.load_optimizer_state(ckpt["optimizer_state"])
         eng.prep_weights()
         self.global_step = int(ckpt.get("global_step", 0))
-        for cb in self.callbacks:                        # top-k bookkeeping of the run being resumed
-            st = ckpt.get("callbacks", {}).get(type(cb).__name__)
+        for i, cb in enumerate(self.callbacks):          # top-k / patience bookkeeping of the run being resumed (keyed by position: two
+            saved = ckpt.get("callbacks", {})            # callbacks of one class keep separate states; round-4 files used the bare class name)
+            st = saved.get(f"{i}:{type(cb).__name__}", saved.get(type(cb).__name__))
             if st is not None and hasattr(cb, "load_state_dict"):
                 cb.load_state_dict(st)
         return int(ckpt.get("epoch", -1)) + 1
@@ -446,7 +464,8 @@ class Trainer:
                     self.validated_epoch = epoch
                     stop = False
                     if rank == 0:
-                        stop = any(cb.on_validation_end(self, module, epoch) for cb in self.callbacks if isinstance(cb, EarlyStopping))
+                        # every callback sees every validation (a generator inside any() would stop updating them at the first True)
+                        stop = any([cb.on_validation_end(self, module, epoch) for cb in self.callbacks if isinstance(cb, EarlyStopping)])
                     if dist and world > 1:               # every rank leaves the loop in the same epoch
                         flag = torch.tensor([1 if stop else 0], device=eng.flat.params.device)
                         dist.broadcast(flag, 0)

@@ -185,6 +185,10 @@ int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, con
                                      const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
                                      float* out_f32, void* out_f16, int M, int F, void* stream);
 
+/* Rows one launch of the packed-stream layer-tail kernels addresses (32-bit buffer offsets, one grid of tiles of prefetch ahead);
+ * eend_ffn_stream_f16 / eend_attnout_ffn_stream_f16 serve larger M in several launches over row ranges of that size. */
+int eend_ffn_stream_max_rows(int lda);
+
 /* Round 4: the same two operators (eend_ffn_fused_f16 / eend_attnout_ffn_fused[_res16]_f16; reference sites as above:
  * nn.TransformerEncoderLayer of FS model :147, merge_tfm_encoder.py:356-399, LS merge_retnet_layer.py:240-253,
  * conformer/feed_forward.py:47-57) on a PACKED WEIGHT STREAM.  eend_ffn_stream_pack_f16 re-orders Wo (optional, [256][256]),

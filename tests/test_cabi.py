@@ -99,6 +99,11 @@ def test_packed_stream_shape_predicates(hip_lib):
     L = hip_lib
     # layer tail: F/32 pairs of 16-KB items (+ 8 out-projection items)
     assert L.eend_ffn_stream_elems(2048, 1) == (8 + 2 * 64) * 8192 and L.eend_ffn_stream_elems(1024, 0) == 2 * 32 * 8192
+    # ... one launch addresses rows with 32-bit offsets: the C ABI serves larger M in ranges of this many rows (the plain
+    # entry returned EEND_EINVAL beyond ~2.03 M rows); a multiple of both tile sizes, inside the kernel's own guard
+    cap = L.eend_ffn_stream_max_rows(256)
+    assert cap % 384 == 0 and 2_000_000 < cap and (cap + 65536) * 1024 < 2 ** 31 and L.eend_ffn_stream_max_rows(512) == cap
+    assert L.eend_ffn_stream_max_rows(1024) % 384 == 0 and (L.eend_ffn_stream_max_rows(1024) + 65536) * 2048 < 2 ** 31
     # decoder layer head: 8 out-projection + 24 in-projection items; 1..12 slots, Tp a multiple of 64 / 32 / 16 frames (C <= 3 / 6 / 12)
     assert L.eend_spk_stream_elems() == 32 * 8192
     assert [c for c in range(0, 14) if L.eend_spk_stream_ok(c, 512)] == list(range(1, 13))

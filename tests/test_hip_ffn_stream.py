@@ -155,3 +155,35 @@ def test_stream_rejects_bad_arguments(hip_lib, dev):
     with pytest.raises(lib.EendHipError):          # both residual forms
         ops.attnout_ffn_stream(x, ops.ffn_stream_pack(rnd((256, 256), dev, 6, F16), w1, w2), v, o32, o16, v, v, 1e-5,
                                torch.zeros(192, device=dev), v, v, v, 1e-5, o32, o16)
+
+
+def test_stream_entries_split_large_row_counts(hip_lib, dev, monkeypatch):
+    """Beyond eend_ffn_stream_max_rows the C ABI serves the rows in several launches (32-bit buffer offsets inside one launch;
+    ADVICE r04).  With the range size forced down to 768 rows the multi-launch result must equal the single launch bit for bit --
+    every row sits at the same tile position -- for both residual forms and the plain-FFN entry."""
+    from fs_eend_amd import ops
+    M, Fh = 2000, 256
+    a = rnd((M, 256), dev, 41, F16)
+    wo, bo = rnd((256, 256), dev, 42, F16, 0.06), rnd((256,), dev, 43) * 0.2
+    w1, b1 = rnd((Fh, 256), dev, 44, F16, 0.08), rnd((Fh,), dev, 45) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 46, F16, 0.04), rnd((256,), dev, 47) * 0.3
+    res = rnd((M, 256), dev, 48)
+    g1, be1 = rnd((256,), dev, 49) * 0.2 + 1, rnd((256,), dev, 50) * 0.1
+    ws, ws0 = ops.ffn_stream_pack(wo, w1, w2), ops.ffn_stream_pack(None, w1, w2)
+    outs = []
+    for cap in (None, "768"):
+        if cap is None:
+            monkeypatch.delenv("EEND_FFN_STREAM_MAX_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("EEND_FFN_STREAM_MAX_ROWS", cap)
+            assert ops.ffn_stream_max_rows() == 768
+        o32, o16 = torch.empty((M, 256), dtype=F32, device=dev), torch.empty((M, 256), dtype=F16, device=dev)
+        ops.attnout_ffn_stream(a, ws, bo, res, None, g1, be1, 1e-5, b1, b2, g1, be1, 1e-5, o32, o16)
+        p16 = torch.empty((M, 256), dtype=F16, device=dev)
+        ops.attnout_ffn_stream(a, ws, bo, None, res.half(), g1, be1, 1e-5, b1, b2, g1, be1, 1e-5, None, p16)
+        q32, q16 = torch.empty((M, 256), dtype=F32, device=dev), torch.empty((M, 256), dtype=F16, device=dev)
+        ops.ffn_stream(a, ws0, b1, b2, res, g1, be1, q32, q16, ops.ACT_SWISH, 0.5, 1e-5, residual_unnormalised=True)
+        torch.cuda.synchronize()
+        outs.append((o32, o16, p16, q32, q16))
+    for x, y in zip(*outs):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
