@@ -188,6 +188,10 @@ int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ld
 int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, float alpha,
                                const float* gamma, const float* beta, float eps, float* out32, void* out16, int M, int K, int mode,
                                hipStream_t stream, float* ln_out32 = nullptr);
+// gemm_f32.hip: f32 linear layers for M > 16 rows on the exact-f32 MFMA (multi-stream frame steps)
+bool eend_linear_f32_mfma_ok(const float* A, int lda, const float* W, int ldw, int M, int N, int K, int ldo);
+int eend_launch_linear_f32_mfma(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldres, float alpha,
+                                int res_mode, int act, float* out32, int ldo, int M, int N, int K, hipStream_t stream);
 int eend_launch_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float eps, float* out32, int M, hipStream_t stream);
 int eend_launch_convert_step_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, int B, int C,
                                  hipStream_t stream);

@@ -213,6 +213,9 @@ int eend_launch_skinny_plain_f32(const float* A, int lda, const float* W, int ld
                                  int K, int act, hipStream_t stream) {
     if (!A || !W || !out32 || M < 1 || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
         return EEND_EINVAL;
+    // more than 16 rows (multi-stream sessions): the f32 MFMA kernel of gemm_f32.hip instead of serial 16-row groups
+    if (eend_linear_f32_mfma_ok(A, lda, W, ldw, M, N, K, ldo) && !((size_t)out32 & 15) && !(bias && ((size_t)bias & 15)))
+        return eend_launch_linear_f32_mfma(A, lda, W, ldw, bias, nullptr, 0, 1.0f, 0, act, out32, ldo, M, N, K, stream);
     SkinnyParams p{A, lda, W, ldw, bias, M, N, K, act, 1.0f, nullptr, 0, out32, nullptr, ldo};
     return launch_skinny<SK_PLAIN, true>(p, stream);
 }
@@ -228,8 +231,14 @@ int eend_launch_skinny_res_f32(const float* A, int lda, const float* W, int ldw,
                                hipStream_t stream, float* ln_out32) {
     if (!A || !W || !out32 || M < 1 || (K & 7) || (lda & 3) || (ldw & 3) || (((size_t)A | (size_t)W) & 15))
         return EEND_EINVAL;
-    SkinnyParams p{A, lda, W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32, mode == 0 ? (_Float16*)out16 : nullptr, 256};
-    int rc = launch_skinny<SK_RES, true>(p, stream);
+    int rc;
+    if (mode != 0 && eend_linear_f32_mfma_ok(A, lda, W, ldw, M, 256, K, 256) && !((size_t)out32 & 15) && !(bias && ((size_t)bias & 15)) &&
+        !(res && ((size_t)res & 15))) {
+        rc = eend_launch_linear_f32_mfma(A, lda, W, ldw, bias, res, 256, alpha, 1, 0, out32, 256, M, 256, K, stream);
+    } else {
+        SkinnyParams p{A, lda, W, ldw, bias, M, 256, K, 0, alpha, res, 256, out32, mode == 0 ? (_Float16*)out16 : nullptr, 256};
+        rc = launch_skinny<SK_RES, true>(p, stream);
+    }
     if (rc != EEND_OK || mode == 0) return rc;
     hipLaunchKernelGGL(skinny_ln_kernel, dim3(M), dim3(64), 0, stream, out32, (_Float16*)out16, gamma, beta, eps, mode == 1 ? 1 : 0, ln_out32);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

@@ -189,7 +189,7 @@ def test_stream_sessions_survive_a_weight_refresh(hip_lib, dev):
     assert torch.equal(run_fs(False), run_fs(True))
 
 
-@pytest.mark.parametrize("N,C", [(10, 10), (1, 1), (16, 8), (6, 3)])
+@pytest.mark.parametrize("N,C", [(10, 10), (1, 1), (16, 8), (6, 3), (640, 10), (64, 1), (200, 10), (33, 3), (17, 1)])
 def test_f32_frame_step_entries_vs_torch(hip_lib, dev, N, C):
     from fs_eend_amd import ops
     """The f32 pieces of the all-f32 decoder frame step (f32 activations AND weights) against plain torch fp32:
