@@ -34,7 +34,7 @@ def flops_per_launch(name, shape, T):
     frames of every sequence, not on the Tp = ceil64(T) slab rows they execute (the 2.4 % padding rows at T = 500 are
     work the layout adds, not work the reference does)."""
     Tp_ = (T + 63) // 64 * 64
-    if name not in ("attn_causal", "inproj_attn_causal", "retention_chunk") and shape and shape[0] % Tp_ == 0:
+    if name not in ("attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "retention_chunk", "retention_stream") and shape and shape[0] % Tp_ == 0:
         shape = (shape[0] // Tp_ * T,) + tuple(shape[1:])
     if name == "attn_causal":          # 2*D*T*(T+1) causal-useful flops per sequence (SURVEY 8d), D = H*64
         nseq, H = shape
@@ -56,6 +56,9 @@ def flops_per_launch(name, shape, T):
     if name in ("attnout_ffn_fused", "attnout_ffn_stream"):    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
+    if name == "retention_stream":     # the fused operator: the four projections (2*T*1024*256 per sequence) + the retention core below
+        nseq, H, Tv, L = shape
+        return nseq * 2.0 * Tv * 1024 * 256 + nseq * H * (Tv // L) * (2 * 64.0 * L * (L + 1) + 2 * 2.0 * L * 64 * 64)
     if name == "retention_chunk":      # (nseq, H, valid frames, L): QK^T + PV causal-useful per chunk, + state build and cross term
         nseq, H, Tv, L = shape
         return nseq * H * (Tv // L) * (2 * 64.0 * L * (L + 1) + 2 * 2.0 * L * 64 * 64)
@@ -69,9 +72,7 @@ def pmc_traffic(kernel, shape):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
     tags = {("fusion_layer_tail", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 2>(FfnParams)",), "131072"),
             ("attnout_ffn_stream", (196608, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 3>",), "65536"),
             ("attnout_ffn_stream", (32768, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 2>",), "65536"),
@@ -95,14 +96,16 @@ def pmc_traffic(kernel, shape):
     return None
 
 
-def ls_retention_traffic(nseq, H, Tv, L):
-    """PMC HBM bytes of the three retention kernels of one layer (the default LS workload, 160 x T = 2000, only)."""
-    path = os.path.join(ROOT, "profiles", "r03_ls_pmc_traffic.json")
+def ls_retention_traffic(nseq, H, Tv, L, fused=False):
+    """PMC HBM bytes of the retention kernels of one layer (the default LS workload, 160 x T = 2000, only): the two passes of
+    ret_stream.hip + the scan (round 5), or the three kernels of the two-call form (round 3 file)."""
+    path = os.path.join(ROOT, "profiles", "r05_ls_pmc_traffic.json" if fused else "r03_ls_pmc_traffic.json")
     if not os.path.exists(path) or (nseq, H, Tv, L) != (160, 4, 2000, 500):
         return None
     ks = json.load(open(path))["kernels"]
     tot = 0.0
-    for name in ("ret_kv_chunk_kernel", "ret_state_scan_kernel", "ret_chunk_full_kernel"):
+    for name in (("ret_stream_kernel<true>", "ret_state_scan_kernel", "ret_stream_kernel<false>") if fused else
+                 ("ret_kv_chunk_kernel", "ret_state_scan_kernel", "ret_chunk_full_kernel")):
         cand = [v["hbm_bytes"] for k, v in ks.items() if name in k]
         if not cand:
             return None
@@ -133,6 +136,9 @@ class OpTimer:
             elif name == "retention_chunk":
                 tv = k.get("t_valid") or a[11]
                 shape = (a[9], a[10], tv // a[12] * a[12], a[12])
+            elif name == "retention_stream":            # (x16, xlo16, wstream, bias, o16, st, cscale, sexp, nseq, Tp, chunk, gn_eps, t_valid=)
+                tv = k.get("t_valid") or a[9]
+                shape = (a[8], 4, tv // a[10] * a[10], a[10])
             elif name in ("linear", "linear_res_ln", "linear_res_scale", "linear_res_scale_ln16"):
                 shape = (a[0].shape[0], a[1].shape[0], a[0].shape[1])
             elif name == "ffn_fused":
@@ -163,7 +169,7 @@ class OpTimer:
 
     def __enter__(self):
         for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm", "conv1d_l2norm_stream",
-                  "convert_fanout", "attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "linear_res_scale_ln16", "linear_glu",
+                  "convert_fanout", "attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "retention_stream", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):
                 continue
@@ -375,8 +381,28 @@ def extras(dev):
                                             "traffic": None, "avg_launch_ms": dom["avg_ms"]}
         # north_star's "retention chunk recurrence": state build + scan + chunk kernel of one decoder layer, HBM-bound
         # (intensity ~126 flop/B < ridge 312): algorithmic bytes = q, k, v, g read + gated output written, 2-byte elements
+        rs = [k for k in ks if k["kernel"] == "retention_stream"]
+        if rs:
+            # round 5: projections + retention in one operator (ret_stream.hip: chunk K^T V pass, scan, row pass).  SURVEY 8d prices the
+            # retention on q, k, v, g read + o written (5 x 512 B per frame and layer) -- tensors this operator never materialises: it
+            # reads the input rows (hi + lo f16 halves for the query path) and writes o, 1.5 KB per frame.  `achieved` keeps the SURVEY
+            # figure (comparable with rounds 2-4); the fused operator's own algorithmic bytes and the MFMA view are reported beside it.
+            r = max(rs, key=lambda k: k["shape"][0])
+            nseq_, H_, Tv_, L_ = r["shape"]
+            byt = nseq_ * H_ * Tv_ * 64 * 2.0 * 5
+            byt_fused = nseq_ * Tv_ * 256 * 2.0 * 3
+            gbs = byt / (r["avg_ms"] * 1e-3) / 1e9
+            res["ls_eend_batch"]["roofline_retention"] = {
+                "kernel": f"retention_stream (ret_stream<kv> + ret_state_scan + ret_stream<rows>; q/k/v/g projections included) nseq={nseq_} H={H_} T={Tv_} L={L_}",
+                "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": r["avg_ms"],
+                "mfma_TFLOPs": r["tflops"], "mfma_frac": None if r["tflops"] is None else r["tflops"] / PEAK_MFMA_TFLOPS,
+                "algorithmic_bytes_survey": byt, "algorithmic_bytes_fused_operator": byt_fused,
+                "traffic": ls_retention_traffic(nseq_, H_, Tv_, L_, fused=True),
+                "traffic_source": "profiles/r05_ls_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes): the three launches of one "
+                                  "decoder layer, bytes per launch",
+                "replaces": "retention_proj + retention_chunk (round 4: 0.38 + 0.44 ms for this shape)"}
         rk = [k for k in ks if k["kernel"] == "retention_chunk"]
-        if rk:
+        if rk and not rs:
             r = max(rk, key=lambda k: k["shape"][0])
             nseq_, H_, Tv_, L_ = r["shape"]
             byt = nseq_ * H_ * Tv_ * 64 * 2.0 * 5
@@ -1075,7 +1101,7 @@ def main():
                            "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
-                           "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, bytes per launch)"}
+                           "traffic_source": "profiles/r05_pmc_traffic.json, else r04 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, bytes per launch)"}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
         # the encoder's time-axis attention launch (nseq = B): the packed-weight form at Tp = 512 (attn_stream.hip), else attn_fused.hip
         fus = [k for k in ksum if k["kernel"] in ("inproj_attn_causal_packed", "inproj_attn_causal") and k["shape"][0] == B]

@@ -27,12 +27,6 @@ template <int V> using IC = std::integral_constant<int, V>;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef EEND_CS_PIN
-#define EEND_CS_PIN 0           // 1: accumulators and fragment registers pinned per item (clean steady loop, but measured 6 % slower)
-#endif
-#ifndef EEND_CS_STUDY
-#define EEND_CS_STUDY 0
-#endif
 constexpr int NR = 4;                // token fragments per wave (64 rows)
 constexpr int NF = 8;                // feature fragments per wave (128 features)
 constexpr int TM = 128, WM = 64;     // rows per tile / per wave
@@ -139,23 +133,11 @@ void conv_stream_kernel(const ConvStreamParams p) {
             // this wave's pieces of the NEXT item have landed (2 younger items x 4 pieces may stay in flight) -- so behind the barrier
             // every wave's have, and its first fragments can be requested under this item's last MFMAs
             if (q > 0) {
-#if !(EEND_CS_STUDY & 1)      // perf-study builds only (results are garbage): 1 = no counted wait, 2 = no barrier, 4 = no weight DMA, 8 = no weight fragment reads, 16 = no input fragment reads
                 __builtin_amdgcn_s_waitcnt(0x0F70 | INFL);
-#endif
-#if !(EEND_CS_STUDY & 2)
                 __builtin_amdgcn_s_barrier();
-#endif
             }
             // accumulators pinned to the accumulator file, the fragment rotation to the vector file, once per item: left alone the
             // compiler renames them around the loop (124 v_accvgpr_mov per item, each waiting for the MFMA that wrote its source)
-#if EEND_CS_PIN
-#pragma unroll
-            for (int i = 0; i < NF; ++i)
-#pragma unroll
-                for (int j = 0; j < NR; ++j) asm volatile("" : "+a"(acc[i][j]));
-#pragma unroll
-            for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(wf[k]));
-#endif
             const char* wc = smem + L_RING + slot * SLOT + nh * (NF * 1024) + lane * 16;
             const char* wn = smem + L_RING + (slot + 1 == NSLOT ? 0 : slot + 1) * SLOT + nh * (NF * 1024) + lane * 16;
             const int sd = slot == 0 ? NSLOT - 1 : slot - 1;
@@ -168,16 +150,10 @@ void conv_stream_kernel(const ConvStreamParams p) {
                 const f16x8 w = wf[pi % NB];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) acc[pi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[j], acc[pi][j], 0, 0, 0);
-#if !(EEND_CS_STUDY & 8)
                 if constexpr (pi + PD < NF) wf[(pi + PD) % NB] = *(const f16x8*)(wc + (pi + PD) * 1024);
                 else wf[(pi + PD) % NB] = *(const f16x8*)(wn + (pi + PD - NF) * 1024);
-#endif
-#if !(EEND_CS_STUDY & 4)
                 if constexpr (pi < 4) dma_piece(sd, IC<pi>{});
-#endif      // the item NSLOT-1 ahead -> the slot every wave finished before this barrier
-#if !(EEND_CS_STUDY & 16)
                 if constexpr (pi == 2) { if (q + 1 < S) read_x(q + 1, xn); }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
 #pragma unroll

@@ -47,43 +47,8 @@ constexpr int B1L = VECS + 6 * 1024;   // b1, up to 2048 hidden units
 constexpr int MAXF = 2048;
 constexpr int DUMP = B1L + MAXF * 4;   // 256-byte dump area of the L2-touch loads
 constexpr int SMEM = DUMP + 256;       // 162048
-#ifndef EEND_FS_NB
-#define EEND_FS_NB 8
-#endif
-constexpr int NB = EEND_FS_NB;     // weight-fragment registers in rotation (divides 32)
-#ifndef EEND_FS_PD
-#define EEND_FS_PD 6
-#endif
-constexpr int PD = EEND_FS_PD;     // fragment prefetch distance (items)
-#ifndef EEND_FS_RES0
-#define EEND_FS_RES0 0            // residual rows of fragment 0: 0 = requested with the tile's input rows, 1 = before the last out-projection item
-#endif
-#ifndef EEND_FS_RES12
-#define EEND_FS_RES12 2           // ... of fragments 1, 2: 0 = before the 7th out-projection item, 1 = under the LayerNorm of the previous fragment,
-                                  // 2 = both behind the first pass of fragment 0's LayerNorm (whole-step timing: -0.7 % against 1)
-#endif
-#ifndef EEND_FS_TOUCH_LEAD
-#define EEND_FS_TOUCH_LEAD 0      // touch the next tile's input rows this many hidden-unit pairs (1.6 us each) before the loop ends; 0: before the last two items
-#endif
-#ifndef EEND_FS_TOUCH_RES
-#define EEND_FS_TOUCH_RES 0
-#endif
-#ifndef EEND_FS_ILV
-#define EEND_FS_ILV 0              // 1: activation VALU instructions interleaved one per MFMA (sched_group_barrier); measured: no difference
-#endif
-#ifndef EEND_FS_STUDY
-#define EEND_FS_STUDY 0
-#endif
-#ifndef EEND_FS_DMA_SPREAD
-#define EEND_FS_DMA_SPREAD 0
-#endif
-#ifndef EEND_FS_PIN
-#define EEND_FS_PIN 15
-#endif
-#ifndef EEND_FS_XFLATE
-#define EEND_FS_XFLATE 2           // next tile's input rows: 0 = loaded fragment by fragment inside the epilogue, 1 = touched before the last
-                                   // two items and loaded after the epilogue, 2 = loaded before the last two items
-#endif
+constexpr int NB = 8;     // weight-fragment registers in rotation (divides 32)
+constexpr int PD = 6;     // fragment prefetch distance (items)
 constexpr int INFL = 4 * (NSLOT - 3);   // this wave's DMA pieces younger than the ones a barrier needs (5 items x 4 pieces)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -155,7 +120,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     // VMEM operations of a wave that are certainly younger than the DMA pieces the first six barriers after an epilogue wait for:
     // the INFL pieces in between plus the epilogue's own f16 row stores (8 per token fragment) and, where they are issued in or
     // behind the epilogue, the next tile's input-row loads (8 per fragment)
-    constexpr int LOOSE = EEND_FS_XFLATE == 2 ? INFL + 8 * NJ : (INFL + 16 * NJ < 63 ? INFL + 16 * NJ : 63);
+    constexpr int LOOSE = INFL + 8 * NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int U = p.F >> 5;                               // half-chunks of 32 hidden units
     const int S = (PRE ? 8 : 0) + 2 * U;                  // stream items per tile
@@ -244,7 +209,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             for (int e = 0; e < 8; ++e) r8[j][e] = __builtin_bit_cast(f16x8, bload(rsR16, off + e * 16));
         }
     };
-    if (blockIdx.x < ntiles) { sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(blockIdx.x, J); }); if (EEND_FS_RES0 == 0) load_res16(blockIdx.x, IC<0>{}); }
+    if (blockIdx.x < ntiles) { sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(blockIdx.x, J); }); load_res16(blockIdx.x, IC<0>{}); }
 
     auto act_cvt = [&](float v) __attribute__((always_inline)) -> _Float16 {
         if (ACT == 1) return (_Float16)__builtin_amdgcn_fmed3f(v, 0.f, 65504.f);       // ReLU + saturation in one instruction
@@ -268,13 +233,9 @@ void ffn_stream_kernel(const FfnStreamParams p) {
         constexpr bool conv = decltype(CONVc)::value;
         constexpr bool cold = decltype(COLDc)::value;    // the previous item did not request this item's first fragments
         constexpr bool pfn = decltype(PFNc)::value;      // request the next item's first fragments (not in front of a VALU phase)
-#if !(EEND_FS_STUDY & 1)      // perf study builds only (results are garbage): 1 = no vmcnt wait, 2 = no barrier, 4 = no activation
         if (loose) __builtin_amdgcn_s_waitcnt(0x0F70 | (LOOSE & 15) | ((LOOSE >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70 | (vw & 15) | ((vw >> 4) << 14));
-#endif
-#if !(EEND_FS_STUDY & 2)
         __builtin_amdgcn_s_barrier();
-#endif
         const char* wc = wl + slot * SLOT;
         const char* wn = wl + ((slot + 1) & (NSLOT - 1)) * SLOT;
         const int sd = (slot + NSLOT - 1) & (NSLOT - 1);
@@ -315,28 +276,10 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 if constexpr (pi + PD < 16) wf[(pi + PD) % NB] = *(const f16x8*)(wc + (pi + PD) * 1024);
                 else if constexpr (pfn) wf[(pi + PD) % NB] = *(const f16x8*)(wn + (pi + PD - 16) * 1024);
                 // the 4 DMA pieces of the item NSLOT-1 ahead, on fragments 0 .. 3
-#if EEND_FS_DMA_SPREAD
-                if constexpr ((pi & 3) == 1) dma_piece(sd, IC<(pi >> 2)>{});      // fragments 1, 5, 9, 13
-#else
                 if constexpr (pi < 4) dma_piece(sd, IC<pi>{});
-#endif
                 // activation of the half-chunk held in h (6 fragment parts) on fragments 2, 4, ..., 12
-#if !(EEND_FS_STUDY & 4)
                 if constexpr (kind == 2 && conv && pi >= 2 && pi < 2 + 4 * NJ && !(pi & 1)) conv_part(IC<(pi - 2) / 2>{}, hbo);
-#endif
             });
-#if EEND_FS_ILV
-            // a pair that carries an activation part (4 clamps + 2 packs): one VALU instruction behind each of its 2 NJ MFMAs.  Left
-            // to the scheduler the six follow the MFMAs in a block, and the matrix pipe idles while they issue (the pipe takes a
-            // new MFMA every 16 cycles, a VALU instruction occupies the wave's issue slot for 4).
-            if constexpr (kind == 2 && conv && decltype(P2)::value >= 1 && decltype(P2)::value < 1 + 2 * NJ) {
-#pragma unroll
-                for (int q = 0; q < 2 * NJ; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                }
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         dma_advance();
@@ -344,24 +287,15 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     };
     // the accumulators sit in the accumulator half of the register file whenever matrix work is about to run on them
     auto pin_acc = [&](int where) __attribute__((always_inline)) {
-        if ((EEND_FS_PIN & where) != 0) {
+        {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
         }
     };
-    // pull rows of a later tile towards the L2 ahead of their loads: one dword per 128-byte line, by LDS-DMA into a dump area
-    // nobody reads -- no destination register, so nothing ever waits for these loads specifically (a VGPR destination gets "used"
-    // or spilled by the compiler, either of which exposes the HBM round trip; that was the shipped state until the ISA was read).
-    auto touch_rows_of = [&](const __amdgpu_buffer_rsrc_t& r, int row_bytes, int t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < NJ; ++q) {
-            const int idx = q * 64 + lane;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_char*)(smem + DUMP), 4, (t * TM + wave * WM + (idx >> 2)) * row_bytes + (idx & 3) * 128, 0, 0, 0);
-        }
-    };
-    auto touch_rows = [&](int t) __attribute__((always_inline)) { touch_rows_of(rsA, p.lda * 2, t); };
+    // (an L2 touch of later tiles' rows by LDS-DMA into the dump area was measured and dropped with the other study switches: round 5 hygiene;
+    // the shipped choice requests the next tile's rows before the last two items)
     bool loose = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         float alpha_l = p.alpha;                          // laundered: 1/alpha hoisted out of the tile loop ended up in scratch
@@ -398,8 +332,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             step(IC<0>{}, IC<4>{}, Fa{}, Fa{}, T{}, IC<0>{}, loose, 0, hbA, hbB);
             step(IC<0>{}, IC<5>{}, Fa{}, Fa{}, T{}, IC<0>{}, loose, 0, hbA, hbB);
             loose = false;
-            if constexpr (RES16 && EEND_FS_RES12 == 0) { load_res16(tile, IC<1>{}); load_res16(tile, IC<2>{}); }
-            step(IC<0>{}, IC<6>{}, Fa{}, Fa{}, T{}, IC<(RES16 && EEND_FS_RES12 == 0 ? 16 : 0)>{}, false, 0, hbA, hbB);
+            step(IC<0>{}, IC<6>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
             // residual rows of token fragment 0 travel under the last Wo item
             f32x4 t4[RES16 ? 1 : 16];
             auto load_res = [&](auto J) __attribute__((always_inline)) {
@@ -411,8 +344,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 }
             };
             load_res(IC<0>{});
-            if constexpr (RES16 && EEND_FS_RES0 == 1) load_res16(tile, IC<0>{});
-            step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, Fa{}, IC<(!RES16 ? 16 : (EEND_FS_RES12 == 0 ? 16 : 0) + (EEND_FS_RES0 == 1 ? 8 : 0))>{}, false, 0, hbA, hbB);
+            step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, Fa{}, IC<(!RES16 ? 16 : 0)>{}, false, 0, hbA, hbB);
             pin_acc(2);
             FS_STAMP(1);
             relaunder();
@@ -440,8 +372,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 const float rstd = 1.0f / __builtin_sqrtf(__builtin_fmaxf(sqs * (1.0f / 256) - mean * mean, 0.f) + p.eps1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (RES16) {
-                    if constexpr (j + 1 < NJ && EEND_FS_RES12 == 1) load_res16(tile, IC<j + 1>{});
-                    if constexpr (j == 0 && EEND_FS_RES12 == 2) { load_res16(tile, IC<1>{}); if constexpr (NJ > 2) load_res16(tile, IC<2>{}); }
+                    if constexpr (j == 0) { load_res16(tile, IC<1>{}); if constexpr (NJ > 2) load_res16(tile, IC<2>{}); }
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -486,11 +417,6 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             FS_STAMP(3);
             step(IC<1>{}, IC<0>{}, Fa{}, T{}, T{}, IC<0>{}, nloose > 1, 1, hbA, hbB);
             for (int k = 2; k < U; k += 2) {                // U is even
-#if EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD > 0
-                if (k == U - 2 * EEND_FS_TOUCH_LEAD || (U <= 2 * EEND_FS_TOUCH_LEAD && k == 2)) {
-                    touch_rows(tile + (int)gridDim.x);
-                }
-#endif
                 step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<0>{}, nloose > 2 * k - 2, 0, hbA, hbB);      // W2h(k-2) x hbA, h(k-1) -> hbB
                 step(IC<1>{}, IC<0>{}, Fa{}, Fa{}, T{}, IC<0>{}, nloose > 2 * k - 1, k, hbA, hbB);      // W1h(k)
                 step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<0>{}, nloose > 2 * k, 0, hbB, hbA);          // W2h(k-1) x hbB, h(k) -> hbA
@@ -498,16 +424,10 @@ void ffn_stream_kernel(const FfnStreamParams p) {
             }
             if constexpr (!PRE) loose = false;
             FS_STAMP(4);
-#if EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0
-            touch_rows(tile + (int)gridDim.x);
-#endif
-#if EEND_FS_XFLATE == 2
             // x is dead: the next tile's input rows are requested here and travel under the last two items and the epilogue
             // (unconditionally -- rows beyond M read as zeros -- so that the wait counts below hold on the last tile too)
             sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(tile + (int)gridDim.x, J); });
-            if constexpr (RES16 && PRE && EEND_FS_TOUCH_RES) touch_rows_of(rsR16, 512, tile + (int)gridDim.x);      // its residual rows towards L2
-#endif
-            constexpr int VWL = EEND_FS_XFLATE == 2 ? 8 * NJ + (RES16 && PRE && EEND_FS_TOUCH_RES ? NJ : 0) : (EEND_FS_XFLATE == 1 && EEND_FS_TOUCH_LEAD == 0 ? NJ : 0);
+            constexpr int VWL = 8 * NJ;
             step(IC<2>{}, IC<0>{}, T{}, Fa{}, T{}, IC<VWL>{}, false, 0, hbA, hbB);     // W2h(U-2) x hbA, h(U-1) -> hbB
             step(IC<2>{}, IC<0>{}, Fa{}, Fa{}, Fa{}, IC<VWL>{}, false, 0, hbB, hbA);    // W2h(U-1) x hbB
             pin_acc(8);
@@ -589,16 +509,9 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                         wave_lds_sync();
                     }
             }
-#if !EEND_FS_XFLATE
-            if (ntile < ntiles) { load_in_frags(ntile, J); if constexpr (j == 0 && EEND_FS_RES0 == 0) load_res16(ntile, J); }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
-#if EEND_FS_XFLATE == 1
-        if (ntile < ntiles) { sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); }); if (EEND_FS_RES0 == 0) load_res16(ntile, IC<0>{}); }
-#elif EEND_FS_XFLATE == 2
-        if (ntile < ntiles && EEND_FS_RES0 == 0) load_res16(ntile, IC<0>{});
-#endif
+        if (ntile < ntiles) load_res16(ntile, IC<0>{});
         FS_STAMP(6);
 #ifdef EEND_FS_TRACE
         if (tix < 8 && threadIdx.x == 0) {

@@ -40,16 +40,6 @@ constexpr int SMEM = VECS + 6 * 1024;    // 153600
 constexpr int NB = 8;                // weight-fragment registers in rotation
 constexpr int PD = 6;                // fragment prefetch distance
 constexpr int INFL = 4 * (NSLOT - 3);
-#ifndef EEND_SPK_XLATE
-#define EEND_SPK_XLATE 0          // next tile's input rows: 0 = requested before the last head's attention, 1 = after it
-#endif
-#ifndef EEND_SPK_RES
-#define EEND_SPK_RES 0            // where the residual rows are requested (see the tile loop)
-#endif
-#ifndef EEND_SPK_STUDY
-#define EEND_SPK_STUDY 0          // perf-study builds only (results are garbage): 1 no attention math, 2 no x1 stores, 4 no O stores,
-                                  // 8 no score FMAs, 16 no reductions / softmax, 32 no PV FMAs
-#endif
 constexpr int NITEMS = 8 + 24;       // Wo1: 8 items; in-projection: 4 heads x {q, k, v} x 2 halves of 32 features
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -258,25 +248,10 @@ void spk_stream_kernel(const SpkStreamParams p) {
         step(IC<0>{}, IC<2>{}, Fa{}, T{}, IC<24>{});
         step(IC<0>{}, IC<3>{}, Fa{}, T{}, IC<24>{});
         step(IC<0>{}, IC<4>{}, Fa{}, T{}, IC<24>{});
-#if EEND_SPK_RES == 1
-        load_res16(tile, IC<0>{});
-        step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<32>{});
-        load_res16(tile, IC<1>{});
-        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<16>{});
-        load_res16(tile, IC<2>{});
-        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<24>{});
-#elif EEND_SPK_RES == 3
-        step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<24>{});
-        load_res16(tile, IC<0>{});
-        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<8>{});
-        load_res16(tile, IC<1>{});
-        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<16>{});
-#else
         step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<24>{});
         step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<0>{});
         load_res16(tile, IC<0>{});
         step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<8>{});
-#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -303,13 +278,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
             const float var = __builtin_fmaxf(sqs * (1.0f / 256) - mean * mean, 0.f);
             const float rstd = 1.0f / __builtin_sqrtf(var + p.eps1);
             __builtin_amdgcn_sched_barrier(0);
-#if EEND_SPK_RES == 0
             if constexpr (j + 1 < NJ) load_res16(tile, IC<j + 1>{});
-#elif EEND_SPK_RES == 2
-            if constexpr (j == 0) { load_res16(tile, IC<1>{}); load_res16(tile, IC<2>{}); }
-#elif EEND_SPK_RES == 3
-            if constexpr (j == 0) load_res16(tile, IC<2>{});
-#endif
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i) - vec4(1, i) * (rstd * mean);
@@ -331,7 +300,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
                     const f16x8 v4 = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));
-                    if (!(EEND_SPK_STUDY & 2) && (FULL || slot_of(j, half * 8 + rr) < CC)) *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
+                    if ((FULL || slot_of(j, half * 8 + rr) < CC)) *(f16x8*)(x16 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + cc * 8) = v4;
                 }
                 wave_lds_sync();
             }
@@ -359,7 +328,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
             step(IC<1>{}, IC<4>{}, Fa{}, T{}, IC<6>{});
             step(IC<1>{}, IC<5>{}, Fa{}, Fa{}, IC<6>{});
             SPK_STAMP_H(3, head);
-            if (EEND_SPK_XLATE == 0 && decltype(LAST)::value && ntile < ntiles)              // x1 is dead: the next tile's input rows travel under the last attention
+            if (decltype(LAST)::value && ntile < ntiles)              // x1 is dead: the next tile's input rows travel under the last attention
                 sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); });
 
             // packed f32 arithmetic (v_pk_fma_f32: two FMAs per lane and instruction) on register pairs of the accumulator quads
@@ -372,7 +341,6 @@ void spk_stream_kernel(const SpkStreamParams p) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) s2[a][c] = f32x2{0.f, 0.f};
             f16x8 of[NJ][2];
-#if !(EEND_SPK_STUDY & 1)
             sfor<4>([&](auto FF) __attribute__((always_inline)) {
                 constexpr int ff = decltype(FF)::value;
                 const f32x4 b4 = bnext;
@@ -392,8 +360,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
                         const f32x2 k1 = f32x2{row_rot<d * G>(k[2]), row_rot<d * G>(k[3])};
 #pragma unroll
                         for (int j1 = 0; j1 < NJ; ++j1) {
-                            if (EEND_SPK_STUDY & 8) { if (j1 == 0) s2[j1][j2 * R + d] += q[j1][1] + k1 + k0; }
-                            else s2[j1][j2 * R + d] = q[j1][1] * k1 + (q[j1][0] * k0 + s2[j1][j2 * R + d]);
+                            s2[j1][j2 * R + d] = q[j1][1] * k1 + (q[j1][0] * k0 + s2[j1][j2 * R + d]);
                         }
                     });
                 });
@@ -406,11 +373,11 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 for (int c = 0; c < C; ++c) {
                     s[a][c] = s2[a][c][0] + s2[a][c][1];
                     if constexpr (!FULL) s[a][c] += kbias[c];
-                    if (!(EEND_SPK_STUDY & 16)) s[a][c] = wave_g_allreduce_add(s[a][c]);
+                    s[a][c] = wave_g_allreduce_add(s[a][c]);
                     mx = __builtin_fmaxf(mx, s[a][c]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) { if (!(EEND_SPK_STUDY & 16)) s[a][c] = __expf(s[a][c] - mx); den += s[a][c]; }
+                for (int c = 0; c < C; ++c) { s[a][c] = __expf(s[a][c] - mx); den += s[a][c]; }
                 const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
                 for (int c = 0; c < C; ++c) s[a][c] *= inv;
@@ -432,11 +399,8 @@ void spk_stream_kernel(const SpkStreamParams p) {
 #pragma unroll
                         for (int j1 = 0; j1 < NJ; ++j1) {
                             const f32x2 pw = f32x2{s[j1][j2 * R + d], s[j1][j2 * R + d]};
-                            if (EEND_SPK_STUDY & 32) { if (j1 == 0) { o[j1][0] += pw + v0; o[j1][1] += v1; } }
-                            else {
-                                o[j1][0] = pw * v0 + o[j1][0];
-                                o[j1][1] = pw * v1 + o[j1][1];
-                            }
+                            o[j1][0] = pw * v0 + o[j1][0];
+                            o[j1][1] = pw * v1 + o[j1][1];
                         }
                     });
                 });
@@ -446,12 +410,6 @@ void spk_stream_kernel(const SpkStreamParams p) {
                     of[j][ff >> 1][(ff & 1) * 4 + 2] = to_f16_sat(o[j][1][0]); of[j][ff >> 1][(ff & 1) * 4 + 3] = to_f16_sat(o[j][1][1]);
                 }
             });
-#else
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { of[j][0][e] = (_Float16)(qkv[0][j][e & 3] + qkv[4][j][e & 3]); of[j][1][e] = (_Float16)qkv[8][j][e & 3]; }
-#endif
             // the head's 64 features of 16 tokens = 16 full 128-byte lines per token fragment, through the staging tile (2 KB per
             // fragment: fragments 0 and 1 in one LDS round trip, fragment 2 in a second)
             auto stage_out = [&](auto J0, auto NF) __attribute__((always_inline)) {
@@ -473,7 +431,7 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 for (int jj = 0; jj < nf; ++jj)
 #pragma unroll
                     for (int half = 0; half < 2; ++half)
-                        if (!(EEND_SPK_STUDY & 4) && (FULL || slot_of(j0 + jj, half * 8 + rr) < CC))
+                        if ((FULL || slot_of(j0 + jj, half * 8 + rr) < CC))
                             *(f16x8*)(O + (size_t)row_tok(tile, j0 + jj, half * 8 + rr) * 256 + head * 64 + cc * 8) = v4[jj][half];
                 wave_lds_sync();
             };
@@ -484,9 +442,6 @@ void spk_stream_kernel(const SpkStreamParams p) {
         };
         for (int head = 0; head < 3; ++head) head_body(head, Fa{});
         head_body(3, T{});
-#if EEND_SPK_XLATE == 1
-        if (ntile < ntiles) sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); });
-#endif
 #ifdef EEND_SPK_TRACE
         if (tix < 4 && threadIdx.x == 0) {
 #pragma unroll
