@@ -148,11 +148,11 @@ int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, 
 int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const float* bo, const float* res,
                                const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
-                               float* out_f32, void* out_f16, void* out_lo_f16, int M, int F, void* stream) {
+                               float* out_f32, void* out_f16, void* out_lo_f16, const void* Wo_lo, int M, int F, void* stream) {
     if (!A || !Wo || !bo || !g1 || !be1) return EEND_EINVAL;
     FfnParams p;
     memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = lda; p.Wo = Wo; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
+    p.A = A; p.lda = lda; p.Wo = Wo; p.Wo_lo = Wo_lo; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
     p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2;
     p.out32 = out_f32; p.out16 = out_f16; p.out16lo = out_lo_f16; p.M = M; p.F = F;
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);

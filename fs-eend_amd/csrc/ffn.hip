@@ -482,7 +482,30 @@ void ffn_fused_kernel(const FfnParams p) {
                 FFN_STAMP(4);
                 __syncthreads();                             // (vmcnt(0): k-tiles 2/3 complete in every wave)
                 FFN_STAMP(5);
+                // Wo as a hi / lo f16 pair (LS-EEND decoder, round 5: the f16 rounding of the speaker-attention out-projection weight was
+                // the largest single contributor to the worst logit of the 12-slot golden): the lo part's k-tiles follow the hi
+                // part's through the same two LDS halves, each requested as soon as every wave is done with the half it overwrites --
+                // the second product costs its 32 MFMAs per wave and half a DMA latency, the A fragments stay in registers
+                const bool lo = p.Wo_lo != nullptr && Wo == p.Wo;
+                const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(lo ? p.Wo_lo : Wo), 0, KD * KD * 2, 0x00020000);
+                auto dma_wl_piece = [&](int piece) __attribute__((always_inline)) {
+                    const int kt = piece >> 5, row = (piece & 31) * 8 + drow;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsl, (lds_char*)(smem + piece * 1024), 16,
+                                                             (row * KD + kt * 64 + (dslot ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+                };
+                if (lo) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dma_wl_piece(wave * 8 + i);          // lo k-tiles 0, 1 (every wave is past the hi ones: barrier above)
+                }
                 static_for<4>([&](auto KS) __attribute__((always_inline)) { gemm_ks(std::integral_constant<int, decltype(KS)::value + 4>{}); });
+                if (lo) {
+                    __syncthreads();                         // lo k-tiles 0 / 1 complete in every wave; every wave past the hi k-tiles 2 / 3
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dma_wl_piece(64 + wave * 8 + i);
+                    static_for<4>([&](auto KS) __attribute__((always_inline)) { gemm_ks(KS); });
+                    __syncthreads();
+                    static_for<4>([&](auto KS) __attribute__((always_inline)) { gemm_ks(std::integral_constant<int, decltype(KS)::value + 4>{}); });
+                }
             } else {
                 __syncthreads();
                 static_for<8>([&](auto KS) __attribute__((always_inline)) { gemm_ks(KS); });

@@ -232,6 +232,7 @@ struct FfnParams {
     // optional fused producer (null A = off): X = LayerNorm1(A Wo^T + bo + res), which also becomes the residual
     const void* A;      // f16 [M][lda] (attention output)
     const void* Wo;     // f16 [256][256]
+    const void* Wo_lo;  // optional f16 [256][256]: f16(W - f16(W)), a second product on the same A fragments (plain PRE kernel only)
     const float* bo;    // [256]
     const float* g1;    // LayerNorm1 affine
     const float* be1;

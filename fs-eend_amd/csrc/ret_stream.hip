@@ -89,7 +89,7 @@ __global__ void ret_stream_pack_kernel(const float* __restrict__ W, _Float16* __
 
 // Perf-study build (-DEEND_RS_TRACE, tools/ret_stream_trace.py): s_memtime stamps of wave 0 of every workgroup, first 8 items of pass 2
 #ifdef EEND_RS_TRACE
-__device__ unsigned long long g_rs_trace[256 * 8 * 24];
+__device__ unsigned long long g_rs_trace[256 * 8 * 32];
 #define RS_STAMP(k) do { if (!KV_ONLY) ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RS_STAMP(k) do {} while (0)
@@ -198,11 +198,11 @@ void ret_stream_kernel(const RetStreamParams p) {
     const int tq0 = (KV_ONLY ? 0 : (upper ? 256 : 0)) + 32 * wave;
     const int to0 = (KV_ONLY ? 256 : 0) + 32 * wave;
 #ifdef EEND_RS_TRACE
-    unsigned long long ts[24];
+    unsigned long long ts[32];
     const int tix0 = (item - (int)blockIdx.x) / (int)gridDim.x;
     const int tix = tix0 < 4 ? tix0 : (tix0 >= 12 && tix0 < 16 ? tix0 - 8 : 8);      // items 0 .. 3 (upper) and 12 .. 15 (lower, in the big launch)
 #pragma unroll
-    for (int k = 0; k < 24; ++k) ts[k] = 0;
+    for (int k = 0; k < 32; ++k) ts[k] = 0;
 #endif
     RS_STAMP(0);
     // the wave's first two token fragments, requested BEFORE the barrier that ends the previous item: a wave that has finished its
@@ -376,8 +376,9 @@ void ret_stream_kernel(const RetStreamParams p) {
         RS_STAMP(5);
         run_item(Vs + 1 * WITEM, IC<4>{}, std::false_type{}, Bc, getql, no_side);
         fold(Bc);
-        // barrier only: every wave is done with Q0H, Q1H (their slots take the K items)
-        __builtin_amdgcn_s_barrier();
+        // every wave is done with Q0H, Q1H (their slots take the K items) -- and this wave's pieces of the G items (requested two items
+        // ago) have landed, so that G0 needs no barrier of its own (a barrier costs 10 - 15 units of wave skew in the s_memtime trace)
+        wait_barrier(0);
         RS_STAMP(6);
         relaunder();
         dma_item(I_K0, Vs + 0 * WITEM); dma_item(I_K1, Vs + 1 * WITEM);
@@ -385,8 +386,6 @@ void ret_stream_kernel(const RetStreamParams p) {
         run_item(Vs + 2 * WITEM, IC<2>{}, std::false_type{}, A, getq, no_side);
         RS_STAMP(7);
         run_item(Vs + 3 * WITEM, IC<2>{}, std::false_type{}, Bc, getq, [&](auto U) __attribute__((always_inline)) { epi_q(A, 0, U); });
-        // the G items have landed (K's 4 pieces are younger)
-        wait_barrier(4);
         RS_STAMP(8);
         seed(A, 3, 0, false);
         run_item(Ks + 2 * WITEM, IC<2>{}, std::false_type{}, A, getq, [&](auto U) __attribute__((always_inline)) { epi_q(Bc, 1, U); });
@@ -420,16 +419,22 @@ void ret_stream_kernel(const RetStreamParams p) {
         };
         // K0: this wave's pieces of K0, K1 have landed; every wave is done with the G weights (where K rows may land).  K1: none.
         wait_barrier(0);
+        RS_STAMP(24);
         seed(A, 1, 0, false);
         run_item(Vs + 0 * WITEM, IC<2>{}, std::false_type{}, A, getq, [&](auto U) __attribute__((always_inline)) { epi_g(Bc, 1, U); });
+        RS_STAMP(25);
         seed(Bc, 1, 1, false);
         run_item(Vs + 1 * WITEM, IC<2>{}, std::false_type{}, Bc, getq, [&](auto U) __attribute__((always_inline)) { epi_k(A, 0, tq0, U); });
+        RS_STAMP(26);
         // V0: every wave is done reading the K weights (lower items: the V^T rows land on them)
         __builtin_amdgcn_s_barrier();
+        RS_STAMP(27);
         seed_v(A, 0);
         run_item(Xs + 0 * WITEM, IC<2>{}, std::true_type{}, A, getq, [&](auto U) __attribute__((always_inline)) { epi_k(Bc, 1, tq0, U); });
+        RS_STAMP(28);
         seed_v(Bc, 1);
         run_item(Xs + 1 * WITEM, IC<2>{}, std::true_type{}, Bc, getq, [&](auto U) __attribute__((always_inline)) { epi_v(A, 0, tq0, U); });
+        RS_STAMP(29);
         relaunder();
         sfor<4>([&](auto U) __attribute__((always_inline)) { epi_v(Bc, 1, tq0, U); });
         RS_STAMP(11);
@@ -715,7 +720,7 @@ void ret_stream_kernel(const RetStreamParams p) {
     if (!KV_ONLY && tix < 8 && threadIdx.x == 0) {
         ts[20] = (unsigned long long)upper; ts[21] = (unsigned long long)c; ts[22] = (unsigned long long)seq;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) g_rs_trace[((size_t)blockIdx.x * 8 + tix) * 24 + k] = ts[k];
+        for (int k = 0; k < 32; ++k) g_rs_trace[((size_t)blockIdx.x * 8 + tix) * 32 + k] = ts[k];
     }
 #endif
     }

@@ -33,6 +33,8 @@ CONV_STREAM = __import__("os").environ.get("EEND_CONV_STREAM", "1") != "0"
 RET_STREAM = __import__("os").environ.get("EEND_RET_STREAM", "1") != "0"
 # ... with the f16 remainder of the decoder's f32 residual stream as the query path's second operand; 0: hi rows only
 RET_XLO = __import__("os").environ.get("EEND_RET_XLO", "1") != "0"
+# the speaker-attention out-projection weight of the decoder layers as a hi / lo f16 pair (two products in the layer-tail kernel); 0: hi only
+OUT2_SPLIT = __import__("os").environ.get("EEND_LS_OUT2_SPLIT", "1") != "0"
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -388,6 +390,7 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 out1_w=_f16(l.self_attn1.out_proj.weight), out1_b=_f32(l.self_attn1.out_proj.bias),
                 in2_w=_f16(l.self_attn2.in_proj_weight), in2_b=_f32(l.self_attn2.in_proj_bias),
                 out2_w=_f16(l.self_attn2.out_proj.weight), out2_b=_f32(l.self_attn2.out_proj.bias),
+                out2_wlo=_f16(l.self_attn2.out_proj.weight.detach().float() - l.self_attn2.out_proj.weight.detach().to(torch.float16).float()),
                 w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
                 g11=_f32(l.norm11.weight), be11=_f32(l.norm11.bias), eps11=l.norm11.eps,
                 g21=_f32(l.norm21.weight), be21=_f32(l.norm21.bias), eps21=l.norm21.eps,
@@ -545,7 +548,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             if FUSED_FFN and FUSED_ATTNOUT:
                 ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
                                       Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16,
-                                      out16lo=ws.a16lo if (xlo and j + 1 < len(P["dec.layers"])) else None)
+                                      out16lo=ws.a16lo if (xlo and j + 1 < len(P["dec.layers"])) else None,
+                                      wo_lo=Ld["out2_wlo"] if OUT2_SPLIT else None)
                 continue
             ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], ws.a32, ws.a16, Ld["eps21"])
             if FUSED_FFN:

@@ -636,20 +636,20 @@ def attnout_ffn_fused_res16(a16, wo, bo, res16, g1, be1, eps1, w1, b1, w2, b2, g
                                                   _stream()), "eend_attnout_ffn_fused_res16_f16")
 
 
-def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, eps2, out32, out16, out16lo=None):
+def attnout_ffn_fused(a16, wo, bo, res, g1, be1, eps1, w1, b1, w2, b2, g2, be2, eps2, out32, out16, out16lo=None, wo_lo=None):
     """x = LN1(a16 @ wo.T + bo + res); out = LN2(relu(x @ w1.T + b1) @ w2.T + b2 + x): the attention
     out-projection, both residual adds, both LayerNorms and the FFN of a post-LN layer in one launch."""
     L = _lib.load()
     _chk(a16, F16, "a16"); _chk(wo, F16, "wo"); _chk(w1, F16, "w1"); _chk(w2, F16, "w2")
     for n, t in (("bo", bo), ("res", res), ("g1", g1), ("be1", be1), ("b1", b1), ("b2", b2), ("g2", g2), ("be2", be2), ("out32", out32)):
         _chk(t, F32, n)
-    _chk(out16, F16, "out16"); _chk(out16lo, F16, "out16lo")
+    _chk(out16, F16, "out16"); _chk(out16lo, F16, "out16lo"); _chk(wo_lo, F16, "wo_lo")
     M, K = a16.shape
     Fh = w1.shape[0]
-    if K != 256 or wo.shape != (256, 256) or w1.shape[1] != 256 or w2.shape != (256, Fh):
+    if K != 256 or wo.shape != (256, 256) or w1.shape[1] != 256 or w2.shape != (256, Fh) or (wo_lo is not None and wo_lo.shape != (256, 256)):
         raise _lib.EendHipError("attnout_ffn_fused: expected d_model 256")
     _lib.check(L.eend_attnout_ffn_fused_f16(_p(a16), a16.stride(0), _p(wo), _p(bo), _p(res), _p(g1), _p(be1), eps1, _p(w1), _p(b1),
-                                            _p(w2), _p(b2), _p(g2), _p(be2), eps2, _p(out32), _p(out16), _p(out16lo), M, Fh, _stream()),
+                                            _p(w2), _p(b2), _p(g2), _p(be2), eps2, _p(out32), _p(out16), _p(out16lo), _p(wo_lo), M, Fh, _stream()),
                "eend_attnout_ffn_fused_f16")
 
 

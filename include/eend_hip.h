@@ -167,11 +167,13 @@ int eend_ffn_fused_f16(const void* X, int ldx, const void* W1, const float* b1, 
  * merge_tfm_encoder.py:371-376,397-399; LS merge_retnet_layer.py:248-253,309-311).  x never leaves the CU.
  * A f16 [M][lda] (attention output), Wo f16 [256][256], res f32 [M][256] (stream before the attention
  * sub-layer; may alias out_f32), out_f32 f32 [M][256], out_f16 f16 [M][256] (may alias A); out_lo_f16 (optional, f16 [M][256]):
- * f16(out - f16(out)), the remainder next to out_f16 (the next layer's retention reads both: eend_retention_stream_f16). */
+ * f16(out - f16(out)), the remainder next to out_f16 (the next layer's retention reads both: eend_retention_stream_f16).  Wo_lo (optional,
+ * f16 [256][256]): f16(Wo_f32 - f16(Wo_f32)) -- the out-projection then runs as two products on the same A fragments (the weight's f16
+ * rounding was the largest single term of the worst LS-EEND logit at 12 speaker slots; +3 % of the launch). */
 int eend_attnout_ffn_fused_f16(const void* A, int lda, const void* Wo, const float* bo, const float* res,
                                const float* g1, const float* be1, float eps1, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g2, const float* be2, float eps2,
-                               float* out_f32, void* out_f16, void* out_lo_f16, int M, int F, void* stream);
+                               float* out_f32, void* out_f16, void* out_lo_f16, const void* Wo_lo, int M, int F, void* stream);
 /* The two post-norm joins above with the residual taken from the f16 stream: in a post-norm stack (nn.TransformerEncoderLayer,
  * merge_tfm_encoder.py:356-376) the residual IS the previous LayerNorm's output, whose f16 copy the next MFMA reads anyway, so
  * the f32 stream's write + read (1 KB per row per sub-layer, the dominant traffic of the HBM-bound out-projection GEMM) can be

@@ -26,18 +26,18 @@ print(f"retention_stream nseq={nseq} Tp={Tp}: {e0.elapsed_time(e1) / 5 * 1e3:.1f
 L_ = _lib.load()
 if not hasattr(L_, "eend_debug_ret_stream_trace"):
     sys.exit(0)
-tr = torch.zeros(256 * 8 * 24, dtype=torch.int64, device=dev)
+tr = torch.zeros(256 * 8 * 32, dtype=torch.int64, device=dev)
 L_.eend_debug_ret_stream_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 assert L_.eend_debug_ret_stream_trace(tr.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
-t = tr.view(256, 8, 24).cpu().double()
+t = tr.view(256, 8, 32).cpu().double()
 NAMES = ["item top (rows requested)", "previous item's barrier", "xq fragments", "xlo fragments", "Q0H barrier", "Q1H barrier", "Q0L barrier", "Q1L barrier",
          "G0 barrier", "G1 barrier", "G done", "own K/V done", "other rows landed", "other fragments", "other K/V done", "K/V barrier", "block done",
-         "q operands staged", "tile loop done", "cross term done"]
-ORDER = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 18, 19, 16]
+         "q operands staged", "tile loop done", "cross term done", "", "", "", "", "K0 barrier", "K0 done", "K1 done", "V0 barrier", "V0 done", "V1 done"]
+ORDER = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 24, 25, 26, 27, 28, 29, 11, 12, 13, 14, 15, 17, 18, 19, 16]
 for up in (1, 0):
     sel = (t[:, :, 20] == up) & (t[:, :, 0] > 0)
-    tt = t[sel][:, :20] / 100.0
+    tt = t[sel][:, :30] / 100.0
     if tt.numel() == 0:
         continue
     print(f"{'upper' if up else 'lower'} items ({tt.shape[0]} samples): mean phase durations [cycles / 100]")
