@@ -291,6 +291,16 @@ int eend_attnout_spk_stream_f16(const void* A, int lda, const void* wstream, con
     return eend_launch_spk_stream(p, (hipStream_t)stream);
 }
 
+int eend_attnout_spk_stream_res32_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res_f32,
+                                      const float* g1, const float* be1, float eps1, float* x_f32, const float* b_in, void* O_f16,
+                                      int B, int C, int Tp, float scale, void* stream) {
+    SpkStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.wstream = wstream; p.bo = bo; p.res32 = res_f32; p.g1 = g1; p.be1 = be1; p.eps1 = eps1;
+    p.x32 = x_f32; p.bin = b_in; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.scale = scale;
+    return eend_launch_spk_stream(p, (hipStream_t)stream);
+}
+
 int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
                                const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
                                const void* Win2, const float* bin2,

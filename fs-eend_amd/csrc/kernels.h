@@ -286,6 +286,8 @@ struct SpkStreamParams {
     float eps1;
     const void* res16;    // residual f16 [B*C*Tp][256]
     void* x16;            // x1 f16 [B*C*Tp][256] (may be res16)
+    const float* res32;   // ... or the f32 form of both (round 5): residual f32 in, x1 f32 out (may be res32), no f16 x1
+    float* x32;
     const float* bin;     // [768] in-projection bias (q, k, v)
     void* O;              // attention output f16 [B*C*Tp][256] (may be A when lda == 256)
     int B, C, Tp;

@@ -92,7 +92,9 @@ __device__ __forceinline__ float row_rot(float x) {          // value of the lan
 // G frames per wave, R = 16/G slot positions per token fragment, C = 3R positions of which the first CC hold the model's slots.
 // CC < C: the phantom positions read the last slot's rows (any valid rows do), are masked as keys (a -1e30 score bias that is rotated
 // with the keys, so it always describes the lane it came from) and are never stored.
-template <int G, int CC>
+// R32 (round 5, LS-EEND's decoder): the residual stream is f32 -- res32 rows in, x1 rows out as f32 (x32; may be res32), no f16 copy of x1
+// (the layer tail behind reads the f32 stream; merge_retnet_layer.py:301-306 with the f32 residual of DESIGN 4).
+template <int G, int CC, bool R32>
 __global__ __launch_bounds__(256, 1)
 void spk_stream_kernel(const SpkStreamParams p) {
     constexpr int R = 16 / G, C = 3 * R;
@@ -157,12 +159,25 @@ void spk_stream_kernel(const SpkStreamParams p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) xf[s][j] = *(const f16x8*)(src + s * 32);
     };
-    f16x8 r8[NJ][8];
+    f16x8 r8[R32 ? 1 : NJ][8];
     auto load_res16 = [&](int tile, auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        const _Float16* src = (const _Float16*)p.res16 + (size_t)row_tok(tile, j, frow) * 256 + fo;
+        if constexpr (!R32) {
+            constexpr int j = decltype(J)::value;
+            const _Float16* src = (const _Float16*)p.res16 + (size_t)row_tok(tile, j, frow) * 256 + fo;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r8[j][e] = *(const f16x8*)(src + e * 8);
+            for (int e = 0; e < 8; ++e) r8[j][e] = *(const f16x8*)(src + e * 8);
+        }
+    };
+    // R32: two 64-register buffers; a fragment's buffer receives its x1 values in place (LayerNorm pass 2) and is the source of its
+    // f32 row stores, then takes the residual rows of the fragment after next
+    f32x4 t4[R32 ? 2 : 1][16];
+    auto load_res32 = [&](int tile, auto J, auto BUF) __attribute__((always_inline)) {
+        if constexpr (R32) {
+            constexpr int j = decltype(J)::value, b = decltype(BUF)::value;
+            const float* src = p.res32 + (size_t)row_tok(tile, j, frow) * 256 + fo;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t4[b][i] = *(const f32x4*)(src + i * 4);
+        }
     };
 
     __builtin_amdgcn_s_waitcnt(0x0070 | ((4 * (NSLOT - 2)) & 15) | (((4 * (NSLOT - 2)) >> 4) << 14));   // item 0 has landed; lgkmcnt(0)
@@ -249,9 +264,11 @@ void spk_stream_kernel(const SpkStreamParams p) {
         step(IC<0>{}, IC<3>{}, Fa{}, T{}, IC<24>{});
         step(IC<0>{}, IC<4>{}, Fa{}, T{}, IC<24>{});
         step(IC<0>{}, IC<5>{}, Fa{}, T{}, IC<24>{});
-        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<0>{});
+        load_res32(tile, IC<0>{}, IC<0>{});              // (R32: 16 loads into the registers of the input fragments 0 .. 5)
+        step(IC<0>{}, IC<6>{}, Fa{}, T{}, IC<(R32 ? 16 : 0)>{});
         load_res16(tile, IC<0>{});
-        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<8>{});
+        load_res32(tile, IC<1>{}, IC<1>{});
+        step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, IC<(R32 ? 32 : 8)>{});
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -260,15 +277,51 @@ void spk_stream_kernel(const SpkStreamParams p) {
         _Float16* x16 = (_Float16*)p.x16;
         sfor<NJ>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
+            constexpr int tb = R32 ? (j & 1) : 0;
+            auto resv = [&](int i, int q) __attribute__((always_inline)) { return (float)r8[R32 ? 0 : j][i >> 1][(i & 1) * 4 + q]; };
             // Two passes over the accumulators (AGPR reads are cheap) instead of a 64-value buffer: the buffer next to the residual
             // rows of this and the next fragment overflowed the register file, and a scratch reload waits for every VMEM
             // operation in flight (stores, weight DMA).  Statistics: sum and sum of squares in one pass (f32; |x| = O(10)).
+            if constexpr (R32) {
+                // f32 stream: the rows carry the decoder's state at full f32 precision, so the statistics are the two-pass form
+                // (mean, then centred squares -- no E[x^2] - mean^2 cancellation); the row values replace the residual buffer in place
+                f32x2 sm = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x4 v = acc[i][j] + t4[tb][i];
+                    t4[tb][i] = v;
+                    sm += f32x2{v[0], v[1]} + f32x2{v[2], v[3]};
+                }
+                const float mean = wave_g_allreduce_add(sm[0] + sm[1]) * (1.0f / 256);
+                f32x2 sq2 = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x4 d = t4[tb][i] - mean;
+                    t4[tb][i] = d;
+                    sq2 = f32x2{d[2], d[3]} * f32x2{d[2], d[3]} + (f32x2{d[0], d[1]} * f32x2{d[0], d[1]} + sq2);
+                }
+                const float rstd = 1.0f / __builtin_sqrtf(wave_g_allreduce_add(sq2[0] + sq2[1]) * (1.0f / 256) + p.eps1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x4 g4 = vec4(1, i), b4 = vec4(2, i);
+                    const f32x4 d = t4[tb][i] * rstd;
+                    f32x4 x;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        x[q] = __builtin_fmaf(d[q], g4[q], b4[q]);
+                        xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)x[q];
+                    }
+                    t4[tb][i] = x;
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             f32x2 sm = f32x2{0.f, 0.f}, sq2 = f32x2{0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const f32x4 a4 = acc[i][j];
-                const f32x2 x0 = f32x2{a4[0] + (float)r8[j][i >> 1][(i & 1) * 4 + 0], a4[1] + (float)r8[j][i >> 1][(i & 1) * 4 + 1]};
-                const f32x2 x1 = f32x2{a4[2] + (float)r8[j][i >> 1][(i & 1) * 4 + 2], a4[3] + (float)r8[j][i >> 1][(i & 1) * 4 + 3]};
+                const f32x2 x0 = f32x2{a4[0] + resv(i, 0), a4[1] + resv(i, 1)};
+                const f32x2 x1 = f32x2{a4[2] + resv(i, 2), a4[3] + resv(i, 3)};
                 sm += x0 + x1;
                 sq2 = x1 * x1 + (x0 * x0 + sq2);
             }
@@ -284,13 +337,36 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 const f32x4 gg = vec4(1, i) * rstd, bb = vec4(2, i) - vec4(1, i) * (rstd * mean);
                 const f32x4 a4 = acc[i][j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)__builtin_fmaf(a4[q] + (float)r8[j][i >> 1][(i & 1) * 4 + q], gg[q], bb[q]);
+                for (int q = 0; q < 4; ++q) xf[i >> 1][j][(i & 1) * 4 + q] = (_Float16)__builtin_fmaf(a4[q] + resv(i, q), gg[q], bb[q]);
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            }
+            if constexpr (R32) {
+                // x1 rows leave as f32 through the staging tile: 8 token rows x one 32-feature half of each 64-feature block per pass
+                float* x32 = p.x32;
+#pragma unroll
+                for (int fh = 0; fh < 2; ++fh)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if ((frow >> 3) == half) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) *(f32x4*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = t4[tb][fh * 8 + e];
+                        }
+                        wave_lds_sync();
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
+                            const f32x4 v4 = *(const f32x4*)(st + rr * 512 + ((cc ^ rr) << 4));
+                            if ((FULL || slot_of(j, half * 8 + rr) < CC))
+                                *(f32x4*)(x32 + (size_t)row_tok(tile, j, half * 8 + rr) * 256 + (cc >> 3) * 64 + fh * 32 + (cc & 7) * 4) = v4;
+                        }
+                        wave_lds_sync();
+                    }
+                if constexpr (j == 0 && NJ > 2) load_res32(tile, IC<2>{}, IC<0>{});
             }
             // x1 rows leave through the staging tile as whole 512-byte rows
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < (R32 ? 0 : 2); ++half) {
                 if ((frow >> 3) == half) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) *(f16x8*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = xf[e][j];
@@ -320,13 +396,16 @@ void spk_stream_kernel(const SpkStreamParams p) {
                 sfor<R>([&](auto D) __attribute__((always_inline)) { kbias[j2 * R + decltype(D)::value] = row_rot<decltype(D)::value * G>(own); });
             });
         }
-        auto head_body = [&](int head, auto LAST) __attribute__((always_inline)) {
-            step(IC<1>{}, IC<0>{}, T{}, T{}, IC<6>{});
-            step(IC<1>{}, IC<1>{}, Fa{}, T{}, IC<6>{});
-            step(IC<1>{}, IC<2>{}, Fa{}, T{}, IC<6>{});
-            step(IC<1>{}, IC<3>{}, Fa{}, T{}, IC<6>{});
-            step(IC<1>{}, IC<4>{}, Fa{}, T{}, IC<6>{});
-            step(IC<1>{}, IC<5>{}, Fa{}, Fa{}, IC<6>{});
+        // YNG: this wave's stores certainly younger than the pieces the head's six waits need -- the 6 output stores of the previous
+        // head, or (head 0) the x1 row stores: 8 per fragment, or 16 as f32 (capped by the 6-bit counter)
+        auto head_body = [&](int head, auto LAST, auto YNG) __attribute__((always_inline)) {
+            constexpr int yng = decltype(YNG)::value;
+            step(IC<1>{}, IC<0>{}, T{}, T{}, IC<yng>{});
+            step(IC<1>{}, IC<1>{}, Fa{}, T{}, IC<yng>{});
+            step(IC<1>{}, IC<2>{}, Fa{}, T{}, IC<yng>{});
+            step(IC<1>{}, IC<3>{}, Fa{}, T{}, IC<yng>{});
+            step(IC<1>{}, IC<4>{}, Fa{}, T{}, IC<yng>{});
+            step(IC<1>{}, IC<5>{}, Fa{}, Fa{}, IC<yng>{});
             SPK_STAMP_H(3, head);
             if (decltype(LAST)::value && ntile < ntiles)              // x1 is dead: the next tile's input rows travel under the last attention
                 sfor<NJ>([&](auto J) __attribute__((always_inline)) { load_in_frags(ntile, J); });
@@ -440,8 +519,9 @@ void spk_stream_kernel(const SpkStreamParams p) {
             SPK_STAMP_H(4, head);
             __builtin_amdgcn_sched_barrier(0);
         };
-        for (int head = 0; head < 3; ++head) head_body(head, Fa{});
-        head_body(3, T{});
+        head_body(0, Fa{}, IC<(R32 ? 63 - INFL : 8 * NJ)>{});
+        for (int head = 1; head < 3; ++head) head_body(head, Fa{}, IC<6>{});
+        head_body(3, T{}, IC<6>{});
 #ifdef EEND_SPK_TRACE
         if (tix < 4 && threadIdx.x == 0) {
 #pragma unroll
@@ -452,10 +532,10 @@ void spk_stream_kernel(const SpkStreamParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int G, int CC>
+template <int G, int CC, bool R32>
 int launch(const SpkStreamParams& p, hipStream_t stream) {
     static EendOncePerDevice attr_once;
-    auto kern = spk_stream_kernel<G, CC>;
+    auto kern = spk_stream_kernel<G, CC, R32>;
     if (!eend_set_dynamic_lds(attr_once, (const void*)kern, SMEM)) return EEND_ELAUNCH;
     const int ncu = eend_cu_count();
     const int ntiles = p.B * (p.Tp / (4 * G));
@@ -489,11 +569,12 @@ int eend_spk_stream_supported(int C, int Tp) {
 }
 
 int eend_launch_spk_stream(const SpkStreamParams& p, hipStream_t stream) {
-    if (!p.A || !p.wstream || !p.bo || !p.g1 || !p.be1 || !p.res16 || !p.x16 || !p.bin || !p.O || p.B <= 0 || (p.lda & 7) ||
-        !eend_spk_stream_supported(p.C, p.Tp))
+    const bool r32 = p.res32 != nullptr;
+    if (!p.A || !p.wstream || !p.bo || !p.g1 || !p.be1 || !p.bin || !p.O || p.B <= 0 || (p.lda & 7) || !eend_spk_stream_supported(p.C, p.Tp) ||
+        (r32 ? (!p.x32 || p.res16 || p.x16 || (((size_t)p.res32 | (size_t)p.x32) & 15)) : (!p.res16 || !p.x16 || p.x32)))
         return EEND_EINVAL;
     switch (p.C) {
-#define SPK_CASE(n) case n: return launch<frames_per_wave(n), n>(p, stream);
+#define SPK_CASE(n) case n: return r32 ? launch<frames_per_wave(n), n, true>(p, stream) : launch<frames_per_wave(n), n, false>(p, stream);
         SPK_CASE(1) SPK_CASE(2) SPK_CASE(3) SPK_CASE(4) SPK_CASE(5) SPK_CASE(6) SPK_CASE(7) SPK_CASE(8) SPK_CASE(9) SPK_CASE(10)
         SPK_CASE(11) SPK_CASE(12)
 #undef SPK_CASE

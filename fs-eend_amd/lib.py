@@ -43,6 +43,7 @@ PROTOTYPES = {
     "eend_spk_stream_ok": [_i, _i],
     "eend_spk_stream_pack_f16": [_vp, _vp, _vp, _vp],
     "eend_attnout_spk_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "eend_attnout_spk_stream_res32_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "eend_ffn_stream_max_rows": [_i],
     "eend_attnout_ffn_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_inproj_attn_causal_f16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -35,6 +35,9 @@ RET_STREAM = __import__("os").environ.get("EEND_RET_STREAM", "1") != "0"
 RET_XLO = __import__("os").environ.get("EEND_RET_XLO", "1") != "0"
 # the speaker-attention out-projection weight of the decoder layers as a hi / lo f16 pair (two products in the layer-tail kernel); 0: hi only
 OUT2_SPLIT = __import__("os").environ.get("EEND_LS_OUT2_SPLIT", "1") != "0"
+# the first half of a decoder layer behind the retention (out-projection + residual + norm11 + speaker-axis attention) as one launch on the
+# f32 residual stream (spk_stream.hip, R32); 0: eend_linear_res_ln_f16 + eend_spk_qkv_attn_f16 (A/B)
+SPK_STREAM_LS = __import__("os").environ.get("EEND_SPK_STREAM_LS", "1") != "0"
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -405,6 +408,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         if RET_STREAM:
             for Ld in dl:
                 Ld["wrs"] = ops.retention_stream_pack(Ld["wqkvg32"])
+        if SPK_STREAM_LS and FUSED_SPK:
+            for Ld in dl:
+                Ld["ws1"] = ops.spk_stream_pack(Ld["out1_w"], Ld["in2_w"])
         P["dec.layers"] = dl
         self._prep, self._prep_key, self._pc = P, key, {}
         return P
@@ -535,12 +541,17 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                                       Ld["in2_w"], Ld["in2_b"], Ld["out2_w"], Ld["out2_b"], Ld["g21"], Ld["be21"], Ld["eps21"],
                                       Ld["w1"], Ld["b1"], Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], B, C, Tp)
                 continue
-            ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
-            if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
-                ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
+            if "ws1" in Ld and H == 4 and ops.spk_stream_ok(C, Tp):
+                # out-projection + residual + norm11 + the speaker-axis attention in one launch, in place on the f32 stream (q, k, v in registers)
+                ops.attnout_spk_stream_res32(o16, Ld["ws1"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], Ld["eps11"], ws.a32, Ld["in2_b"],
+                                             o16, B, C, Tp)
             else:
-                ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
-                ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
+                ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
+                if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
+                    ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
+                else:
+                    ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
+                    ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
             if FUSED_FFN and FUSED_ATTNOUT and "ws" in Ld:
                 ops.attnout_ffn_stream(o16, Ld["ws"], Ld["out2_b"], ws.a32, None, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["b1"], Ld["b2"],
                                        Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)

@@ -360,6 +360,21 @@ def attnout_spk_stream(a16, wstream, bo, res16, g1, be1, eps1, x16, b_in, out16,
                                              _p(b_in), _p(out16), B, C, Tp, 0.125, _stream()), "eend_attnout_spk_stream_f16")
 
 
+def attnout_spk_stream_res32(a16, wstream, bo, res32, g1, be1, eps1, x32, b_in, out16, B, C, Tp):
+    """attnout_spk_stream on an f32 residual stream: x32 = LN11(a16 @ Wo1.T + bo + res32) (f32 rows; x32 may be res32), out16 as above."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wstream, F16, "wstream"); _chk(res32, F32, "res32"); _chk(x32, F32, "x32"); _chk(out16, F16, "out16")
+    for n, t in (("bo", bo), ("g1", g1), ("be1", be1), ("b_in", b_in)):
+        _chk(t, F32, n)
+    M = B * C * Tp
+    if a16.shape != (M, 256) or res32.shape != (M, 256) or x32.shape != (M, 256) or out16.shape != (M, 256) or b_in.numel() != 768:
+        raise _lib.EendHipError("attnout_spk_stream_res32: shape mismatch")
+    if wstream.numel() != L.eend_spk_stream_elems():
+        raise _lib.EendHipError("attnout_spk_stream_res32: weight stream has the wrong size")
+    _lib.check(L.eend_attnout_spk_stream_res32_f16(_p(a16), a16.stride(0), _p(wstream), _p(bo), _p(res32), _p(g1), _p(be1), eps1, _p(x32),
+                                                   _p(b_in), _p(out16), B, C, Tp, 0.125, _stream()), "eend_attnout_spk_stream_res32_f16")
+
+
 def spk_attn(qkv16, o16, B, C, Tp, H):
     L = _lib.load()
     _chk(qkv16, F16, "qkv16"); _chk(o16, F16, "o16")

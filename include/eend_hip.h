@@ -225,6 +225,12 @@ int eend_spk_stream_pack_f16(const void* Wo, const void* W_in, void* stream_out,
 int eend_attnout_spk_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const void* res_f16,
                                 const float* g1, const float* be1, float eps1, void* x_f16, const float* b_in, void* O_f16,
                                 int B, int C, int Tp, float scale, void* stream);
+/* ... with an f32 residual stream (round 5; LS-EEND's decoder, merge_retnet_layer.py:301-306 behind the retention's out-projection: replaces
+ * eend_linear_res_ln_f16 + eend_spk_qkv_attn_f16 there): res_f32 rows in, x1 rows out as f32 (x_f32 may be res_f32), no f16 copy of x1.
+ * 16-byte aligned f32 buffers; same shapes and weight stream as above. */
+int eend_attnout_spk_stream_res32_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res_f32,
+                                      const float* g1, const float* be1, float eps1, float* x_f32, const float* b_in, void* O_f16,
+                                      int B, int C, int Tp, float scale, void* stream);
 
 /* The whole row-local tail of a fusion (attractor decoder) layer in ONE launch, after the time-axis
  * attention / retention core (FS merge_tfm_encoder.py:364-376: out_proj of self_attn1 + norm11, _sa_block2 +

@@ -117,6 +117,50 @@ def test_attnout_ffn_fused(hip_lib, dev, M, Fh):
     assert torch.equal(res2, o32) and torch.equal(a2, o16)
 
 
+@pytest.mark.parametrize("M,Fh", [(128, 2048), (1500, 2048), (77, 1024)])
+def test_attnout_ffn_fused_split_weight_and_remainder(hip_lib, dev, M, Fh):
+    """Round 5 (LS-EEND decoder): wo_lo = the f16 remainder of the f32 out-projection weight (second MFMA product in the
+    same launch) brings x = LN1(a Wo^T + ...) to the f32-weight result; out16lo = the f16 remainder of the f32 output rows, so
+    out16 + out16lo carries the row to ~2^-21 for the next layer's query path."""
+    from fs_eend_amd import ops
+    a = rnd((M, 256), dev, 41, F16)
+    wo32 = rnd((256, 256), dev, 42, F32, 0.06)
+    wo, bo = wo32.half(), rnd((256,), dev, 43) * 0.2
+    wlo = (wo32 - wo.float()).half()
+    w1, b1 = rnd((Fh, 256), dev, 44, F16, 0.08), rnd((Fh,), dev, 45) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 46, F16, 0.04), rnd((256,), dev, 47) * 0.3
+    res = rnd((M, 256), dev, 48)
+    g1, be1 = rnd((256,), dev, 49) * 0.2 + 1, rnd((256,), dev, 50) * 0.1
+    g2, be2 = rnd((256,), dev, 51) * 0.2 + 1, rnd((256,), dev, 52) * 0.1
+    # the FFN half is switched off (zero W2 / b2, unit norm2 skipped by comparing through it) to expose x: out = LN2(x)
+    z2, zb2 = torch.zeros_like(w2), torch.zeros_like(b2)
+    one, zero = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    outs = {}
+    for tag, lo in (("hi", None), ("split", wlo)):
+        o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev)
+        o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+        l16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+        ops.attnout_ffn_fused(a, wo, bo, res, g1, be1, 1e-5, w1, b1, z2, zb2, one, zero, 1e-5, o32, o16, out16lo=l16, wo_lo=lo)
+        assert torch.isfinite(o32).all() and torch.isfinite(o16).all() and torch.isfinite(l16).all()
+        # remainder rows: out16 + out16lo == out32 to f16-of-remainder precision
+        assert ((o16.float() + l16.float()) - o32).abs().max().item() < 2e-6 * max(1.0, o32.abs().max().item())
+        outs[tag] = o32
+    x64 = torch.nn.functional.layer_norm(a.double() @ wo32.double().t() + bo.double() + res.double(), (256,), g1.double(), be1.double(), 1e-5)
+    want = torch.nn.functional.layer_norm(x64, (256,), None, None, 1e-5).float()
+    e_hi = (outs["hi"] - want).abs().max().item()
+    e_split = (outs["split"] - want).abs().max().item()
+    assert e_split < 2e-5, e_split                       # f32 accumulation noise only
+    assert e_hi > 4 * e_split, (e_hi, e_split)           # the f16 weight rounding was the error of the single product
+    # full layer with the split weight against float64 on the f32 weight (h rounds to f16 as an MFMA operand: same bar as above)
+    o32 = torch.empty((M, 256), dtype=F32, device=dev)
+    o16 = torch.empty((M, 256), dtype=F16, device=dev)
+    ops.attnout_ffn_fused(a, wo, bo, res, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, o32, o16, wo_lo=wlo)
+    x = x64.float()
+    h = (x.to(F16).float() @ w1.float().t() + b1).relu().to(F16).float()
+    full = torch.nn.functional.layer_norm(h @ w2.float().t() + b2 + x, (256,), g2, be2, 1e-5)
+    assert (o32 - full).abs().max().item() < 3e-3
+
+
 @pytest.mark.parametrize("B,C,Tp,Fh", [(1, 6, 64, 2048), (2, 4, 128, 2048), (1, 10, 64, 1024), (1, 12, 64, 2048), (3, 3, 64, 2048),
                                         (1, 1, 64, 2048), (8, 6, 512, 2048)])
 def test_fusion_layer_tail(hip_lib, dev, B, C, Tp, Fh):

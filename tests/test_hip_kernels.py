@@ -157,6 +157,26 @@ def test_convert_fanout(hip_lib, dev, B, Tp, C):
     close(o16.view(B, C, Tp, 256), y, 3e-3, 2e-3, "convert fan-out f16")
 
 
+@pytest.mark.parametrize("B,Tp,C", [(2, 64, 4), (1, 128, 12), (3, 64, 1)])
+def test_convert_fanout_f32_with_remainder(hip_lib, dev, B, Tp, C):
+    """f32-operand form (exact-f32 MFMA) with the f16 remainder rows of round 5: out16 + out16lo == out32 to ~2^-22."""
+    from fs_eend_amd import ops
+    e, w1 = rnd((B * Tp, 256), dev, 36), rnd((256, 256), dev, 37, F32, 0.1)
+    pc = rnd((C, 256), dev, 38)
+    o32 = torch.full((B * C * Tp, 256), float("nan"), dtype=F32, device=dev)
+    o16 = torch.full((B * C * Tp, 256), float("nan"), dtype=F16, device=dev)
+    l16 = torch.full((B * C * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.convert_fanout_f32(e, w1, pc, o32, o16, B, Tp, C, out16lo=l16)
+    y = ((e.double() @ w1.double().t()).view(B, 1, Tp, 256) + pc.double().view(1, C, 1, 256)).float()
+    close(o32.view(B, C, Tp, 256), y, 2e-5, 2e-5, "convert fan-out f32 operands")
+    assert torch.equal(o16, o32.half())
+    assert torch.isfinite(l16).all()
+    assert ((o16.float() + l16.float()) - o32).abs().max().item() < 2e-6 * max(1.0, o32.abs().max().item())
+    o32b, o16b = torch.empty_like(o32), torch.empty_like(o16)
+    ops.convert_fanout_f32(e, w1, pc, o32b, o16b, B, Tp, C)                       # without the remainder: same main outputs
+    assert torch.equal(o32b, o32) and torch.equal(o16b, o16)
+
+
 def attn_ref(q, k, v, delay, kv_len):
     """q,k,v (nseq,H,Tp,64) fp32 -> (nseq,Tp,H*64)."""
     Tp = q.shape[2]

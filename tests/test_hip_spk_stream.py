@@ -77,3 +77,43 @@ def test_attnout_spk_stream_unsupported_shapes():
     ws = ops.spk_stream_pack(wo, win)
     with pytest.raises(_lib.EendHipError):
         ops.attnout_spk_stream(a, ws, bo, res, g1, be1, 1e-5, torch.empty_like(res), bin_, torch.empty_like(a), B, C, Tp)
+
+
+# ---- the f32-residual form (round 5; LS-EEND's decoder: merge_retnet_layer.py:301-306 on the f32 stream of DESIGN 4)
+@pytest.mark.parametrize("B,C,Tp", [(2, 6, 64), (3, 10, 512), (2, 12, 64), (1, 3, 128), (3, 4, 64), (2, 7, 64), (1, 9, 128), (2, 1, 64),
+                                    (16, 10, 2048)])
+def test_attnout_spk_stream_res32_vs_torch(B, C, Tp):
+    a, res16, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 31 + C)
+    g = torch.Generator(device="cpu").manual_seed(77 + C)
+    res = torch.randn(B * C * Tp, 256, generator=g).cuda()                    # a genuinely f32 residual
+    ws = ops.spk_stream_pack(wo, win)
+    x32 = torch.full_like(res, float("nan")); o16 = torch.full_like(a, float("nan"))
+    ops.attnout_spk_stream_res32(a, ws, bo, res, g1, be1, 1e-5, x32, bin_, o16, B, C, Tp)
+    torch.cuda.synchronize()
+    xr, orf = _torch_ref(a, res, wo, win, bo, g1, be1, bin_, B, C, Tp)
+    assert torch.isfinite(o16).all() and torch.isfinite(x32).all()
+    assert (x32 - xr).abs().max().item() < 2e-4                               # f32 rows: accumulation order only
+    assert (o16.float() - orf).abs().max().item() < 2e-2
+    # the two launches it replaces in ls_model._decode_span
+    x2 = torch.empty_like(res); x2h = torch.empty_like(a); o2 = torch.empty_like(a)
+    ops.linear_res_ln(a, wo, bo, res, g1, be1, x2, x2h, 1e-5)
+    ops.spk_qkv_attn(x2h, win, bin_, o2, B, C, Tp, 4)
+    torch.cuda.synchronize()
+    assert (x32 - x2).abs().max().item() < 2e-4
+    assert (o16.float() - o2.float()).abs().max().item() < 2e-2
+    # in place, as the model calls it: x over res, O over A
+    a2, r2 = a.clone(), res.clone()
+    ops.attnout_spk_stream_res32(a2, ws, bo, r2, g1, be1, 1e-5, r2, bin_, a2, B, C, Tp)
+    torch.cuda.synchronize()
+    assert torch.equal(r2, x32) and torch.equal(a2, o16)
+
+
+def test_attnout_spk_stream_res32_rejects_mixed_forms():
+    B, C, Tp = 1, 6, 64
+    a, res16, wo, win, bo, g1, be1, bin_ = _inputs(B, C, Tp, 3)
+    ws = ops.spk_stream_pack(wo, win)
+    with pytest.raises(_lib.EendHipError):                                    # unsupported padded length
+        ops.attnout_spk_stream_res32(a[:6 * 40], ws, bo, res16[:6 * 40].float(), g1, be1, 1e-5, torch.empty(6 * 40, 256, device="cuda"), bin_,
+                                     torch.empty_like(a[:6 * 40]), 1, 6, 40)
+    with pytest.raises(_lib.EendHipError):                                    # dtype check: an f16 residual is the other entry's
+        ops.attnout_spk_stream_res32(a, ws, bo, res16, g1, be1, 1e-5, res16, bin_, torch.empty_like(a), B, C, Tp)
