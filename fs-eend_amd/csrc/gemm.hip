@@ -633,13 +633,9 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 0>(p, stream);
 }
 
-// K >= 1024 with whole-row epilogues (training: FFN2 forward, dX of FFN1): the 128-row tile instantiations -- OFF: measured slower than
-// the 64-row tiles (same box, round 5: [196608, 256, 2048] forward 0.539 vs 0.464 ms, dX 0.428 vs 0.361 ms; 444 registers = one wave per
-// SIMD, no second workgroup to hide the k-tile barrier).  EEND_GEMM_BM128=1 selects them for A/B.
-bool bm128(const GemmParams& p) {
-    static const bool on = getenv("EEND_GEMM_BM128") && atoi(getenv("EEND_GEMM_BM128")) == 1;
-    return on && p.K >= 1024 && p.M >= 32768;
-}
+// (128-row tile instantiations for the K >= 1024 whole-row epilogues of the training step were measured slower than the 64-row tiles --
+// same box, round 5: [196608, 256, 2048] forward 0.539 vs 0.464 ms, dX 0.428 vs 0.361 ms; 444 registers = one wave per SIMD, no second
+// workgroup to hide the k-tile barrier -- and removed: profiles/OPTIMISATION_LOG.md, profiles/r05_c_train_bm{0,1}.json)
 
 }  // namespace
 
@@ -654,7 +650,6 @@ int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
                 return launch<B, 128, 128, 2, 2, true, ALOAD_PLAIN, EPI_MASK_BF16>(p, stream);
             case EPI_RES_SCALE:
                 if (p.N != 256) return EEND_EINVAL;
-                if (bm128(p)) return launch<B, 128, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
                 return launch<B, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
             case EPI_F32_ROWMASK:
                 if (p.N != 256 || !p.ilens || !p.mask_lens || !p.out32) return EEND_EINVAL;
@@ -676,7 +671,6 @@ int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
             return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN>(p, stream);
         case EPI_RES_LN_TRAIN:
             if (p.N != 256) return EEND_EINVAL;
-            if (bm128(p)) return launch<H, 128, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN_TRAIN>(p, stream);
             return launch<H, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LN_TRAIN>(p, stream);
         case EPI_RES_SCALE_LN16_TRAIN:
             if (p.N != 256 || p.ldo != 256) return EEND_EINVAL;
