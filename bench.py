@@ -248,7 +248,7 @@ def cpu_baseline(T, C, batch=4, budget_s=25.0):
 
 def batch_sweep(dev, model, T, C, sizes=(1, 512)):
     """the same model.test at B in {1, 64, 512} utterances per GPU (64 is the headline line): frames/s and
-    ms/step under hipGraph replay, 5 timed steps each.  B = 1 is the latency end (4 + 2*C sequence-heads cannot fill 256
+    ms/step under hipGraph replay, median of 7 timed replays each.  B = 1 is the latency end (4 + 2*C sequence-heads cannot fill 256
     CUs), B = 512 the throughput end (8x the workgroups of the headline batch)."""
     out = {}
     for Bs in sizes:
@@ -269,12 +269,12 @@ def batch_sweep(dev, model, T, C, sizes=(1, 512)):
             for _ in range(2):
                 gr.replay()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 5
-            for _ in range(n):
-                gr.replay()
+            n = 7                                               # median of per-replay event times (see length_sweep)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in evs:
+                a.record(); gr.replay(); b.record()
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / n
+            dt = sorted(a.elapsed_time(b) for a, b in evs)[n // 2] * 1e-3
             out[str(Bs)] = dict(frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3, peak_hbm_bytes=int(torch.cuda.max_memory_allocated(dev)))
             del gr, keep, src
             model._ws.clear() if hasattr(model, "_ws") else None
@@ -306,20 +306,26 @@ def length_sweep(dev, model, C, lengths=(300, 500, 1000, 2000), frames_per_step=
             torch.cuda.current_stream().wait_stream(st)
             with torch.cuda.graph(gr):
                 keep = model.test(src, il, C)
-            for _ in range(2):
+            for _ in range(3):
                 gr.replay()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 10
-            for _ in range(n):
-                gr.replay()
+            # median of per-replay event times: a one-off stall inside the window (seen in round 5 right after the previous capture's
+            # pool was released: 60 ms once, which a mean over 10 replays reported as 8 ms per step for the headline shape) is not the rate
+            n = 15
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in evs:
+                a.record(); gr.replay(); b.record()
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / n
-            out[str(T)] = dict(batch=Bs, padded_frames=Tp, frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3,
+            ts = sorted(a.elapsed_time(b) for a, b in evs)
+            dt = ts[n // 2] * 1e-3
+            out[str(T)] = dict(batch=Bs, padded_frames=Tp, frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3, ms_per_step_max=ts[-1],
                                attention_kernel="attn_stream.hip (packed weights)" if Tp == 512 else ("attn_fused.hip" if Tp <= 512 else "proj.hip + attn.hip (tiled)"))
             del gr, keep, src
         except Exception as e:                                   # noqa: BLE001
             out[str(T)] = dict(error=str(e)[:200])
+        # every length starts from an empty allocator, like every size of batch_sweep
+        model._ws.clear() if hasattr(model, "_ws") else None
+        torch.cuda.empty_cache()
     return out
 
 
