@@ -542,11 +542,7 @@ int launch(const FfnStreamParams& p, hipStream_t stream) {
     const long t3 = (p.M + 191) / 192, t2 = (p.M + 127) / 128;
     const long c3 = ((t3 + ncu - 1) / ncu) * (3 * 10 + 9), c2 = ((t2 + ncu - 1) / ncu) * (2 * 10 + 9);     // per-tile cost model: rows + fixed part
     const char* e = getenv("EEND_FS_NJ");
-    int nj = e ? atoi(e) : (c2 < c3 ? 2 : 3);
-#ifdef EEND_FS_NJ4
-    if constexpr (MODE == 1 && RES16) { if (nj == 4 && (p.M + 255) / 256 >= 2 * ncu) return launch_nj<MODE, ACT, EPI, RES16, 4>(p, ncu, stream); }
-    if (nj == 4) nj = c2 < c3 ? 2 : 3;
-#endif
+    const int nj = e ? atoi(e) : (c2 < c3 ? 2 : 3);
     return nj == 2 ? launch_nj<MODE, ACT, EPI, RES16, 2>(p, ncu, stream) : launch_nj<MODE, ACT, EPI, RES16, 3>(p, ncu, stream);
 }
 

@@ -187,3 +187,42 @@ def test_stream_entries_split_large_row_counts(hip_lib, dev, monkeypatch):
         outs.append((o32, o16, p16, q32, q16))
     for x, y in zip(*outs):
         assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+@pytest.mark.parametrize("M,with32", [(300, False), (1000, True), (70000, False)])
+def test_attnout_ffn_stream_tile_sizes_agree(hip_lib, dev, M, with32, monkeypatch):
+    """128- and 192-row tiles (NJ = 2 / 3) are the same arithmetic per row -- bit-identical outputs whichever the launcher's cost model
+    (or EEND_FS_NJ) picks, including ragged last tiles and in place.  (Round 5 tried 256-row tiles, NJ = 4: this test caught a variant that
+    was 4 % faster because it skipped one activation part; done right it was no faster than NJ = 3 and was removed -- OPTIMISATION_LOG.)"""
+    from fs_eend_amd import ops
+    Fh = 2048
+    a = rnd((M, 256), dev, 61, F16)
+    wo, bo = rnd((256, 256), dev, 62, F16, 0.06), rnd((256,), dev, 63) * 0.2
+    w1, b1 = rnd((Fh, 256), dev, 64, F16, 0.08), rnd((Fh,), dev, 65) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 66, F16, 0.04), rnd((256,), dev, 67) * 0.3
+    r16 = rnd((M, 256), dev, 68, F16)
+    g1, be1 = rnd((256,), dev, 69) * 0.2 + 1, rnd((256,), dev, 70) * 0.1
+    g2, be2 = rnd((256,), dev, 71) * 0.2 + 1, rnd((256,), dev, 72) * 0.1
+    ws = ops.ffn_stream_pack(wo, w1, w2)
+    outs = {}
+    for nj in ("2", "3"):
+        monkeypatch.setenv("EEND_FS_NJ", nj)
+        o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev) if with32 else None
+        o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
+        ops.attnout_ffn_stream(a, ws, bo, None, r16, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, o32, o16)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o16).all()
+        outs[nj] = (o16, o32)
+    assert torch.equal(outs["2"][0], outs["3"][0])
+    if with32:
+        assert torch.equal(outs["2"][1], outs["3"][1])
+    # in place (out16 over the residual stream, as fs_model calls it)
+    monkeypatch.setenv("EEND_FS_NJ", "2")
+    a2, r2 = a.clone(), r16.clone()
+    ops.attnout_ffn_stream(a2, ws, bo, None, r2, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, None, r2)
+    torch.cuda.synchronize()
+    assert torch.equal(r2, outs["2"][0])
+    x = torch.nn.functional.layer_norm(a.float() @ wo.float().t() + bo + r16.float(), (256,), g1, be1, 1e-5)
+    h = (x.to(F16).float() @ w1.float().t() + b1).relu().to(F16).float()
+    want = torch.nn.functional.layer_norm(h @ w2.float().t() + b2 + x, (256,), g2, be2, 1e-5)
+    assert (outs["3"][0].float() - want).abs().max().item() < 6e-3
