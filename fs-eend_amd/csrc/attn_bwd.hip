@@ -432,12 +432,8 @@ int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
         return EEND_EINVAL;
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)attn_bwd_dkv_kernel<false>, 2 * DKV_STAGE)) return EEND_ELAUNCH;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((p.Tp + DKV_NW * 32 - 1) / (DKV_NW * 32), p.H, p.nseq), dim3(DKV_NW * 64), 2 * DKV_STAGE, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
@@ -452,12 +448,8 @@ int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream) {
     // full-slab grids: the blocks beyond the nc * L valid frames only write the zero rows of dQKV
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)attn_bwd_dkv_kernel<true>, 2 * DKV_STAGE)) return EEND_ELAUNCH;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((p.Tp + DKV_NW * 32 - 1) / (DKV_NW * 32), p.H, p.nseq), dim3(DKV_NW * 64), 2 * DKV_STAGE, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

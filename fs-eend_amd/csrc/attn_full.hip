@@ -335,15 +335,14 @@ void attn_causal_full_kernel(const AttnParams p) {
 int eend_launch_attn_causal_full(const AttnParams& p, hipStream_t stream) {
     if (p.Tp <= 0 || p.Tp > TMAX || (p.Tp % 64) != 0 || (p.ldo & 7)) return EEND_EINVAL;
     const int smem = 2 * (p.Tp / KB) * TILE + NW * OSTG;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static EendOncePerDevice attr_once[4];
+    {
         const int cap = 2 * (TMAX / KB) * TILE + NW * OSTG;
-        if (hipFuncSetAttribute((const void*)attn_causal_full_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attn_causal_full_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attn_causal_full_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attn_causal_full_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
+        if (!eend_set_dynamic_lds(attr_once[0], (const void*)attn_causal_full_kernel<false, false>, cap) ||
+            !eend_set_dynamic_lds(attr_once[1], (const void*)attn_causal_full_kernel<true, false>, cap) ||
+            !eend_set_dynamic_lds(attr_once[2], (const void*)attn_causal_full_kernel<false, true>, cap) ||
+            !eend_set_dynamic_lds(attr_once[3], (const void*)attn_causal_full_kernel<true, true>, cap))
             return EEND_ELAUNCH;
-        attr_done = true;
     }
     const float dev1 = p.scale_log2 - 1.0f;
     const bool lazy = dev1 < 1e-6f && dev1 > -1e-6f;   // scores arrive in the log2 domain (scale folded into the q projection)

@@ -393,21 +393,11 @@ void inproj_attn_kernel(const InprojAttnParams p) {
 int eend_launch_inproj_attn(const InprojAttnParams& p, hipStream_t stream) {
     if (p.Tp <= 0 || p.Tp > 512 || (p.Tp % 64) != 0 || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0) return EEND_EINVAL;
     const int smem = 2 * (p.Tp / KB) * TILE + NW * OSTG;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)inproj_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * TILE + NW * OSTG) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-        n_cu &= ~31;                                 // multiple of 32: a persistent workgroup keeps its head (and its XCD)
-        if (n_cu <= 0) n_cu = 32;
-        if (const char* e = getenv("EEND_AF_PERSIST")) { if (atoi(e) == 0) n_cu = 1 << 30; }     // A/B: one workgroup per item
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_kernel, 2 * 8 * TILE + NW * OSTG)) return EEND_ELAUNCH;
+    int n_cu = eend_cu_count() & ~31;                // multiple of 32: a persistent workgroup keeps its head (and its XCD)
+    if (n_cu <= 0) n_cu = 32;
+    if (const char* e = getenv("EEND_AF_PERSIST")) { if (atoi(e) == 0) n_cu = 1 << 30; }     // A/B: one workgroup per item
     const int nitems = p.nseq * 4;
     hipLaunchKernelGGL(inproj_attn_kernel, dim3(nitems < n_cu ? nitems : n_cu), dim3(512), smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

@@ -85,13 +85,9 @@ void convert_fanout_f32_kernel(const float* __restrict__ emb, const float* __res
 int eend_launch_convert_fanout_f32(const float* emb, const float* W, int ldw, const float* pc, float* out32, void* out16, void* out16lo,
                                    int B, int Tp, int C, hipStream_t stream) {
     if (!emb || !W || !pc || !out16 || B <= 0 || Tp <= 0 || C <= 0 || ldw < 256) return EEND_EINVAL;
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     constexpr int smem_bytes = 64 * 260 * 4;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)convert_fanout_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    if (!eend_set_dynamic_lds(attr_once, (const void*)convert_fanout_f32_kernel, smem_bytes)) return EEND_ELAUNCH;
     const long M = (long)B * Tp;
     hipLaunchKernelGGL(convert_fanout_f32_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), smem_bytes, stream, emb, W, ldw, pc, out32,
                        (_Float16*)out16, (_Float16*)out16lo, B, Tp, C);

@@ -88,11 +88,7 @@ void convert_fanout_rows_kernel(const _Float16* __restrict__ E, const _Float16* 
 int eend_launch_convert_fanout_rows(const void* E, const void* W1, const float* pc, float* out32, void* out16, int B, int Tp, int C,
                                     hipStream_t stream) {
     if (!E || !W1 || !pc || !out16 || B <= 0 || Tp <= 0 || C <= 0 || C > 32 || (long)B * Tp * 512 >= (1L << 31)) return EEND_EINVAL;
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    const int ncu = eend_cu_count();
     const int ntiles = (B * Tp + 31) / 32;
     hipLaunchKernelGGL(convert_fanout_rows_kernel, dim3(ntiles < 2 * ncu ? ntiles : 2 * ncu), dim3(256), C * 1024, stream, (const _Float16*)E,
                        (const _Float16*)W1, pc, out32, (_Float16*)out16, B, Tp, C);

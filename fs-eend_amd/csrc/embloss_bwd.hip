@@ -157,12 +157,8 @@ int eend_launch_emb_consistency_bwd(const void* emb16, const float* tgt, const i
                                     int B, int T, int Tp, int D, int C, hipStream_t stream) {
     if (!emb16 || !tgt || !de || B <= 0 || B > 65535 || T <= 0 || Tp < T || D != DM || C < 1 || C > CMAX) return EEND_EINVAL;
     const int smem = 98304 + (2 * TS * CMAX + 2 * TS) * 4;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute((const void*)emb_consistency_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return EEND_ELAUNCH;
-        done = true;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)emb_consistency_bwd_kernel, smem)) return EEND_ELAUNCH;
     const float inv = inv_count > 0.f ? inv_count : 1.0f / ((float)B * (float)T * (float)T);
     hipLaunchKernelGGL(emb_consistency_bwd_kernel, dim3((T + TS - 1) / TS, B), dim3(256), smem, stream, (const _Float16*)emb16, tgt,
                        lens, 4.0f * inv, de, T, Tp, C);

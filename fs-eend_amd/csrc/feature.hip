@@ -169,12 +169,8 @@ void splice_subsample_kernel(const float* __restrict__ Y, int T, int F, int ctx,
 int eend_launch_stft_logmel(const float* y, long len, long first, int n_frames, const float* dft, const float* melT, float* out,
                             hipStream_t stream) {
     if (!y || !dft || !melT || !out || len <= 0 || n_frames <= 0) return EEND_EINVAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)stft_logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)stft_logmel_kernel, SM_BYTES)) return EEND_ELAUNCH;
     hipLaunchKernelGGL(stft_logmel_kernel, dim3((n_frames + FB - 1) / FB), dim3(256), SM_BYTES, stream, y, len, first, n_frames, dft, melT, out);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

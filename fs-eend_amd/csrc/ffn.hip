@@ -940,19 +940,11 @@ void ffn_fused_kernel(const FfnParams p) {
 
 template <int ACT, int EPI, int MODE>
 int launch(const FfnParams& p, hipStream_t stream) {
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     auto kern = ffn_fused_kernel<ACT, EPI, MODE>;
     const int smem_bytes = V2_SMEM;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    if (!eend_set_dynamic_lds(attr_once, (const void*)kern, smem_bytes)) return EEND_ELAUNCH;
+    const int ncu = eend_cu_count();
     const int ntiles = MODE == 2 ? p.B * ((p.Tp + BM / p.C - 1) / (BM / p.C)) : (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(NT), smem_bytes, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

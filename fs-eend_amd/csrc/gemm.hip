@@ -605,13 +605,9 @@ void gemm_f16_kernel(const GemmParams p) {
 template <class ET, int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
 int launch_pf(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     auto kern = gemm_f16_kernel<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, PF>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    if (!eend_set_dynamic_lds(attr_once, (const void*)kern, smem)) return EEND_ELAUNCH;
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WGM * WGN * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

@@ -244,12 +244,8 @@ int eend_launch_proj_xres(const ProjParams& p, hipStream_t stream) {
         if (p.kind[g] != PROJ_ROWMAJOR && (p.Tp <= 0 || (p.Tp % 64) != 0 || (p.M % p.Tp) != 0)) return EEND_EINVAL;
         if (p.kind[g] == PROJ_ROWMAJOR && (p.ld[g] & 7)) return EEND_EINVAL;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)proj_xres_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)proj_xres_kernel, SMEM_BYTES)) return EEND_ELAUNCH;
     hipLaunchKernelGGL(proj_xres_kernel, dim3((p.M + BM - 1) / BM), dim3(NT), SMEM_BYTES, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -258,13 +258,8 @@ int eend_launch_ret_chunk_full(const RetParams& p, hipStream_t stream) {
         return EEND_EINVAL;
     const int ntl = ((p.L < p.Tp ? p.L : p.Tp) + KB - 1) / KB;
     const int smem = 2 * ntl * TILE + NW * OSTG;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)ret_chunk_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * (LMAX / KB) * TILE + NW * OSTG) != hipSuccess)
-            return EEND_ELAUNCH;
-        attr_done = true;
-    }
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)ret_chunk_full_kernel, 2 * (LMAX / KB) * TILE + NW * OSTG)) return EEND_ELAUNCH;
     hipLaunchKernelGGL(ret_chunk_full_kernel, dim3(p.nc, p.H, p.nseq), dim3(512), smem, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

@@ -248,17 +248,10 @@ void spk_qkv_attn_kernel(const SpkFusedParams p) {
 
 template <int C>
 int launch(const SpkFusedParams& p, hipStream_t stream) {
-    static bool attr_done = false;
+    static EendOncePerDevice attr_once;
     auto kern = spk_qkv_attn_kernel<C>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess) return EEND_ELAUNCH;
-        attr_done = true;
-    }
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    if (!eend_set_dynamic_lds(attr_once, (const void*)kern, SMEM_BYTES)) return EEND_ELAUNCH;
+    const int ncu = eend_cu_count();
     constexpr int G = BM / C;
     const int ntiles = p.B * ((p.Tv + G - 1) / G);
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(NT), SMEM_BYTES, stream, p);

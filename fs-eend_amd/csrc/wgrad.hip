@@ -359,13 +359,8 @@ int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((p.N / bt) * (p.K / bt) * p.nsplit));
 #define WG_LAUNCH(F16, CV, BT, BS)                                                                                      \
     do {                                                                                                                \
-        static bool done = false;                                                                                       \
-        if (!done) {                                                                                                    \
-            if (hipFuncSetAttribute((const void*)wgrad_tn_kernel<F16, CV, BT, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    smem) != hipSuccess)                                                                \
-                return EEND_ELAUNCH;                                                                                    \
-            done = true;                                                                                                \
-        }                                                                                                               \
+        static EendOncePerDevice attr_once;                                                                             \
+        if (!eend_set_dynamic_lds(attr_once, (const void*)wgrad_tn_kernel<F16, CV, BT, BS>, smem)) return EEND_ELAUNCH;  \
         hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV, BT, BS>), grid, dim3(BT * 2), smem, stream, p);                    \
     } while (0)
 #define WG_PICK(BT)                                                                                                     \
