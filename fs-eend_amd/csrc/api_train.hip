@@ -77,6 +77,19 @@ int eend_linear_relu_train_f16(const void* A, int lda, const void* W, int ldw, c
     return eend_launch_gemm(p, EPI_PLAIN_RELU_F16, (hipStream_t)stream);
 }
 
+int eend_ffn_train_f16(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, const float* res,
+                       float alpha, const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* hid_f16,
+                       void* xhat_f16, float* rstd, int M, int F, const eend_dropout* drop_hidden, const eend_dropout* drop_out,
+                       void* stream) {
+    if (!X || !W1 || !b1 || !W2 || !b2 || !res || !gamma || !beta || !out_f32 || !out_f16 || !hid_f16 || !xhat_f16 || !rstd) return EEND_EINVAL;
+    FfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = X; p.ldx = ldx; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta;
+    p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F; p.hid16 = hid_f16; p.xhat16 = xhat_f16; p.rstat = rstd;
+    p.drop1 = drop_spec(drop_hidden); p.drop2 = drop_spec(drop_out);
+    return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
 int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                             const eend_dropout* drop, void* stream) {
     if (!qkv || !O_f16 || H != 4) return EEND_EINVAL;

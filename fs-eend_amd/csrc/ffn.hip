@@ -51,6 +51,10 @@ __device__ unsigned long long g_ffn_trace[256 * 16 * 12];
 #define FFN_STAMP(k) do {} while (0)
 #endif
 
+// dropout without the "off" branch (thresh24 == 0 keeps every element: (h >> 8) >= 0, and the host passes scale = 1 with it): the uniform
+// branch of drop_apply, taken 16 times per hidden chunk, splits the MFMA / LDS schedule of the chunk loop into pieces
+DEV float drop_nb(const DropSpec d, float v, unsigned a, unsigned b) { return drop_keep(d, a, b) ? v * d.scale : 0.f; }
+
 constexpr int BM = 128;
 constexpr int KD = 256;            // model dim (K of GEMM1, N of GEMM2)
 constexpr int FC = 64;             // hidden chunk
@@ -68,19 +72,39 @@ struct RowsContiguous {              // tile row -> global row (or -1): plain 12
     __device__ __forceinline__ long operator()(int r) const { return m0 + r < M ? (long)(m0 + r) : -1L; }
 };
 
-template <int EPI, class RowMap>
+// TRAIN (round 5): the accumulators hold b2 + h W2^T only; dropout of the sub-layer output, scale and residual happen here, and the LayerNorm
+// also saves 1/sigma per row and the normalised pre-affine rows (third staged tile) for the backward.
+template <int EPI, bool TRAIN, class RowMap>
 __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4][4], char* smem, int wave, int frow, int fkg,
                                              int g2m, int g2n, const RowMap rowmap) {
     // acc[i][j][r]: feature n = g2n + i*16 + fkg*4 + r ; tile row = g2m + j*16 + frow
     float* red = (float*)(smem + 131072);                    // [4 n-waves][128 rows]; clear of the staging tiles
     const int wn = wave & 3;
     const int N0 = g2n + fkg * 4;
+    if constexpr (TRAIN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long gr = rowmap(g2m + j * 16 + frow);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned n = (unsigned)(N0 + i * 16);
+                float4 r4 = make_float4(0, 0, 0, 0);
+                if (gr >= 0) r4 = *(const float4*)(p.res + (size_t)gr * KD + n);
+                const unsigned m = (unsigned)(gr >= 0 ? gr : 0);
+                acc[i][j][0] = drop_nb(p.drop2, acc[i][j][0], m, n) * p.alpha + r4.x;
+                acc[i][j][1] = drop_nb(p.drop2, acc[i][j][1], m, n + 1) * p.alpha + r4.y;
+                acc[i][j][2] = drop_nb(p.drop2, acc[i][j][2], m, n + 2) * p.alpha + r4.z;
+                acc[i][j][3] = drop_nb(p.drop2, acc[i][j][3], m, n + 3) * p.alpha + r4.w;
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] *= p.alpha;
+    }
     auto block_rowsum = [&](float (&part)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -122,6 +146,15 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
     block_rowsum(part);
 #pragma unroll
     for (int j = 0; j < 4; ++j) rstd[j] = 1.0f / __builtin_sqrtf(part[j] * (1.0f / KD) + p.eps);
+    if constexpr (TRAIN) {
+        if (wn == 0 && fkg == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long gr = rowmap(g2m + j * 16 + frow);
+                if (gr >= 0) p.rstat[gr] = rstd[j];
+            }
+        }
+    }
 
     float* __restrict__ o32 = p.out32;
     _Float16* __restrict__ o16 = (_Float16*)p.out16;
@@ -144,7 +177,8 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
                 h16[i][j][0] = to_f16_sat(v[0]); h16[i][j][1] = to_f16_sat(v[1]);
                 h16[i][j][2] = to_f16_sat(v[2]); h16[i][j][3] = to_f16_sat(v[3]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) l16[i][j][r] = (_Float16)(v[r] - (float)h16[i][j][r]);
+                for (int r = 0; r < 4; ++r)
+                    l16[i][j][r] = TRAIN ? to_f16_sat((acc[i][j][r] - mean[j]) * rstd[j]) : (_Float16)(v[r] - (float)h16[i][j][r]);
                 *(f32x4*)(smem + row * 1024 + (((n >> 2) ^ (row & 7)) << 4)) =
                     EPI == FFN_EPI_RES_SCALE_LN16 ? acc[i][j] : v;       // LS: the residual stream stays un-normalised
             }
@@ -178,8 +212,8 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
             const long gr = rowmap(row);
             if (gr >= 0) *(u32x4*)(o16 + (size_t)gr * KD + c * 8) = v;
         }
-        if (p.out16lo) {                                     // the f16 remainder tile, same way
-            _Float16* __restrict__ o16l = (_Float16*)p.out16lo;
+        if (TRAIN || p.out16lo) {                            // the f16 remainder tile (TRAIN: the normalised pre-affine rows), same way
+            _Float16* __restrict__ o16l = (_Float16*)(TRAIN ? p.xhat16 : p.out16lo);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -249,7 +283,7 @@ struct RowsGathered {                // tile row r = c * G + t' -> row (b*C + c)
 template <int ACT, int EPI, int MODE>
 __global__ __launch_bounds__(NT)
 void ffn_fused_kernel(const FfnParams p) {
-    constexpr bool PRE = MODE >= 1, LAYER = MODE == 2;
+    constexpr bool PRE = MODE == 1 || MODE == 2, LAYER = MODE == 2, TRAIN = MODE == 3;      // MODE 3: training forward of the plain FFN
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nF = p.F / FC;
     const int lyG = LAYER ? BM / p.C : 1;                       // frames per tile
@@ -302,6 +336,7 @@ void ffn_fused_kernel(const FfnParams p) {
     int drow = lane >> 3, dslot = lane & 7;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.F * KD * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.F * KD * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(TRAIN ? p.hid16 : nullptr, 0, TRAIN ? (unsigned)((size_t)p.M * p.F * 2) : 0u, 0x00020000);
     int vo1[4], vo2[4];                                      // per-lane byte offsets of the 4 pieces this wave moves
     auto dma_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -737,7 +772,7 @@ void ffn_fused_kernel(const FfnParams p) {
 #ifdef EEND_FFN_ABLATE
                 if (p.dbg & 2) {} else
 #endif
-                if (p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);
+                if (!TRAIN && p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);      // (TRAIN: the residual joins behind the dropout, in the epilogue)
                 acc[i][j] = f32x4{r.x * ralpha + b4.x, r.y * ralpha + b4.y, r.z * ralpha + b4.z, r.w * ralpha + b4.w};
             }
         }
@@ -777,9 +812,14 @@ void ffn_fused_kernel(const FfnParams p) {
                     v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
                     v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
                 }
+                const int row = g1m + j * 16 + frow;
+                if constexpr (TRAIN) {                       // chunk 0: dropout after the activation, indices (row, hidden unit)
+                    const unsigned m = (unsigned)(m0 + row), n = (unsigned)fl;
+                    v0 = drop_nb(p.drop1, v0, m, n); v1 = drop_nb(p.drop1, v1, m, n + 1);
+                    v2 = drop_nb(p.drop1, v2, m, n + 2); v3 = drop_nb(p.drop1, v3, m, n + 3);
+                }
                 f16x4 o;
                 o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
-                const int row = g1m + j * 16 + frow;
                 *(f16x4*)(Hs + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
             }
         }
@@ -891,10 +931,26 @@ void ffn_fused_kernel(const FfnParams p) {
                 v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1));
                 v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
             }
+            const int row = g1m + j * 16 + frow;
+            if constexpr (TRAIN) {
+                const unsigned m = (unsigned)(m0 + row), n = (unsigned)((c + 1) * FC + fl);
+                v0 = drop_nb(p.drop1, v0, m, n); v1 = drop_nb(p.drop1, v1, m, n + 1);
+                v2 = drop_nb(p.drop1, v2, m, n + 2); v3 = drop_nb(p.drop1, v3, m, n + 3);
+            }
             f16x4 o;
             o[0] = to_f16_sat(v0); o[1] = to_f16_sat(v1); o[2] = to_f16_sat(v2); o[3] = to_f16_sat(v3);
-            const int row = g1m + j * 16 + frow;
             *(f16x4*)(Hn + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
+        };
+        // TRAIN: the hidden chunk this iteration consumes leaves for HBM as whole 128-byte row pieces, read back from its LDS tile (stable for
+        // the whole iteration).  Buffer stores: rows beyond M are dropped by the bounds check, so exactly two stores per thread are issued
+        // BEHIND the iteration's weight DMA and the barrier can wait with vmcnt(2).
+        auto store_hidden = [&](auto PASS) __attribute__((always_inline)) {
+            if constexpr (TRAIN) {
+                constexpr int pass = decltype(PASS)::value;
+                const int row = pass * 64 + (tid >> 3), c8 = tid & 7;
+                const u32x4 v = *(const u32x4*)(Hc + swz128(row, c8));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsH, (m0 + row) * (p.F * 2) + (c * FC + c8 * 8) * 2, 0, 0);
+            }
         };
 
         // fragments of items 0, 1 and of GEMM2 ks = 0
@@ -917,23 +973,35 @@ void ffn_fused_kernel(const FfnParams p) {
             }
             ld_item(std::integral_constant<int, t + 2>{});
             if constexpr (t < 8) dma_piece(std::integral_constant<int, t>{});
+            if constexpr (t == 9) store_hidden(std::integral_constant<int, 0>{});
+            if constexpr (t == 10) store_hidden(std::integral_constant<int, 1>{});
             if constexpr (t == HB1_T) ld_hb(std::integral_constant<int, 1>{});
             if constexpr (t == ACT_T0) { act_part(std::integral_constant<int, 0>{}); act_part(std::integral_constant<int, 1>{}); }
             if constexpr (t == ACT_T1) { act_part(std::integral_constant<int, 2>{}); act_part(std::integral_constant<int, 3>{}); }
             __builtin_amdgcn_sched_barrier(0);
         });
         bcur[0] = bnext[0]; bcur[1] = bnext[1];
-        __syncthreads();
+        if constexpr (TRAIN) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // weight DMA landed; the two hidden-row stores stay in flight
+        else __syncthreads();
     }
     {
         const int cb = (nF - 1) & 1;
+        if constexpr (TRAIN) {                               // the last hidden chunk
+            const char* Hl = smem + V2_HS + cb * HS_BYTES;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = pass * 64 + (tid >> 3), c8 = tid & 7;
+                const u32x4 v = *(const u32x4*)(Hl + swz128(row, c8));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsH, (m0 + row) * (p.F * 2) + ((nF - 1) * FC + c8 * 8) * 2, 0, 0);
+            }
+        }
         gemm2(smem + V2_W2 + cb * W2_BYTES, smem + V2_HS + cb * HS_BYTES);
     }
     __syncthreads();
 
     FFN_STAMP(8);
-    if constexpr (LAYER) ffn_epilogue<EPI>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_g);
-    else ffn_epilogue<EPI>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
+    if constexpr (LAYER) ffn_epilogue<EPI, false>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_g);
+    else ffn_epilogue<EPI, TRAIN>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
     FFN_STAMP(9);
     }
 }
@@ -974,6 +1042,12 @@ int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stre
         return launch<1, FFN_EPI_RES_LN, 1>(p, stream);
     }
     if (!p.X) return EEND_EINVAL;
+    if (p.hid16) {                                           // training forward (post-norm ReLU block)
+        if (!p.res || !p.out32 || !p.xhat16 || !p.rstat || act != 1 || epi != FFN_EPI_RES_LN || p.out16lo ||
+            (size_t)p.M * p.F * 2 >= (1ull << 32) || (((size_t)p.hid16 | (size_t)p.xhat16) & 15))
+            return EEND_EINVAL;
+        return launch<1, FFN_EPI_RES_LN, 3>(p, stream);
+    }
     if (epi == FFN_EPI_RES_LN) {
         if (act == 1) return launch<1, FFN_EPI_RES_LN, 0>(p, stream);
         if (act == 2) return launch<2, FFN_EPI_RES_LN, 0>(p, stream);

@@ -248,6 +248,13 @@ struct FfnParams {
     const float* be21;
     float eps21, spk_scale;
     int B, C, Tp;       // M = B*C*Tp, row = (b*C + c)*Tp + t
+    // training forward of a post-norm FFN block (round 5, eend_ffn_train_f16; null hid16 = off): h = drop1(relu(X W1^T + b1)) is ALSO written to
+    // hid16 (the saved activation of the backward; its zeros are the ReLU-and-dropout mask), y = drop2(h W2^T + b2) * alpha + res,
+    // out32 / out16 = LayerNorm(y), xhat16 = the normalised pre-affine rows, rstat = 1/sigma per row (what eend_layernorm_bwd_f32 reads)
+    void* hid16;        // f16 [M][F]
+    void* xhat16;       // f16 [M][256]
+    float* rstat;       // [M]
+    DropSpec drop1, drop2;
     int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read, 4 no in-loop weight DMA
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);

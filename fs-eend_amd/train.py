@@ -39,6 +39,9 @@ F16, BF16, F32, I32 = torch.float16, torch.bfloat16, torch.float32, torch.int32
 D = 256
 H = 4
 WS_FLOATS = 32 * 1024 * 1024          # f32 scratch for split-sum partials (128 MB)
+# the FFN of a post-norm block (linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm) as one launch (ffn.hip MODE 3, round 5);
+# EEND_TRAIN_FFN_FUSED=0: the two GEMM launches (A/B)
+FFN_TRAIN_FUSED = __import__("os").environ.get("EEND_TRAIN_FFN_FUSED", "1") != "0"
 
 
 def _call(name: str, *args):
@@ -295,6 +298,17 @@ class TrainStepBase:
     def _linear_ln(self, a16, w, bias, res, ln, site, out32, M, K, drop=None, alpha=1.0):
         _call("eend_linear_res_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, res, alpha, self._P(ln + ".weight"),
               self._P(ln + ".bias"), 1e-5, out32, site.out16, site.xhat, site.rstd, M, K, drop)
+
+    def _ffn(self, x16, w1, b1, hid, w2, b2, res, ln, site, out32, M, drop_hidden=None, drop_out=None):
+        """linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm of a post-norm block.  One launch (ffn.hip MODE 3: the hidden
+        activations are written once for the backward and never re-read) where the shape allows, else the two GEMM launches."""
+        F = hid.shape[1]
+        if FFN_TRAIN_FUSED and F % 64 == 0 and M * F * 2 < (1 << 32) and x16.shape[1] == 256:
+            _call("eend_ffn_train_f16", x16, x16.stride(0), w1, b1, w2, b2, res, 1.0, self._P(ln + ".weight"), self._P(ln + ".bias"), 1e-5,
+                  out32, site.out16, hid, site.xhat, site.rstd, M, F, drop_hidden, drop_out)
+            return
+        self._linear_relu(x16, w1, b1, hid, drop_hidden)
+        self._linear_ln(hid, w2, b2, res, ln, site, out32, M, F, drop_out)
 
     def _linear_relu(self, a16, w, bias, out16, drop=None):
         M, K = a16.shape
@@ -570,9 +584,8 @@ class FsTrainStep(TrainStepBase):
             self._attn_fwd(x16, W[f"e{i}.in_w"], W[f"e{i}.in_b"], sv["att"], B, Tp, delay_e, kv_e, dr(so + self.SITE_ATT))
             self._linear_ln(sv["att"].ctx, W[f"e{i}.out_w"], self._P(p_ + "self_attn.out_proj.bias"), bf.h32, p_ + "norm1", sv["s1"],
                             bf.h32, Me, D, dr(so + self.SITE_OUT1))
-            self._linear_relu(sv["s1"].out16, W[f"e{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], dr(so + self.SITE_FF))
-            self._linear_ln(sv["hid"], W[f"e{i}.w2"], self._P(p_ + "linear2.bias"), bf.h32, p_ + "norm2", sv["s2"], bf.h32, Me,
-                            sv["hid"].shape[1], dr(so + self.SITE_FFOUT))
+            self._ffn(sv["s1"].out16, W[f"e{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], W[f"e{i}.w2"], self._P(p_ + "linear2.bias"),
+                      bf.h32, p_ + "norm2", sv["s2"], bf.h32, Me, dr(so + self.SITE_FF), dr(so + self.SITE_FFOUT))
             x16 = sv["s2"].out16
         bf.enc_out16 = x16
 
@@ -596,9 +609,8 @@ class FsTrainStep(TrainStepBase):
             _call("eend_spk_attn_train_f16", sv["qkv"], sv["o2"], B, C, Tp, H, 0.125, dr(so + self.SITE_SPK))
             self._linear_ln(sv["o2"], W[f"d{i}.out2_w"], self._P(p_ + "self_attn2.out_proj.bias"), bf.a32, p_ + "norm21", sv["s21"],
                             bf.a32, Md, D, dr(so + self.SITE_OUT2))
-            self._linear_relu(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], dr(so + self.SITE_FF))
-            self._linear_ln(sv["hid"], W[f"d{i}.w2"], self._P(p_ + "linear2.bias"), bf.a32, p_ + "norm22", sv["s22"], bf.a32, Md,
-                            sv["hid"].shape[1], dr(so + self.SITE_FFOUT))
+            self._ffn(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], W[f"d{i}.w2"], self._P(p_ + "linear2.bias"),
+                      bf.a32, p_ + "norm22", sv["s22"], bf.a32, Md, dr(so + self.SITE_FF), dr(so + self.SITE_FFOUT))
             x16 = sv["s22"].out16
 
         # ---- head + BCE (+ PIT label choice) + emb-consistency loss, and their gradients w.r.t. attractors / embeddings

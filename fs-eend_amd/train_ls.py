@@ -342,9 +342,8 @@ class LsTrainStep(TrainStepBase):
             _call("eend_spk_attn_train_f16", sv["qkv"], sv["o2"], B, C, Tp, H, 0.125, dr(so + SITE_SPK))
             self._linear_ln(sv["o2"], W[f"d{i}.out2_w"], self._P(p_ + "self_attn2.out_proj.bias"), bf.a32, p_ + "norm21", sv["s21"],
                             bf.a32, Md, D, dr(so + SITE_OUT2))
-            self._linear_relu(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], dr(so + SITE_FF))
-            self._linear_ln(sv["hid"], W[f"d{i}.w2"], self._P(p_ + "linear2.bias"), bf.a32, p_ + "norm22", sv["s22"], bf.a32, Md,
-                            sv["hid"].shape[1], dr(so + SITE_FFOUT))
+            self._ffn(sv["s21"].out16, W[f"d{i}.w1"], self._P(p_ + "linear1.bias"), sv["hid"], W[f"d{i}.w2"], self._P(p_ + "linear2.bias"),
+                      bf.a32, p_ + "norm22", sv["s22"], bf.a32, Md, dr(so + SITE_FF), dr(so + SITE_FFOUT))
             x16 = sv["s22"].out16
 
         # ---- head + BCE (+ PIT label choice) + masked emb-consistency loss, and their gradients (LS model :89-117)

@@ -518,6 +518,17 @@ int eend_linear_res_ln_train_f16(const void* A, int lda, const void* W, int ldw,
  * the stored activation is the dropped one, so its zeros are the ReLU-and-dropout mask of the backward. */
 int eend_linear_relu_train_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
                                int M, int N, int K, const eend_dropout* drop, void* stream);
+/* The two entries above as ONE launch for a post-norm ReLU block (round 5; FS nn.TransformerEncoderLayer._ff_block + norm2,
+ * merge_tfm_encoder.py:397-399 / :612-614; LS merge_retnet_layer.py:250-253):
+ *   hid = drop_hidden(relu(X W1^T + b1))            f16 [M][F], written once and never re-read by this launch
+ *   y   = drop_out(hid W2^T + b2) * alpha + res     out_f32 / out_f16 = LayerNorm(y); xhat_f16, rstd as eend_linear_res_ln_train_f16
+ * Same dropout indexing (row, column) per site as the two-launch form, so a given eend_dropout produces the same masks.
+ * K = N = 256, F a multiple of 64, M * F * 2 < 2^32 bytes, 16-byte aligned hid / xhat; out_f32 may be res (in place).
+ * EEND_EINVAL outside that: the caller keeps the two launches. */
+int eend_ffn_train_f16(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, const float* res,
+                       float alpha, const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* hid_f16,
+                       void* xhat_f16, float* rstd, int M, int F, const eend_dropout* drop_hidden, const eend_dropout* drop_out,
+                       void* stream);
 /* eend_spk_attn_f16 with dropout of the attention probabilities. */
 int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                             const eend_dropout* drop, void* stream);

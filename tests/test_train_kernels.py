@@ -262,6 +262,69 @@ def test_ffn_hidden_dropout_fwd_bwd(T, dev):
     assert (out[h == 0] == 0).all()
 
 
+@pytest.mark.parametrize("M,F,pdrop", [(1000, 1024, 0.25), (300, 2048, 0.0), (70001, 2048, 0.1), (64, 64, 0.25)])
+def test_ffn_train_fused(T, dev, M, F, pdrop):
+    """eend_ffn_train_f16 (ffn.hip MODE 3, round 5): the FFN of a post-norm block in one launch == eend_linear_relu_train_f16 +
+    eend_linear_res_ln_train_f16 with the same two dropout sites (same masks), and == torch on the kernels' masks: saved hidden activation
+    (its zeros are the ReLU-and-dropout mask of the backward), LayerNorm output, normalised rows, 1/sigma; in place on the residual stream."""
+    import ctypes
+    gen = g(dev, 33)
+    x = torch.randn(M, 256, device=dev, generator=gen).to(F16)
+    w1 = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(F16)
+    b1 = torch.randn(F, device=dev, generator=gen) * 0.1
+    w2 = (torch.randn(256, F, device=dev, generator=gen) / math.sqrt(F)).to(F16)
+    b2 = torch.randn(256, device=dev, generator=gen) * 0.1
+    res = torch.randn(M, 256, device=dev, generator=gen)
+    gm = 1 + 0.2 * torch.randn(256, device=dev, generator=gen)
+    be = 0.1 * torch.randn(256, device=dev, generator=gen)
+    if pdrop > 0:
+        s1, d1 = _drop_spec(pdrop, 64, site=4)
+        s2, d2 = _drop_spec(pdrop, 64, site=5)
+        r1, r2 = ctypes.byref(s1), ctypes.byref(s2)
+    else:
+        r1 = r2 = None
+    nan16 = lambda *sh: torch.full(sh, float("nan"), dtype=F16, device=dev)
+    o32, o16, hid, xh, rs = torch.full((M, 256), float("nan"), device=dev), nan16(M, 256), nan16(M, F), nan16(M, 256), torch.full((M,), float("nan"), device=dev)
+    T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res, 1.0, gm, be, 1e-5, o32, o16, hid, xh, rs, M, F, r1, r2)
+    torch.cuda.synchronize()
+    for t in (o32, o16, hid, xh, rs):
+        assert torch.isfinite(t).all()
+    z = x.float() @ w1.float().t() + b1
+    sure = z.abs() > 1e-2                                            # away from the ReLU kink the zero patterns agree
+    if F % 128 == 0:                                                 # the two launches it replaces (the tiled GEMM wants N % 128 == 0)
+        h2 = torch.empty(M, F, dtype=F16, device=dev)
+        p32, p16, pxh, prs = torch.empty(M, 256, device=dev), torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, device=dev)
+        T._call("eend_linear_relu_train_f16", x, 256, w1, 256, b1, h2, F, M, F, 256, r1)
+        T._call("eend_linear_res_ln_train_f16", h2, F, w2, F, b2, res, 1.0, gm, be, 1e-5, p32, p16, pxh, prs, M, F, r2)
+        assert ((hid == 0) == (h2 == 0))[sure].all()
+        assert rel(hid, h2) < 2e-3                                   # (bias position in the f32 sum differs: a unit may round to the neighbouring f16)
+        assert (o32 - p32).abs().max() < 3e-3 and (xh.float() - pxh.float()).abs().max() < 4e-3
+        assert ((rs - prs).abs() / prs).max() < 2e-3
+    # torch on the kernels' masks
+    rows = torch.arange(M, device=dev)
+    hh = torch.relu(z)
+    if pdrop > 0:
+        hh = d1.rows(hh, 4, rows)
+    hh = hh.to(F16).float()
+    y = hh @ w2.float().t() + b2
+    if pdrop > 0:
+        y = d2.rows(y, 5, rows)
+    y = y + res
+    want = Fn.layer_norm(y, (256,), gm, be, 1e-5)
+    assert rel(hid, hh) < 3e-3
+    assert ((hid == 0) == (hh == 0))[sure].all()
+    assert (o32 - want).abs().max() < 3e-3 and (o16.float() - want).abs().max() < 6e-3
+    mu, var = y.mean(-1, keepdim=True), y.var(-1, unbiased=False, keepdim=True)
+    assert (xh.float() - (y - mu) / torch.sqrt(var + 1e-5)).abs().max() < 6e-3
+    assert ((rs - 1 / torch.sqrt(var.squeeze(-1) + 1e-5)).abs() * torch.sqrt(var.squeeze(-1) + 1e-5)).max() < 2e-3
+    # in place on the residual stream (out_f32 = res), as the training step calls it; deterministic
+    res2 = res.clone()
+    q16, qh, qxh, qrs = torch.empty_like(o16), torch.empty_like(hid), torch.empty_like(xh), torch.empty_like(rs)
+    T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res2, 1.0, gm, be, 1e-5, res2, q16, qh, qxh, qrs, M, F, r1, r2)
+    torch.cuda.synchronize()
+    assert torch.equal(res2, o32) and torch.equal(q16, o16) and torch.equal(qh, hid) and torch.equal(qxh, xh) and torch.equal(qrs, rs)
+
+
 def _attn_ref(q, k, v, delay, kv_len, scale, pdrop=None):
     """q,k,v (n,H,T,64) fp32 -> output (n,T,256), with the index-predicate mask."""
     Tq = q.shape[2]
