@@ -90,6 +90,16 @@ int eend_ffn_train_f16(const void* X, int ldx, const void* W1, const float* b1, 
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_ffn_bwd_data_bf16(const void* dY, int ldy, const void* W2T, const void* hid_f16, const void* W1T, float drop_scale,
+                           void* dH_bf16, float* g_f32, int M, int F, void* stream) {
+    if (!dY || !W2T || !hid_f16 || !W1T || !dH_bf16 || !g_f32) return EEND_EINVAL;
+    FfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = dY; p.ldx = ldy; p.W1 = W2T; p.W2 = W1T; p.hidmask = hid_f16; p.hid16 = dH_bf16; p.res = g_f32; p.out32 = g_f32; p.alpha = 1.0f;
+    p.M = M; p.F = F; p.drop1 = DropSpec{0u, 0u, drop_scale};
+    return eend_launch_ffn_fused(p, 0, FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
 int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                             const eend_dropout* drop, void* stream) {
     if (!qkv || !O_f16 || H != 4) return EEND_EINVAL;

@@ -236,6 +236,35 @@ __device__ __forceinline__ void ffn_epilogue(const FfnParams& p, f32x4 (&acc)[4]
     }
 }
 
+// MODE 4 epilogue: out32 = acc + res (the f32 residual-gradient stream, in place), whole-row stores through the staging tile; no LayerNorm.
+template <class RowMap>
+__device__ __forceinline__ void ffn_epilogue_acc(const FfnParams& p, f32x4 (&acc)[4][4], char* smem, int wave, int frow, int fkg,
+                                                 int g2m, int g2n, const RowMap rowmap) {
+    const int N0 = g2n + fkg * 4;
+    const int lane = frow + fkg * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = g2m + j * 16 + frow;
+        const long gr = rowmap(row);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = N0 + i * 16;
+            float4 r4 = make_float4(0, 0, 0, 0);
+            if (gr >= 0) r4 = *(const float4*)(p.res + (size_t)gr * KD + n);
+            const f32x4 v = f32x4{acc[i][j][0] * p.alpha + r4.x, acc[i][j][1] * p.alpha + r4.y, acc[i][j][2] * p.alpha + r4.z, acc[i][j][3] * p.alpha + r4.w};
+            *(f32x4*)(smem + row * 1024 + (((n >> 2) ^ (row & 7)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int row = k * 8 + wave;
+        const f32x4 v = *(const f32x4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+        const long gr = rowmap(row);
+        if (gr >= 0) *(f32x4*)(p.out32 + (size_t)gr * KD + lane * 4) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The kernel: one barrier per hidden chunk.
 //   * the wave's X fragments (32 tokens x 256) live in registers for the whole block (64 VGPRs), so
@@ -283,7 +312,14 @@ struct RowsGathered {                // tile row r = c * G + t' -> row (b*C + c)
 template <int ACT, int EPI, int MODE>
 __global__ __launch_bounds__(NT)
 void ffn_fused_kernel(const FfnParams p) {
-    constexpr bool PRE = MODE == 1 || MODE == 2, LAYER = MODE == 2, TRAIN = MODE == 3;      // MODE 3: training forward of the plain FFN
+    // MODE 3: training forward of the plain FFN; MODE 4: its data-gradient backward (bf16 operands: X = dY, W1 = W2^T, W2 = W1^T, the
+    // "activation" is the ReLU-and-dropout mask read from the saved hidden activations, the "hidden" tile is dH and leaves for HBM too, the
+    // epilogue accumulates into the f32 residual-gradient stream)
+    constexpr bool PRE = MODE == 1 || MODE == 2, LAYER = MODE == 2, TRAIN = MODE == 3, BWD = MODE == 4, HSTORE = TRAIN || BWD;
+    auto mfma = [](f16x8 a, f16x8 b, f32x4 c) __attribute__((always_inline)) {
+        if constexpr (BWD) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nF = p.F / FC;
     const int lyG = LAYER ? BM / p.C : 1;                       // frames per tile
@@ -336,7 +372,7 @@ void ffn_fused_kernel(const FfnParams p) {
     int drow = lane >> 3, dslot = lane & 7;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.F * KD * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.F * KD * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(TRAIN ? p.hid16 : nullptr, 0, TRAIN ? (unsigned)((size_t)p.M * p.F * 2) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(HSTORE ? p.hid16 : nullptr, 0, HSTORE ? (unsigned)((size_t)p.M * p.F * 2) : 0u, 0x00020000);
     int vo1[4], vo2[4];                                      // per-lane byte offsets of the 4 pieces this wave moves
     auto dma_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -743,9 +779,28 @@ void ffn_fused_kernel(const FfnParams p) {
         dma_offsets();
     }
     FFN_STAMP(6);
-    float4 bcur[2];
-    bcur[0] = *(const float4*)(p.b1 + bofs);
-    bcur[1] = *(const float4*)(p.b1 + bofs + 16);
+    float4 bcur[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if constexpr (!BWD) {
+        bcur[0] = *(const float4*)(p.b1 + bofs);
+        bcur[1] = *(const float4*)(p.b1 + bofs + 16);
+    }
+    // BWD: the 4 x 4 saved hidden activations this lane's dH values are masked with (hm[i*2 + j]: row g1m + j*16 + frow, units fl .. fl + 3 of
+    // the chunk), requested a chunk ahead like the bias
+    f16x4 hm[BWD ? 4 : 1];
+    auto load_mask = [&](int chunk, f16x4 (&dst)[BWD ? 4 : 1]) __attribute__((always_inline)) {
+        if constexpr (BWD) {
+            const _Float16* hid = (const _Float16*)p.hidmask;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int m = m0 + g1m + j * 16 + frow;
+                    m = m < p.M ? m : p.M - 1;
+                    dst[i * 2 + j] = *(const f16x4*)(hid + (size_t)m * p.F + chunk * FC + g1f + i * 16 + fkg * 4);
+                }
+        }
+    };
+    load_mask(0, hm);
     __syncthreads();
     f16x8 xf[4][2][2];
 #pragma unroll
@@ -764,7 +819,7 @@ void ffn_fused_kernel(const FfnParams p) {
         const int N0 = g2n + fkg * 4, M0 = m0 + g2m + frow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float4 b4 = *(const float4*)(p.b2 + N0 + i * 16);
+            const float4 b4 = BWD ? make_float4(0, 0, 0, 0) : *(const float4*)(p.b2 + N0 + i * 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int m = M0 + j * 16;
@@ -772,7 +827,7 @@ void ffn_fused_kernel(const FfnParams p) {
 #ifdef EEND_FFN_ABLATE
                 if (p.dbg & 2) {} else
 #endif
-                if (!TRAIN && p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);      // (TRAIN: the residual joins behind the dropout, in the epilogue)
+                if (!TRAIN && !BWD && p.res && m < p.M) r = *(const float4*)(p.res + (size_t)m * KD + N0 + i * 16);      // (TRAIN: the residual joins behind the dropout, in the epilogue)
                 acc[i][j] = f32x4{r.x * ralpha + b4.x, r.y * ralpha + b4.y, r.z * ralpha + b4.z, r.w * ralpha + b4.w};
             }
         }
@@ -797,7 +852,7 @@ void ffn_fused_kernel(const FfnParams p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xf[kt][ks][j], h[i][j], 0, 0, 0);
+                        h[i][j] = mfma(a[i], xf[kt][ks][j], h[i][j]);
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -813,6 +868,15 @@ void ffn_fused_kernel(const FfnParams p) {
                     v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
                 }
                 const int row = g1m + j * 16 + frow;
+                if constexpr (BWD) {                         // (ACT == 0) dH = scale * (dY W2) where the saved activation is non-zero, bf16
+                    const f16x4 mk = hm[i * 2 + j];
+                    const float sc = p.drop1.scale;
+                    bf16x4 ob;
+                    ob[0] = (__bf16)(mk[0] != (_Float16)0 ? v0 * sc : 0.f); ob[1] = (__bf16)(mk[1] != (_Float16)0 ? v1 * sc : 0.f);
+                    ob[2] = (__bf16)(mk[2] != (_Float16)0 ? v2 * sc : 0.f); ob[3] = (__bf16)(mk[3] != (_Float16)0 ? v3 * sc : 0.f);
+                    *(bf16x4*)(Hs + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = ob;
+                    continue;
+                }
                 if constexpr (TRAIN) {                       // chunk 0: dropout after the activation, indices (row, hidden unit)
                     const unsigned m = (unsigned)(m0 + row), n = (unsigned)fl;
                     v0 = drop_nb(p.drop1, v0, m, n); v1 = drop_nb(p.drop1, v1, m, n + 1);
@@ -837,7 +901,7 @@ void ffn_fused_kernel(const FfnParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma(a[i], b[j], acc[i][j]);
         }
     };
 
@@ -845,8 +909,11 @@ void ffn_fused_kernel(const FfnParams p) {
     dma_w2(0, 0);
     gemm1(smem + V2_W1, smem + V2_HS, bcur);
     if (nF > 1) {
-        bcur[0] = *(const float4*)(p.b1 + FC + bofs);
-        bcur[1] = *(const float4*)(p.b1 + FC + bofs + 16);
+        if constexpr (!BWD) {
+            bcur[0] = *(const float4*)(p.b1 + FC + bofs);
+            bcur[1] = *(const float4*)(p.b1 + FC + bofs + 16);
+        }
+        load_mask(1, hm);
     }
     __syncthreads();
     FFN_STAMP(7);
@@ -864,10 +931,18 @@ void ffn_fused_kernel(const FfnParams p) {
         const int cb = c & 1, nb = cb ^ 1;
         float4 bnext[2] = {bcur[0], bcur[1]};
         const bool more = c + 2 < nF;
+        f16x4 hmn[BWD ? 4 : 1];
+        if constexpr (BWD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hmn[q] = hm[q];
+        }
         if (more) {
             // b1 of chunk c+2, requested a whole iteration before the barrier's vmcnt(0) has to cover it
-            bnext[0] = *(const float4*)(p.b1 + (c + 2) * FC + bofs);
-            bnext[1] = *(const float4*)(p.b1 + (c + 2) * FC + bofs + 16);
+            if constexpr (!BWD) {
+                bnext[0] = *(const float4*)(p.b1 + (c + 2) * FC + bofs);
+                bnext[1] = *(const float4*)(p.b1 + (c + 2) * FC + bofs + 16);
+            }
+            load_mask(c + 2, hmn);
         }
         // The 8 DMA pieces of this iteration (W2 slice c+1, W1 slice c+2) are issued one per early item instead
         // of as a burst in front of the first MFMA: an LDS-DMA instruction occupies the issuing wave for
@@ -932,6 +1007,15 @@ void ffn_fused_kernel(const FfnParams p) {
                 v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
             }
             const int row = g1m + j * 16 + frow;
+            if constexpr (BWD) {
+                const f16x4 mk = hm[i * 2 + j];
+                const float sc = p.drop1.scale;
+                bf16x4 ob;
+                ob[0] = (__bf16)(mk[0] != (_Float16)0 ? v0 * sc : 0.f); ob[1] = (__bf16)(mk[1] != (_Float16)0 ? v1 * sc : 0.f);
+                ob[2] = (__bf16)(mk[2] != (_Float16)0 ? v2 * sc : 0.f); ob[3] = (__bf16)(mk[3] != (_Float16)0 ? v3 * sc : 0.f);
+                *(bf16x4*)(Hn + swz128(row, fl >> 3) + ((fl >> 2) & 1) * 8) = ob;
+                return;
+            }
             if constexpr (TRAIN) {
                 const unsigned m = (unsigned)(m0 + row), n = (unsigned)((c + 1) * FC + fl);
                 v0 = drop_nb(p.drop1, v0, m, n); v1 = drop_nb(p.drop1, v1, m, n + 1);
@@ -945,7 +1029,7 @@ void ffn_fused_kernel(const FfnParams p) {
         // the whole iteration).  Buffer stores: rows beyond M are dropped by the bounds check, so exactly two stores per thread are issued
         // BEHIND the iteration's weight DMA and the barrier can wait with vmcnt(2).
         auto store_hidden = [&](auto PASS) __attribute__((always_inline)) {
-            if constexpr (TRAIN) {
+            if constexpr (HSTORE) {
                 constexpr int pass = decltype(PASS)::value;
                 const int row = pass * 64 + (tid >> 3), c8 = tid & 7;
                 const u32x4 v = *(const u32x4*)(Hc + swz128(row, c8));
@@ -965,11 +1049,11 @@ void ffn_fused_kernel(const FfnParams p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[a % 3][i], xf[a >> 1][a & 1][j], h[i][j], 0, 0, 0);
+                        h[i][j] = mfma(wa[a % 3][i], xf[a >> 1][a & 1][j], h[i][j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[a & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2a[a % 3], hb[a >> 2][j], acc[a & 3][j], 0, 0, 0);
+                    acc[a & 3][j] = mfma(w2a[a % 3], hb[a >> 2][j], acc[a & 3][j]);
             }
             ld_item(std::integral_constant<int, t + 2>{});
             if constexpr (t < 8) dma_piece(std::integral_constant<int, t>{});
@@ -981,12 +1065,16 @@ void ffn_fused_kernel(const FfnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         });
         bcur[0] = bnext[0]; bcur[1] = bnext[1];
-        if constexpr (TRAIN) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // weight DMA landed; the two hidden-row stores stay in flight
+        if constexpr (BWD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hm[q] = hmn[q];
+        }
+        if constexpr (HSTORE) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // weight DMA landed; the two hidden-row stores stay in flight
         else __syncthreads();
     }
     {
         const int cb = (nF - 1) & 1;
-        if constexpr (TRAIN) {                               // the last hidden chunk
+        if constexpr (HSTORE) {                              // the last hidden chunk
             const char* Hl = smem + V2_HS + cb * HS_BYTES;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -1001,6 +1089,7 @@ void ffn_fused_kernel(const FfnParams p) {
 
     FFN_STAMP(8);
     if constexpr (LAYER) ffn_epilogue<EPI, false>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_g);
+    else if constexpr (BWD) ffn_epilogue_acc(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
     else ffn_epilogue<EPI, TRAIN>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
     FFN_STAMP(9);
     }
@@ -1027,9 +1116,14 @@ extern "C" int eend_debug_ffn_trace(void* dst, void* stream) {
 #endif
 
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream) {
-    if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.W1 || !p.W2 || !p.b1 || !p.b2 || !p.gamma ||
-        !p.beta || !p.out16)
-        return EEND_EINVAL;
+    if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.W1 || !p.W2) return EEND_EINVAL;
+    if (p.hidmask) {                                         // data-gradient backward of the block (bf16 operands)
+        if (!p.X || p.A || !p.hid16 || !p.res || !p.out32 || act != 0 || (size_t)p.M * p.F * 2 >= (1ull << 32) ||
+            (((size_t)p.hid16 | (size_t)p.hidmask | (size_t)p.res | (size_t)p.out32) & 15))
+            return EEND_EINVAL;
+        return launch<0, FFN_EPI_RES_LN, 4>(p, stream);
+    }
+    if (!p.b1 || !p.b2 || !p.gamma || !p.beta || !p.out16) return EEND_EINVAL;
     if (!p.out32 && (!p.A || p.Win2 || epi != FFN_EPI_RES_LN)) return EEND_EINVAL;   // f16-only output: the attnout + FFN form only
     if (p.A) {                                               // fused attention out-projection + norm1 producer
         if (!p.Wo || !p.bo || !p.g1 || !p.be1 || (p.lda & 7) || epi != FFN_EPI_RES_LN || act != 1) return EEND_EINVAL;

@@ -255,6 +255,10 @@ struct FfnParams {
     void* xhat16;       // f16 [M][256]
     float* rstat;       // [M]
     DropSpec drop1, drop2;
+    // data-gradient backward of the same block (MODE 4, eend_ffn_bwd_data_bf16; null hidmask = off): X = dY bf16, W1 = W2^T bf16 [F][256],
+    // W2 = W1^T bf16 [256][F], hidmask = the saved activations f16 [M][F]; hid16 receives dH = drop1.scale * (dY W2) where hidmask != 0
+    // (bf16), out32 = dH W1 * alpha + res (f32, may alias res)
+    const void* hidmask;
     int dbg;            // ablation flags, only honoured by -DEEND_FFN_ABLATE builds (perf studies): 1 no output stores, 2 no residual read, 4 no in-loop weight DMA
 };
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream);

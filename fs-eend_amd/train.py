@@ -341,6 +341,12 @@ class TrainStepBase:
         Fh = hid.shape[1]
         dh = dh16[:M * Fh].view(M, Fh)
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
+        if FFN_TRAIN_FUSED and Fh % 64 == 0 and M * Fh * 2 < (1 << 32):
+            # dH = scale * (dY W2) under the saved mask, and g += dH W1, in one launch (ffn.hip MODE 4): dH is written once for the weight
+            # gradient below and not re-read by the data path
+            _call("eend_ffn_bwd_data_bf16", ds16, D, W[wkey + ".w2T"], hid, W[wkey + ".w1T"], drop_scale, dh, g32, M, Fh)
+            self._wgrad_bias(dh, x_in16, M, Fh, D, p_ + "linear1.weight", p_ + "linear1.bias")
+            return
         _call("eend_gemm_relu_bwd_bf16", ds16, D, W[wkey + ".w2T"], D, hid, Fh, dh, Fh, M, Fh, D, drop_scale)
         self._wgrad_bias(dh, x_in16, M, Fh, D, p_ + "linear1.weight", p_ + "linear1.bias")
         _call("eend_gemm_acc_bf16", dh, Fh, W[wkey + ".w1T"], Fh, g32, 1.0, g32, None, M, Fh)

@@ -529,6 +529,13 @@ int eend_ffn_train_f16(const void* X, int ldx, const void* W1, const float* b1, 
                        float alpha, const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* hid_f16,
                        void* xhat_f16, float* rstd, int M, int F, const eend_dropout* drop_hidden, const eend_dropout* drop_out,
                        void* stream);
+/* Data-gradient backward of the same block in one launch (round 5; replaces eend_gemm_relu_bwd_bf16 + eend_gemm_acc_bf16 of its FFN):
+ *   dH = drop_scale * (dY W2) where hid_f16 != 0, else 0     bf16 [M][F], written once (the weight gradient of linear1 reads it)
+ *   g  += dH W1                                              the f32 residual-gradient stream [M][256], in place
+ * dY bf16 [M][ldy], W2T = W2 transposed, bf16 [F][256]; W1T = W1 transposed, bf16 [256][F] (the copies the two-launch form uses).
+ * F a multiple of 64, M * F * 2 < 2^32 bytes, 16-byte aligned buffers; EEND_EINVAL outside that. */
+int eend_ffn_bwd_data_bf16(const void* dY, int ldy, const void* W2T, const void* hid_f16, const void* W1T, float drop_scale,
+                           void* dH_bf16, float* g_f32, int M, int F, void* stream);
 /* eend_spk_attn_f16 with dropout of the attention probabilities. */
 int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                             const eend_dropout* drop, void* stream);

@@ -65,6 +65,35 @@ def test_gemm_relu_bwd(T, dev, M, F):
     assert (out[act == 0] == 0).all()
 
 
+@pytest.mark.parametrize("M,F,scale", [(1000, 1024, 1.0 / 0.75), (300, 2048, 1.0), (70001, 2048, 1.0 / 0.9), (64, 64, 1.0)])
+def test_ffn_bwd_data_fused(T, dev, M, F, scale):
+    """eend_ffn_bwd_data_bf16 (ffn.hip MODE 4, round 5) == eend_gemm_relu_bwd_bf16 + eend_gemm_acc_bf16: dH bit-comparable (same bf16
+    operands, f32 accumulation in a different k order), the residual-gradient stream accumulated in place; both == torch fp32."""
+    gen = g(dev, M + F)
+    dy = (torch.randn(M, 256, device=dev, generator=gen) * 1e-4).to(BF16)
+    w2t = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(BF16)        # [F][256] = W2^T
+    w1t = (torch.randn(256, F, device=dev, generator=gen) / math.sqrt(F)).to(BF16)   # [256][F] = W1^T
+    act = torch.relu(torch.randn(M, F, device=dev, generator=gen)).to(F16)
+    g32 = torch.randn(M, 256, device=dev, generator=gen) * 1e-4
+    dh = torch.full((M, F), 3.0, dtype=BF16, device=dev)
+    gout = g32.clone()
+    T._call("eend_ffn_bwd_data_bf16", dy, 256, w2t, act, w1t, scale, dh, gout, M, F)
+    torch.cuda.synchronize()
+    want_dh = (dy.float() @ w2t.float().t()) * scale * (act > 0)
+    assert torch.isfinite(dh.float()).all() and torch.isfinite(gout).all()
+    assert rel(dh, want_dh) < 6e-3
+    assert (dh[act == 0] == 0).all()
+    want_g = dh.float() @ w1t.float().t() + g32                                   # from the kernel's own (rounded) dH
+    assert rel(gout - g32, want_g - g32) < 3e-3
+    if F % 128 == 0:                                                              # the two launches it replaces
+        dh2 = torch.empty(M, F, dtype=BF16, device=dev)
+        g2 = g32.clone()
+        T._call("eend_gemm_relu_bwd_bf16", dy, 256, w2t, 256, act, F, dh2, F, M, F, 256, scale)
+        T._call("eend_gemm_acc_bf16", dh2, F, w1t, F, g2, 1.0, g2, None, M, F)
+        assert rel(dh, dh2) < 5e-3                                                # a value may round to the neighbouring bf16
+        assert rel(gout - g32, g2 - g32) < 5e-3
+
+
 @pytest.mark.parametrize("M,K", [(300, 256), (777, 768), (200, 2048)])
 def test_gemm_acc(T, dev, M, K):
     gen = g(dev, K)
