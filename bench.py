@@ -800,6 +800,10 @@ class TrainCallTimer:
                 shape = (int(a[18]), int(a[19]), int(a[22]), int(a[21]))
             elif name == "eend_retention_chunk_train_f16":
                 shape = (int(a[12]), int(a[13]), int(a[19]), int(a[15]))
+            elif name == "eend_ffn_train_f16":                # (rows, hidden units, d_model): both linears in one launch
+                shape = (int(a[16]), int(a[17]), 256)
+            elif name == "eend_ffn_bwd_data_bf16":
+                shape = (int(a[8]), int(a[9]), 256)
             else:
                 shape = ()
             self.rec.append((name, shape, s, e))
@@ -819,6 +823,9 @@ class TrainCallTimer:
                     "eend_linear_res_scale_ln_train_f16", "ops.linear", "ops.retention_proj", "ops.convert_fanout"):
             M, N, K = shape
             return 2.0 * M * N * K
+        if name in ("eend_ffn_train_f16", "eend_ffn_bwd_data_bf16"):           # two products of M x F x 256
+            M, F_, K = shape
+            return 4.0 * M * F_ * K
         if name in ("eend_retention_bwd_bf16", "eend_retention_chunk_train_f16"):
             # per chunk-sequence-head: masked products of L x L x 64 (causal-useful L*(L+1)*64*2 flops each) -- forward 2
             # (QK^T, PV), backward 5 (S, A, dQ, dK, dV) -- plus the cross-chunk terms 2*L*64*64 each (forward 2: state
