@@ -60,6 +60,9 @@ CASES = [
     # BASELINE config 4 shapes: the shipped yaml, 4-speaker mixtures, T = 500 chunks
     dict(name="fs_train_full", cfg=cfg(), lengths=[500, 500, 500, 463], nspk=[4, 4, 3, 4], seed=34, pseed=44, xseed=807,
          lseed=808, steps=1, warm=100, clip=5.0, pit=False),
+    # ... at the batch size bench.py --mode train times (round 5): 64 utterances, a few of them shorter
+    dict(name="fs_train_b64", cfg=cfg(), lengths=[500] * 60 + [463, 377, 251, 500], nspk=[4, 4, 3, 4] * 16, seed=35, pseed=45, xseed=809,
+         lseed=810, steps=1, warm=100, clip=5.0, pit=False),
 ]
 
 
@@ -97,7 +100,10 @@ def main():
     (step_pit,) = reference_defs(f"{REF}/train/oln_tfm_enc_dec_spk_pit.py", ["training_step"], ns_pit,
                                  cls="SpeakerDiarization")
 
+    only = set(sys.argv[1:])                                  # optional: the case names to (re)generate
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
         torch.manual_seed(case["seed"])
         model = OnlineTransformerDADiarization(n_speakers=None, in_size=345, **case["cfg"])
         FX.perturb_(model, case["pseed"])

@@ -63,6 +63,9 @@ CASES = [
     # BASELINE config 4 shapes: the shipped yaml, 4-speaker mixtures, T = 1000 chunks (two retention chunks of 500)
     dict(name="ls_train_full", cfg=cfg(), lengths=[1000, 1000, 930], nspk=[4, 4, 3], seed=54, pseed=64, xseed=817,
          lseed=818, steps=1, warm=100, clip=5.0, pit=False),
+    # ... at the batch size bench.py --mode train --flavour ls times (round 5): 64 utterances, a few of them shorter
+    dict(name="ls_train_b64", cfg=cfg(), lengths=[1000] * 60 + [930, 777, 501, 1000], nspk=[4, 4, 3, 4] * 16, seed=55, pseed=65, xseed=819,
+         lseed=820, steps=1, warm=100, clip=5.0, pit=False),
 ]
 
 
@@ -104,7 +107,10 @@ def main():
     (step_pit,) = reference_defs(f"{REF}/train/oln_tfm_enc_dec_spk_pit_on_the_fly.py", ["training_step"], ns_pit,
                                  cls="SpeakerDiarization")
 
+    only = set(sys.argv[1:])                                  # optional: the case names to (re)generate
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
         torch.manual_seed(case["seed"])
         model = OnlineConformerRetentionDADiarization(n_speakers=None, in_size=345, **case["cfg"])
         FX.perturb_(model, case["pseed"])

@@ -9,7 +9,10 @@ from oracle import fixtures as FX
 from oracle import train_ls_ref as TL
 from tests.helpers import build_ls_mirror
 
-CASES = [c for c in FX.list_cases("ls_train_")]
+import os
+# ls_train_b64 (the bench's batch size; 64 x T=1000 through the fp64-free CPU oracle: 2+ minutes) only with EEND_SLOW_TESTS=1 -- the GPU
+# test tests/test_train_step_ls.py runs it always; measured once here: passes (round 5)
+CASES = [c for c in FX.list_cases("ls_train_") if c != "ls_train_b64" or os.environ.get("EEND_SLOW_TESTS") == "1"]
 
 
 def _slice_index(numel, n=24):
