@@ -8,7 +8,10 @@ from oracle import fixtures as FX
 from oracle import train_ref as TR
 from tests.helpers import build_fs_mirror
 
-CASES = [c for c in FX.list_cases("fs_train_")]
+import os
+# fs_train_b64 (the bench's batch size: 64 x T=500 through the CPU oracle takes minutes inside the full suite) only with EEND_SLOW_TESTS=1 --
+# the GPU test tests/test_train_step.py runs it always; measured here once: passes (round 5)
+CASES = [c for c in FX.list_cases("fs_train_") if c != "fs_train_b64" or os.environ.get("EEND_SLOW_TESTS") == "1"]
 
 
 def _slice_index(numel, n=24):
