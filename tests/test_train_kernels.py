@@ -94,6 +94,26 @@ def test_ffn_bwd_data_fused(T, dev, M, F, scale):
         assert rel(gout - g32, g2 - g32) < 5e-3
 
 
+def test_fused_ffn_entries_reject_what_they_do_not_cover(T, dev):
+    """EEND_EINVAL (never a silent wrong answer) outside the fused training FFN's shapes: the host then keeps the GEMM launches."""
+    from fs_eend_amd.lib import EendHipError
+    M, F = 128, 96                                                                # F not a multiple of the 64-unit chunk
+    x = torch.zeros(M, 256, dtype=F16, device=dev)
+    w1, b1 = torch.zeros(F, 256, dtype=F16, device=dev), torch.zeros(F, device=dev)
+    w2, b2 = torch.zeros(256, F, dtype=F16, device=dev), torch.zeros(256, device=dev)
+    res, gm = torch.zeros(M, 256, device=dev), torch.ones(256, device=dev)
+    o32, o16, hid, xh, rs = torch.empty(M, 256, device=dev), torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, F, dtype=F16, device=dev), torch.empty(M, 256, dtype=F16, device=dev), torch.empty(M, device=dev)
+    with pytest.raises(EendHipError):
+        T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res, 1.0, gm, b2, 1e-5, o32, o16, hid, xh, rs, M, F, None, None)
+    with pytest.raises(EendHipError):                                             # missing statistics buffers
+        T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res, 1.0, gm, b2, 1e-5, o32, o16, hid, None, None, M, 64, None, None)
+    dy = torch.zeros(M, 256, dtype=BF16, device=dev)
+    with pytest.raises(EendHipError):
+        T._call("eend_ffn_bwd_data_bf16", dy, 256, w1.to(BF16), hid, w2.to(BF16), 1.0, torch.empty(M, F, dtype=BF16, device=dev), res, M, F)
+    with pytest.raises(EendHipError):                                             # no residual-gradient stream
+        T._call("eend_ffn_bwd_data_bf16", dy, 256, w1.to(BF16), hid, w2.to(BF16), 1.0, torch.empty(M, 64, dtype=BF16, device=dev), None, M, 64)
+
+
 @pytest.mark.parametrize("M,K", [(300, 256), (777, 768), (200, 2048)])
 def test_gemm_acc(T, dev, M, K):
     gen = g(dev, K)
