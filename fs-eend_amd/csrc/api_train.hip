@@ -90,6 +90,19 @@ int eend_ffn_train_f16(const void* X, int ldx, const void* W1, const float* b1, 
     return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_ffn_swish_train_f16(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, const float* res,
+                             float alpha, const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* z_f16,
+                             void* a_f16, void* xhat_f16, float* rstd, int M, int F, int residual_stream_unnormalised,
+                             const eend_dropout* drop_hidden, const eend_dropout* drop_out, void* stream) {
+    if (!X || !W1 || !b1 || !W2 || !b2 || !res || !gamma || !beta || !out_f32 || !out_f16 || !z_f16 || !a_f16 || !xhat_f16 || !rstd) return EEND_EINVAL;
+    FfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = X; p.ldx = ldx; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta;
+    p.eps = eps; p.out32 = out_f32; p.out16 = out_f16; p.M = M; p.F = F; p.hid16 = a_f16; p.z16 = z_f16; p.xhat16 = xhat_f16; p.rstat = rstd;
+    p.drop1 = drop_spec(drop_hidden); p.drop2 = drop_spec(drop_out);
+    return eend_launch_ffn_fused(p, 2, residual_stream_unnormalised ? FFN_EPI_RES_SCALE_LN16 : FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
 int eend_ffn_bwd_data_bf16(const void* dY, int ldy, const void* W2T, const void* hid_f16, const void* W1T, float drop_scale,
                            void* dH_bf16, float* g_f32, int M, int F, void* stream) {
     if (!dY || !W2T || !hid_f16 || !W1T || !dH_bf16 || !g_f32) return EEND_EINVAL;

@@ -373,6 +373,20 @@ void ffn_fused_kernel(const FfnParams p) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.F * KD * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.F * KD * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(HSTORE ? p.hid16 : nullptr, 0, HSTORE ? (unsigned)((size_t)p.M * p.F * 2) : 0u, 0x00020000);
+    // TRAIN + Swish (LS-EEND Macaron FFN): the pre-activation z is saved too (its backward needs swish'(z)); four 8-byte buffer stores per lane
+    // and chunk, straight from the accumulators (rows beyond M dropped by the bounds check, so the count the chunk barrier relies on is exact)
+    constexpr bool ZSTORE = TRAIN && ACT == 2;
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(ZSTORE ? p.z16 : nullptr, 0, ZSTORE ? (unsigned)((size_t)p.M * p.F * 2) : 0u, 0x00020000);
+    // (the activation is then taken of the ROUNDED z, as the two-launch form does: the backward differentiates at exactly the saved point)
+    auto store_z = [&](int row, int col, float& z0, float& z1, float& z2, float& z3) __attribute__((always_inline)) {
+        if constexpr (ZSTORE) {
+            f16x4 zz;
+            zz[0] = to_f16_sat(z0); zz[1] = to_f16_sat(z1); zz[2] = to_f16_sat(z2); zz[3] = to_f16_sat(z3);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, zz), rsZ, (m0 + row) * (p.F * 2) + col * 2, 0, 0);
+            z0 = (float)zz[0]; z1 = (float)zz[1]; z2 = (float)zz[2]; z3 = (float)zz[3];
+        }
+    };
     int vo1[4], vo2[4];                                      // per-lane byte offsets of the 4 pieces this wave moves
     auto dma_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -860,6 +874,7 @@ void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v0 = h[i][j][0] + bb[i].x, v1 = h[i][j][1] + bb[i].y, v2 = h[i][j][2] + bb[i].z, v3 = h[i][j][3] + bb[i].w;
+                store_z(g1m + j * 16 + frow, fl, v0, v1, v2, v3);
                 if (ACT == 1) {
                     v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
                     v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
@@ -999,6 +1014,7 @@ void ffn_fused_kernel(const FfnParams p) {
             constexpr int i = decltype(Q)::value >> 1, j = decltype(Q)::value & 1;
             const int fl = g1f + i * 16 + fkg * 4;
             float v0 = h[i][j][0], v1 = h[i][j][1], v2 = h[i][j][2], v3 = h[i][j][3];
+            store_z(g1m + j * 16 + frow, (c + 1) * FC + fl, v0, v1, v2, v3);
             if (ACT == 1) {
                 v0 = __builtin_fmaxf(v0, 0.f); v1 = __builtin_fmaxf(v1, 0.f);
                 v2 = __builtin_fmaxf(v2, 0.f); v3 = __builtin_fmaxf(v3, 0.f);
@@ -1069,7 +1085,8 @@ void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) hm[q] = hmn[q];
         }
-        if constexpr (HSTORE) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // weight DMA landed; the two hidden-row stores stay in flight
+        if constexpr (ZSTORE) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... and the four z stores of the activation parts
+        else if constexpr (HSTORE) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // weight DMA landed; the two hidden-row stores stay in flight
         else __syncthreads();
     }
     {
@@ -1137,10 +1154,15 @@ int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stre
     }
     if (!p.X) return EEND_EINVAL;
     if (p.hid16) {                                           // training forward (post-norm ReLU block)
-        if (!p.res || !p.out32 || !p.xhat16 || !p.rstat || act != 1 || epi != FFN_EPI_RES_LN || p.out16lo ||
-            (size_t)p.M * p.F * 2 >= (1ull << 32) || (((size_t)p.hid16 | (size_t)p.xhat16) & 15))
+        if (!p.res || !p.out32 || !p.xhat16 || !p.rstat || p.out16lo || (size_t)p.M * p.F * 2 >= (1ull << 32) ||
+            (((size_t)p.hid16 | (size_t)p.xhat16 | (size_t)p.z16) & 15))
             return EEND_EINVAL;
-        return launch<1, FFN_EPI_RES_LN, 3>(p, stream);
+        if (act == 1 && epi == FFN_EPI_RES_LN && !p.z16) return launch<1, FFN_EPI_RES_LN, 3>(p, stream);
+        if (act == 2 && p.z16) {                             // LS-EEND Macaron FFN (Swish; pre-activation saved)
+            if (epi == FFN_EPI_RES_LN) return launch<2, FFN_EPI_RES_LN, 3>(p, stream);
+            if (epi == FFN_EPI_RES_SCALE_LN16) return launch<2, FFN_EPI_RES_SCALE_LN16, 3>(p, stream);
+        }
+        return EEND_EINVAL;
     }
     if (epi == FFN_EPI_RES_LN) {
         if (act == 1) return launch<1, FFN_EPI_RES_LN, 0>(p, stream);

@@ -252,6 +252,7 @@ struct FfnParams {
     // hid16 (the saved activation of the backward; its zeros are the ReLU-and-dropout mask), y = drop2(h W2^T + b2) * alpha + res,
     // out32 / out16 = LayerNorm(y), xhat16 = the normalised pre-affine rows, rstat = 1/sigma per row (what eend_layernorm_bwd_f32 reads)
     void* hid16;        // f16 [M][F]
+    void* z16;          // f16 [M][F], Swish blocks only: the pre-activation X W1^T + b1 (the backward's swish'(z))
     void* xhat16;       // f16 [M][256]
     float* rstat;       // [M]
     DropSpec drop1, drop2;

@@ -92,6 +92,7 @@ PROTOTYPES = {
     # ---- training step
     "eend_linear_res_ln_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "eend_linear_relu_train_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "eend_ffn_swish_train_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "eend_ffn_bwd_data_bf16": [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_ffn_train_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "eend_spk_attn_train_f16": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],

@@ -529,6 +529,15 @@ int eend_ffn_train_f16(const void* X, int ldx, const void* W1, const float* b1, 
                        float alpha, const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* hid_f16,
                        void* xhat_f16, float* rstd, int M, int F, const eend_dropout* drop_hidden, const eend_dropout* drop_out,
                        void* stream);
+/* The Macaron half-step FFN of a Conformer block (LS-EEND conformer/feed_forward.py:47-57 inside modules.py:32-33's residual) as one
+ * launch: z = X W1^T + b1 (saved, f16), a = drop_hidden(swish(z)) (saved, f16), y = drop_out(a W2^T + b2) * alpha + res; then either
+ * (residual_stream_unnormalised = 1, the pre-norm join: eend_linear_res_scale_ln_train_f16) out_f32 = y and out_f16 / xhat / rstd = the NEXT
+ * sub-layer's LayerNorm of y, or (0: the block-final LayerNorm, eend_linear_res_ln_train_f16) out_f32 = out_f16 = LayerNorm(y).
+ * Replaces eend_linear_f16 + eend_swish_dropout_f16 + that GEMM entry.  Shapes as eend_ffn_train_f16. */
+int eend_ffn_swish_train_f16(const void* X, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, const float* res,
+                             float alpha, const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* z_f16,
+                             void* a_f16, void* xhat_f16, float* rstd, int M, int F, int residual_stream_unnormalised,
+                             const eend_dropout* drop_hidden, const eend_dropout* drop_out, void* stream);
 /* Data-gradient backward of the same block in one launch (round 5; replaces eend_gemm_relu_bwd_bf16 + eend_gemm_acc_bf16 of its FFN):
  *   dH = drop_scale * (dY W2) where hid_f16 != 0, else 0     bf16 [M][F], written once (the weight gradient of linear1 reads it)
  *   g  += dH W1                                              the f32 residual-gradient stream [M][256], in place

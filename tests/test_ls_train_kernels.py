@@ -206,3 +206,59 @@ def test_retention_train_outputs_consistent_with_the_forward(hip_lib, dev):
     want_rc = (c_t / torch.sqrt(var.squeeze(-1).transpose(1, 2) + 1e-6)).transpose(1, 2)        # (nseq, Tv, H)
     got_rc = rc.view(nseq, Tp, H)[:, v].double().cpu()
     assert float(((got_rc - want_rc) / want_rc).abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("M,Fh,prenorm,pdrop", [(384, 1024, 1, 0.0), (777, 1024, 1, 0.25), (1000, 1024, 0, 0.25), (70001, 1024, 0, 0.0), (130, 64, 1, 0.1)])
+def test_ffn_swish_train_fused(hip_lib, dev, M, Fh, prenorm, pdrop):
+    """eend_ffn_swish_train_f16 (ffn.hip MODE 3 with Swish, round 5): the Macaron half-step FFN in one launch == eend_linear_f16 +
+    eend_swish_dropout_f16 + eend_linear_res_scale_ln_train_f16 (pre-norm join) / eend_linear_res_ln_train_f16 (block-final LayerNorm):
+    saved pre-activation z and dropped activation a, residual stream, LayerNorm output, normalised rows, 1/sigma."""
+    from fs_eend_amd import ops
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g) * sc).to(dev)
+    x = r(M, 256).half()
+    w1, b1 = r(Fh, 256, sc=1 / 16).half(), r(Fh, sc=0.1)
+    w2, b2 = r(256, Fh, sc=1 / math.sqrt(Fh)).half(), r(256, sc=0.1)
+    res = r(M, 256)
+    gm, be = 1 + r(256, sc=0.2), r(256, sc=0.1)
+    s1, s2 = (_spec(pdrop, 11), _spec(pdrop, 12)) if pdrop else (None, None)
+    r1, r2 = (ctypes.byref(s1), ctypes.byref(s2)) if pdrop else (None, None)
+    nan = lambda *sh, dt=torch.float16: torch.full(sh, float("nan"), dtype=dt, device=dev)
+    o32, o16, z, a, xh, rs = nan(M, 256, dt=torch.float32), nan(M, 256), nan(M, Fh), nan(M, Fh), nan(M, 256), nan(M, dt=torch.float32)
+    _call("eend_ffn_swish_train_f16", x, 256, w1, b1, w2, b2, res, 0.5, gm, be, 1e-5, o32, o16, z, a, xh, rs, M, Fh, prenorm, r1, r2)
+    torch.cuda.synchronize()
+    for t in (o32, o16, z, a, xh, rs):
+        assert torch.isfinite(t).all()
+    # torch on the saved z (what the backward differentiates at)
+    zr = x.float() @ w1.float().t() + b1
+    assert float((z.float() - zr).abs().max()) < 4e-3
+    sw = z.float() * torch.sigmoid(z.float())
+    keep = (a != 0) | (sw.abs() < 1e-4)
+    if pdrop:
+        assert abs(float((a != 0).float().mean()) - (1 - pdrop)) < 1e-2
+        assert float((a.float()[a != 0] - sw[a != 0] / (1 - pdrop)).abs().max()) < 6e-3
+    else:
+        assert float((a.float() - sw).abs().max()) < 3e-3
+    if Fh % 128 == 0:                                                 # the launches it replaces, same dropout specs -> same masks
+        z2, a2 = torch.empty_like(z), torch.empty_like(a)
+        p32, p16, pxh, prs = torch.empty_like(o32), torch.empty_like(o16), torch.empty_like(xh), torch.empty_like(rs)
+        ops.linear(x, w1, b1, z2)
+        _call("eend_swish_dropout_f16", z2, a2, M, Fh, r1)
+        name = "eend_linear_res_scale_ln_train_f16" if prenorm else "eend_linear_res_ln_train_f16"
+        _call(name, a2, Fh, w2, Fh, b2, res, 0.5, gm, be, 1e-5, p32, p16, pxh, prs, M, Fh, r2)
+        assert float((z.float() - z2.float()).abs().max()) < 4e-3
+        big = sw.abs() > 1e-2                                          # away from swish's zero the dropout zero patterns agree exactly
+        assert ((a == 0) == (a2 == 0))[big].all()
+        assert float((a.float() - a2.float()).abs().max()) < 8e-3
+        assert float((o32 - p32).abs().max()) < 3e-3 and float((o16.float() - p16.float()).abs().max()) < 6e-3
+        assert float((xh.float() - pxh.float()).abs().max()) < 6e-3 and float(((rs - prs).abs() / prs).max()) < 2e-3
+    # the operator itself, from the kernel's own a (masks included)
+    y = a.float() @ w2.float().t() + b2
+    if pdrop:                                                         # output dropout: infer the mask from the two-launch comparison above
+        return
+    y = y * 0.5 + res
+    ln = F.layer_norm(y, (256,), gm, be, 1e-5)
+    assert float((o32 - (y if prenorm else ln)).abs().max()) < 3e-3
+    assert float((o16.float() - ln).abs().max()) < 6e-3
+    mu, var = y.mean(-1, keepdim=True), y.var(-1, unbiased=False, keepdim=True)
+    assert float((xh.float() - (y - mu) / torch.sqrt(var + 1e-5)).abs().max()) < 6e-3
