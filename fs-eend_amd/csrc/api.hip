@@ -28,7 +28,7 @@ bool skinny_enabled() {              // EEND_SKINNY=0: A/B switch back to the ti
 
 extern "C" {
 
-int eend_abi_version(void) { return 3; }
+int eend_abi_version(void) { return 4; }
 
 int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                          const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,

@@ -22,20 +22,21 @@ DropSpec drop_spec(const eend_dropout* d) {
     return s;
 }
 
-// Output tile and token split of a weight gradient.  Large token counts with 256-aligned shapes take the 256 x 256 tile
-// (one 8-wave workgroup per CU, half the operand bytes per flop: wgrad.hip); the token axis is split so that about one
-// round of workgroups runs (512 for the 128-tile, 256 for the 256-tile), in multiples of 8 so that every XCD owns whole
-// splits, within the workspace.  EEND_WGRAD_TILE=128 forces the small tile (A/B).
+// Output tile and token split of a weight gradient (wgrad.hip).  256-aligned shapes take the 256 x 256 tile (one 8-wave
+// workgroup per CU, half the operand bytes per flop), the others the 128 x 128 tile (two 4-wave workgroups per CU); the token
+// axis is split so that about one round of workgroups runs, in multiples of 8 so that every XCD owns whole splits, within the
+// workspace.
 int plan_wgrad(long M, int N, int K, int conv_cin, long ws_floats, int* tile, int* nsplit, long* m_per_split, bool with_bias = false) {
     const long tile_floats = (long)N * K + (with_bias ? N : 0);      // per split: the partial tile (+ the partial column sums)
     if (tile_floats <= 0 || ws_floats < tile_floats) return EEND_EINVAL;
-    static const int force = getenv("EEND_WGRAD_TILE") ? atoi(getenv("EEND_WGRAD_TILE")) : 0;
-    // (a single 256 x 256 output -- N = K = 256 -- keeps the small tile: same speed, half the partials to reduce)
-    const bool big = force != 128 && M >= 131072 && (N % 256) == 0 && (K % 256) == 0 && (long)N * K > 65536 && conv_cin == 0;
-    // (with the bias gradient on the side the 128-tile is used: the 256-tile has no registers left for the column sums --
-    //  measured with them spilled: FS step 17.86 vs 17.60 ms, LS 40.78 vs 40.67 ms)
-    const bool big_ok = big && !with_bias;
-    const int bt = big_ok ? 256 : 128, slots = big_ok ? 256 : 512;
+    const bool big = (N % 256) == 0 && (K % 256) == 0 && (conv_cin == 0 || (conv_cin % 256) == 0) && M >= 16384;
+#ifdef EEND_WG_FORCE128                                   // study build (tools/ab_one_source.sh)
+    const int bt = 128;
+    const int slots = eend_cu_count() * 2;
+#else
+    const int bt = big ? 256 : 128;
+    const int slots = eend_cu_count() * (big ? 1 : 2);
+#endif
     *tile = bt;
     const int ntiles = (N / bt) * (K / bt);
     long want = (slots + ntiles - 1) / ntiles;
@@ -218,7 +219,7 @@ int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f1
     if (rc != EEND_OK) return rc;
     rc = eend_launch_wgrad(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    return eend_launch_wgrad_reduce(ws, (long)N * K, p.nsplit, N, K, K_out, out, ld_out, scale, accumulate, (hipStream_t)stream);
+    return eend_launch_wgrad_reduce_tiles(ws, p.tile, p.nsplit, N, K, K_out, out, ld_out, scale, accumulate, (hipStream_t)stream);
 }
 
 int eend_wgrad_bias_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
@@ -232,7 +233,7 @@ int eend_wgrad_bias_bf16(const void* dY, int lda, const void* X, int ldb, int x_
     p.bias_partial = ws + (size_t)p.nsplit * N * K;
     rc = eend_launch_wgrad(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws, (long)N * K, p.nsplit, N, K, K_out, out, ld_out, scale, accumulate, (hipStream_t)stream);
+    rc = eend_launch_wgrad_reduce_tiles(ws, p.tile, p.nsplit, N, K, K_out, out, ld_out, scale, accumulate, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     return eend_launch_wgrad_reduce(p.bias_partial, N, p.nsplit, 1, N, N, bias_out, N, scale, accumulate, (hipStream_t)stream);
 }
@@ -250,7 +251,7 @@ int eend_conv1d_wgrad_bf16(const void* dY, const void* X_f16, const int* ilens, 
     if (rc != EEND_OK) return rc;
     rc = eend_launch_wgrad(p, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws, (long)N * K, p.nsplit, N, K, K, tmp, K, 1.0f, 0, (hipStream_t)stream);
+    rc = eend_launch_wgrad_reduce_tiles(ws, p.tile, p.nsplit, N, K, K, tmp, K, 1.0f, 0, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     return eend_launch_conv_wgrad_unpermute(tmp, out, N, cin, ktaps, (hipStream_t)stream);
 }

@@ -383,7 +383,7 @@ void ffn_fused_kernel(const FfnParams p) {
             f16x4 zz;
             zz[0] = to_f16_sat(z0); zz[1] = to_f16_sat(z1); zz[2] = to_f16_sat(z2); zz[3] = to_f16_sat(z3);
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, zz), rsZ, (m0 + row) * (p.F * 2) + col * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, zz), rsZ, (unsigned)(m0 + row) * (unsigned)(p.F * 2) + col * 2, 0, 0);
             z0 = (float)zz[0]; z1 = (float)zz[1]; z2 = (float)zz[2]; z3 = (float)zz[3];
         }
     };
@@ -1049,7 +1049,7 @@ void ffn_fused_kernel(const FfnParams p) {
                 constexpr int pass = decltype(PASS)::value;
                 const int row = pass * 64 + (tid >> 3), c8 = tid & 7;
                 const u32x4 v = *(const u32x4*)(Hc + swz128(row, c8));
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsH, (m0 + row) * (p.F * 2) + (c * FC + c8 * 8) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsH, (unsigned)(m0 + row) * (unsigned)(p.F * 2) + (c * FC + c8 * 8) * 2, 0, 0);
             }
         };
 
@@ -1097,7 +1097,7 @@ void ffn_fused_kernel(const FfnParams p) {
             for (int pass = 0; pass < 2; ++pass) {
                 const int row = pass * 64 + (tid >> 3), c8 = tid & 7;
                 const u32x4 v = *(const u32x4*)(Hl + swz128(row, c8));
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsH, (m0 + row) * (p.F * 2) + ((nF - 1) * FC + c8 * 8) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsH, (unsigned)(m0 + row) * (unsigned)(p.F * 2) + ((nF - 1) * FC + c8 * 8) * 2, 0, 0);
             }
         }
         gemm2(smem + V2_W2 + cb * W2_BYTES, smem + V2_HS + cb * HS_BYTES);
@@ -1135,7 +1135,7 @@ extern "C" int eend_debug_ffn_trace(void* dst, void* stream) {
 int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || (p.F % FC) != 0 || (p.ldx & 7) || !p.W1 || !p.W2) return EEND_EINVAL;
     if (p.hidmask) {                                         // data-gradient backward of the block (bf16 operands)
-        if (!p.X || p.A || !p.hid16 || !p.res || !p.out32 || act != 0 || (size_t)p.M * p.F * 2 >= (1ull << 32) ||
+        if (!p.X || p.A || !p.hid16 || !p.res || !p.out32 || act != 0 || ((size_t)p.M + 128) * p.F * 2 >= (1ull << 32) ||
             (((size_t)p.hid16 | (size_t)p.hidmask | (size_t)p.res | (size_t)p.out32) & 15))
             return EEND_EINVAL;
         return launch<0, FFN_EPI_RES_LN, 4>(p, stream);
@@ -1154,7 +1154,7 @@ int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stre
     }
     if (!p.X) return EEND_EINVAL;
     if (p.hid16) {                                           // training forward (post-norm ReLU block)
-        if (!p.res || !p.out32 || !p.xhat16 || !p.rstat || p.out16lo || (size_t)p.M * p.F * 2 >= (1ull << 32) ||
+        if (!p.res || !p.out32 || !p.xhat16 || !p.rstat || p.out16lo || ((size_t)p.M + 128) * p.F * 2 >= (1ull << 32) ||
             (((size_t)p.hid16 | (size_t)p.xhat16 | (size_t)p.z16) & 15))
             return EEND_EINVAL;
         if (act == 1 && epi == FFN_EPI_RES_LN && !p.z16) return launch<1, FFN_EPI_RES_LN, 3>(p, stream);

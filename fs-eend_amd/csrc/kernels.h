@@ -392,19 +392,22 @@ int eend_launch_ret_state_scan_only(const RetParams& p, hipStream_t stream);
 struct WgradParams {          // wgrad.hip: partial[s][n][k] = sum_{m in split s} A[m][n] * B[m][k]
     const void* A;            // dY, bf16 [M][lda]
     const void* B;            // X, f16 (b_is_f16) or bf16 [M][ldb]
-    float* partial;           // f32 [nsplit][N][K]
+    float* partial;           // f32 [nsplit][N * K]: per split, the output tiles in the accumulator order of wgrad_tr_kernel
+                              // (summed and scattered to [N][K] by eend_launch_wgrad_reduce_tiles)
     float* bias_partial;      // optional f32 [nsplit][N]: column sums of A per split (the bias gradient on the side)
     long M;
     int N, K, lda, ldb;
     int nsplit;
     long m_per_split;         // multiple of 64
-    int tile;                 // output tile edge: 128 (default) or 256 (N, K, conv_cin multiples of 256)
+    int tile;                 // output tile edge: 128 or 256 (N, K, conv_cin multiples of it)
     int b_is_f16;
     // Conv1d weight gradient: B rows of k-tile (tap, c_in block) are read at frame t + tap - conv_pad (zero outside [0, ilen))
     int conv, conv_cin, conv_pad, Tp;
     const int* ilens;
 };
 int eend_launch_wgrad(const WgradParams& p, hipStream_t stream);
+int eend_launch_wgrad_reduce_tiles(const float* partial, int tile, int nsplit, int N, int K, int K_out, float* out, int ld_out,
+                                   float scale, int accumulate, hipStream_t stream);
 int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit, int N, int K, int K_out, float* out,
                              int ld_out, float scale, int accumulate, hipStream_t stream);
 int eend_launch_colsum_partial(const void* Y, int ld, long M, int N, int is_bf16, int nsplit, float* partial,

@@ -1,57 +1,131 @@
 // Weight gradients of the training step:  dW[n][k] = sum_m dY[m][n] * X[m][k]   ("TN" GEMM: both operands are
 // stored token-major, the contraction runs over the token axis m).
 //
-// MFMA fragments want the contraction index contiguous per lane, the operands have it strided.  The transpose
-// happens once, in registers, on the way from HBM to LDS: a thread loads an 8-token x 8-feature block (8 coalesced
-// 16-byte loads), transposes it with 32 byte-permutes (transpose8x8_b16) and writes 8 feature rows of 8 tokens.
-// After that the LDS tiles are [feature][64 tokens] -- exactly the K-contiguous image of gemm.hip -- and the inner
-// loop is the same conflict-free ds_read_b128 + v_mfma_f32_16x16x32_bf16 stream.
+// MFMA fragments want the contraction index contiguous per lane, the operands have it strided.  Round 6: the
+// transposition is done by the LDS read itself.  The token rows go from HBM / L2 straight into LDS by LDS-DMA
+// (buffer_load ... lds, 16 bytes per lane, no staging registers, no VALU), row-major [32 tokens][BT features] per operand and
+// stage, and the fragments are fetched with ds_read_b64_tr_b16: a 16-lane group reads a [4 tokens][16 features] block and every
+// lane receives the 4 tokens of ITS feature -- two reads make the 8-token k-group of a v_mfma_f32_32x32x16_bf16 operand
+// (lane = feature, lane / 32 = k-group).  Which tokens form a k-group is irrelevant as long as both operands agree.
+// (Rounds 2 - 5 transposed 8 x 8 blocks in registers on the way to LDS: 32 byte-permutes + 8 ds_write_b128 per thread and step,
+// one 64-token register set in flight: ~30 GB/s per CU = 0.2 of the MFMA peak on the FFN shapes; the f16 -> bf16 conversion of
+// a saved activation sat in the same staging path.)
 //
-// dY is bf16 (gradients need the exponent range).  X is a saved forward activation: f16 (converted to bf16 in the
-// staging registers) or bf16.  Accumulation is f32.  The token range is split over `nsplit` workgroups per output
-// tile; every workgroup writes its partial tile to a workspace and wgrad_reduce_kernel sums the partials in a fixed
-// order (deterministic: no atomics), optionally scales, and writes the f32 gradient with the destination's own row
-// stride (the flat gradient buffer of the optimiser).
+//   * LDS image: row r (token) of an operand is BT * 2 bytes; its 64-byte chunk c is stored at chunk c ^ (r & 3), so the four
+//     token rows a half-wave reads (4 rows x 64 bytes) fall into four distinct quarters of the 256-byte bank row: conflict-free
+//     by the (address / 4) % 64 rule.  The swizzle costs nothing: LDS-DMA writes lane-linear, the SOURCE address of a lane is
+//     permuted instead (still whole 512- / 256-byte rows per instruction).
+//   * 4 stages of 32 tokens (128 KB at BT = 256): three stages = 96 KB per CU in flight, one barrier per stage with a counted
+//     vmcnt (every wave issues exactly four DMA instructions per stage; rows beyond the split are out of bounds of the buffer
+//     resource and arrive as zeros, so the count never changes).
+//   * dY is bf16 (gradients need the exponent range).  X is a saved forward activation: f16 or bf16; f16 fragments are
+//     converted behind the read (v_cvt_f32_f16 + v_cvt_pk_bf16_f32: 24 VALU per 8 MFMAs, on the 64-feature side of the
+//     wave tile).  Accumulation is f32.
+//   * workgroup = BT x BT outputs (BT = 256: 8 waves, 128 accumulator registers each, wave tile 64 k x 128 n; BT = 128: 4 waves,
+//     64 x 64).  The FFN shapes are bound by operand delivery (128 flop per byte from L2 at BT = 256; HBM floor of
+//     [196608, 2048, 256]: 0.9 GB = 113 us) -- not by the MFMA pipe.
+//   * the token range is split over `nsplit` workgroups per output tile; every workgroup writes its partial tile in ACCUMULATOR
+//     ORDER (whole 1-KB lines per store instruction) and wgrad_reduce_tr_kernel sums the partials in a fixed order
+//     (deterministic: no atomics), scales, and scatters to the f32 gradient with the destination's own row stride.
+//   * bias gradient on the side (column sums of dY): one more MFMA per k-step against a fragment of ones, by the wave whose
+//     k-group index equals the n-fragment index, in the workgroups of k-tile 0 only (every dY element is seen there once).
 //
 // Conv1d weight gradient (FS model :30,:40): the same kernel with the X rows of k-tile (tap, c_in block) read at
-// frame t + tap - pad of the same sequence, zero outside [0, ilen) -- the implicit-GEMM loader of gemm.hip mirrored.
+// frame t + tap - pad of the same sequence, zero outside [0, ilen) -- an out-of-bounds source offset per lane.
 #include "train_common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
-#ifndef EEND_WGRAD_PF
-#define EEND_WGRAD_PF 2         // register sets of the global -> LDS staging pipeline (prefetch distance in 64-token steps)
-#endif
-#ifndef EEND_WGRAD_XCD
-#define EEND_WGRAD_XCD 1        // 0: the plain block order (kept for the same-box A/B, tools/ab_variants.sh)
-#endif
-constexpr int TN_BM = 64;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// BT = output tile edge: 128 (4 waves, 64 KB LDS, two workgroups per CU) or 256 (8 waves, 128 KB LDS, one per CU).
-// The kernel is bound by operand delivery, not by HBM or the MFMA pipe (PMC on [393216, 256, 2048]: FETCH_SIZE = the
-// algorithmic 1.8 GB, MFMA pipe 19 % busy, L2 serving 6.5 GB = every tile's own copy of its dY / X rows at ~7.5 TB/s,
-// ~30 GB/s per CU, for every shape tried), so the lever is bytes per flop: a 256 x 256 tile needs half of them.
-// Measured, same box: 15-18 % faster on the shapes with more than one 256-tile (e.g. [393216, 256, 2048] 866 -> 737 us,
-// 559 TFLOP/s); deeper register prefetch (2 / 3 sets, branch-free loads so that the waits are partial) changed nothing.
-template <bool B_F16, bool CONV, int BT, bool BIAS>
+constexpr int TR_TS = 32;           // tokens per stage
+#ifndef EEND_WG_NST
+#define EEND_WG_NST 4
+#endif
+constexpr int TR_NST = EEND_WG_NST; // stages in the ring
+// timing-only study builds (tools/ab_one_source.sh; results are garbage): EEND_WG_NOREAD = no fragment reads, EEND_WG_NODMA = no LDS-DMA
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 tokens of this lane's feature (see the header): the lane supplies the LDS address of ITS 8 bytes of the [4][16] block.
+// By hand: behind the builtin (__builtin_amdgcn_ds_read_tr16_b64_*) hipcc 7.2 waits for vmcnt(0) -- every LDS-DMA piece in
+// flight -- before the first read of a stage (it does not for plain LDS loads); the price is that lgkmcnt is counted by hand too
+// (tr_wait ties the registers it releases, so that their consumers cannot be scheduled in front of the wait).
+template <int OFF>
+DEV u32x2 tr_read(unsigned addr) {
+    u32x2 v;
+#ifdef EEND_WG_NOREAD
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v[0]) : "v"(addr));
+    v[1] = v[0];
+#else
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#endif
+    return v;
+}
+template <int N>
+DEV void tr_wait(u32x2 (&a)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) : "n"(N));
+}
+template <int N>
+DEV void tr_wait(u32x2 (&a)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]),
+                 "+v"(a[3][0]), "+v"(a[3][1]) : "n"(N));
+}
+template <int N>
+DEV void tr_wait(u32x2 (&a)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+}
+// ... and an accumulator of the previous k-step's last MFMA: keeps the wait of k-step 1 behind the MFMAs of k-step 0
+// (volatile asm statements keep their order among themselves only; hipcc had hoisted all waits in front of the first MFMA)
+template <int N>
+DEV void tr_wait_after(u32x2 (&a)[2][2], f32x16& c) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(c) : "n"(N));
+}
+
+template <bool F16>
+DEV bf16x8 tr_frag(const u32x2 (&r)[2]) {
+    if constexpr (F16) {
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v fl = __builtin_convertvector(__builtin_bit_cast(f16x4, r[0]), f32x4v);
+        const f32x4v fh = __builtin_convertvector(__builtin_bit_cast(f16x4, r[1]), f32x4v);
+        const bf16x4 bl = __builtin_convertvector(fl, bf16x4), bh = __builtin_convertvector(fh, bf16x4);
+        return __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+        return __builtin_shufflevector(__builtin_bit_cast(bf16x4, r[0]), __builtin_bit_cast(bf16x4, r[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+// uniform 32-bit load through the scalar cache (a kernel that stores gets vector loads + vmcnt(0) for p.ilens[seq] otherwise)
+DEV int sload_i32(const int* base, int idx) {
+    int v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(idx * 4) : "memory");
+    return v;
+}
+
+template <bool B_F16, bool CONV, bool BIAS, int BT>
 __global__ __launch_bounds__(BT * 2)
-void wgrad_tn_kernel(const WgradParams p) {
-    constexpr int TN_BN = BT, TN_BK = BT;
-    constexpr int HT = BT;                                            // threads staging one operand (BT / 8 feature groups x 8)
-    constexpr int JN = BT / 32;                                       // 16-wide n fragments per wave (wave tile 64 k x BT / 2 n)
-    constexpr int PF = BT == 128 ? EEND_WGRAD_PF : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x (A^T [BT][128 B] + B^T [BT][128 B])
+void wgrad_tr_kernel(const WgradParams p) {
+    constexpr int ROWB = BT * 2;                                      // bytes of a token row of one operand
+    constexpr int OPB = TR_TS * ROWB;                                 // one operand of one stage
+    constexpr int STB = 2 * OPB;                                      // one stage: dY rows, then X rows
+    constexpr int NJ = BT / 64;                                       // 32-wide n fragments per wave (wave tile 64 k x BT / 2 n)
+    constexpr int RPI = 1024 / ROWB;                                  // token rows per DMA instruction (2 / 4)
+    constexpr int LPR = 64 / RPI;                                     // lanes per row (32 / 16)
+    constexpr int NDA = BT / 16;                                      // DMA instructions per operand and stage (16 / 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave >> 1, wn = wave & 1;                          // wave tile: 64 k-rows x BT / 2 n-cols
-    const int ntk = p.K / TN_BK, ntn = p.N / TN_BN;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int ntk = p.K / BT, ntn = p.N / BT;
     // block -> (output tile, token split).  XCD-aware when the split count allows it: workgroup b runs on XCD b % 8
     // (hardware round-robin), and ALL output tiles of a token split go to one XCD, so that the split's dY / X rows are
-    // fetched from HBM once and the ntk / ntn-fold re-reads by the other tiles are hits in that XCD's L2 (same-box A/B:
-    // 5-8 % on every shape; the plain b % ntiles order put the four tiles of a [M, 256, 256] split on four XCDs).
+    // fetched from HBM once and the re-reads by the other tiles are hits in that XCD's L2.
     int tile, split;
-    if (EEND_WGRAD_XCD && (p.nsplit & 7) == 0) {
+    if ((p.nsplit & 7) == 0) {
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
         split = (i / (ntk * ntn)) * 8 + xcd;
         tile = i % (ntk * ntn);
@@ -59,189 +133,226 @@ void wgrad_tn_kernel(const WgradParams p) {
         tile = blockIdx.x % (ntk * ntn);
         split = blockIdx.x / (ntk * ntn);
     }
-    const int n0 = (tile / ntk) * TN_BN, k0 = (tile % ntk) * TN_BK;
+    const int n0 = (tile / ntk) * BT, k0 = (tile % ntk) * BT;
     const long m_begin = (long)split * p.m_per_split;
     long m_end = m_begin + p.m_per_split;
     if (m_end > p.M) m_end = p.M;
-    const int nsteps = m_end > m_begin ? (int)((m_end - m_begin + TN_BM - 1) / TN_BM) : 0;
+    const int m_len = m_end > m_begin ? (int)(m_end - m_begin) : 0;
+    const int nsteps = (m_len + TR_TS - 1) / TR_TS;
 
-    // staging role: the first half of the threads transposes the dY tile, the second the X tile; unit = (8 tokens mg, 8 features fc)
-    const bool isB = tid >= HT;
-    const int u = tid & (HT - 1), fc = u & (BT / 8 - 1), mg = u / (BT / 8);
-    const unsigned short* src = isB ? (const unsigned short*)p.B + (CONV ? 0 : k0) + fc * 8
-                                    : (const unsigned short*)p.A + n0 + fc * 8;
-    const int ld = isB ? p.ldb : p.lda;
+    // ---- LDS-DMA role of this wave: instructions d = wave * 4 + e of the BT / 8 per stage; the first NDA fill dY, the rest X
+    const bool isB = wave * 4 >= NDA;                                 // (wave-uniform)
+    const int dl0 = wave * 4 - (isB ? NDA : 0);                       // first instruction of this wave inside its operand
+    const int rl = lane / LPR, p16 = lane % LPR;                      // row inside the instruction, 16-byte position inside the row
     int conv_shift = 0, conv_c0 = 0;
     if constexpr (CONV) {
         const int tap = k0 / p.conv_cin;
         conv_c0 = k0 - tap * p.conv_cin;
         conv_shift = tap - p.conv_pad;
     }
+    const bool convB = CONV && isB;
+    const int ld = isB ? p.ldb : p.lda;
+    __amdgpu_buffer_rsrc_t rs;
+    if (convB) {
+        // absolute rows (the shifted rows of the first / last stage of a split lie outside the split)
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned)((size_t)p.M * p.ldb * 2)), 0x00020000);
+    } else {
+        const char* base = isB ? (const char*)p.B + ((size_t)m_begin * p.ldb + k0) * 2 : (const char*)p.A + ((size_t)m_begin * p.lda + n0) * 2;
+        // rows >= m_len are out of bounds -> zeros (the last row's reach, n0 * 2 + BT * 2 <= ld * 2, stays inside)
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)((size_t)m_len * ld * 2)), 0x00020000);
+    }
+    unsigned voff[4];                                                 // byte offset of this lane's 16 bytes, per instruction, stage 0
+    int vrow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = (dl0 + e) * RPI + rl;                           // token row inside the stage
+        const int q16 = (((p16 >> 2) ^ (r & 3)) << 2) | (p16 & 3);   // the 16-byte chunk that lives at position p16 of row r
+        vrow[e] = r;
+        voff[e] = convB ? (unsigned)(conv_c0 * 2 + q16 * 16) : (unsigned)(r * ld * 2 + q16 * 16);
+    }
+    const unsigned stage_step = (unsigned)(TR_TS * ld * 2);
+    // CONV: sequence / frame of the next stage to be requested, and that sequence's length (loaded one stage ahead)
+    int cseq = 0, ct0 = 0, clen = 0;
+    if constexpr (CONV) {
+        cseq = (int)(m_begin / p.Tp);
+        ct0 = (int)(m_begin - (long)cseq * p.Tp);
+        clen = sload_i32(p.ilens, cseq < (int)((p.M + p.Tp - 1) / p.Tp) ? cseq : 0);
+    }
+    int issued = 0;                                                   // stages requested so far
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+#ifdef EEND_WG_NODMA
+        ++issued;
+        return;
+#endif
+        char* dst = smem + buf * STB + (isB ? OPB : 0) + dl0 * 1024;
+        if (convB) {
+            const bool live = issued < nsteps;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ts = ct0 + vrow[e] + conv_shift;
+                const bool ok = live && ts >= 0 && ts < clen;
+                const unsigned off = ok ? (unsigned)(((long)cseq * p.Tp + ts) * p.ldb * 2) + voff[e] : 0xFFFFFF00u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_char*)(dst + e * 1024), 16, off, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_char*)(dst + e * 1024), 16, voff[e], 0, 0, 0);
+                voff[e] += stage_step;
+            }
+        }
+        if constexpr (CONV) {
+            ct0 += TR_TS;
+            if (ct0 >= p.Tp) {
+                ct0 = 0;
+                ++cseq;
+                if ((long)cseq * p.Tp < p.M) clen = sload_i32(p.ilens, cseq);
+            }
+        }
+        ++issued;
+    };
 
-    // Bias gradient on the side (p.bias_partial): the column sums of dY are accumulated from the staging registers of the dY
-    // stagers -- by the workgroups of k-tile 0 only, every dY element is seen there exactly once -- instead of by a separate
-    // pass over dY (eend_colsum_f32: 3-5 % of a training step, HBM-bound).
+    // ---- fragment addresses of this lane (stage 0, k-step 0): token rows (g >> 1) * 8 + (i16 >> 2) (+ 4 for the second read),
+    // features fb + (g & 1) * 16 + (i16 & 3) * 4 .. + 3 of the 64-byte chunk c = fb / 32, stored at chunk c ^ (row & 3)
+    const int g = lane >> 4, i16 = lane & 15, x2 = i16 >> 2;
+    const int lrow = ((g >> 1) * 8 + x2) * ROWB + (g & 1) * 32 + (i16 & 3) * 8;
+    auto chunk_off = [&](int c) __attribute__((always_inline)) { return ((c & ~3) | ((c & 3) ^ x2)) << 6; };
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+    unsigned addrB[2], addrA[NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) addrB[i] = lds0 + OPB + lrow + chunk_off(wk * 2 + i);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) addrA[j] = lds0 + lrow + chunk_off(wn * NJ + j);
     const bool do_bias = BIAS && (tile % ntk) == 0;
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned addrAb = lds0 + lrow + chunk_off(wn * NJ + (wk & (NJ - 1)));   // the n fragment whose column sums this wave carries
 
-    // PF register sets: the rows of step s are requested PF steps ahead (an MFMA phase is ~0.2 us, a loaded-HBM round trip
-    // ten times that: with one set -- request at s-1, transpose at the end of s-1 -- every step waited for its own loads),
-    // transposed into the LDS buffer one step ahead, consumed at step s.  The loads are branch-free (clamped address +
-    // select) so that the compiler can wait with vmcnt(8 * (PF - 1)) instead of vmcnt(0).
-    u32x4 reg[PF][8];
-    auto gload = [&](int step, u32x4 (&rg)[8]) __attribute__((always_inline)) {
+    f32x16 acc[2][NJ], accb;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const long m = m_begin + (long)step * TN_BM + mg * 8 + r;
-            if constexpr (CONV) {
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (m < m_end) {
-                    if (isB) {
-                        const int seq = (int)(m / p.Tp), t = (int)(m - (long)seq * p.Tp);
-                        const int ts = t + conv_shift;
-                        if (ts >= 0 && ts < p.ilens[seq])
-                            v = *(const u32x4*)(src + ((long)seq * p.Tp + ts) * ld + conv_c0);
-                    } else {
-                        v = *(const u32x4*)(src + m * ld);
-                    }
-                }
-                rg[r] = v;
-            } else {
-                const bool ok = m < m_end;
-                const u32x4 v = *(const u32x4*)(src + (ok ? m : m_begin) * ld);
-                rg[r] = ok ? v : u32x4{0u, 0u, 0u, 0u};
-            }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    // ---- main loop, software-pipelined ACROSS the stage barrier: the fragments of a k-step are requested one k-step ahead
+    // (two register sets, 48 registers), and the barrier that publishes stage st + 1 sits between the two MFMA groups of stage st,
+    // so that no wave meets it with an empty MFMA queue and the first fragments of the next stage travel under this stage's
+    // second group.  (First version: barrier at the stage top, all reads of the stage behind it -- the MFMA pipe was 58 % busy
+    // even with the DMA compiled out: 163 of 198 us at [196608, 2048, 256].)
+    constexpr int RPK = 2 * (2 + NJ + (BIAS ? 1 : 0));                 // fragment reads per k-step
+    u32x2 rb[2][2][2], ra[2][NJ][2], rs1[2][2];
+    auto request = [&](auto SET, unsigned sb) __attribute__((always_inline)) {   // k-step SET of the stage at LDS offset sb -> register set SET
+        constexpr int ks = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { rb[ks][i][0] = tr_read<ks * 16 * ROWB>(addrB[i] + sb); rb[ks][i][1] = tr_read<(ks * 16 + 4) * ROWB>(addrB[i] + sb); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { ra[ks][j][0] = tr_read<ks * 16 * ROWB>(addrA[j] + sb); ra[ks][j][1] = tr_read<(ks * 16 + 4) * ROWB>(addrA[j] + sb); }
+        if constexpr (BIAS) { rs1[ks][0] = tr_read<ks * 16 * ROWB>(addrAb + sb); rs1[ks][1] = tr_read<(ks * 16 + 4) * ROWB>(addrAb + sb); }
+    };
+    auto consume = [&](auto SET) __attribute__((always_inline)) {     // wait for register set SET (the younger set may stay in flight), 8 MFMAs
+        constexpr int ks = decltype(SET)::value;
+        tr_wait_after<RPK>(rb[ks], acc[1][NJ - 1]);                    // (tied to the previous group's last accumulator: keeps the order)
+        tr_wait<RPK>(ra[ks]);
+        if constexpr (BIAS) tr_wait<RPK>(rs1[ks]);
+        bf16x8 bfr[2], afr[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bfr[i] = tr_frag<B_F16>(rb[ks][i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) afr[j] = tr_frag<false>(ra[ks][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[i], afr[j], acc[i][j], 0, 0, 0);
+        if constexpr (BIAS) {
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, tr_frag<false>(rs1[ks]), accb, 0, 0, 0);
         }
     };
-    auto lstore = [&](int buf, const u32x4 (&rg)[8]) __attribute__((always_inline)) {
-        if (do_bias && !isB) {
+    typedef std::integral_constant<int, 0> K0;
+    typedef std::integral_constant<int, 1> K1;
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned v = rg[r][j];
-                    cs[2 * j] += bf16_lo(v);
-                    cs[2 * j + 1] += bf16_hi(v);
-                }
-        }
-        u32x4 in[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (B_F16 && isB) ? f16x8_to_bf16x8(rg[r]) : rg[r];
-        char* base = smem + buf * (2 * TN_BN * 128) + (isB ? TN_BN * 128 : 0);
-        if constexpr (BT == 256) {
-            // 128 accumulator registers: one transposed row at a time (4 live registers instead of 32), addresses recomputed
-            int fc_ = fc, mg_ = mg;
-            asm volatile("" : "+v"(fc_), "+v"(mg_));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                u32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned a = in[2 * j][e >> 1], b = in[2 * j + 1][e >> 1];
-                    o[j] = (e & 1) ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16));
-                }
-                *(u32x4*)(base + swzT(fc_ * 8 + e, mg_)) = o;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            u32x4 out[8];
-            transpose8x8_b16(in, out);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *(u32x4*)(base + swzT(fc * 8 + e, mg)) = out[e];
-        }
-    };
-
-    f32x4 acc[4][JN];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow_c = lane & 15, fkg_c = lane >> 4;
-
-    auto mma_step = [&](int buf) __attribute__((always_inline)) {
-        int frow = frow_c, fkg = fkg_c;
-        if (BT == 256) asm volatile("" : "+v"(frow), "+v"(fkg));     // 128 accumulator registers: recompute the 24 fragment
-                                                                      // addresses per step instead of keeping them (and spilling)
-        const char* at = smem + buf * (2 * TN_BN * 128);              // dY^T: [n][64 m]
-        const char* bt = at + TN_BN * 128;                           // X^T : [k][64 m]
-        if constexpr (BT == 256) {
-            // 128 accumulator registers: fragments are fetched in small groups (4 n-fragments, then one k-fragment per 4 MFMAs)
-            // and the groups are fenced, so that at most 20 fragment registers are live
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int jh = 0; jh < 2; ++jh) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    bf16x8 lf[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) lf[j] = *(const bf16x8*)(at + swzT(wn * 128 + (jh * 4 + j) * 16 + frow, ks * 4 + fkg));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bf16x8 rf = *(const bf16x8*)(bt + swzT(wk * 64 + i * 16 + frow, ks * 4 + fkg));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf, lf[j], acc[i][jh * 4 + j], 0, 0, 0);
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 rf[4], lf[JN];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rf[i] = *(const bf16x8*)(bt + swzT(wk * 64 + i * 16 + frow, ks * 4 + fkg));
-#pragma unroll
-            for (int j = 0; j < JN; ++j) lf[j] = *(const bf16x8*)(at + swzT(wn * (BT / 2) + j * 16 + frow, ks * 4 + fkg));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < JN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[i], lf[j], acc[i][j], 0, 0, 0);
-        }
-        }
-    };
-    // steps beyond nsteps load nothing (all rows >= m_end select zero) and add zero: the trip count is rounded up to the
-    // unroll factor instead of breaking out of the unrolled body
-#pragma unroll
-    for (int d = 0; d < PF; ++d) gload(d, reg[d]);
-    lstore(0, reg[0]);
-    __syncthreads();
-    constexpr int UN = (PF & 1) ? 2 * PF : PF;                        // register set AND LDS buffer static inside the body
-    for (int st0 = 0; st0 < nsteps; st0 += UN) {
-#pragma unroll
-        for (int dd = 0; dd < UN; ++dd) {
-            const int st = st0 + dd;
-            gload(st + PF, reg[dd % PF]);                             // reg[dd % PF] (step st) went to LDS during step st - 1
-            mma_step(dd & 1);
-            lstore((dd & 1) ^ 1, reg[(dd + 1) % PF]);
-            __syncthreads();
-        }
+    for (int s = 0; s < TR_NST - 1; ++s) issue(s);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * (TR_NST - 2)));           // this wave's pieces of stage 0 (two younger stages in flight)
+    __builtin_amdgcn_s_barrier();
+    request(K0{}, 0u);
+    int buf = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        const unsigned sb = buf * STB;
+        const int nb = buf + 1 == TR_NST ? 0 : buf + 1;
+        request(K1{}, sb);
+        consume(K0{});
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's pieces of stage st + 1 have landed (one younger stage may stay in flight); behind the barrier every wave's
+        // have, and every wave has its last fragments of stage st - 1 in registers: that buffer takes stage st + 3
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * (TR_NST - 3)));
+        __builtin_amdgcn_s_barrier();
+        issue(buf == 0 ? TR_NST - 1 : buf - 1);
+        request(K0{}, (unsigned)(nb * STB));                           // (beyond the last stage: zero rows, never consumed)
+        consume(K1{});
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nb;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the trailing request
 
-    if (do_bias) {                                                    // the loop ended on a barrier: the LDS tiles are free
-        float* red = (float*)smem;                                    // [8 token groups][BT]
-        if (!isB) {
+    // ---- partial tile in accumulator order: [split][tile][wave][i][j][register quad][lane] as f32x4
+    // acc[i][j][r]: k = k0 + wk*64 + i*32 + 8*(r>>2) + (lane>>5)*4 + (r&3),  n = n0 + wn*(BT/2) + j*32 + (lane&31)
+    float* __restrict__ out = p.partial + (size_t)split * p.N * p.K + (size_t)tile * (BT * BT) + (size_t)wave * (2 * NJ * 16 * 64);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[mg * BT + fc * 8 + e] = cs[e];
-        }
-        __syncthreads();
-        if (tid < BT) {
-            float t = 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int gsum = 0; gsum < 8; ++gsum) t += red[gsum * BT + tid];
-            p.bias_partial[(size_t)split * p.N + n0 + tid] = t;
-        }
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = f32x4{acc[i][j][r4 * 4], acc[i][j][r4 * 4 + 1], acc[i][j][r4 * 4 + 2], acc[i][j][r4 * 4 + 3]};
+                *(f32x4*)(out + (((i * NJ + j) * 4 + r4) * 64 + lane) * 4) = v;
+            }
+    if constexpr (BIAS) {
+        // every row of accb is the column sum: register 0 of lanes 0..31 (row 0) carries n = lane
+        if (do_bias && wk < NJ && lane < 32)
+            p.bias_partial[(size_t)split * p.N + n0 + wn * (BT / 2) + wk * 32 + lane] = accb[0];
     }
-    // acc[i][j][r]: k = k0 + wk*64 + i*16 + fkg*4 + r (4 consecutive k per lane), n = n0 + wn*(BT/2) + j*16 + frow
-    const int frow = frow_c, fkg = fkg_c;
-    float* __restrict__ out = p.partial + (size_t)split * p.N * p.K;
+}
+
+// out[n][k] (row stride ld_out, k < K_out) = scale * sum_s partial[s][...]   (+ out if accumulate), partial in the accumulator order
+// of wgrad_tr_kernel<BT>: one thread per f32x4, consecutive threads read consecutive 16 bytes of every split's partial.
+template <int BT>
+__global__ __launch_bounds__(256)
+void wgrad_reduce_tr_kernel(const float* __restrict__ partial, long split_stride, int nsplit, int N, int K, int K_out,
+                            float* __restrict__ out, int ld_out, float scale, int accumulate) {
+    constexpr int NJ = BT / 64;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // f32x4 slot
+    if (idx >= (long)N * K / 4) return;
+    const int ntk = K / BT;
+    const int tile = (int)(idx / (BT * BT / 4));
+    int rem = (int)(idx - (long)tile * (BT * BT / 4));
+    const int wave = rem / (2 * NJ * 4 * 64);
+    rem -= wave * (2 * NJ * 4 * 64);
+    const int q = rem >> 6, lane = rem & 63;
+    const int i = q / (NJ * 4), j = (q >> 2) % NJ, r4 = q & 3;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int n = (tile / ntk) * BT + wn * (BT / 2) + j * 32 + (lane & 31);
+    const int k = (tile % ntk) * BT + wk * 64 + i * 32 + 8 * r4 + (lane >> 5) * 4;
+    const f32x4* src = (const f32x4*)partial + idx;
+    const long ss4 = split_stride / 4;
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        s0 += src[(size_t)(s + 0) * ss4];
+        s1 += src[(size_t)(s + 1) * ss4];
+        s2 += src[(size_t)(s + 2) * ss4];
+        s3 += src[(size_t)(s + 3) * ss4];
+    }
+    for (; s < nsplit; ++s) s0 += src[(size_t)s * ss4];
+    const f32x4 v = ((s0 + s1) + (s2 + s3)) * scale;
+    float* o = out + (size_t)n * ld_out + k;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < JN; ++j) {
-            const int k = k0 + wk * 64 + i * 16 + fkg * 4, n = n0 + wn * (BT / 2) + j * 16 + frow;
-            *(f32x4*)(out + (size_t)n * p.K + k) = acc[i][j];
-        }
+    for (int e = 0; e < 4; ++e)
+        if (k + e < K_out) o[e] = accumulate ? o[e] + v[e] : v[e];
 }
 
 // out[n][k] (row stride ld_out, k < K_out) = scale * sum_s partial[s][n][k]   (+ out if accumulate)
@@ -352,27 +463,46 @@ void conv_wgrad_unpermute_kernel(const float* __restrict__ tmp, float* __restric
 int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if (!p.A || !p.B || !p.partial || p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
     const int bt = p.tile == 256 ? 256 : 128;
-    if ((p.N % bt) || (p.K % bt) || (p.lda & 7) || (p.ldb & 7) || p.nsplit <= 0 || p.m_per_split <= 0 || (p.m_per_split % TN_BM))
+    if ((p.N % bt) || (p.K % bt) || (p.lda & 7) || (p.ldb & 7) || p.nsplit <= 0 || p.m_per_split <= 0 || (p.m_per_split % 64))
         return EEND_EINVAL;
-    if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % bt) || p.Tp <= 0)) return EEND_EINVAL;
-    const int smem = 2 * 2 * bt * 128;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return EEND_EINVAL;
+    if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % bt) || p.Tp <= 0 || (p.Tp % 64))) return EEND_EINVAL;
+    // 32-bit byte offsets inside a split (inside the whole X tensor for the Conv1d form), four stages of run-ahead included
+    const size_t reach_a = ((size_t)p.m_per_split + 256) * p.lda * 2, reach_b = ((size_t)(p.conv ? p.M : p.m_per_split) + 256) * p.ldb * 2;
+    if (reach_a >= 0xFFFF0000ull || reach_b >= 0xFFFF0000ull) return EEND_EINVAL;
+    const int smem = TR_NST * 2 * TR_TS * bt * 2;
     const dim3 grid((unsigned)((p.N / bt) * (p.K / bt) * p.nsplit));
-#define WG_LAUNCH(F16, CV, BT, BS)                                                                                      \
+#define WG_LAUNCH(F16, CV, BS, BT)                                                                                      \
     do {                                                                                                                \
         static EendOncePerDevice attr_once;                                                                             \
-        if (!eend_set_dynamic_lds(attr_once, (const void*)wgrad_tn_kernel<F16, CV, BT, BS>, smem)) return EEND_ELAUNCH;  \
-        hipLaunchKernelGGL((wgrad_tn_kernel<F16, CV, BT, BS>), grid, dim3(BT * 2), smem, stream, p);                    \
+        if (!eend_set_dynamic_lds(attr_once, (const void*)wgrad_tr_kernel<F16, CV, BS, BT>, smem)) return EEND_ELAUNCH;  \
+        hipLaunchKernelGGL((wgrad_tr_kernel<F16, CV, BS, BT>), grid, dim3(BT * 2), smem, stream, p);                    \
     } while (0)
 #define WG_PICK(BT)                                                                                                     \
     do {                                                                                                                \
-        if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true, BT, false); else WG_LAUNCH(false, true, BT, false); }       \
-        else if (p.bias_partial) { if (p.b_is_f16) WG_LAUNCH(true, false, BT, (BT == 128)); else WG_LAUNCH(false, false, BT, (BT == 128)); } \
-        else { if (p.b_is_f16) WG_LAUNCH(true, false, BT, false); else WG_LAUNCH(false, false, BT, false); }            \
+        if (p.conv) { if (p.b_is_f16) WG_LAUNCH(true, true, false, BT); else WG_LAUNCH(false, true, false, BT); }       \
+        else if (p.bias_partial) { if (p.b_is_f16) WG_LAUNCH(true, false, true, BT); else WG_LAUNCH(false, false, true, BT); } \
+        else { if (p.b_is_f16) WG_LAUNCH(true, false, false, BT); else WG_LAUNCH(false, false, false, BT); }            \
     } while (0)
-    if (p.bias_partial && (p.conv || bt != 128)) return EEND_EINVAL;      // the column sums ride on the 128-tile kernel only
+    if (p.bias_partial && p.conv) return EEND_EINVAL;
     if (bt == 256) WG_PICK(256); else WG_PICK(128);
 #undef WG_PICK
 #undef WG_LAUNCH
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+// the partial tiles of eend_launch_wgrad (accumulator order of its `tile`) -> out[n][k]
+int eend_launch_wgrad_reduce_tiles(const float* partial, int tile, int nsplit, int N, int K, int K_out, float* out, int ld_out,
+                                   float scale, int accumulate, hipStream_t stream) {
+    const int bt = tile == 256 ? 256 : 128;
+    if (!partial || !out || nsplit <= 0 || N <= 0 || K <= 0 || (N % bt) || (K % bt) || K_out <= 0 || K_out > K || ld_out < K_out)
+        return EEND_EINVAL;
+    const long n4 = (long)N * K / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (bt == 256)
+        hipLaunchKernelGGL(wgrad_reduce_tr_kernel<256>, grid, dim3(256), 0, stream, partial, (long)N * K, nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_tr_kernel<128>, grid, dim3(256), 0, stream, partial, (long)N * K, nsplit, N, K, K_out, out, ld_out, scale, accumulate);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

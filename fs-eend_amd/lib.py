@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("EEND_HIP_LIB") or os.path.join(_HERE, "csrc", "libeen
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _l = ctypes.c_long
 
+ABI_VERSION = 4          # EEND_ABI_VERSION of include/eend_hip.h; load() refuses a library that reports another
+
 # name -> argtypes, exactly the prototypes of include/eend_hip.h
 PROTOTYPES = {
     "eend_abi_version": [],
@@ -177,6 +179,9 @@ def load():
             raise EendHipError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    got = lib.eend_abi_version()
+    if got != ABI_VERSION and not os.environ.get("EEND_HIP_LIB"):     # (an A/B study may load an older build on purpose)
+        raise EendHipError(f"{LIB_PATH} has ABI version {got}, this binding was written for {ABI_VERSION} (include/eend_hip.h)")
     _lib = lib
     return lib
 

@@ -303,7 +303,7 @@ class TrainStepBase:
         """linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm of a post-norm block.  One launch (ffn.hip MODE 3: the hidden
         activations are written once for the backward and never re-read) where the shape allows, else the two GEMM launches."""
         F = hid.shape[1]
-        if FFN_TRAIN_FUSED and F % 64 == 0 and M * F * 2 < (1 << 32) and x16.shape[1] == 256:
+        if FFN_TRAIN_FUSED and F % 64 == 0 and (M + 128) * F * 2 < (1 << 32) and x16.shape[1] == 256:
             _call("eend_ffn_train_f16", x16, x16.stride(0), w1, b1, w2, b2, res, 1.0, self._P(ln + ".weight"), self._P(ln + ".bias"), 1e-5,
                   out32, site.out16, hid, site.xhat, site.rstd, M, F, drop_hidden, drop_out)
             return
@@ -341,7 +341,7 @@ class TrainStepBase:
         Fh = hid.shape[1]
         dh = dh16[:M * Fh].view(M, Fh)
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
-        if FFN_TRAIN_FUSED and Fh % 64 == 0 and M * Fh * 2 < (1 << 32):
+        if FFN_TRAIN_FUSED and Fh % 64 == 0 and (M + 128) * Fh * 2 < (1 << 32):
             # dH = scale * (dY W2) under the saved mask, and g += dH W1, in one launch (ffn.hip MODE 4): dH is written once for the weight
             # gradient below and not re-read by the data path
             _call("eend_ffn_bwd_data_bf16", ds16, D, W[wkey + ".w2T"], hid, W[wkey + ".w1T"], drop_scale, dh, g32, M, Fh)

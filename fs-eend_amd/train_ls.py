@@ -23,6 +23,7 @@ probabilities, 3 dropout21, 4 FFN hidden, 5 dropout2}.
 There is no autograd / eager fallback: everything below is a call into libeend_hip.so.
 """
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -32,6 +33,10 @@ from . import ops
 from .lib import EendHipError
 from .shard import all_reduce_bn_sums, gather_bn_stats
 from .train import (BF16, D, F16, F32, H, I32, WS_FLOATS, TrainStepBase, _Site, _call, drop_step_seed)
+
+# EXPERIMENTAL (read once at import): the Macaron half-step FFNs of the Conformer blocks as one training-forward launch each
+# (eend_ffn_swish_train_f16); bit 0 = FFN_a, bit 1 = FFN_b.  See the comment at its use in _forward and INTEGRATION.md.
+MACARON_FUSED = int(os.environ.get("EEND_TRAIN_MACARON_FUSED", "0"))
 
 ENC_FFA_HID, ENC_FFA_OUT, ENC_RET, ENC_CONV, ENC_FFB_HID, ENC_FFB_OUT = 0, 1, 2, 3, 4, 5
 SITE_OUT1, SITE_SPK, SITE_OUT2, SITE_FF, SITE_FFOUT = 1, 2, 3, 4, 5
@@ -291,8 +296,8 @@ class LsTrainStep(TrainStepBase):
         # FFN_b.  Measured 38.45 -> 37.8 ms per step with both, every golden loss within 1e-6 -- but in golden ls_train_clip the gradient norms
         # of decoder layer 1's retention q / k projections (2e-2 of a 1.2 total: the per-head LayerNorm at its eps floor makes them swing with
         # the rounding sample of everything in front) move from 1e-3 off the reference to 0.8e-2 (a), 2.7e-2 (b), 1.5e-2 (both): over the 1e-2 bar.
-        _mac = int(__import__("os").environ.get("EEND_TRAIN_MACARON_FUSED", "0"))
-        fused_ffn = _TR.FFN_TRAIN_FUSED and self.F_enc % 64 == 0 and Me * self.F_enc * 2 < (1 << 32)      # the Macaron FFNs as one launch each
+        _mac = MACARON_FUSED
+        fused_ffn = _TR.FFN_TRAIN_FUSED and self.F_enc % 64 == 0 and (Me + 128) * self.F_enc * 2 < (1 << 32)      # the Macaron FFNs as one launch each
         fused_a, fused_b = fused_ffn and bool(_mac & 1), fused_ffn and bool(_mac & 2)
         for i, sv in enumerate(bf.enc):
             s_ = f"enc.encoder.layers.{i}.sequential."

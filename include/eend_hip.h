@@ -29,7 +29,10 @@ extern "C" {
 #define EEND_EINVAL (-1)
 #define EEND_ELAUNCH (-2)
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change).
+ *   4 (round 6): eend_attnout_ffn_fused_f16 gained out_lo_f16 / Wo_lo and eend_convert_fanout_f32 gained out_lo_f16 (round 5, shipped
+ *      under 3 by mistake); a caller built against the version-3 header must refuse this library. */
+#define EEND_ABI_VERSION 4
 int eend_abi_version(void);
 
 /* Eval-mode BatchNorm1d over features + cast + zero pad to the frame slab.

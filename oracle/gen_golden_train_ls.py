@@ -20,7 +20,10 @@ per-parameter gradient norms and a few gradient entries, parameter entries and t
 statistics after each step.  No reference source or bytecode enters the repository.
 """
 import ast
+import copy
+import functools
 import os
+import math
 import sys
 import types
 from itertools import permutations
@@ -65,7 +68,7 @@ CASES = [
          lseed=818, steps=1, warm=100, clip=5.0, pit=False),
     # ... at the batch size bench.py --mode train --flavour ls times (round 5): 64 utterances, a few of them shorter
     dict(name="ls_train_b64", cfg=cfg(), lengths=[1000] * 60 + [930, 777, 501, 1000], nspk=[4, 4, 3, 4] * 16, seed=55, pseed=65, xseed=819,
-         lseed=820, steps=1, warm=100, clip=5.0, pit=False),
+         lseed=820, steps=1, warm=100, clip=5.0, pit=False, ckpt64=True),
 ]
 
 
@@ -155,6 +158,50 @@ def main():
                     slices.append(sl)
                 arrays["grad_norms"] = np.array(norms, dtype=np.float64)
                 arrays["grad_slices"] = np.stack(slices)
+                # Conditioning of every gradient tensor, measured with the reference itself: the same step in float64 (a double copy
+                # of the model, default dtype float64 while it runs so that the tensors the reference creates on the fly follow).
+                # gap_norm / gap_l2 = |fp32 - fp64| relative to max(||g64||, 1e-3 ||g_total||): what the reference's OWN working
+                # precision does to this tensor.  tests/test_train_step_ls.py scales its per-tensor bar with it (COND_K).
+                m64 = copy.deepcopy(model).double()
+                for p_ in m64.parameters():
+                    p_.grad = None
+                if case.get("ckpt64"):
+                    # the 64-utterance case does not fit this container's memory in float64: every encoder block / decoder layer of
+                    # the double copy is recomputed in the backward (torch.utils.checkpoint around the reference module's own
+                    # forward; same arithmetic, same gradients)
+                    from torch.utils.checkpoint import checkpoint
+                    for layer in list(m64.enc.encoder.layers) + list(m64.dec.layers):
+                        layer.forward = functools.partial(checkpoint, layer.forward, use_reentrant=False)
+                me64 = types.SimpleNamespace(model=m64, loss_func1=pit_multispk, loss_func2=standard_loss, label_delay=0, opt=opt,
+                                             log=lambda k, v, **kw: None)
+                me64.detect = types.MethodType(detect, me64)
+                step64 = types.MethodType(step_pit if case["pit"] else step_plain, me64)
+                torch.set_default_dtype(torch.float64)
+                try:
+                    b64 = [tuple(f.double() for f in feats), tuple(l.double() for l in labels), tuple(range(len(feats)))]
+                    loss64 = step64(b64, 0)
+                    loss64.backward()
+                finally:
+                    torch.set_default_dtype(torch.float32)
+                g64 = {n: (None if p_.grad is None else p_.grad.detach().flatten()) for n, p_ in m64.named_parameters()}
+                tot64 = math.sqrt(sum(float((g ** 2).sum()) for g in g64.values() if g is not None))
+                n64, gap_n, gap_l2 = [], [], []
+                for n, p in model.named_parameters():
+                    if p.grad is None:
+                        n64.append(-1.0); gap_n.append(0.0); gap_l2.append(0.0)
+                        continue
+                    a, b = p.grad.detach().flatten().double() / coef, g64[n]
+                    den = max(float(b.norm()), 1e-3 * tot64)
+                    n64.append(float(b.norm()))
+                    gap_n.append(abs(float(a.norm()) - float(b.norm())) / den)
+                    gap_l2.append(float((a - b).norm()) / den)
+                arrays["grad_norms_f64"] = np.array(n64, dtype=np.float64)
+                arrays["grad_gap_norm"] = np.array(gap_n, dtype=np.float64)
+                arrays["grad_gap_l2"] = np.array(gap_l2, dtype=np.float64)
+                arrays["s0_loss_f64"] = np.array([float(loss64)], dtype=np.float64)
+                worst = sorted(zip(gap_n, names), reverse=True)[:4]
+                print(f"  fp64 rerun: loss {float(loss64):.9f}; median gap {np.median(gap_n):.2e}; worst " +
+                      ", ".join(f"{k} {g:.2e}" for g, k in worst))
             opt.step()
             sched.step()
             sd = model.state_dict()

@@ -146,6 +146,15 @@ def test_wgrad(T, dev, ws, M, N, K, f16):
     assert relnorm(out2, want) < 2e-3 and rel(out2, out) < 1e-4        # (a different split plan: not bit-identical to `out`)
     wantb = dy.double().sum(0)
     assert float((bias.double() - wantb).abs().max()) < 2e-5 * float(dy.double().abs().sum(0).max()), float((bias.double() - wantb).abs().max())
+    # operands that are column blocks of wider tensors (lda > N, ldb > K), as the LS trainer passes them
+    if K == 512:
+        wide_dy = torch.zeros(M, 4 * N, dtype=BF16, device=dev)
+        wide_dy[:, 2 * N:3 * N] = dy
+        wide_x = torch.zeros(M, 2 * K, dtype=x.dtype, device=dev)
+        wide_x[:, K:] = x
+        out3 = torch.full((N, K), 1.0, dtype=F32, device=dev)
+        T._call("eend_wgrad_bf16", wide_dy[:, 2 * N:], 4 * N, wide_x[:, K:], 2 * K, 1 if f16 else 0, M, N, K, ws, ws.numel(), out3, K, K, 1.0, 0)
+        assert (out3 == out).all()
     # transpose-detecting: an asymmetric case is already covered (N != K); accumulate + narrow destination
     if K == 384:
         dst = torch.ones(N, 345, dtype=F32, device=dev)
@@ -170,8 +179,11 @@ def _conv_case(dev, seed, nseq=3, Tp=128, lens=(100, 128, 37)):
     return x, w, dy, list(lens)
 
 
-def test_conv1d_grads(T, dev, ws):
-    x, w, dy, lens = _conv_case(dev, 11)
+@pytest.mark.parametrize("big", [False, True])
+def test_conv1d_grads(T, dev, ws, big):
+    # big: >= 16384 token rows -> the 256 x 256 output tile of wgrad.hip (one tap x all 256 input channels per k-tile)
+    x, w, dy, lens = _conv_case(dev, 12, nseq=36, Tp=512, lens=tuple(512 - 13 * (i % 7) - (300 if i == 5 else 0) for i in range(36))) if big \
+        else _conv_case(dev, 11)
     nseq, Tp = x.shape[0], x.shape[1]
     Tmax = max(lens)
     x16 = x.to(F16)

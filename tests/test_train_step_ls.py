@@ -6,6 +6,14 @@ an fp64 restatement, and size-independent properties at BASELINE config 4's LS s
 Bars: loss within 1e-4; per-parameter gradient norms within 1e-2 relative (plus a small absolute
 floor for parameters whose gradient is ~0); single gradient entries within ENTRY_BAR of the tensor's gradient norm;
 parameters after Adam within a fraction of the learning rate; BatchNorm running statistics within 1e-4 / 1e-3.
+
+Conditioned bar: no hand-picked constant above 1e-2.  A few gradient tensors -- the retention q / k
+projections behind a per-head LayerNorm at its eps floor -- are ill-conditioned at random init: the reference's own fp32
+step and the same step in fp64 disagree on them ten to ninety times more than on the median tensor (stored per tensor in
+the golden as `grad_gap_l2` by oracle/gen_golden_train_ls.py; measured on the fly with the fp32 / fp64 oracle in the dropout
+test).  The bar of a tensor is max(1e-2, COND_K * gap), COND_K = 2^13 = the ratio of the unit roundoffs of f16 (the forward
+operand type of the HIP path; its gradient operands are bf16, 2^16) and f32 (the reference's): what the reference's own
+discrepancy on that tensor becomes at the HIP path's working precision.
 """
 import math
 
@@ -19,6 +27,12 @@ from tests.helpers import build_ls_mirror
 pytestmark = pytest.mark.gpu
 CASES = FX.list_cases("ls_train_")
 ENTRY_BAR = 5e-2        # |entry error| / ||gradient of that tensor||: bf16 gradient operands, a handful of entries per tensor
+COND_K = 8192.0         # 2^13 = eps(f16) / eps(f32): see the module docstring
+
+
+def cond_bar(gap):
+    """Relative error allowed on a gradient tensor whose fp32-vs-fp64 discrepancy in the reference is `gap`."""
+    return max(1e-2, COND_K * float(gap))
 
 
 def _slice_index(numel, n=24):
@@ -59,6 +73,7 @@ def test_ls_train_step_vs_reference(hip_lib, dev, name):
         assert abs(got[1] - want[1]) < ltol and abs(got[2] - want[2]) < ltol and abs(got[0] - want[0]) < ltol
         if s == 0:
             tot = arr["s0_gradnorm"][0]
+            gaps = arr["grad_gap_l2"]                    # the reference's own fp32-vs-fp64 discrepancy per tensor
             entries = []
             for i, k in enumerate(names):
                 g = eng.flat.g(k)
@@ -68,16 +83,16 @@ def test_ls_train_step_vs_reference(hip_lib, dev, name):
                 assert bool(torch.isfinite(g).all()), k
                 gn = float(g.double().norm())
                 ref = arr["grad_norms"][i]
-                report.append((abs(gn - ref) / max(ref, 1e-3 * tot), k, gn, ref))
+                report.append((abs(gn - ref) / max(ref, 1e-3 * tot), k, gn, ref, cond_bar(gaps[i])))
                 idx = _slice_index(g.numel())
                 sl = g.flatten()[torch.as_tensor(idx, device=dev)].cpu().numpy()
                 entries.append((np.abs(sl - arr["grad_slices"][i][:len(idx)]).max() / max(ref, 1e-3 * tot), k))
             report.sort(reverse=True)
             entries.sort(reverse=True)
-            for err, k, a, b in report[:12]:
-                print(f"   {err:.3e}  {k}: {a:.4e} vs {b:.4e}")
+            for err, k, a, b, bar in report[:12]:
+                print(f"   {err:.3e}  (bar {bar:.1e})  {k}: {a:.4e} vs {b:.4e}")
             print("   worst single entries:", [(f"{e:.2e}", k) for e, k in entries[:4]])
-            bad = [(e, k) for e, k, _, _ in report if e > 1e-2]
+            bad = [(e, k, bar) for e, k, _, _, bar in report if e > bar]
             assert not bad, bad[:10]
             assert entries[0][0] < ENTRY_BAR, entries[:5]
         lr = mod.optimizer_step()
@@ -141,6 +156,13 @@ def test_ls_train_step_with_dropout_vs_oracle(hip_lib, dev, p_drop):
         tot, bce, emb, _, _ = TL.train_loss(sdd, [f.cpu().double() for f in feats], [l.cpu().double() for l in raw], cfg,
                                             dtype=torch.float64, drop=drop)
         grads = dict(zip(pn, torch.autograd.grad(tot, [leaves[k] for k in pn], allow_unused=True)))
+        # the same step with the same masks in fp32: the oracle's own discrepancy per tensor (conditioning, module docstring)
+        leaves32 = {k: sd[k].float().clone().requires_grad_(True) for k in pn}
+        sd32 = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+        sd32.update(leaves32)
+        tot32 = TL.train_loss(sd32, [f.cpu().float() for f in feats], [l.cpu().float() for l in raw], cfg, dtype=torch.float32,
+                              drop=DR.HashDropout(p_drop, 4321, fwd, Tp))[0]
+        grads32 = dict(zip(pn, torch.autograd.grad(tot32, [leaves32[k] for k in pn], allow_unused=True)))
         got = (float(bf.loss[0]), float(bf.loss[1]))
         print(f"LS p={p_drop} fwd {fwd}: bce {got[0]:.6f} (oracle {float(bce):.6f})  emb {got[1]:.6f} ({float(emb):.6f})")
         assert abs(got[0] - float(bce)) < 2e-4 and abs(got[1] - float(emb)) < 1e-4
@@ -153,17 +175,17 @@ def test_ls_train_step_with_dropout_vs_oracle(hip_lib, dev, p_drop):
                 assert float(g.abs().max()) == 0.0, k
                 continue
             ref = grads[k]
-            err = float((g.detach().cpu().double() - ref).norm()) / max(float(ref.norm()), 1e-3 * totn)
-            worst.append((err, k))
+            den = max(float(ref.norm()), 1e-3 * totn)
+            err = float((g.detach().cpu().double() - ref).norm()) / den
+            gap = float((grads32[k].double() - ref).norm()) / den
+            worst.append((err, k, cond_bar(gap)))
         worst.sort(reverse=True)
-        print("   worst rel. gradient errors:", [(f"{e:.2e}", k) for e, k in worst[:5]])
-        # whole-tensor relative L2 error against the fp64 oracle (bf16 gradient operands).  Measured on MI355X: every tensor
-        # <= 6e-3 except the first encoder block's retention q / k projections (the per-head LayerNorm backward in front of
-        # them cancels most of its input): 1.1e-2 at p = 0, 1.3e-2 at the shipped p = 0.1, 2.6e-2 at the stress value 0.3
-        # (30 % of every gradient row zeroed, the rest scaled by 1.43).
-        qk = lambda k: k.endswith(("self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight", "self_attn.k_proj.bias"))
-        assert all(e < (4e-2 if p_drop > 0.1 else 2e-2) for e, k in worst if qk(k)), worst[:5]
-        assert all(e < 1e-2 for e, k in worst if not qk(k)), [w for w in worst if not qk(w[1])][:5]
+        print("   worst rel. gradient errors:", [(f"{e:.2e} (bar {b:.1e})", k) for e, k, b in worst[:5]])
+        # whole-tensor relative L2 error against the fp64 oracle (bf16 gradient operands), bar = max(1e-2, COND_K * the oracle's own
+        # fp32-vs-fp64 discrepancy on that tensor).  Measured on MI355X (round 3 - 5): every tensor <= 6e-3 except the first encoder
+        # block's retention q / k projections (the per-head LayerNorm backward in front of them cancels most of its input): 1.1e-2
+        # at p = 0, 1.3e-2 at the shipped p = 0.1, 2.6e-2 at the stress value 0.3 -- the tensors with the largest gaps (3 - 4e-6).
+        assert all(e < b for e, k, b in worst), [w for w in worst if w[0] >= w[2]][:5]
     assert p_drop == 0.0 or losses[0] != losses[1]    # a new mask every forward
     bf = eng.forward(feats, labels, meta["lengths"], dropout=False)
     torch.cuda.synchronize()
