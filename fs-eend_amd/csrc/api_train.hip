@@ -29,7 +29,9 @@ DropSpec drop_spec(const eend_dropout* d) {
 int plan_wgrad(long M, int N, int K, int conv_cin, long ws_floats, int* tile, int* nsplit, long* m_per_split, bool with_bias = false) {
     const long tile_floats = (long)N * K + (with_bias ? N : 0);      // per split: the partial tile (+ the partial column sums)
     if (tile_floats <= 0 || ws_floats < tile_floats) return EEND_EINVAL;
-    const bool big = (N % 256) == 0 && (K % 256) == 0 && (conv_cin == 0 || (conv_cin % 256) == 0) && M >= 16384;
+    // (a single 256 x 256 output keeps the small tile: four tiles x half the splits halve the partials the reduction reads --
+    //  same box, [196608, 256, 256]: 50 + 21 us vs 48 + 12 us; [32768, 256, 256]: 19 + 21 vs 16 + 11)
+    const bool big = (N % 256) == 0 && (K % 256) == 0 && (long)N * K > 65536 && (conv_cin == 0 || (conv_cin % 256) == 0) && M >= 16384;
 #ifdef EEND_WG_FORCE128                                   // study build (tools/ab_one_source.sh)
     const int bt = 128;
     const int slots = eend_cu_count() * 2;
@@ -165,13 +167,15 @@ int eend_attn_causal_bwd_bf16(const void* Q, const void* Qt, const void* K, cons
     if (!dO || !O_f16 || !dOt_ws || !dh_ws || H != 4 || ldo != 256 || ldout != 256) return EEND_EINVAL;
     int rc = eend_launch_attn_rowdot(dO, O_f16, dh_ws, nseq, H, Tp, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_heads_transpose(dO, ldo, dOt_ws, nseq, H, Tp, (hipStream_t)stream);
-    if (rc != EEND_OK) return rc;
     AttnBwdParams p;
     memset(&p, 0, sizeof(p));
     p.Q = Q; p.Qt = Qt; p.K = K; p.Kt = Kt; p.V = V; p.dO = dO; p.dOt = dOt_ws; p.Lse = lse; p.Dh = dh_ws; p.dQKV = dQKV;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.ldg = ldg; p.mask_delay = mask_delay; p.kv_len = kv_len; p.q_len = q_len;
     p.scale_log2 = scale_log2; p.sq = sq; p.sk = sk; p.drop = drop_spec(drop);
+    if (!eend_attn_bwd_fused_ok(p, false)) {              // windows beyond 512 frames: the two-kernel form reads dO^T (attn_bwd.hip)
+        rc = eend_launch_heads_transpose(dO, ldo, dOt_ws, nseq, H, Tp, (hipStream_t)stream);
+        if (rc != EEND_OK) return rc;
+    }
     return eend_launch_attn_bwd(p, (hipStream_t)stream);
 }
 
@@ -274,11 +278,8 @@ int eend_layernorm_bwd_f32(const float* g, const void* xhat_f16, const float* rs
     int nb = 0;
     int rc = eend_launch_ln_bwd(g, xhat_f16, rstd, gamma, ds_f32, ds_bf16, ws, &nb, M, drop_spec(drop), (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws, 768, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
-    if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws + 256, 768, nb, 1, 256, 256, dbeta, 256, 1.0f, 0, (hipStream_t)stream);
-    if (rc != EEND_OK || !dbias) return rc;
-    return eend_launch_wgrad_reduce(ws + 512, 768, nb, 1, 256, 256, dbias, 256, 1.0f, 0, (hipStream_t)stream);
+    // d gamma | d beta | d bias: the three column blocks of the row pass's partials, one reduction launch
+    return eend_launch_wgrad_reduce_multi(ws, 768, nb, 256, dgamma, dbeta, dbias, (hipStream_t)stream);
 }
 
 int eend_head_bce_f32(const float* emb, const float* attr, const float* labels, const int* ilens, const int* ncols,
@@ -348,6 +349,7 @@ int eend_bn_bwd_f32(const void* const* x_ptrs, const int* lens, float pad_value,
     int rc = eend_launch_bn_bwd((const float* const*)x_ptrs, lens, pad_value, mean, var, eps, dy_bf16, ld, ws, B, T, Tp, F, (int)ns,
                                 (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
+    if ((F & 31) == 0) return eend_launch_wgrad_reduce_multi(ws, 2L * F, (int)ns, F, dgamma, dbeta, nullptr, (hipStream_t)stream);
     rc = eend_launch_wgrad_reduce(ws, 2L * F, (int)ns, 1, 2 * F, F, dgamma, F, 1.0f, 0, (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
     return eend_launch_wgrad_reduce(ws + F, 2L * F, (int)ns, 1, 2 * F, F, dbeta, F, 1.0f, 0, (hipStream_t)stream);
@@ -400,11 +402,8 @@ int eend_layernorm_bwd2_f32(const void* g, int g_is_bf16, const void* xhat_f16, 
     int rc = eend_launch_ln_bwd2(g, g_is_bf16, xhat_f16, rstd, gamma, ds_f32, accumulate, ds_bf16, alpha16, ws, &nb, M, drop_spec(drop),
                                  (hipStream_t)stream);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws, 768, nb, 1, 256, 256, dgamma, 256, 1.0f, 0, (hipStream_t)stream);
-    if (rc != EEND_OK) return rc;
-    rc = eend_launch_wgrad_reduce(ws + 256, 768, nb, 1, 256, 256, dbeta, 256, 1.0f, 0, (hipStream_t)stream);
-    if (rc != EEND_OK || !dbias) return rc;
-    return eend_launch_wgrad_reduce(ws + 512, 768, nb, 1, 256, 256, dbias, 256, 1.0f, 0, (hipStream_t)stream);
+    // d gamma | d beta | d bias: the three column blocks of the row pass's partials, one reduction launch
+    return eend_launch_wgrad_reduce_multi(ws, 768, nb, 256, dgamma, dbeta, dbias, (hipStream_t)stream);
 }
 
 int eend_resgrad_cast_bf16(const float* g, void* ds_bf16, float alpha, float* ws, long ws_floats, float* dbias, long M,

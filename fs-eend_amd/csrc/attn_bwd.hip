@@ -430,6 +430,9 @@ int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) || (p.ldo & 7) || (p.ldg & 3) || p.kv_len <= 0 ||
         p.kv_len > p.Tp || p.q_len <= 0)
         return EEND_EINVAL;
+#ifndef EEND_ATTN_BWD_TWO_KERNELS                       // (study build: the round-2 two-kernel form at every size)
+    if (eend_attn_bwd_fused_ok(p, false)) return eend_launch_attn_bwd_fused(p, false, stream);
+#endif
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
     static EendOncePerDevice attr_once;
@@ -445,6 +448,9 @@ int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream) {
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) || (p.ldo & 7) || (p.ldg & 3) || p.L <= 0 || p.nc <= 0 ||
         (long)p.nc * p.L > p.Tp || p.mask_delay != 0 || p.kv_len != p.nc * p.L || p.q_len != p.nc * p.L)
         return EEND_EINVAL;
+#ifndef EEND_ATTN_BWD_TWO_KERNELS
+    if (eend_attn_bwd_fused_ok(p, true)) return eend_launch_attn_bwd_fused(p, true, stream);
+#endif
     // full-slab grids: the blocks beyond the nc * L valid frames only write the zero rows of dQKV
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;

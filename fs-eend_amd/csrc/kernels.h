@@ -410,6 +410,8 @@ int eend_launch_wgrad_reduce_tiles(const float* partial, int tile, int nsplit, i
                                    float scale, int accumulate, hipStream_t stream);
 int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit, int N, int K, int K_out, float* out,
                              int ld_out, float scale, int accumulate, hipStream_t stream);
+int eend_launch_wgrad_reduce_multi(const float* partial, long split_stride, int nsplit, int W, float* out0, float* out1, float* out2,
+                                   hipStream_t stream);
 int eend_launch_colsum_partial(const void* Y, int ld, long M, int N, int is_bf16, int nsplit, float* partial,
                                hipStream_t stream);
 int eend_launch_conv_wgrad_unpermute(const float* tmp, float* g, int cout, int cin, int ktaps, hipStream_t stream);
@@ -433,6 +435,9 @@ struct AttnBwdParams {        // attn_bwd.hip
     const void* St;           // bf16 [nseq][H][nc][6][64][64]: Spre hi/lo [kd][hd], R hi/lo [kd][hd], R^T hi/lo [hd][kd]
 };
 int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream);
+// attn_bwd_fused.hip: windows of up to 512 frames in one launch (Qt / Kt / dOt are not read); the launchers above dispatch to it
+bool eend_attn_bwd_fused_ok(const AttnBwdParams& p, bool ret);
+int eend_launch_attn_bwd_fused(const AttnBwdParams& p, bool ret, hipStream_t stream);
 int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream);
 int eend_launch_ret_bwd_states(const void* Kt, const void* Vt, const void* Qt, const void* dOt, float* kv_ws, float* g_ws, void* St,
                                int nseq, int H, int Tp, int L, int nc, hipStream_t stream);

@@ -414,6 +414,38 @@ void wgrad_reduce_small_kernel(const float* __restrict__ partial, long split_str
     }
 }
 
+// Up to three vectors from one partial matrix [nsplit][ncols] (row stride split_stride): columns [j * W, (j + 1) * W) -> outs j
+// (LayerNorm backward: d gamma | d beta | d bias of one pass over the rows -- one launch instead of three; a null
+// destination skips its columns).  Same walk and combination order as wgrad_reduce_small_kernel.
+__global__ __launch_bounds__(256)
+void wgrad_reduce_multi_kernel(const float* __restrict__ partial, long split_stride, int nsplit, int ncols, int W,
+                               float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2) {
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + o;
+    const int seg = col / W;
+    float* dst = seg == 0 ? out0 : (seg == 1 ? out1 : out2);
+    const bool live = col < ncols && dst != nullptr;
+    float s = 0.f;
+    if (live) {
+        const float* src = partial + col;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = g;
+        for (; sp + 56 < nsplit; sp += 64) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += src[(size_t)(sp + 8 * j) * split_stride];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (sp + 8 * j < nsplit) a[j] += src[(size_t)(sp + 8 * j) * split_stride];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g == 0 && live)
+        dst[col - seg * W] = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+}
+
 // Column sums of a 2-byte-float matrix [M][N] (bias gradients): partial[s][n] = sum over the split's rows.
 // A block covers 256 columns (32 threads x 16-byte loads) in 8 row phases; N % 8 == 0.
 template <bool IS_BF16>
@@ -516,6 +548,15 @@ int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, split_stride,
                            nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+int eend_launch_wgrad_reduce_multi(const float* partial, long split_stride, int nsplit, int W, float* out0, float* out1, float* out2,
+                                   hipStream_t stream) {
+    if (!partial || nsplit <= 0 || W <= 0 || (W & 31) || !out0) return EEND_EINVAL;
+    const int ncols = 3 * W;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)(ncols / 32)), dim3(256), 0, stream, partial, split_stride, nsplit, ncols, W,
+                       out0, out1, out2);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

@@ -16,12 +16,17 @@ for nseq in (64, 384):
     dot_ws = torch.empty(nseq * Tp * 256, dtype=torch.bfloat16, device=dev)
     dh_ws = torch.empty(nseq * H * Tp, device=dev)
     dqkv = torch.empty(nseq * Tp, 768, dtype=torch.bfloat16, device=dev)
-    fn = lambda: _call("eend_attn_causal_bwd_bf16", q, qt, k, kt, v, dO, 256, O, 256, lse, dot_ws, dh_ws, dqkv, 768, nseq, H, Tp, 0, T, T,
-                       1.0, 0.125, ops.LN2, None)
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20): fn()
-    b.record(); torch.cuda.synchronize()
-    print(f"attn bwd nseq={nseq}: {a.elapsed_time(b) / 20 * 1e3:8.1f} us   chk {float(dqkv.float().abs().sum()):.5e}", flush=True)
+    import ctypes
+    from fs_eend_amd import lib as L
+    for pd in (0.0, 0.1):
+        spec = None if pd == 0 else L.Dropout(12345, int(round(pd * (1 << 24))), 1.0 / (1.0 - pd))
+        dref = None if spec is None else ctypes.byref(spec)
+        fn = lambda: _call("eend_attn_causal_bwd_bf16", q, qt, k, kt, v, dO, 256, O, 256, lse, dot_ws, dh_ws, dqkv, 768, nseq, H, Tp, 0, T, T,
+                           1.0, 0.125, ops.LN2, dref)
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20): fn()
+        b.record(); torch.cuda.synchronize()
+        print(f"attn bwd nseq={nseq} p_drop={pd}: {a.elapsed_time(b) / 20 * 1e3:8.1f} us   chk {float(dqkv.float().abs().sum()):.5e}", flush=True)
