@@ -68,13 +68,23 @@ def flops_per_launch(name, shape, T):
     return 0.0
 
 
+def pmc_traffic_file(prefix="pmc_traffic"):
+    """(path, first 16 hex digits of its sha256) of the newest committed PMC traffic summary, profiles/rNN_<prefix>.json: the bench line
+    names the file it looked the bytes up in (the traffic figure is a repository lookup, not a measurement of this run)."""
+    import hashlib
+    for r in (6, 5, 4, 3):
+        q = os.path.join(ROOT, "profiles", f"r0{r}_{prefix}.json")
+        if os.path.exists(q):
+            return q, hashlib.sha256(open(q, "rb").read()).hexdigest()[:16]
+    return "", None
+
+
 def pmc_traffic(kernel, shape):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
-    tags = {("fusion_layer_tail", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 2>(FfnParams)",), "131072"),
-            ("attnout_ffn_stream", (196608, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 3>",), "65536"),
+    path = pmc_traffic_file()[0]
+    tags = {("attnout_ffn_stream", (196608, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 3>",), "65536"),
             ("attnout_ffn_stream", (32768, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 2>",), "65536"),
             ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
@@ -82,8 +92,6 @@ def pmc_traffic(kernel, shape):
             ("conv1d_l2norm_stream", (32768, 256, 4864)): (("conv_stream_kernel",), "65536"),
             ("inproj_attn_causal_packed", (64, 4)): (("inproj_attn_stream_kernel(InprojAttnParams) #lo",), "131072"),
             ("inproj_attn_causal_packed", (384, 4)): (("inproj_attn_stream_kernel(InprojAttnParams) #hi",), "131072"),
-            ("inproj_attn_causal", (64, 4)): (("inproj_attn_kernel(InprojAttnParams) #lo",), "131072"),      # persistent launch:
-            ("inproj_attn_causal", (384, 4)): (("inproj_attn_kernel(InprojAttnParams) #hi",), "131072"),     # same grid, two sizes
             ("attn_causal", (64, 4)): (("attn_causal_full_kernel",), "131072"),
             ("attn_causal", (384, 4)): (("attn_causal_full_kernel",), "786432"),
             ("linear_res_ln", (196608, 256, 256)): (("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4", "gemm_f16_kernelIDF16_Li64ELi256ELi1ELi4ELb1ELi0ELi4ELi0E"), "786432")}
@@ -99,7 +107,7 @@ def pmc_traffic(kernel, shape):
 def ls_retention_traffic(nseq, H, Tv, L, fused=False):
     """PMC HBM bytes of the retention kernels of one layer (the default LS workload, 160 x T = 2000, only): the two passes of
     ret_stream.hip + the scan (round 5), or the three kernels of the two-call form (round 3 file)."""
-    path = os.path.join(ROOT, "profiles", "r05_ls_pmc_traffic.json" if fused else "r03_ls_pmc_traffic.json")
+    path = pmc_traffic_file("ls_pmc_traffic")[0] if fused else os.path.join(ROOT, "profiles", "r03_ls_pmc_traffic.json")
     if not os.path.exists(path) or (nseq, H, Tv, L) != (160, 4, 2000, 500):
         return None
     ks = json.load(open(path))["kernels"]
@@ -168,8 +176,8 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "fusion_layer_tail", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm", "conv1d_l2norm_stream",
-                  "convert_fanout", "attn_causal", "inproj_attn_causal", "inproj_attn_causal_packed", "spk_attn", "spk_qkv_attn", "head_l2dot", "retention_proj", "retention_chunk", "retention_stream", "linear_res_scale_ln16", "linear_glu",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm", "conv1d_l2norm_stream",
+                  "convert_fanout", "attn_causal", "inproj_attn_causal_packed", "spk_attn", "head_l2dot", "retention_proj", "retention_chunk", "retention_stream", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):
                 continue
@@ -407,7 +415,9 @@ def extras(dev):
                 "algorithmic_bytes_survey": byt, "algorithmic_bytes_fused_operator": byt_fused,
                 "survey_comparable_GBs": byt / (r["avg_ms"] * 1e-3) / 1e9,
                 "traffic": ls_retention_traffic(nseq_, H_, Tv_, L_, fused=True),
-                "traffic_source": "profiles/r05_ls_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes): the three launches of one "
+                "traffic_file": os.path.relpath(pmc_traffic_file("ls_pmc_traffic")[0], ROOT) if pmc_traffic_file("ls_pmc_traffic")[0] else None,
+                "traffic_file_sha256_16": pmc_traffic_file("ls_pmc_traffic")[1],
+                "traffic_source": "repository lookup (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes): the three launches of one "
                                   "decoder layer, bytes per launch",
                 "replaces": "retention_proj + retention_chunk (round 4: 0.38 + 0.44 ms for this shape)"}
         rk = [k for k in ks if k["kernel"] == "retention_chunk"]
@@ -1117,7 +1127,9 @@ def main():
                            "achieved": fl / (dom["avg_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / (dom["avg_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
                            "traffic": pmc_traffic(dom["kernel"], dom["shape"]), "avg_launch_ms": dom["avg_ms"],
-                           "traffic_source": "profiles/r05_pmc_traffic.json, else r04 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, bytes per launch)"}
+                           "traffic_source": "repository lookup: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (tools/gpu_pmc.sh), bytes per launch",
+                           "traffic_file": os.path.relpath(pmc_traffic_file()[0], ROOT) if pmc_traffic_file()[0] else None,
+                           "traffic_file_sha256_16": pmc_traffic_file()[1]}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
         # the encoder's time-axis attention launch (nseq = B): the packed-weight form at Tp = 512 (attn_stream.hip), else attn_fused.hip
         fus = [k for k in ksum if k["kernel"] in ("inproj_attn_causal_packed", "inproj_attn_causal") and k["shape"][0] == B]

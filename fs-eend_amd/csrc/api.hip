@@ -12,17 +12,11 @@ GemmParams base_params(const void* A, int lda, const void* W, int ldw, const flo
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldo = N; p.Tp = 64; p.H = 4; p.dh = 64; p.C = 1;
     p.alpha = 1.0f; p.eps = 1e-5f; p.conv_cin = 64; p.conv_pad = 0; p.drop.scale = 1.0f;
-    const char* d = getenv("EEND_GEMM_DBG");          // perf-study ablations only; unset in normal use
+#ifdef EEND_GEMM_ABLATE                               // perf-study build only (tools/gemm_ablate.py)
+    const char* d = getenv("EEND_GEMM_DBG");
     p.dbg = d ? atoi(d) : 0;
+#endif
     return p;
-}
-bool proj_xres_enabled() {          // EEND_PROJ_XRES=0: A/B switch back to the generic 128x128-tile GEMM
-    static const bool on = !(getenv("EEND_PROJ_XRES") && atoi(getenv("EEND_PROJ_XRES")) == 0);
-    return on;
-}
-bool skinny_enabled() {              // EEND_SKINNY=0: A/B switch back to the tiled GEMM for M <= 16 rows
-    static const bool on = [] { const char* e = getenv("EEND_SKINNY"); return !(e && e[0] == '0'); }();
-    return on;
 }
 }  // namespace
 
@@ -51,9 +45,9 @@ int eend_gather_bn_cast_pad_f16(const void* const* x_ptrs, const int* lens, floa
 int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* out_f16, int ldo,
                     int M, int N, int K, int act, void* stream) {
     if (!A || !W || !out_f16 || (ldo & 3) || act < 0 || act > 2) return EEND_EINVAL;
-    if (skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))        // streaming steps: a few rows, weights spread over the chip
+    if (eend_skinny_ok(A, lda, W, ldw, M, K))        // streaming steps: a few rows, weights spread over the chip
         return eend_launch_skinny_plain(A, lda, W, ldw, bias, out_f16, ldo, M, N, K, act, (hipStream_t)stream);
-    if (act == 0 && K == 256 && ldw == 256 && bias && (N % 256) == 0 && N <= 1024 && (ldo & 7) == 0 && proj_xres_enabled()) {
+    if (act == 0 && K == 256 && ldw == 256 && bias && (N % 256) == 0 && N <= 1024 && (ldo & 7) == 0) {
         ProjParams q;                                     // X-resident projection kernel (proj.hip)
         memset(&q, 0, sizeof(q));
         q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = M; q.N = N; q.Tp = 64; q.H = 4;
@@ -69,7 +63,7 @@ int eend_linear_f16(const void* A, int lda, const void* W, int ldw, const float*
 int eend_linear_glu_f16(const void* A, int lda, const void* Wi, int ldw, const float* bias_i, void* out_f16,
                         int ldo, int M, int N2, int K, void* stream) {
     if (!A || !Wi || !bias_i || !out_f16 || (ldo & 1) || (N2 & 1)) return EEND_EINVAL;
-    if (skinny_enabled() && eend_skinny_ok(A, lda, Wi, ldw, M, K))
+    if (eend_skinny_ok(A, lda, Wi, ldw, M, K))
         return eend_launch_skinny_glu(A, lda, Wi, ldw, bias_i, out_f16, ldo, M, N2, K, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, Wi, ldw, bias_i, M, N2, K);
     p.out16 = out_f16; p.ldo = ldo;
@@ -81,7 +75,7 @@ int eend_inproj_heads_bf16(const void* A, int lda, const void* W, int ldw, const
     if (!A || !W || !bias || !Q_bf16 || !K_bf16 || !Vt_bf16) return EEND_EINVAL;
     if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || dh != 64 || H <= 0 || ((H * dh) % 128) != 0) return EEND_EINVAL;
     const int D = H * dh;
-    if (K == 256 && ldw == 256 && H == 4 && proj_xres_enabled()) {
+    if (K == 256 && ldw == 256 && H == 4) {
         ProjParams q;
         memset(&q, 0, sizeof(q));
         q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = nseq * Tp; q.N = 768; q.Tp = Tp; q.H = H;
@@ -103,7 +97,7 @@ int eend_linear_res_ln_f16(const void* A, int lda, const void* W, int ldw, const
                            float alpha, const float* gamma, const float* beta, float eps, float* out_f32,
                            void* out_f16, int M, int K, void* stream) {
     if (!A || !W || (!out_f32 && !out_f16) || ((gamma == nullptr) != (beta == nullptr))) return EEND_EINVAL;
-    if (out_f32 && skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))
+    if (out_f32 && eend_skinny_ok(A, lda, W, ldw, M, K))
         return eend_launch_skinny_res(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 1, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
@@ -123,7 +117,7 @@ int eend_linear_res_scale_ln16_f16(const void* A, int lda, const void* W, int ld
                                    const float* res, float alpha, const float* gamma, const float* beta, float eps,
                                    float* out_f32, void* out_f16, int M, int K, void* stream) {
     if (!A || !W || !out_f32 || !out_f16 || !gamma || !beta) return EEND_EINVAL;
-    if (skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))
+    if (eend_skinny_ok(A, lda, W, ldw, M, K))
         return eend_launch_skinny_res(A, lda, W, ldw, bias, res, alpha, gamma, beta, eps, out_f32, out_f16, M, K, 2, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out32 = out_f32; p.out16 = out_f16;
@@ -189,8 +183,8 @@ int eend_ffn_stream_pack_f16(const void* Wo, const void* W1, const void* W2, voi
 int eend_ffn_stream_max_rows(int lda) {
     const long row_bytes = (long)(lda > 512 ? lda : 512) * 2;       // widest row the kernel addresses: f32 residual / output rows are 1 KB
     long m = ((1L << 31) - 1) / row_bytes - 65536 - 1;
-    const char* e = getenv("EEND_FFN_STREAM_MAX_ROWS");              // tests: exercise the multi-launch path at small sizes
-    if (e && atol(e) > 0 && atol(e) < m) m = atol(e);
+    const long cap = eend_ffn_stream_debug_row_cap();               // tests: exercise the multi-launch path at small sizes
+    if (cap > 0 && cap < m) m = cap;
     m = m / 384 * 384;
     return m > 0 ? (int)m : 0;
 }
@@ -301,26 +295,6 @@ int eend_attnout_spk_stream_res32_f16(const void* A, int lda, const void* wstrea
     return eend_launch_spk_stream(p, (hipStream_t)stream);
 }
 
-int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
-                               const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
-                               const void* Win2, const float* bin2,
-                               const void* Wo2, const float* bo2, const float* g21, const float* be21, float eps21,
-                               const void* W1, const float* b1, const void* W2, const float* b2,
-                               const float* g22, const float* be22, float eps22,
-                               int B, int C, int Tp, int F, void* stream) {
-    if (!A1 || !stream_f32 || !out_f16 || !Wo1 || !bo1 || !g11 || !be11 || !Win2 || !bin2 || !Wo2 || !bo2 || !g21 || !be21)
-        return EEND_EINVAL;
-    if (B <= 0 || C < 1 || C > 12 || Tp <= 0) return EEND_EINVAL;
-    FfnParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A1; p.lda = lda; p.Wo = Wo1; p.bo = bo1; p.g1 = g11; p.be1 = be11; p.eps1 = eps11;
-    p.Win2 = Win2; p.bin2 = bin2; p.Wo2 = Wo2; p.bo2 = bo2; p.g21 = g21; p.be21 = be21; p.eps21 = eps21; p.spk_scale = 0.125f;
-    p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.gamma = g22; p.beta = be22; p.eps = eps22; p.alpha = 1.0f;
-    p.res = stream_f32; p.out32 = stream_f32; p.out16 = out_f16;
-    p.B = B; p.C = C; p.Tp = Tp; p.M = B * C * Tp; p.F = F;
-    return eend_launch_ffn_fused(p, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
-}
-
 int eend_emb_consistency_f32(const float* emb, const float* labels, const int* lens, float inv_count,
                              float* partial_ws, float* out, int B, int T, int Tp, int D, int C, void* stream) {
     return eend_launch_emb_consistency(emb, labels, lens, inv_count, partial_ws, out, B, T, Tp, D, C, (hipStream_t)stream);
@@ -367,7 +341,7 @@ int eend_retention_proj_f16(const void* A, int lda, const void* Wqkvg, int ldw, 
     if (!A || !Wqkvg || !bias || !Q || !K || !Kt || !Vt || !G) return EEND_EINVAL;
     if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || dh != 64 || H <= 0 || ((H * dh) % 128) != 0) return EEND_EINVAL;
     const int D = H * dh, M = nseq * Tp;
-    if (Kdim == 256 && ldw == 256 && H == 4 && proj_xres_enabled()) {
+    if (Kdim == 256 && ldw == 256 && H == 4) {
         ProjParams q;
         memset(&q, 0, sizeof(q));
         q.X = A; q.ldx = lda; q.W = Wqkvg; q.bias = bias; q.M = M; q.N = 1024; q.Tp = Tp; q.H = H;
@@ -403,8 +377,7 @@ int eend_retention_chunk_f16(const void* Q, const void* K, const void* Kt, const
     // chunk sizes that fit on chip (500 in every shipped config) take the chunk-resident kernel, one block per
     // (chunk, head, sequence): there, chunks that start at or beyond T_valid (pure slab padding) are skipped
     // altogether.  The tiled kernel's waves span chunk boundaries, so it always sees every chunk.
-    static const bool use_full_env = !(getenv("EEND_RET_FULL") && atoi(getenv("EEND_RET_FULL")) == 0);
-    const bool use_full = use_full_env && L <= 512 && (L & 3) == 0 && (ldo & 7) == 0;
+    const bool use_full = L <= 512 && (L & 3) == 0 && (ldo & 7) == 0;
     const int Tv = (use_full && T_valid > 0 && T_valid < Tp) ? T_valid : Tp;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.L = L; p.nc = (Tv + L - 1) / L; p.ldo = ldo; p.ldg = ldg; p.gn_eps = gn_eps;
     p.state_in = state_in; p.state_out = state_out;
@@ -512,7 +485,7 @@ int eend_linear_res_scale_f16(const void* A, int lda, const void* W, int ldw, co
                               const float* res, float alpha, float* out_f32, void* out_f16, int M, int K,
                               void* stream) {
     if (!A || !W || (!out_f32 && !out_f16)) return EEND_EINVAL;
-    if (skinny_enabled() && eend_skinny_ok(A, lda, W, ldw, M, K))
+    if (eend_skinny_ok(A, lda, W, ldw, M, K))
         return eend_launch_skinny_res(A, lda, W, ldw, bias, res, alpha, nullptr, nullptr, 0.f, out_f32, out_f16, M, K, 0, (hipStream_t)stream);
     GemmParams p = base_params(A, lda, W, ldw, bias, M, 256, K);
     p.res = res; p.alpha = alpha; p.out32 = out_f32; p.out16 = out_f16;
@@ -533,8 +506,7 @@ int eend_conv1d_l2norm_f16(const void* X, const void* Wr, const float* bias, con
 int eend_convert_fanout_f16(const void* E, const void* W1, const float* pc, float* out_f32, void* out_f16,
                             int B, int Tp, int C, void* stream) {
     if (!E || !W1 || !pc || !out_f16 || B <= 0 || C <= 0 || Tp <= 0) return EEND_EINVAL;     // out_f32 may be NULL (f16 stream only)
-    static const bool gemm_path = [] { const char* e = getenv("EEND_CONVERT_GEMM"); return e && atoi(e) != 0; }();      // A/B: the round-1 GEMM epilogue
-    if (!gemm_path && C <= 32 && (long)B * Tp * 512 < (1L << 31))
+    if (C <= 32 && (long)B * Tp * 512 < (1L << 31))
         return eend_launch_convert_fanout_rows(E, W1, pc, out_f32, out_f16, B, Tp, C, (hipStream_t)stream);
     GemmParams p = base_params(E, 256, W1, 256, nullptr, B * Tp, 256, 256);
     p.Tp = Tp; p.C = C; p.pc = pc; p.out32 = out_f32; p.out16 = out_f16;
@@ -551,15 +523,6 @@ int eend_attn_causal_bf16(const void* Q, const void* K, const void* Vt, void* O_
     return eend_launch_attn_causal(p, (hipStream_t)stream);
 }
 
-int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, const float* b_in, void* Q_scratch_bf16,
-                                void* O_f16, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream) {
-    if (!X_f16 || !W_in || !b_in || !Q_scratch_bf16 || !O_f16 || nseq > 16383) return EEND_EINVAL;
-    InprojAttnParams p;
-    p.X = X_f16; p.ldx = ldx; p.W = W_in; p.bias = b_in; p.Qs = Q_scratch_bf16; p.O = O_f16;
-    p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.mask_delay = mask_delay; p.kv_len = kv_len;
-    return eend_launch_inproj_attn(p, (hipStream_t)stream);
-}
-
 int eend_inproj_attn_packed_elems(void) { return (int)eend_inproj_attn_packed_nelems(); }
 
 int eend_inproj_attn_pack_f16(const void* W_in, void* packed_out, void* stream) {
@@ -570,18 +533,9 @@ int eend_inproj_attn_causal_packed_f16(const void* X_f16, int ldx, const void* W
                                        int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream) {
     if (!X_f16 || !W_packed || !b_in || !O_f16 || nseq > 16383) return EEND_EINVAL;
     InprojAttnParams p;
-    p.X = X_f16; p.ldx = ldx; p.W = W_packed; p.bias = b_in; p.Qs = nullptr; p.O = O_f16;
+    p.X = X_f16; p.ldx = ldx; p.W = W_packed; p.bias = b_in; p.O = O_f16;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.mask_delay = mask_delay; p.kv_len = kv_len;
     return eend_launch_inproj_attn_stream(p, (hipStream_t)stream);
-}
-
-int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
-                          int B, int C, int Tp, int T_valid, int H, float scale, void* stream) {
-    if (H != 4 || T_valid < 0 || T_valid > Tp) return EEND_EINVAL;
-    SpkFusedParams p;
-    p.X = x_f16; p.ldx = ldx; p.W = W_in; p.bias = b_in; p.O = O_f16; p.B = B; p.C = C; p.Tp = Tp; p.scale = scale;
-    p.Tv = T_valid > 0 ? T_valid : Tp;
-    return eend_launch_spk_qkv_attn(p, (hipStream_t)stream);
 }
 
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale, void* stream) {

@@ -269,9 +269,8 @@ int eend_launch_attn_causal(const AttnParams& p, hipStream_t stream) {
     if (p.nseq <= 0 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) != 0 || (p.ldo & 3) || p.kv_len <= 0 || p.kv_len > p.Tp)
         return EEND_EINVAL;
     // chunks that fit on chip (the T = 500 training / benchmark chunks) take the whole-sequence-resident
-    // kernel (attn_full.hip); longer sequences the tiled flash loop below.  EEND_ATTN_FULL=0: A/B switch.
-    static const bool use_full = !(getenv("EEND_ATTN_FULL") && atoi(getenv("EEND_ATTN_FULL")) == 0);
-    if (use_full && p.Tp <= 512 && (p.ldo & 7) == 0) return eend_launch_attn_causal_full(p, stream);
+    // kernel (attn_full.hip); longer sequences the tiled flash loop below.
+    if (p.Tp <= 512 && (p.ldo & 7) == 0) return eend_launch_attn_causal_full(p, stream);
     const int nqt = (p.Tp + QB - 1) / QB;
     hipLaunchKernelGGL(attn_causal_kernel, dim3(nqt, p.H, p.nseq), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;

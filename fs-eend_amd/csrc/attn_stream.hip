@@ -1,21 +1,16 @@
-// In-projection + causal multi-head attention of one (sequence, head) per workgroup, second form (round 4): the same
-// operator, flash loop and persistent item walk as attn_fused.hip (nn.TransformerEncoderLayer.self_attn, FS model :147;
-// self_attn1 of the fusion layers, merge_tfm_encoder.py:379-385), with the projection phase turned around:
-//
-//   attn_fused.hip : the head's weight slices live in registers, split by FEATURE across the 8 waves; the X rows stream through
-//                    a staging tile in LDS that every wave reads completely -- 128 KB of LDS reads per 32 rows for 24 MFMAs per
-//                    wave, LDS-read-bound (19 us of the 32 us a decoder item took), and Q leaves the CU (L2 scratch) because it
-//                    is produced feature-split and consumed query-split.
-//   here           : a wave owns the 64 TOKENS whose queries it will run in the flash loop (query blocks w and 15 - w) and
-//                    keeps their X rows in registers as MFMA operand fragments (128 VGPRs, read from global memory once);
-//                    the head's 96 KB of weights, pre-packed per layer in fragment order (eend_inproj_attn_pack_f16), are
-//                    requested by LDS-DMA in one go at the start of the item into space that is free at that time -- four
-//                    16-KB items into the V^T tile region (written only by the last two projection items, after a barrier
-//                    behind their last reader), two into the 32-KB staging region -- and every 1-KB fragment read feeds
-//                    four MFMAs.  768 KB of LDS reads per item instead of 2 MB; six barriers per item instead of sixteen.
-//                    Q never leaves the wave: packed bf16 in 32 registers until its pass, then through the wave's 4-KB
-//                    staging tile into the flash loop's operand layout.  No Q scratch buffer, no HBM / L2 round trip.
-// Tp = 512 only (eight waves x two query blocks); other chunk lengths keep attn_fused.hip.
+// In-projection + causal multi-head attention of one (sequence, head) per persistent workgroup
+// (nn.TransformerEncoderLayer.self_attn, FS model :147; self_attn1 of the fusion layers, merge_tfm_encoder.py:379-385):
+//   a wave owns the 64 TOKENS whose queries it will run in the flash loop (query blocks w and 15 - w) and keeps their X rows in
+//   registers as MFMA operand fragments (128 VGPRs, read from global memory once); the head's 96 KB of weights, pre-packed per
+//   layer in fragment order (eend_inproj_attn_pack_f16), are requested by LDS-DMA in one go at the start of the item into space
+//   that is free at that time -- four 16-KB items into the V^T tile region (written only by the last two projection items, after
+//   a barrier behind their last reader), two into the 32-KB staging region -- and every 1-KB fragment read feeds four MFMAs.
+//   768 KB of LDS reads and six barriers per item.  Q never leaves the wave: packed bf16 in 32 registers until its pass, then
+//   through the wave's 4-KB staging tile into the flash loop's operand layout.  K and V live in LDS only: no HBM / L2 round trip.
+// (Round 3's form of the operator, attn_fused.hip -- weight slices in registers split by FEATURE across the waves, X streamed through
+//  an LDS tile every wave read completely, Q through an L2 scratch -- was LDS-read-bound, 19 us of a 32-us decoder item; removed in
+//  round 6 together with its A/B switch.)
+// Tp = 512 only (eight waves x two query blocks); other chunk lengths take eend_inproj_heads_bf16 + eend_attn_causal_bf16.
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
@@ -393,7 +388,7 @@ int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-// p.W = the packed weights (eend_launch_inproj_attn_pack); p.Qs unused
+// p.W = the packed weights (eend_launch_inproj_attn_pack)
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream) {
     if (p.Tp != TP || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O) return EEND_EINVAL;
     static EendOncePerDevice attr_once;

@@ -291,23 +291,6 @@ constexpr int V2_SMEM = V2_HS + 2 * HS_BYTES;  // 163840
 // fragments come straight from global memory, and the result lands in the same accumulator layout that
 // seeds GEMM2 (fp32 residual) and, as f16, in the X staging tile.
 //
-// MODE 2 (LAYER) runs the whole row-local second half of a fusion (decoder) layer on one tile:
-//     x1 = LN11(A1 Wo1^T + bo1 + res)                        (time-axis attention out-projection, norm11)
-//     o  = MHA over the C slots of each frame of x1 Win2^T    (speaker-axis attention, as spk_fused.hip)
-//     x2 = LN21(o Wo2^T + bo2 + x1)                          (its out-projection, norm21)
-//     out = LN22(relu(x2 W1^T + b1) W2^T + b2 + x2)          (FFN, norm22)
-// A tile is "all C slots of G = 128/C consecutive frames" (rows gathered with stride Tp), which makes the
-// speaker mix tile-local.  x1 (fp32) is parked in the output stream buffer between the two
-// projection phases (each thread reads back exactly what it wrote); qkv, o, x2 and the hidden
-// activations never leave the CU.
-struct RowsGathered {                // tile row r = c * G + t' -> row (b*C + c)*Tp + t0 + t' of the (b,c)-major slab
-    int b, t0, G, C, Tp, rows;
-    __device__ __forceinline__ long operator()(int r) const {
-        if (r >= rows) return -1L;
-        const int c = r / G, t = t0 + r - c * G;
-        return t < Tp ? ((long)b * C + c) * Tp + t : -1L;
-    }
-};
 
 template <int ACT, int EPI, int MODE>
 __global__ __launch_bounds__(NT)
@@ -315,36 +298,24 @@ void ffn_fused_kernel(const FfnParams p) {
     // MODE 3: training forward of the plain FFN; MODE 4: its data-gradient backward (bf16 operands: X = dY, W1 = W2^T, W2 = W1^T, the
     // "activation" is the ReLU-and-dropout mask read from the saved hidden activations, the "hidden" tile is dH and leaves for HBM too, the
     // epilogue accumulates into the f32 residual-gradient stream)
-    constexpr bool PRE = MODE == 1 || MODE == 2, LAYER = MODE == 2, TRAIN = MODE == 3, BWD = MODE == 4, HSTORE = TRAIN || BWD;
+    constexpr bool PRE = MODE == 1, TRAIN = MODE == 3, BWD = MODE == 4, HSTORE = TRAIN || BWD;
     auto mfma = [](f16x8 a, f16x8 b, f32x4 c) __attribute__((always_inline)) {
         if constexpr (BWD) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nF = p.F / FC;
-    const int lyG = LAYER ? BM / p.C : 1;                       // frames per tile
-    const int tiles_per_b = LAYER ? (p.Tp + lyG - 1) / lyG : 1;
-    const int ntiles = LAYER ? p.B * tiles_per_b : (p.M + BM - 1) / BM;
+    const int ntiles = (p.M + BM - 1) / BM;
     // Persistent over row tiles (grid = #CUs, 1 block/CU): the output stores of a tile are never waited
     // for, so they drain under the next tile's loads instead of being an exposed phase of every block.
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m0 = tile * BM;
-    const int lyb = LAYER ? tile / tiles_per_b : 0, lyt0 = LAYER ? (tile - lyb * tiles_per_b) * lyG : 0;
-    const RowsGathered rows_g{lyb, lyt0, lyG, LAYER ? p.C : 1, p.Tp, lyG * (LAYER ? p.C : 1)};
     const RowsContiguous rows_c{m0, p.M};
     auto rowmap = [&](int r) __attribute__((always_inline)) -> long {
-        if constexpr (LAYER) return rows_g(r); else return rows_c(r);
+        return rows_c(r);
     };
     auto rowclamp = [&](int r) __attribute__((always_inline)) -> long {      // always a valid row (for loads)
-        if constexpr (LAYER) {
-            r = r < rows_g.rows ? r : rows_g.rows - 1;
-            const int c = r / lyG;
-            int t = lyt0 + r - c * lyG;
-            t = t < p.Tp ? t : p.Tp - 1;
-            return ((long)lyb * p.C + c) * p.Tp + t;
-        } else {
-            return m0 + r < p.M ? (long)(m0 + r) : (long)p.M - 1;
-        }
+        return m0 + r < p.M ? (long)(m0 + r) : (long)p.M - 1;
     };
     FFN_STAMP(0);
     if (tile != (int)blockIdx.x) {
@@ -412,16 +383,6 @@ void ffn_fused_kernel(const FfnParams p) {
                                                      f0 * 2, 0, 0);
     };
 
-    // LAYER: slice ch = 3*head + {q,k,v} of the speaker attention's in_proj_weight, same LDS image as a W1 slice
-    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(LAYER ? p.Win2 : p.W1), 0, 3 * KD * KD * 2, 0x00020000);
-    auto dma_spk = [&](int ch, int buf) __attribute__((always_inline)) {
-        const int wrow = (ch % 3) * KD + (ch / 3) * FC;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_char*)(smem + V2_W1 + buf * W1_BYTES + (wave * 4 + i) * 1024), 16, vo1[i],
-                                                     wrow * KD * 2, 0, 0);
-    };
-
     const int g1m = (wave >> 1) * 32, g1f = (wave & 1) * 32;   // GEMM1 wave tile: 32 tokens x 32 hidden
     const int g2m = (wave >> 2) * 64, g2n = (wave & 3) * 64;   // GEMM2 wave tile: 64 tokens x 64 outputs
     int bofs = g1f + fkg * 4;                                  // this lane's b1 offsets inside a chunk: bofs, bofs+16
@@ -469,7 +430,7 @@ void ffn_fused_kernel(const FfnParams p) {
             }
         };
         // SRC: 0 = A fragments straight from global (each of the 4 n-waves of a token group fetches the same rows),
-        //      1 = A is the f16 tile already in the staging region (LAYER),
+        //      1 = A is the f16 tile already in the staging region (the round-2 whole-layer form; no caller left),
         //      2 = plain PRE tiles: A rows are fetched ONCE (compact, 8 x 16 B per thread) and shared through the staging
         //          tile, and Wo arrives in two halves -- k-tiles 0/1 with the inputs, k-tiles 2/3 (whose LDS image
         //          overlaps the staging tile) behind the fragment reads, under the first half of the GEMM.  The input
@@ -606,13 +567,8 @@ void ffn_fused_kernel(const FfnParams p) {
             block_rowsum(part);
             // every wave is past its Wo reads: the next phase's first two weight slices can land in the first
             // 64 KB now (the staging barrier below, with its vmcnt(0), is the completion wait)
-            if constexpr (last) {
-                dma_w1(0, 0);
-                if (nF > 1) dma_w1(FC, 1);
-            } else {
-                dma_spk(0, 0);
-                dma_spk(1, 1);
-            }
+            dma_w1(0, 0);
+            if (nF > 1) dma_w1(FC, 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) mean[j] = part[j] * (1.0f / KD);
 #pragma unroll
@@ -652,145 +608,7 @@ void ffn_fused_kernel(const FfnParams p) {
             }
         };
 
-        if constexpr (!LAYER) {
-            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::integral_constant<int, EEND_FFN_PRE_SRC>{}, std::true_type{});
-        } else {
-            // ---- x1 = LN11(A1 Wo1^T + bo1 + res): f16 -> staging tile, fp32 -> out32 stream
-            proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::integral_constant<int, 0>{}, std::false_type{});
-            __syncthreads();
-            f16x8 xs[4][2][2];                               // x1 fragments of the wave's 32 tokens
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        xs[kt][ks][j] = *(const f16x8*)(Xst + kt * (BM * 128) + swz128(g1m + j * 16 + frow, ks * 4 + fkg));
-            __syncthreads();                                 // staging tile free: it becomes the q / k / v tiles
-
-            // ---- speaker-axis attention (see spk_fused.hip): 12 weight slices, after each head's v slice
-            // 4 threads per (slot, frame) run the C-slot softmax for 16 of the 64 head dims
-            const int item = tid >> 2, part = tid & 3;
-            const int cq = item / lyG, tq = item - cq * lyG;
-            f16x8 oreg[4][2];                                // this thread's 16 output dims of each head
-            for (int head = 0; head < 4; ++head) {
-                static_for<3>([&](auto SS) __attribute__((always_inline)) {
-                    constexpr int sidx = decltype(SS)::value;          // 0 q, 1 k, 2 v
-                    const int ch = head * 3 + sidx;
-                    const char* Ws = smem + V2_W1 + (ch & 1) * W1_BYTES;
-                    char* S = Xst + sidx * HS_BYTES;
-                    const int wrow = sidx * KD + head * FC;
-                    f32x4 h[2][2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float4 bb = *(const float4*)(p.bin2 + wrow + g1f + i * 16 + fkg * 4);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) h[i][j] = f32x4{bb.x, bb.y, bb.z, bb.w};
-                    }
-                    f16x8 wa[3][2];
-                    auto ld = [&](auto K) __attribute__((always_inline)) {
-                        constexpr int k = decltype(K)::value;
-                        if constexpr (k < 8) {
-#pragma unroll
-                            for (int i = 0; i < 2; ++i)
-                                wa[k % 3][i] = *(const f16x8*)(Ws + (k >> 1) * (FC * 128) + swz128(g1f + i * 16 + frow, (k & 1) * 4 + fkg));
-                        }
-                    };
-                    ld(std::integral_constant<int, 0>{});
-                    ld(std::integral_constant<int, 1>{});
-                    static_for<8>([&](auto K) __attribute__((always_inline)) {
-                        constexpr int k = decltype(K)::value;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[k % 3][i], xs[k >> 1][k & 1][j], h[i][j], 0, 0, 0);
-                        ld(std::integral_constant<int, k + 2>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int fl = g1f + i * 16 + fkg * 4;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            f16x4 o;
-                            o[0] = to_f16_sat(h[i][j][0]); o[1] = to_f16_sat(h[i][j][1]);
-                            o[2] = to_f16_sat(h[i][j][2]); o[3] = to_f16_sat(h[i][j][3]);
-                            *(f16x4*)(S + swz128(g1m + j * 16 + frow, fl >> 3) + ((fl >> 2) & 1) * 8) = o;
-                        }
-                    }
-                    __syncthreads();          // tile visible; this slice's buffer is free; slice ch+1 has landed
-                    if (ch + 2 < 12) dma_spk(ch + 2, ch & 1);
-                });
-                // attention of this head: online softmax over the C slots of the frame (fp32)
-                {
-                    const char* Sq = Xst;
-                    const char* Sk = Sq + HS_BYTES;
-                    const char* Sv = Sk + HS_BYTES;
-                    float o[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[e] = 0.f;
-                    if (item < rows_g.rows) {
-                        const f16x8 q0 = *(const f16x8*)(Sq + swz128(item, 2 * part));
-                        const f16x8 q1 = *(const f16x8*)(Sq + swz128(item, 2 * part + 1));
-                        float mrun = -INFINITY, lrun = 0.f;
-                        for (int c2 = 0; c2 < p.C; ++c2) {
-                            const int row = c2 * lyG + tq;
-                            const f16x8 k0 = *(const f16x8*)(Sk + swz128(row, 2 * part));
-                            const f16x8 k1 = *(const f16x8*)(Sk + swz128(row, 2 * part + 1));
-                            float d = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)q0[e], (float)k0[e], d);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)q1[e], (float)k1[e], d);
-                            int tt;
-                            tt = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false);
-                            d += __builtin_bit_cast(float, tt);
-                            tt = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false);
-                            d += __builtin_bit_cast(float, tt);
-                            const float sc = d * p.spk_scale;
-                            const float mnew = __builtin_fmaxf(mrun, sc);
-                            const float al = __expf(mrun - mnew), pw = __expf(sc - mnew);
-                            lrun = lrun * al + pw;
-                            mrun = mnew;
-                            const f16x8 v0 = *(const f16x8*)(Sv + swz128(row, 2 * part));
-                            const f16x8 v1 = *(const f16x8*)(Sv + swz128(row, 2 * part + 1));
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pw, (float)v0[e], o[e] * al);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[8 + e] = __builtin_fmaf(pw, (float)v1[e], o[8 + e] * al);
-                        }
-                        const float inv = 1.0f / lrun;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) o[e] *= inv;
-                    }
-                    static_for<4>([&](auto HH) __attribute__((always_inline)) {      // oreg[head] with a static index
-                        if (decltype(HH)::value == head) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { oreg[decltype(HH)::value][0][e] = to_f16_sat(o[e]); oreg[decltype(HH)::value][1][e] = to_f16_sat(o[8 + e]); }
-                        }
-                    });
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // q / k / v tiles are free again
-            }
-            // attention output tile (A operand of the second projection) -> staging region, k-tile = head
-#pragma unroll
-            for (int hd = 0; hd < 4; ++hd) {
-                *(f16x8*)(Xst + hd * (BM * 128) + swz128(item, 2 * part)) = oreg[hd][0];
-                *(f16x8*)(Xst + hd * (BM * 128) + swz128(item, 2 * part + 1)) = oreg[hd][1];
-            }
-            __syncthreads();
-            // ---- x2 = LN21(o Wo2^T + bo2 + x1): x1 is read back from the out32 stream (same thread, same addresses)
-            proj_ln_phase(p.Wo2, p.bo2, p.g21, p.be21, p.eps21, p.out32, std::integral_constant<int, 1>{}, std::true_type{});
-        }
-    }
-    if constexpr (LAYER) {
-        // launder the thread index again: the lane-derived addresses of the phases above must not stay live
-        // (or be spilled and reloaded) inside the register-tight chunk loop below
-        asm volatile("" : "+v"(tid));
-        lane = tid & 63; frow = lane & 15; fkg = lane >> 4; drow = lane >> 3; dslot = lane & 7;
-        bofs = g1f + fkg * 4;
-        dma_offsets();
+        proj_ln_phase(p.Wo, p.bo, p.g1, p.be1, p.eps1, p.res, std::integral_constant<int, EEND_FFN_PRE_SRC>{}, std::true_type{});
     }
     FFN_STAMP(6);
     float4 bcur[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
@@ -1105,8 +923,7 @@ void ffn_fused_kernel(const FfnParams p) {
     __syncthreads();
 
     FFN_STAMP(8);
-    if constexpr (LAYER) ffn_epilogue<EPI, false>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_g);
-    else if constexpr (BWD) ffn_epilogue_acc(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
+    if constexpr (BWD) ffn_epilogue_acc(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
     else ffn_epilogue<EPI, TRAIN>(p, acc, smem, wave, frow, fkg, g2m, g2n, rows_c);
     FFN_STAMP(9);
     }
@@ -1119,7 +936,7 @@ int launch(const FfnParams& p, hipStream_t stream) {
     const int smem_bytes = V2_SMEM;
     if (!eend_set_dynamic_lds(attr_once, (const void*)kern, smem_bytes)) return EEND_ELAUNCH;
     const int ncu = eend_cu_count();
-    const int ntiles = MODE == 2 ? p.B * ((p.Tp + BM / p.C - 1) / (BM / p.C)) : (p.M + BM - 1) / BM;
+    const int ntiles = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(NT), smem_bytes, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
@@ -1141,15 +958,9 @@ int eend_launch_ffn_fused(const FfnParams& p, int act, int epi, hipStream_t stre
         return launch<0, FFN_EPI_RES_LN, 4>(p, stream);
     }
     if (!p.b1 || !p.b2 || !p.gamma || !p.beta || !p.out16) return EEND_EINVAL;
-    if (!p.out32 && (!p.A || p.Win2 || epi != FFN_EPI_RES_LN)) return EEND_EINVAL;   // f16-only output: the attnout + FFN form only
+    if (!p.out32 && (!p.A || epi != FFN_EPI_RES_LN)) return EEND_EINVAL;   // f16-only output: the attnout + FFN form only
     if (p.A) {                                               // fused attention out-projection + norm1 producer
         if (!p.Wo || !p.bo || !p.g1 || !p.be1 || (p.lda & 7) || epi != FFN_EPI_RES_LN || act != 1) return EEND_EINVAL;
-        if (p.Win2) {                                        // whole second half of a fusion layer
-            if (!p.bin2 || !p.Wo2 || !p.bo2 || !p.g21 || !p.be21 || !p.res || p.res != p.out32 || p.B <= 0 || p.Tp <= 0 ||
-                p.C < 1 || p.C > 12 || (long)p.B * p.C * p.Tp != p.M)
-                return EEND_EINVAL;
-            return launch<1, FFN_EPI_RES_LN, 2>(p, stream);
-        }
         return launch<1, FFN_EPI_RES_LN, 1>(p, stream);
     }
     if (!p.X) return EEND_EINVAL;

@@ -26,6 +26,22 @@
 #include <utility>
 #include <cstdlib>
 
+#include <atomic>
+
+namespace {
+// test hooks (eend_debug_ffn_stream_set): force the tile size (2 / 3 fragments; 0 = the cost model) and cap the rows of one launch
+// (0 = no cap) so that the tile-size agreement and the multi-launch path can be exercised at small sizes
+std::atomic<int> g_debug_nj{0};
+std::atomic<long> g_debug_row_cap{0};
+}  // namespace
+long eend_ffn_stream_debug_row_cap() { return g_debug_row_cap.load(std::memory_order_relaxed); }
+extern "C" int eend_debug_ffn_stream_set(int tile_fragments, long max_rows_per_launch) {
+    if ((tile_fragments != 0 && tile_fragments != 2 && tile_fragments != 3) || max_rows_per_launch < 0) return EEND_EINVAL;
+    g_debug_nj.store(tile_fragments, std::memory_order_relaxed);
+    g_debug_row_cap.store(max_rows_per_launch, std::memory_order_relaxed);
+    return EEND_OK;
+}
+
 namespace {
 
 template <class F, int... I>
@@ -541,8 +557,8 @@ int launch(const FfnStreamParams& p, hipStream_t stream) {
     // 128-row tiles finish earlier: compare rounds x rows-per-tile (the time of a tile is close to linear in its rows).
     const long t3 = (p.M + 191) / 192, t2 = (p.M + 127) / 128;
     const long c3 = ((t3 + ncu - 1) / ncu) * (3 * 10 + 9), c2 = ((t2 + ncu - 1) / ncu) * (2 * 10 + 9);     // per-tile cost model: rows + fixed part
-    const char* e = getenv("EEND_FS_NJ");
-    const int nj = e ? atoi(e) : (c2 < c3 ? 2 : 3);
+    const int forced = g_debug_nj.load(std::memory_order_relaxed);              // tests only (eend_debug_ffn_stream_set)
+    const int nj = forced ? forced : (c2 < c3 ? 2 : 3);
     return nj == 2 ? launch_nj<MODE, ACT, EPI, RES16, 2>(p, ncu, stream) : launch_nj<MODE, ACT, EPI, RES16, 3>(p, ncu, stream);
 }
 

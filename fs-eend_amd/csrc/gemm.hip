@@ -620,11 +620,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EEND_EINVAL;
     if (p.N % BN != 0 || p.K % 64 != 0 || (p.lda & 7) || (p.ldw & 7)) return EEND_EINVAL;
     if constexpr (BM + BN <= 256 && ALOAD == ALOAD_PLAIN) {
-        if (p.K == 256) {
-            static const int pf = getenv("EEND_GEMM_PF") ? atoi(getenv("EEND_GEMM_PF")) : 2;
-            if (pf == 4) return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 4>(p, stream);
-            if (pf == 2) return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 2>(p, stream);
-        }
+        if (p.K == 256) return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 2>(p, stream);
     }
     return launch_pf<ET, BM, BN, WGM, WGN, SWAP, ALOAD, EPI, 0>(p, stream);
 }

@@ -87,16 +87,6 @@ struct SpkAttnParams {
     DropSpec drop;    // training: dropout of the probabilities (a = ((b*Tp + t)*4 + head)*16 + query slot, b = key slot)
 };
 
-struct SpkFusedParams {
-    const void* X;      // f16 [B*C*Tp][ldx], row = (b*C + c)*Tp + t
-    const void* W;      // f16 [768][256] in_proj_weight (q rows, k rows, v rows)
-    const float* bias;  // [768]
-    void* O;            // f16 [B*C*Tp][256]
-    int B, C, Tp, ldx;
-    int Tv;             // frames t < Tv of every slab are computed (rows beyond keep their previous, finite, contents)
-    float scale;        // 1/sqrt(dh)
-};
-int eend_launch_spk_qkv_attn(const SpkFusedParams& p, hipStream_t stream);
 
 int eend_launch_emb_consistency(const float* emb, const float* tgt, const int* lens, float inv_count, float* partial_ws, float* out,
                                 int B, int T, int Tp, int D, int C, hipStream_t stream);
@@ -137,17 +127,14 @@ struct RetParams {
 
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 
-// attn_fused.hip: packed in-projection + causal attention of one (sequence, head) per workgroup (Tp <= 512, H = 4)
+// attn_stream.hip: in-projection + causal attention in one launch, token-owning waves and fragment-packed weights (Tp = 512, H = 4)
 struct InprojAttnParams {
     const void* X; int ldx;      // f16 [nseq*Tp][ldx], 256 model dims
-    const void* W;               // f16 [768][256] packed in_proj_weight, q rows pre-scaled (ops.QSCALE_LOG2)
+    const void* W;               // f16 packed in_proj_weight (eend_launch_inproj_attn_pack), q rows pre-scaled (ops.QSCALE_LOG2)
     const float* bias;           // [768]
-    void* Qs;                    // bf16 scratch [nseq][4][Tp][64]
     void* O;                     // f16 [nseq*Tp][ldo]
     int nseq, H, Tp, ldo, mask_delay, kv_len;
 };
-int eend_launch_inproj_attn(const InprojAttnParams& p, hipStream_t stream);
-// attn_stream.hip: the same operator with token-owning waves and fragment-packed weights (Tp = 512); p.W = packed weights, p.Qs unused
 long eend_inproj_attn_packed_nelems();
 int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream);
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream);
@@ -238,16 +225,6 @@ struct FfnParams {
     const float* be1;
     float eps1;
     int lda;
-    // optional speaker-attention stage between two projection+LN producers (null Win2 = off; needs A):
-    // x1 = LN(A Wo^T + bo + res) [g1, be1]; o = MHA_slots(x1 Win2^T + bin2); X = LN(o Wo2^T + bo2 + x1) [g21, be21]
-    const void* Win2;   // f16 [768][256]
-    const float* bin2;  // [768]
-    const void* Wo2;    // f16 [256][256]
-    const float* bo2;
-    const float* g21;
-    const float* be21;
-    float eps21, spk_scale;
-    int B, C, Tp;       // M = B*C*Tp, row = (b*C + c)*Tp + t
     // training forward of a post-norm FFN block (round 5, eend_ffn_train_f16; null hid16 = off): h = drop1(relu(X W1^T + b1)) is ALSO written to
     // hid16 (the saved activation of the backward; its zeros are the ReLU-and-dropout mask), y = drop2(h W2^T + b2) * alpha + res,
     // out32 / out16 = LayerNorm(y), xhat16 = the normalised pre-affine rows, rstat = 1/sigma per row (what eend_layernorm_bwd_f32 reads)
@@ -285,6 +262,7 @@ struct FfnStreamParams {
     int M, F;
 };
 long eend_ffn_stream_nelems(int F, int with_wo);
+long eend_ffn_stream_debug_row_cap();                    // test hook (eend_debug_ffn_stream_set), 0 = none
 int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
 int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream);
 // spk_stream.hip: x1 = LN11(A Wo1^T + bo1 + res16), O = speaker-axis MHA(x1 Win2^T + bin2) in one launch (C in {3, 6, 12})

@@ -25,37 +25,15 @@ from .lib import EendHipError
 
 _D_SUPPORTED = 256
 _H_SUPPORTED = 4
-# A/B switch for perf studies: EEND_FFN_FUSED=0 runs linear1 / linear2 as two GEMM launches
-FUSED_FFN = __import__("os").environ.get("EEND_FFN_FUSED", "1") != "0"
-# EEND_ATTNOUT_FUSED=0 keeps the attention out-projection + norm1 as its own launch in front of the FFN
-FUSED_ATTNOUT = __import__("os").environ.get("EEND_ATTNOUT_FUSED", "1") != "0"
-# EEND_SPK_FUSED=0 runs the speaker-axis qkv projection and attention as two launches
-FUSED_SPK = __import__("os").environ.get("EEND_SPK_FUSED", "1") != "0"
-# EEND_TAIL_FUSED=1 runs out-proj+norm11 / speaker attention / out-proj+norm21+FFN as ONE launch
-# (eend_fusion_layer_tail_f16).  Off by default: measured 1.00 ms vs 0.875 ms for the three launches at
-# B=64, C=6, T=500 -- with one 160 KB block per CU every extra phase is exposed latency, and the gathered
-# 126-row tiles need a 7th round on 256 CUs.
-FUSED_TAIL = __import__("os").environ.get("EEND_TAIL_FUSED", "0") == "1"
-# time-axis attention: in-projection + causal attention in one launch per layer, K / V never leave the CU (attn_fused.hip;
-# chunks up to 512 frames).  EEND_ATTN_FUSED=0 keeps the two-kernel path (A/B, and the only path for longer chunks).
-FUSED_INPROJ_ATTN = __import__("os").environ.get("EEND_ATTN_FUSED", "1") != "0"
-# packed-weight-stream layer-tail kernel (ffn_stream.hip, round 4) in place of ffn.hip's; EEND_FFN_STREAM=0: the round-3 kernel (A/B)
-FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM", "1") != "0"
-# f16 residual stream between the sub-layers of the (post-norm) FS-EEND stacks; EEND_RES16=0: the f32 stream (A/B)
-RES16 = __import__("os").environ.get("EEND_RES16", "1") != "0"
-# look-ahead conv + L2 norm on a packed weight stream (conv_stream.hip; 256 channels)
-CONV_STREAM = __import__("os").environ.get("EEND_CONV_STREAM", "1") != "0"
-# encoder input (pad_sequence + BatchNorm + projection + LayerNorm) in one launch (encin.hip; 320 < in_size <= 384)
-ENCIN_FUSED = __import__("os").environ.get("EEND_ENCIN_FUSED", "1") != "0"
-# time-axis attention with token-owning waves, packed in-projection weights and Q kept in registers (attn_stream.hip; Tp = 512 only)
-ATTN_STREAM = __import__("os").environ.get("EEND_ATTN_STREAM", "1") != "0"
-# the first half of a decoder layer (out-projection + norm11 + speaker-axis in-projection + C x C attention) in one launch on a
-# packed weight stream (spk_stream.hip), any slot count C = 1 .. 12 (3 / 6 / 12 fill the tiling, the others run with phantom slots);
-# 0: linear_res16_ln + spk_qkv_attn.  Unlike spk_qkv_attn it takes no T_valid: the slab's padded frames [T, Tp) are computed too (finite
-# don't-care rows, masked as keys and dropped by the head) -- 2.4 % of the rows at T = 500 / Tp = 512, the bench configuration; for
-# lengths far below their padded length (T = 260, Tp = 320: 19 %) that is work the two-launch path skipped (kept deliberately:
-# a per-tile T_valid test costs the packed kernel its tile-uniform control flow).
-SPK_STREAM = __import__("os").environ.get("EEND_SPK_STREAM", "1") != "0"
+# One fast form + one general fallback per operator, selected by SHAPE (round 6: the A/B environment switches of rounds 1 - 5 are gone;
+# their questions are answered in profiles/OPTIMISATION_LOG.md):
+#   encoder input      encin.hip (320 < in_size <= 384)              | gather + BatchNorm + linear_res_ln
+#   time-axis MHA      attn_stream.hip (Tp = 512, packed weights)    | in-projection + attn_full.hip (Tp <= 512) / attn.hip (longer)
+#   layer head         spk_stream.hip (C <= 12: the limit of every speaker-axis kernel)
+#   layer tail         ffn_stream.hip (F % 64 == 0)                  | attnout_ffn_fused_res16 (ffn.hip)
+#   look-ahead conv    conv_stream.hip (256 channels)                | implicit-GEMM epilogue (gemm.hip)
+# The stacks are post-norm, so the residual of every sub-layer is the previous LayerNorm's output: its f16 copy (the next MFMA operand
+# anyway) IS the residual stream; no f32 stream exists between the layers (oracle emulation: max |d logit| 2.4e-4 -> 2.6e-4).
 
 
 class PositionalEncoding(nn.Module):
@@ -167,16 +145,13 @@ class _Workspace:
         Mx = max(Me, Md)
         e = lambda *s, dt: torch.empty(*s, dtype=dt, device=dev)
         self.xin16 = torch.zeros(Me, Fin_pad, dtype=f16, device=dev)
-        self.h32, self.h16 = e(Me, D, dt=f32), e(Me, D, dt=f16)
-        self.q = e(Mx * D, dt=bf16)
-        self.k = e(Mx * D, dt=bf16)
-        self.vt = e(Mx * D, dt=bf16)
+        self.h16 = e(Me, D, dt=f16)
+        # bf16 Q / K / V^T of the un-packed attention path: only chunk lengths other than 512 frames read them
+        n_qkv = Mx * D if Tp != 512 else 0
+        self.q, self.k, self.vt = e(n_qkv, dt=bf16), e(n_qkv, dt=bf16), e(n_qkv, dt=bf16)
         self.o16 = e(Mx, D, dt=f16)
-        # hidden activations / speaker qkv only exist in HBM on the un-fused A/B paths (EEND_FFN_FUSED=0 / EEND_SPK_FUSED=0)
-        self.ff16 = e(max(Me * F_enc, Md * F_dec) if not FUSED_FFN else 0, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
-        self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
-        self.qkv16 = e(Md if not FUSED_SPK else 0, 3 * D, dt=f16)
+        self.a16 = e(Md, D, dt=f16)
 
 
 class WorkspaceCache:
@@ -281,19 +256,16 @@ class OnlineTransformerDADiarization(nn.Module):
                 w1=_f16(l.linear1.weight), b1=_f32(l.linear1.bias), w2=_f16(l.linear2.weight), b2=_f32(l.linear2.bias),
                 g1=_f32(l.norm1.weight), be1=_f32(l.norm1.bias), eps1=l.norm1.eps,
                 g2=_f32(l.norm2.weight), be2=_f32(l.norm2.bias), eps2=l.norm2.eps))
-        if FFN_STREAM and FUSED_FFN and FUSED_ATTNOUT:
-            for L in layers:
-                if ops.stream_ok(L["w1"].shape[0]):
-                    L["ws"] = ops.ffn_stream_pack(L["out_w"], L["w1"], L["w2"])
-        if ATTN_STREAM and FUSED_INPROJ_ATTN and enc.n_heads == 4:
-            for L in layers:
-                L["in_wp"] = ops.inproj_attn_pack(L["in_w"])
+        for L in layers:
+            if ops.stream_ok(L["w1"].shape[0]):
+                L["ws"] = ops.ffn_stream_pack(L["out_w"], L["w1"], L["w2"])
+            L["in_wp"] = ops.inproj_attn_pack(L["in_w"])
         P["enc.layers"] = layers
         cw = self.cnn.weight.detach()                       # (Dout, Din, k)
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
         P["cnn.b"] = _f32(self.cnn.bias)
         P["cnn.k"], P["cnn.pad"] = cw.shape[2], self.cnn.padding[0]
-        if CONV_STREAM and ops.conv_stream_ok(cw.shape[1], cw.shape[2], self.cnn.padding[0]) and cw.shape[0] == 256:
+        if ops.conv_stream_ok(cw.shape[1], cw.shape[2], self.cnn.padding[0]) and cw.shape[0] == 256:
             P["cnn.ws"] = ops.conv_stream_pack(P["cnn.w"], cw.shape[2])
         D = enc.n_units
         P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
@@ -308,16 +280,11 @@ class OnlineTransformerDADiarization(nn.Module):
                 g11=_f32(l.norm11.weight), be11=_f32(l.norm11.bias), eps11=l.norm11.eps,
                 g21=_f32(l.norm21.weight), be21=_f32(l.norm21.bias), eps21=l.norm21.eps,
                 g22=_f32(l.norm22.weight), be22=_f32(l.norm22.bias), eps22=l.norm22.eps))
-        if FFN_STREAM and FUSED_FFN and FUSED_ATTNOUT:
-            for L in dl:
-                if ops.stream_ok(L["w1"].shape[0]):
-                    L["ws"] = ops.ffn_stream_pack(L["out2_w"], L["w1"], L["w2"])
-        if SPK_STREAM and FUSED_SPK:
-            for L in dl:
-                L["ws1"] = ops.spk_stream_pack(L["out1_w"], L["in2_w"])
-        if ATTN_STREAM and FUSED_INPROJ_ATTN and enc.n_heads == 4:
-            for L in dl:
-                L["in1_wp"] = ops.inproj_attn_pack(L["in1_w"])
+        for L in dl:
+            if ops.stream_ok(L["w1"].shape[0]):
+                L["ws"] = ops.ffn_stream_pack(L["out2_w"], L["w1"], L["w2"])
+            L["ws1"] = ops.spk_stream_pack(L["out1_w"], L["in2_w"])
+            L["in1_wp"] = ops.inproj_attn_pack(L["in1_w"])
         P["dec.layers"] = dl
         self._prep, self._prep_key = P, key
         self._pc = {}
@@ -371,119 +338,63 @@ class OnlineTransformerDADiarization(nn.Module):
         kv_e = T          # keys are the T real frames of the padded batch (the reference's mask is (T, T)), never slab padding
 
         # ---- embedding encoder (model :162-188)
-        # pad_sequence(-1) (model :165) + BatchNorm + cast + slab padding: one gather launch
-        res16 = RES16 and FUSED_FFN and FUSED_ATTNOUT
-        encin = ENCIN_FUSED and ops.encoder_input_ok(srcs, Tp, P["enc.in.w"])
-        if encin:      # gather + BatchNorm + input projection + LayerNorm in one launch, the f32 features read once (encin.hip)
-            ops.encoder_input(srcs, P["bn"], P["enc.in.w"], P["enc.in.b"], P["enc.in.g"], P["enc.in.beta"], None if res16 else ws.h32,
-                              ws.h16, T, Tp, -1.0, P["bn.eps"], P["enc.in.eps"])
+        if ops.encoder_input_ok(srcs, Tp, P["enc.in.w"]):
+            # pad_sequence(-1) (model :165) + BatchNorm + input projection + LayerNorm in one launch, the f32 features read once (encin.hip)
+            ops.encoder_input(srcs, P["bn"], P["enc.in.w"], P["enc.in.b"], P["enc.in.g"], P["enc.in.beta"], None, ws.h16, T, Tp, -1.0,
+                              P["bn.eps"], P["enc.in.eps"])
         else:
             ops.gather_bn_cast_pad(srcs, P["bn"], ws.xin16, T, Tp, -1.0, True, P["bn.eps"])
-        # RES16 (default): the stack is post-norm, so the residual of every sub-layer is the previous LayerNorm's output; its
-        # f16 copy (the next MFMA operand anyway) serves as the residual and the f32 stream is only written where something
-        # reads it in f32 (the head).  Oracle emulation: max |d logit| 2.4e-4 -> 2.6e-4.
-        if not encin:
-            ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"],
-                              None if res16 else ws.h32, ws.h16, P["enc.in.eps"])
-        q, k, vt = ws.q[:Me * D], ws.k[:Me * D], ws.vt[:Me * D]
+            ops.linear_res_ln(ws.xin16, P["enc.in.w"], P["enc.in.b"], None, P["enc.in.g"], P["enc.in.beta"], None, ws.h16, P["enc.in.eps"])
         o16 = ws.o16[:Me]
+
+        def time_attention(x16, Ly, wkey, bkey, nseq, delay, kv):
+            """in-projection + causal MHA over the frames of `nseq` sequences -> ws.o16 rows (merge_tfm_encoder.py:379-385)"""
+            o = ws.o16[:nseq * Tp]
+            if Tp == 512:            # token-owning waves, packed weights, Q in registers, K / V never leave the CU (attn_stream.hip)
+                ops.inproj_attn_causal_packed(x16, Ly[wkey + "p"], Ly[bkey], o, nseq, H, Tp, delay, kv)
+            else:                    # other chunk lengths: bf16 Q / K / V^T through HBM, resident (<= 512) or tiled attention kernel
+                n = nseq * Tp * D
+                ops.inproj_heads(x16, Ly[wkey], Ly[bkey], ws.q[:n], ws.k[:n], ws.vt[:n], nseq, Tp, H)
+                ops.attn_causal(ws.q[:n], ws.k[:n], ws.vt[:n], o, nseq, H, Tp, delay, kv, scale=ops.LN2)
+            return o
+
         for L in P["enc.layers"]:
-            F = L["w1"].shape[0]
-            ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
-            if FUSED_INPROJ_ATTN and Tp == 512 and "in_wp" in L:
-                ops.inproj_attn_causal_packed(ws.h16, L["in_wp"], L["in_b"], o16, B, H, Tp, delay_e, kv_e)
-            elif FUSED_INPROJ_ATTN and Tp <= 512:
-                ops.inproj_attn_causal(ws.h16, L["in_w"], L["in_b"], q, o16, B, H, Tp, delay_e, kv_e)
-            else:
-                ops.inproj_heads(ws.h16, L["in_w"], L["in_b"], q, k, vt, B, Tp, H)
-                ops.attn_causal(q, k, vt, o16, B, H, Tp, delay_e, kv_e, scale=ops.LN2)
-            if "ws" in L and FUSED_FFN and FUSED_ATTNOUT:   # the same launch on the packed weight stream (ffn_stream.hip)
-                ops.attnout_ffn_stream(o16, L["ws"], L["out_b"], None if res16 else ws.h32, ws.h16 if res16 else None, L["g1"], L["be1"],
-                                       L["eps1"], L["b1"], L["b2"], L["g2"], L["be2"], L["eps2"], None if res16 else ws.h32, ws.h16)
-                continue
-            if res16:
+            time_attention(ws.h16, L, "in_w", "in_b", B, delay_e, kv_e)
+            if "ws" in L:            # out-projection + norm1 + FFN + norm2 in one launch on the packed weight stream (ffn_stream.hip)
+                ops.attnout_ffn_stream(o16, L["ws"], L["out_b"], None, ws.h16, L["g1"], L["be1"], L["eps1"], L["b1"], L["b2"], L["g2"],
+                                       L["be2"], L["eps2"], None, ws.h16)
+            else:                    # hidden sizes the packed stream does not take (ffn.hip)
                 ops.attnout_ffn_fused_res16(o16, L["out_w"], L["out_b"], ws.h16, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
                                             L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], None, ws.h16)
-                continue
-            if FUSED_FFN and FUSED_ATTNOUT:   # out_proj + norm1 + FFN + norm2 in one launch (x never leaves the CU)
-                ops.attnout_ffn_fused(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], L["eps1"], L["w1"], L["b1"],
-                                      L["w2"], L["b2"], L["g2"], L["be2"], L["eps2"], ws.h32, ws.h16)
-                continue
-            ops.linear_res_ln(o16, L["out_w"], L["out_b"], ws.h32, L["g1"], L["be1"], ws.h32, ws.h16, L["eps1"])
-            if FUSED_FFN:      # linear1 + ReLU + linear2 + residual + norm2 in one launch (hidden stays on chip)
-                ops.ffn_fused(ws.h16, L["w1"], L["b1"], L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16,
-                              ops.ACT_RELU, 1.0, L["eps2"])
-            else:
-                ops.linear(ws.h16, L["w1"], L["b1"], ff, relu=True)
-                ops.linear_res_ln(ff, L["w2"], L["b2"], ws.h32, L["g2"], L["be2"], ws.h32, ws.h16, L["eps2"])
 
         # ---- truncate to ilen / zero re-pad, look-ahead conv, L2 norm (model :38-41)
         emb32 = torch.empty(Me, D, dtype=torch.float32, device=dev)       # returned to the caller (views, no copies)
-        if "cnn.ws" in P:        # the same operator on the packed weight stream (conv_stream.hip)
+        if "cnn.ws" in P:        # packed weight stream (conv_stream.hip)
             ops.conv1d_l2norm_stream(ws.h16, P["cnn.ws"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, P["cnn.k"], P["cnn.pad"])
         else:
             ops.conv1d_l2norm(ws.h16, P["cnn.w"], P["cnn.b"], il, emb32, ws.emb16, B, Tp, D, P["cnn.k"], P["cnn.pad"])
 
         # ---- attractor decoder (model :112-118, merge_tfm_encoder.py:356-376)
-        res16 = res16 and FUSED_SPK and not FUSED_TAIL
-        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), None if res16 else ws.a32, ws.a16, B, Tp, C)
-        q, k, vt = ws.q[:Md * D], ws.k[:Md * D], ws.vt[:Md * D]
+        ops.convert_fanout(ws.emb16, P["convert.w1"], self._convert_const(C), None, ws.a16, B, Tp, C)
         o16 = ws.o16[:Md]
         for L in P["dec.layers"]:
-            F = L["w1"].shape[0]
-            ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
-            if FUSED_INPROJ_ATTN and Tp == 512 and "in1_wp" in L:
-                ops.inproj_attn_causal_packed(ws.a16, L["in1_wp"], L["in1_b"], o16, B * C, H, Tp, self.dec.mask_delay, T)
-            elif FUSED_INPROJ_ATTN and Tp <= 512:
-                ops.inproj_attn_causal(ws.a16, L["in1_w"], L["in1_b"], q, o16, B * C, H, Tp, self.dec.mask_delay, T)
+            time_attention(ws.a16, L, "in1_w", "in1_b", B * C, self.dec.mask_delay, T)
+            # out-projection + norm11 + speaker-axis in-projection + C x C attention in one launch (spk_stream.hip; any slot count the
+            # speaker-axis kernels take, C <= 12).  It takes no T_valid: the slab's padded frames [T, Tp) are computed too (finite
+            # don't-care rows, masked as keys and dropped by the head) -- 2.4 % of the rows at T = 500 / Tp = 512; a per-tile T_valid test
+            # would cost the kernel its tile-uniform control flow
+            ops.attnout_spk_stream(o16, L["ws1"], L["out1_b"], ws.a16, L["g11"], L["be11"], L["eps11"], ws.a16, L["in2_b"], o16, B, C, Tp)
+            if "ws" in L:
+                ops.attnout_ffn_stream(o16, L["ws"], L["out2_b"], None, ws.a16, L["g21"], L["be21"], L["eps21"], L["b1"], L["b2"],
+                                       L["g22"], L["be22"], L["eps22"], None, ws.a16)
             else:
-                ops.inproj_heads(ws.a16, L["in1_w"], L["in1_b"], q, k, vt, B * C, Tp, H)
-                ops.attn_causal(q, k, vt, o16, B * C, H, Tp, self.dec.mask_delay, T, scale=ops.LN2)
-            if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
-                ops.fusion_layer_tail(o16, ws.a32, ws.a16, L["out1_w"], L["out1_b"], L["g11"], L["be11"], L["eps11"],
-                                      L["in2_w"], L["in2_b"], L["out2_w"], L["out2_b"], L["g21"], L["be21"], L["eps21"],
-                                      L["w1"], L["b1"], L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], B, C, Tp)
-                continue
-            if res16:
-                if "ws1" in L and H == 4 and ops.spk_stream_ok(C, Tp):
-                    ops.attnout_spk_stream(o16, L["ws1"], L["out1_b"], ws.a16, L["g11"], L["be11"], L["eps11"], ws.a16, L["in2_b"],
-                                           o16, B, C, Tp)
-                else:
-                    ops.linear_res16_ln(o16, L["out1_w"], L["out1_b"], ws.a16, L["g11"], L["be11"], None, ws.a16, L["eps11"])
-                    ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
-                if "ws" in L:
-                    ops.attnout_ffn_stream(o16, L["ws"], L["out2_b"], None, ws.a16, L["g21"], L["be21"], L["eps21"], L["b1"], L["b2"],
-                                           L["g22"], L["be22"], L["eps22"], None, ws.a16)
-                    continue
                 ops.attnout_ffn_fused_res16(o16, L["out2_w"], L["out2_b"], ws.a16, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
                                             L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], None, ws.a16)
-                continue
-            ops.linear_res_ln(o16, L["out1_w"], L["out1_b"], ws.a32, L["g11"], L["be11"], ws.a32, ws.a16, L["eps11"])
-            if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
-                ops.spk_qkv_attn(ws.a16, L["in2_w"], L["in2_b"], o16, B, C, Tp, H, t_valid=T)
-            else:
-                ops.linear(ws.a16, L["in2_w"], L["in2_b"], ws.qkv16)
-                ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
-            if FUSED_FFN and FUSED_ATTNOUT and "ws" in L:
-                ops.attnout_ffn_stream(o16, L["ws"], L["out2_b"], ws.a32, None, L["g21"], L["be21"], L["eps21"], L["b1"], L["b2"],
-                                       L["g22"], L["be22"], L["eps22"], ws.a32, ws.a16)
-                continue
-            if FUSED_FFN and FUSED_ATTNOUT:
-                ops.attnout_ffn_fused(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], L["eps21"], L["w1"], L["b1"],
-                                      L["w2"], L["b2"], L["g22"], L["be22"], L["eps22"], ws.a32, ws.a16)
-                continue
-            ops.linear_res_ln(o16, L["out2_w"], L["out2_b"], ws.a32, L["g21"], L["be21"], ws.a32, ws.a16, L["eps21"])
-            if FUSED_FFN:
-                ops.ffn_fused(ws.a16, L["w1"], L["b1"], L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16,
-                              ops.ACT_RELU, 1.0, L["eps22"])
-            else:
-                ops.linear(ws.a16, L["w1"], L["b1"], ff, relu=True)
-                ops.linear_res_ln(ff, L["w2"], L["b2"], ws.a32, L["g22"], L["be22"], ws.a32, ws.a16, L["eps22"])
 
         # ---- attractor L2 norm + embedding . attractor head (model :43,:60)
         attr = torch.empty(B, T, C, D, dtype=torch.float32, device=dev)
         logits = torch.empty(B, T, C, dtype=torch.float32, device=dev)
-        ops.head_l2dot(emb32, ws.a16 if res16 else ws.a32, attr, logits, B, T, Tp, C, D)
+        ops.head_l2dot(emb32, ws.a16, attr, logits, B, T, Tp, C, D)
         emb = emb32.view(B, Tp, D)
         return logits, emb, attr, T, Tp
 

@@ -47,11 +47,8 @@ PROTOTYPES = {
     "eend_attnout_spk_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "eend_attnout_spk_stream_res32_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "eend_ffn_stream_max_rows": [_i],
+    "eend_debug_ffn_stream_set": [_i, _l],
     "eend_attnout_ffn_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
-    "eend_inproj_attn_causal_f16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    "eend_spk_qkv_attn_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
-    "eend_fusion_layer_tail_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f,
-                                   _i, _i, _i, _i, _vp],
     "eend_emb_consistency_f32": [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "eend_activity_median_u8": [_vp, _i, _i, _i, _f, _i, _vp, _vp],
     "eend_activity_segments_i32": [_vp, _i, _i, _vp, _vp, _i, _vp],

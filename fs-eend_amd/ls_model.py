@@ -19,25 +19,16 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from .fs_model import FUSED_ATTNOUT, FUSED_FFN, FUSED_SPK, FUSED_TAIL, PositionalEncoding, WorkspaceCache, _f16, _f32
+from .fs_model import PositionalEncoding, WorkspaceCache, _f16, _f32
 
-# The packed-weight-stream layer-tail kernels (ffn_stream.hip) are parity-tested on this model too but measured slower here than
-# ffn.hip's (f32 residual stream + f32 output: 576 KB of row traffic per 192-row tile; Swish on the single wave per SIMD) --
-# 848 vs 829 us for the decoder launch, 71 vs 62 us for a Conformer FFN (profiles/r04_ls_kernel_stats_stream{1,0}.csv): off unless
-# EEND_FFN_STREAM_LS=1.
-FFN_STREAM = __import__("os").environ.get("EEND_FFN_STREAM_LS", "0") != "0"
-# decoder input linear of the batch forward in f32 (convert_f32.hip); EEND_LS_CONVERT_F32=0: the f16 MFMA form (A/B)
-CONVERT_F32 = __import__("os").environ.get("EEND_LS_CONVERT_F32", "1") != "0"
-CONV_STREAM = __import__("os").environ.get("EEND_CONV_STREAM", "1") != "0"
-# the retention with its projections fused on chip (ret_stream.hip); EEND_RET_STREAM=0: retention_proj + retention_chunk (A/B)
-RET_STREAM = __import__("os").environ.get("EEND_RET_STREAM", "1") != "0"
-# ... with the f16 remainder of the decoder's f32 residual stream as the query path's second operand; 0: hi rows only
-RET_XLO = __import__("os").environ.get("EEND_RET_XLO", "1") != "0"
-# the speaker-attention out-projection weight of the decoder layers as a hi / lo f16 pair (two products in the layer-tail kernel); 0: hi only
-OUT2_SPLIT = __import__("os").environ.get("EEND_LS_OUT2_SPLIT", "1") != "0"
-# the first half of a decoder layer behind the retention (out-projection + residual + norm11 + speaker-axis attention) as one launch on the
-# f32 residual stream (spk_stream.hip, R32); 0: eend_linear_res_ln_f16 + eend_spk_qkv_attn_f16 (A/B)
-SPK_STREAM_LS = __import__("os").environ.get("EEND_SPK_STREAM_LS", "1") != "0"
+# One fast form + one general fallback per operator, selected by SHAPE (round 6: the A/B environment switches of rounds 2 - 5 are gone;
+# their questions are answered in profiles/OPTIMISATION_LOG.md):
+#   retention + projections   ret_stream.hip (H = 4, chunk <= 512, ...)   | retention_proj + retention_chunk (retention.hip / _full.hip)
+#   decoder layer head        spk_stream.hip, f32 residual (C <= 12: the limit of every speaker-axis kernel)
+#   decoder layer tail        ffn.hip PRE form, out-projection weight as a hi / lo f16 pair, hi / lo f16 copies of the f32 output rows
+#   Conformer half-step FFNs  ffn.hip (the packed-stream form measured slower on this model's f32 residual stream: round 4)
+#   decoder input             convert_f32.hip (f32 MFMA; the batch forward hands over f32 embeddings) | f16 form (chunked long-form path)
+#   look-ahead conv           conv_stream.hip (256 channels)              | implicit-GEMM epilogue (gemm.hip)
 from .lib import EendHipError
 from . import ls_stream
 from .ls_stream import StreamingConv1d  # noqa: F401  (re-exported: the reference defines it next to the model)
@@ -247,7 +238,7 @@ def _ret_pack32(msr: MultiScaleRetention):
 
 
 class _Workspace:
-    def __init__(self, dev, B, Tp, C, D, F_enc, F_dec, Fin_pad, H, nc):
+    def __init__(self, dev, B, Tp, C, D, F_enc, F_dec, Fin_pad, H, nc, with_lo=True):
         f16, f32 = torch.float16, torch.float32
         Me, Md = B * Tp, B * C * Tp
         Mx = max(Me, Md)
@@ -258,12 +249,11 @@ class _Workspace:
         self.g = e(Mx, D, dt=f16)
         self.o16 = torch.zeros(Mx, D, dtype=f16, device=dev)     # rows of skipped padding chunks are never written: keep them finite
         self.glu16, self.dw16 = e(Me, D, dt=f16), e(Me, D, dt=f16)
-        # hidden activations / speaker qkv only exist in HBM on the un-fused A/B paths (EEND_FFN_FUSED=0 / EEND_SPK_FUSED=0)
-        self.ff16 = e(max(Me * F_enc, Md * F_dec) if not FUSED_FFN else 0, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
         self.a32, self.a16 = e(Md, D, dt=f32), e(Md, D, dt=f16)
-        self.a16lo = e(Md if (RET_STREAM and RET_XLO) else 0, D, dt=f16)     # f16 remainder of a32's rows (query path of ret_stream.hip)
-        self.qkv16 = e(Md if not FUSED_SPK else 0, 3 * D, dt=f16)
+        # f16 remainder of a32's rows: the second operand of the fused retention's query path (ret_stream.hip); only allocated where
+        # that operator runs (~3 GB at B = 512, C = 12, Tp = 1024 that nothing read on the fallback path)
+        self.a16lo = e(Md if with_lo else 0, D, dt=f16)
         nseq = max(B, B * C)
         self.st = e(nseq * H * nc * 2 * 4096, dt=f16)
         self.cscale, self.sexp = e(nseq * H * nc, dt=f32), e(nseq * H * nc, dt=f32)
@@ -368,19 +358,13 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 w1a32=_f32(ffa[1].linear.weight), w2a32=_f32(ffa[4].linear.weight),
                 w1b32=_f32(ffb[1].linear.weight), w2b32=_f32(ffb[4].linear.weight),
                 lne=(_f32(ln_e.weight), _f32(ln_e.bias), ln_e.eps)))
-        if RET_STREAM:
-            for Bk in blocks:
-                Bk["wrs"] = ops.retention_stream_pack(Bk["wqkvg32"])
-        if FFN_STREAM and FUSED_FFN:
-            for Bk in blocks:
-                if ops.stream_ok(Bk["w1a"].shape[0]):
-                    Bk["wsa"] = ops.ffn_stream_pack(None, Bk["w1a"], Bk["w2a"])
-                    Bk["wsb"] = ops.ffn_stream_pack(None, Bk["w1b"], Bk["w2b"])
+        for Bk in blocks:
+            Bk["wrs"] = ops.retention_stream_pack(Bk["wqkvg32"])
         P["blocks"] = blocks
         cw = self.cnn.weight.detach()
         P["cnn.w"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float16).contiguous()
         P["cnn.b"], P["cnn.k"], P["cnn.pad"] = _f32(self.cnn.bias), cw.shape[2], self.cnn.padding[0]
-        if CONV_STREAM and cw.shape[0] == 256 and ops.conv_stream_ok(cw.shape[1], cw.shape[2], self.cnn.padding[0]):
+        if cw.shape[0] == 256 and ops.conv_stream_ok(cw.shape[1], cw.shape[2], self.cnn.padding[0]):
             P["cnn.ws"] = ops.conv_stream_pack(P["cnn.w"], cw.shape[2])      # the look-ahead conv on the packed weight stream (conv_stream.hip)
         P["cnn.w32"] = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).to(torch.float32).contiguous()     # f32 frame steps
         P["convert.w1"] = _f16(self.dec.convert.weight[:, :D])
@@ -401,16 +385,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 # f32 weights of the all-f32 frame step (ls_stream.dec_step: <= 16 rows per frame)
                 out1_w32=_f32(l.self_attn1.out_proj.weight), in2_w32=_f32(l.self_attn2.in_proj_weight),
                 out2_w32=_f32(l.self_attn2.out_proj.weight), w1_32=_f32(l.linear1.weight), w2_32=_f32(l.linear2.weight)))
-        if FFN_STREAM and FUSED_FFN and FUSED_ATTNOUT:
-            for Ld in dl:
-                if ops.stream_ok(Ld["w1"].shape[0]):
-                    Ld["ws"] = ops.ffn_stream_pack(Ld["out2_w"], Ld["w1"], Ld["w2"])
-        if RET_STREAM:
-            for Ld in dl:
-                Ld["wrs"] = ops.retention_stream_pack(Ld["wqkvg32"])
-        if SPK_STREAM_LS and FUSED_SPK:
-            for Ld in dl:
-                Ld["ws1"] = ops.spk_stream_pack(Ld["out1_w"], Ld["in2_w"])
+        for Ld in dl:
+            Ld["wrs"] = ops.retention_stream_pack(Ld["wqkvg32"])
+            Ld["ws1"] = ops.spk_stream_pack(Ld["out1_w"], Ld["in2_w"])
         P["dec.layers"] = dl
         self._prep, self._prep_key, self._pc = P, key, {}
         return P
@@ -438,7 +415,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             P = self._prep
             F_enc = P["blocks"][0]["w1a"].shape[0] if P["blocks"] else 0
             F_dec = P["dec.layers"][0]["w1"].shape[0] if P["dec.layers"] else 0
-            ws = _Workspace(dev, B, Tp, C, self.n_units, F_enc, F_dec, P["Fin_pad"], self._n_heads, nc)
+            with_lo = self._n_heads == 4 and ops.retention_stream_ok(self.recurrent_chunk_size, Tp)
+            ws = _Workspace(dev, B, Tp, C, self.n_units, F_enc, F_dec, P["Fin_pad"], self._n_heads, nc, with_lo=with_lo)
             self._ws.put(key, ws)
         return ws
 
@@ -460,21 +438,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         for i, Bk in enumerate(P["blocks"]):
             if i == 0:
                 ops.layernorm_f16(ws.h32, Bk["lna"][0], Bk["lna"][1], ws.x16, Bk["lna"][2])
-            F = Bk["w1a"].shape[0]
-            ff = None if FUSED_FFN else ws.ff16[:Me * F].view(Me, F)
-            # x += fa * FFN(LN_a x)                      -> x16 = LN_b(x)
-            if FUSED_FFN and "wsa" in Bk:
-                ops.ffn_stream(ws.x16, Bk["wsa"], Bk["b1a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
-                               ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
-            elif FUSED_FFN:
-                ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
-                              ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
-            else:
-                ops.linear(ws.x16, Bk["w1a"], Bk["b1a"], ff, act=ops.ACT_SWISH)
-                ops.linear_res_scale_ln16(ff, Bk["w2a"], Bk["b2a"], ws.h32, Bk["fa"], Bk["lnb"][0], Bk["lnb"][1],
-                                          ws.h32, ws.x16, Bk["lnb"][2])
+            # x += fa * FFN(LN_a x)                      -> x16 = LN_b(x)      (hidden activations stay on chip: ffn.hip)
+            ops.ffn_fused(ws.x16, Bk["w1a"], Bk["b1a"], Bk["w2a"], Bk["b2a"], ws.h32, Bk["lnb"][0], Bk["lnb"][1],
+                          ws.h32, ws.x16, ops.ACT_SWISH, Bk["fa"], Bk["lnb"][2], residual_unnormalised=True)
             # x += Retention(LN_b x)                     -> x16 = LN_c(x)
-            if "wrs" in Bk and H == 4 and ops.retention_stream_ok(L, Tp):      # projections + retention in one operator (ret_stream.hip)
+            if H == 4 and ops.retention_stream_ok(L, Tp):      # projections + retention in one operator (ret_stream.hip)
                 ops.retention_stream(ws.x16, None, Bk["wrs"], Bk["bqkvg"], o16, ws.st, ws.cscale, ws.sexp, B, Tp, L, Bk["gn_eps"], t_valid=Tc,
                                      state_in=states[i] if (states is not None and carry_in) else None,
                                      state_out=states[i] if states is not None else None)
@@ -493,16 +461,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.linear_res_scale_ln16(ws.dw16, Bk["pw2"], Bk["pb2"], ws.h32, 1.0, Bk["lnd"][0], Bk["lnd"][1],
                                       ws.h32, ws.x16, Bk["lnd"][2])
             # x = LN_e(x + fb * FFN(LN_d x))
-            if FUSED_FFN and "wsb" in Bk:
-                ops.ffn_stream(ws.x16, Bk["wsb"], Bk["b1b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
-                               ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
-            elif FUSED_FFN:
-                ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
-                              ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
-            else:
-                ops.linear(ws.x16, Bk["w1b"], Bk["b1b"], ff, act=ops.ACT_SWISH)
-                ops.linear_res_ln(ff, Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1], ws.h32, ws.h16,
-                                  Bk["lne"][2], alpha=Bk["fb"])
+            ops.ffn_fused(ws.x16, Bk["w1b"], Bk["b1b"], Bk["w2b"], Bk["b2b"], ws.h32, Bk["lne"][0], Bk["lne"][1],
+                          ws.h32, ws.h16, ops.ACT_SWISH, Bk["fb"], Bk["lne"][2])
             if i + 1 < nb:
                 nx = P["blocks"][i + 1]["lna"]
                 ops.layernorm_f16(ws.h32, nx[0], nx[1], ws.x16, nx[2])
@@ -512,11 +472,11 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         embeddings -> ws.a32 (f32 attractor rows (b, c, t)).  `states`: as in _encode_span, per decoder layer."""
         D, H, L = self.n_units, self._n_heads, self.recurrent_chunk_size
         Md = B * C * Tp
-        # the retention's query path reads the decoder rows as a hi / lo f16 pair (ret_stream.hip; DESIGN 4): the producers of the
-        # layer inputs -- the f32 decoder-input linear and the un-streamed layer tail -- write the remainder next to the f16 copy
-        plain_tail = FUSED_FFN and FUSED_ATTNOUT and not (FUSED_SPK and FUSED_TAIL) and not any("ws" in Ld for Ld in P["dec.layers"])
-        xlo = RET_STREAM and RET_XLO and emb32 is not None and CONVERT_F32 and plain_tail and ws.a16lo.numel() > 0
-        if emb32 is not None and CONVERT_F32:
+        # the fused retention's query path reads the decoder rows as a hi / lo f16 pair (ret_stream.hip; DESIGN 4): the producers of the
+        # layer inputs -- the f32 decoder-input linear and the layer tail -- write the remainder next to the f16 copy
+        ret_fused = H == 4 and ops.retention_stream_ok(L, Tp)
+        xlo = ret_fused and emb32 is not None and ws.a16lo.numel() > 0
+        if emb32 is not None:
             # decoder input in f32 (exact-f32 MFMA): the retention's per-head LayerNorm (eps 1e-6) amplifies the f16 operand rounding
             # of this linear; at 12 speaker slots the f16 form left the 1e-3 bar (golden ls_c12_T1000: 1.3e-3)
             ops.convert_fanout_f32(emb32, P["convert.w32"], pc, ws.a32, ws.a16, B, Tp, C, out16lo=ws.a16lo if xlo else None)
@@ -524,10 +484,9 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.convert_fanout(emb16, P["convert.w1"], pc, ws.a32, ws.a16, B, Tp, C)
         q, k, kt, vt = ws.q[:Md * D], ws.k[:Md * D], ws.kt[:Md * D], ws.vt[:Md * D]
         g, o16 = ws.g[:Md], ws.o16[:Md]
+        nd = len(P["dec.layers"])
         for j, Ld in enumerate(P["dec.layers"]):
-            F = Ld["w1"].shape[0]
-            ff = None if FUSED_FFN else ws.ff16[:Md * F].view(Md, F)
-            if "wrs" in Ld and H == 4 and ops.retention_stream_ok(L, Tp):
+            if ret_fused:
                 ops.retention_stream(ws.a16, ws.a16lo if xlo else None, Ld["wrs"], Ld["bqkvg"], o16, ws.st, ws.cscale, ws.sexp, B * C, Tp, L,
                                      Ld["gn_eps"], t_valid=Tc, state_in=states[j] if (states is not None and carry_in) else None,
                                      state_out=states[j] if states is not None else None)
@@ -536,39 +495,14 @@ class OnlineConformerRetentionDADiarization(nn.Module):
                 ops.retention_chunk(q, k, kt, vt, g, o16, ws.st, ws.cscale, ws.sexp, B * C, H, Tp, L, Ld["gn_eps"], t_valid=Tc,
                                     state_in=states[j] if (states is not None and carry_in) else None,
                                     state_out=states[j] if states is not None else None)
-            if FUSED_FFN and FUSED_ATTNOUT and FUSED_SPK and FUSED_TAIL:   # the rest of the layer is one row-local launch
-                ops.fusion_layer_tail(o16, ws.a32, ws.a16, Ld["out1_w"], Ld["out1_b"], Ld["g11"], Ld["be11"], Ld["eps11"],
-                                      Ld["in2_w"], Ld["in2_b"], Ld["out2_w"], Ld["out2_b"], Ld["g21"], Ld["be21"], Ld["eps21"],
-                                      Ld["w1"], Ld["b1"], Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], B, C, Tp)
-                continue
-            if "ws1" in Ld and H == 4 and ops.spk_stream_ok(C, Tp):
-                # out-projection + residual + norm11 + the speaker-axis attention in one launch, in place on the f32 stream (q, k, v in registers)
-                ops.attnout_spk_stream_res32(o16, Ld["ws1"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], Ld["eps11"], ws.a32, Ld["in2_b"],
-                                             o16, B, C, Tp)
-            else:
-                ops.linear_res_ln(o16, Ld["out1_w"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], ws.a32, ws.a16, Ld["eps11"])
-                if FUSED_SPK:      # speaker-axis in-projection + attention in one launch (qkv stays in LDS)
-                    ops.spk_qkv_attn(ws.a16, Ld["in2_w"], Ld["in2_b"], o16, B, C, Tp, H)
-                else:
-                    ops.linear(ws.a16, Ld["in2_w"], Ld["in2_b"], ws.qkv16)
-                    ops.spk_attn(ws.qkv16, o16, B, C, Tp, H)
-            if FUSED_FFN and FUSED_ATTNOUT and "ws" in Ld:
-                ops.attnout_ffn_stream(o16, Ld["ws"], Ld["out2_b"], ws.a32, None, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["b1"], Ld["b2"],
-                                       Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16)
-                continue
-            if FUSED_FFN and FUSED_ATTNOUT:
-                ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
-                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16,
-                                      out16lo=ws.a16lo if (xlo and j + 1 < len(P["dec.layers"])) else None,
-                                      wo_lo=Ld["out2_wlo"] if OUT2_SPLIT else None)
-                continue
-            ops.linear_res_ln(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], ws.a32, ws.a16, Ld["eps21"])
-            if FUSED_FFN:
-                ops.ffn_fused(ws.a16, Ld["w1"], Ld["b1"], Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16,
-                              ops.ACT_RELU, 1.0, Ld["eps22"])
-            else:
-                ops.linear(ws.a16, Ld["w1"], Ld["b1"], ff, relu=True)
-                ops.linear_res_ln(ff, Ld["w2"], Ld["b2"], ws.a32, Ld["g22"], Ld["be22"], ws.a32, ws.a16, Ld["eps22"])
+            # out-projection + residual + norm11 + the speaker-axis attention in one launch, in place on the f32 stream (q, k, v in
+            # registers; spk_stream.hip, any slot count the speaker-axis kernels take, C <= 12)
+            ops.attnout_spk_stream_res32(o16, Ld["ws1"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], Ld["eps11"], ws.a32, Ld["in2_b"],
+                                         o16, B, C, Tp)
+            # out-projection (hi / lo f16 weight pair) + norm21 + FFN + norm22 in one launch; f32 rows out, plus their hi / lo f16 copies
+            ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
+                                  Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16,
+                                  out16lo=ws.a16lo if (xlo and j + 1 < nd) else None, wo_lo=Ld["out2_wlo"])
 
     def _run(self, src: Sequence[Tensor], ilens: Sequence[int], C: int):
         P = self._prepare()

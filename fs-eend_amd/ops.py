@@ -287,16 +287,6 @@ def attn_causal(q, k, vt, o16, nseq, H, Tp, mask_delay=0, kv_len=None, scale=1.0
                                        Tp if kv_len is None else kv_len, scale, _stream()), "eend_attn_causal_bf16")
 
 
-def inproj_attn_causal(x16, w_in, b_in, q_scratch, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
-    """o16 = causal MHA of x16 (rows (seq, t)) with the packed in-projection fused (K / V stay in LDS); w_in / b_in with
-    the q rows pre-multiplied by QSCALE_LOG2; q_scratch: bf16 buffer of nseq*Tp*256 elements.  Tp <= 512, H = 4."""
-    L = _lib.load()
-    _chk(x16, F16, "x16"); _chk(w_in, F16, "w_in"); _chk(b_in, F32, "b_in"); _chk(q_scratch, BF16, "q_scratch"); _chk(o16, F16, "o16")
-    _lib.check(L.eend_inproj_attn_causal_f16(_p(x16), x16.stride(0), _p(w_in), _p(b_in), _p(q_scratch), _p(o16), nseq, H, Tp,
-                                             o16.stride(0), mask_delay, Tp if kv_len is None else kv_len, _stream()),
-               "eend_inproj_attn_causal_f16")
-
-
 def inproj_attn_pack(w_in):
     """Pack in_proj_weight f16 [768][256] (q rows pre-scaled by QSCALE_LOG2) for inproj_attn_causal_packed."""
     L = _lib.load()
@@ -309,7 +299,7 @@ def inproj_attn_pack(w_in):
 
 
 def inproj_attn_causal_packed(x16, w_packed, b_in, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
-    """inproj_attn_causal on packed weights (attn_stream.hip; Tp = 512, H = 4): no Q scratch, Q stays in registers."""
+    """Packed in-projection + causal attention in one launch (attn_stream.hip; Tp = 512, H = 4): Q, K, V never reach HBM."""
     L = _lib.load()
     _chk(x16, F16, "x16"); _chk(w_packed, F16, "w_packed"); _chk(b_in, F32, "b_in"); _chk(o16, F16, "o16")
     if w_packed.numel() != L.eend_inproj_attn_packed_elems() or b_in.numel() != 768 or x16.shape[0] < nseq * Tp or o16.shape[0] < nseq * Tp:
@@ -317,16 +307,6 @@ def inproj_attn_causal_packed(x16, w_packed, b_in, o16, nseq, H, Tp, mask_delay=
     _lib.check(L.eend_inproj_attn_causal_packed_f16(_p(x16), x16.stride(0), _p(w_packed), _p(b_in), _p(o16), nseq, H, Tp,
                                                     o16.stride(0), mask_delay, Tp if kv_len is None else kv_len, _stream()),
                "eend_inproj_attn_causal_packed_f16")
-
-
-def spk_qkv_attn(x16, w_in, b_in, out16, B, C, Tp, H=4, t_valid=0):
-    """Speaker-axis MHA with its in-projection fused: out = MHA_over_slots(x16 @ w_in.T + b_in)."""
-    L = _lib.load()
-    _chk(x16, F16, "x16"); _chk(w_in, F16, "w_in"); _chk(b_in, F32, "b_in"); _chk(out16, F16, "out16")
-    if x16.shape != (B * C * Tp, 256) or w_in.shape != (768, 256) or out16.shape != (B * C * Tp, 256):
-        raise _lib.EendHipError("spk_qkv_attn: shape mismatch")
-    _lib.check(L.eend_spk_qkv_attn_f16(_p(x16), x16.stride(0), _p(w_in), _p(b_in), _p(out16), B, C, Tp, int(t_valid), H, 0.125,
-                                       _stream()), "eend_spk_qkv_attn_f16")
 
 
 def spk_stream_pack(wo16, win16):
@@ -441,9 +421,8 @@ def retention_step_f32(qkvg32, kv_state, scale_in, scale_out, out16, N, H, gn_ep
 
 
 # The f32 frame-step linears (skinny.hip) serve any number of rows in groups of 16 (round 4: multi-stream sessions take the
-# all-f32 step too -- their f16 step drifted past the 1e-3 bar within an hour).  EEND_STREAM_F32_MAX_ROWS=16
-# restores the round-3 behaviour (f16 MFMA steps above 16 rows per frame) for A/B.
-STEP_F32_MAX_ROWS = int(__import__("os").environ.get("EEND_STREAM_F32_MAX_ROWS", str(1 << 30)))
+# all-f32 step too -- their f16 step drifted past the 1e-3 bar within an hour): no row limit.
+STEP_F32_MAX_ROWS = 1 << 30
 
 
 def linear_step_f32(a32, w32, bias, out32, act=ACT_NONE):
@@ -691,6 +670,11 @@ def ffn_stream_max_rows(lda=256):
     return int(_lib.load().eend_ffn_stream_max_rows(int(lda)))
 
 
+def debug_ffn_stream_set(tile_fragments=0, max_rows_per_launch=0):
+    """Test hook: force the tile size (2 / 3 fragments) / cap the rows per launch of the packed-stream layer-tail kernels (0 = default)."""
+    _lib.check(_lib.load().eend_debug_ffn_stream_set(int(tile_fragments), int(max_rows_per_launch)), "eend_debug_ffn_stream_set")
+
+
 def stream_ok(Fh):
     """Whether the packed-stream kernels take this hidden width."""
     return Fh % 64 == 0 and 64 <= Fh <= 2048
@@ -725,28 +709,6 @@ def ffn_stream(x16, wstream, b1, b2, res, gamma, beta, out32, out16, act=ACT_REL
     _lib.check(L.eend_ffn_stream_f16(_p(x16), x16.stride(0), _p(wstream), _p(b1), _p(b2), _p(res), float(alpha),
                                      _p(gamma), _p(beta), eps, _p(out32), _p(out16), M, Fh, act,
                                      1 if residual_unnormalised else 0, _stream()), "eend_ffn_stream_f16")
-
-
-def fusion_layer_tail(a16, stream32, out16, wo1, bo1, g11, be11, eps11, win2, bin2, wo2, bo2, g21, be21, eps21,
-                      w1, b1, w2, b2, g22, be22, eps22, B, C, Tp):
-    """Everything of a fusion (decoder) layer after the time-axis attention core, in one launch:
-    out-proj + norm11, speaker-axis MHA (in-proj, attention), its out-proj + norm21, FFN + norm22.
-    stream32 is updated in place, out16 receives the f16 copy."""
-    L = _lib.load()
-    for n, t in (("a16", a16), ("out16", out16), ("wo1", wo1), ("win2", win2), ("wo2", wo2), ("w1", w1), ("w2", w2)):
-        _chk(t, F16, n)
-    for n, t in (("stream32", stream32), ("bo1", bo1), ("g11", g11), ("be11", be11), ("bin2", bin2), ("bo2", bo2), ("g21", g21),
-                 ("be21", be21), ("b1", b1), ("b2", b2), ("g22", g22), ("be22", be22)):
-        _chk(t, F32, n)
-    M = B * C * Tp
-    Fh = w1.shape[0]
-    if a16.shape != (M, 256) or stream32.shape != (M, 256) or out16.shape != (M, 256) or win2.shape != (768, 256) or \
-            wo1.shape != (256, 256) or wo2.shape != (256, 256) or w1.shape[1] != 256 or w2.shape != (256, Fh):
-        raise _lib.EendHipError("fusion_layer_tail: shape mismatch")
-    _lib.check(L.eend_fusion_layer_tail_f16(_p(a16), a16.stride(0), _p(stream32), _p(out16), _p(wo1), _p(bo1), _p(g11), _p(be11), eps11,
-                                            _p(win2), _p(bin2), _p(wo2), _p(bo2), _p(g21), _p(be21), eps21,
-                                            _p(w1), _p(b1), _p(w2), _p(b2), _p(g22), _p(be22), eps22, B, C, Tp, Fh, _stream()),
-               "eend_fusion_layer_tail_f16")
 
 
 def ffn_fused(x16, w1, b1, w2, b2, res, gamma, beta, out32, out16, act=ACT_RELU, alpha=1.0, eps=1e-5,

@@ -39,9 +39,8 @@ F16, BF16, F32, I32 = torch.float16, torch.bfloat16, torch.float32, torch.int32
 D = 256
 H = 4
 WS_FLOATS = 32 * 1024 * 1024          # f32 scratch for split-sum partials (128 MB)
-# the FFN of a post-norm block (linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm) as one launch (ffn.hip MODE 3, round 5);
-# EEND_TRAIN_FFN_FUSED=0: the two GEMM launches (A/B)
-FFN_TRAIN_FUSED = __import__("os").environ.get("EEND_TRAIN_FFN_FUSED", "1") != "0"
+# (the FFN of a post-norm block -- linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm -- is one launch forward and one for
+#  the data gradients, ffn.hip MODE 3 / 4, wherever its shape allows: hidden width a multiple of 64, 32-bit row offsets; else GEMM launches)
 
 
 def _call(name: str, *args):
@@ -303,7 +302,7 @@ class TrainStepBase:
         """linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm of a post-norm block.  One launch (ffn.hip MODE 3: the hidden
         activations are written once for the backward and never re-read) where the shape allows, else the two GEMM launches."""
         F = hid.shape[1]
-        if FFN_TRAIN_FUSED and F % 64 == 0 and (M + 128) * F * 2 < (1 << 32) and x16.shape[1] == 256:
+        if F % 64 == 0 and (M + 128) * F * 2 < (1 << 32) and x16.shape[1] == 256:
             _call("eend_ffn_train_f16", x16, x16.stride(0), w1, b1, w2, b2, res, 1.0, self._P(ln + ".weight"), self._P(ln + ".bias"), 1e-5,
                   out32, site.out16, hid, site.xhat, site.rstd, M, F, drop_hidden, drop_out)
             return
@@ -341,7 +340,7 @@ class TrainStepBase:
         Fh = hid.shape[1]
         dh = dh16[:M * Fh].view(M, Fh)
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
-        if FFN_TRAIN_FUSED and Fh % 64 == 0 and (M + 128) * Fh * 2 < (1 << 32):
+        if Fh % 64 == 0 and (M + 128) * Fh * 2 < (1 << 32):
             # dH = scale * (dY W2) under the saved mask, and g += dH W1, in one launch (ffn.hip MODE 4): dH is written once for the weight
             # gradient below and not re-read by the data path
             _call("eend_ffn_bwd_data_bf16", ds16, D, W[wkey + ".w2T"], hid, W[wkey + ".w1T"], drop_scale, dh, g32, M, Fh)

@@ -193,6 +193,12 @@ int eend_attnout_ffn_fused_res16_f16(const void* A, int lda, const void* Wo, con
 /* Rows one launch of the packed-stream layer-tail kernels addresses (32-bit buffer offsets, one grid of tiles of prefetch ahead);
  * eend_ffn_stream_f16 / eend_attnout_ffn_stream_f16 serve larger M in several launches over row ranges of that size. */
 int eend_ffn_stream_max_rows(int lda);
+/* TEST HOOK (process-wide, not for production callers): force the row-tile size of the packed-stream layer-tail kernels
+ * (tile_fragments = 2 / 3 for 128- / 192-row tiles, 0 = the launcher's cost model) and cap the rows of one launch
+ * (max_rows_per_launch > 0; 0 = the 32-bit addressing limit), so that the tile-size agreement and the multi-launch path can be
+ * exercised at small sizes (tests/test_hip_ffn_stream.py).  Replaces the EEND_FS_NJ / EEND_FFN_STREAM_MAX_ROWS environment
+ * switches of rounds 4 - 5. */
+int eend_debug_ffn_stream_set(int tile_fragments, long max_rows_per_launch);
 
 /* Round 4: the same two operators (eend_ffn_fused_f16 / eend_attnout_ffn_fused[_res16]_f16; reference sites as above:
  * nn.TransformerEncoderLayer of FS model :147, merge_tfm_encoder.py:356-399, LS merge_retnet_layer.py:240-253,
@@ -235,22 +241,6 @@ int eend_attnout_spk_stream_res32_f16(const void* A, int lda, const void* wstrea
                                       const float* g1, const float* be1, float eps1, float* x_f32, const float* b_in, void* O_f16,
                                       int B, int C, int Tp, float scale, void* stream);
 
-/* The whole row-local tail of a fusion (attractor decoder) layer in ONE launch, after the time-axis
- * attention / retention core (FS merge_tfm_encoder.py:364-376: out_proj of self_attn1 + norm11, _sa_block2 +
- * norm21, _ff_block + norm22; LS merge_retnet_layer.py:240-253 likewise with the retention out_proj):
- *   x1  = LayerNorm11(A1 Wo1^T + bo1 + stream)
- *   o   = MHA over the C slots of each frame of (x1 Win2^T + bin2)              (H = 4, dh = 64)
- *   x2  = LayerNorm21(o Wo2^T + bo2 + x1)
- *   out = LayerNorm22(relu(x2 W1^T + b1) W2^T + b2 + x2)
- * stream_f32 f32 [B*C*Tp][256] is read (layer input) and overwritten (layer output) in place, out_f16 gets
- * the f16 copy; A1 f16 [B*C*Tp][lda] is the attention-core output.  Rows are (b*C + c)*Tp + t; 1 <= C <= 12. */
-int eend_fusion_layer_tail_f16(const void* A1, int lda, float* stream_f32, void* out_f16,
-                               const void* Wo1, const float* bo1, const float* g11, const float* be11, float eps11,
-                               const void* Win2, const float* bin2,
-                               const void* Wo2, const float* bo2, const float* g21, const float* be21, float eps21,
-                               const void* W1, const float* b1, const void* W2, const float* b2,
-                               const float* g22, const float* be22, float eps22,
-                               int B, int C, int Tp, int F, void* stream);
 
 /* Embedding-consistency loss (FS model :46-57; LS model :92-113): mean over (b,i,j) of
  * (cos(emb_i, emb_j) - cos(label_i, label_j))^2 with the reference's "+1e-6" denominators, without
@@ -444,35 +434,21 @@ int eend_dwconv_step_f16(const void* x_f16, float* cache, const float* w, const 
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                       void* stream);
 
-/* Packed in-projection + causal multi-head attention in one launch (nn.MultiheadAttention(x, x, x) on the time axis:
- * nn.TransformerEncoderLayer.self_attn, FS model :147; self_attn1 of the fusion layers, merge_tfm_encoder.py:379-385)
- * for chunks that fit on chip: Tp <= 512, H = 4, d_model = 256.  K and V never reach HBM; Q_scratch (bf16
- * [nseq][4][Tp][64]) is an L2-resident hand-over buffer.  W_in f16 [768][256] / b_in [768] = in_proj_weight / bias with
- * the q rows pre-multiplied by 1/sqrt(64) * log2(e); mask: key j visible to query i iff j - i <= mask_delay and
- * j < kv_len.  Equivalent to eend_inproj_heads_bf16 followed by eend_attn_causal_bf16(scale = ln 2). */
-int eend_inproj_attn_causal_f16(const void* X_f16, int ldx, const void* W_in, const float* b_in, void* Q_scratch_bf16,
-                                void* O_f16, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
 
-/* The same operator with the in-projection weights pre-packed in MFMA fragment order (attn_stream.hip): a wave keeps the X rows
- * of the 64 tokens whose queries it runs in registers, the head's 96 KB of weights arrive by LDS-DMA, Q never leaves the wave --
- * no Q scratch buffer.  eend_inproj_attn_pack_f16 re-orders W_in f16 [768][256] (q rows pre-scaled as above) into
- * eend_inproj_attn_packed_elems() f16 elements, once per parameter version.  Tp must be 512 (EEND_EINVAL otherwise: the
- * caller keeps eend_inproj_attn_causal_f16 for other chunk lengths); H = 4.  The key bias is not applied (it cancels in the
- * softmax); b_in is the same [768] vector. */
+/* Packed in-projection + causal multi-head attention in one launch (nn.MultiheadAttention(x, x, x) on the time axis:
+ * nn.TransformerEncoderLayer.self_attn, FS model :147; self_attn1 of the fusion layers, merge_tfm_encoder.py:379-385),
+ * Tp = 512, H = 4, d_model = 256 (attn_stream.hip): the in-projection weights pre-packed in MFMA fragment order, a wave keeps
+ * the X rows of the 64 tokens whose queries it runs in registers, the head's 96 KB of weights arrive by LDS-DMA, Q, K and V never
+ * reach HBM.  eend_inproj_attn_pack_f16 re-orders W_in f16 [768][256] (= in_proj_weight with the q rows pre-multiplied by
+ * 1/sqrt(64) * log2(e)) into eend_inproj_attn_packed_elems() f16 elements, once per parameter version.  mask: key j visible to
+ * query i iff j - i <= mask_delay and j < kv_len.  Equivalent to eend_inproj_heads_bf16 followed by
+ * eend_attn_causal_bf16(scale = ln 2), which is what the caller uses for other chunk lengths (EEND_EINVAL here).  The key bias
+ * is not applied (it cancels in the softmax); b_in is the [768] in_proj_bias, q part pre-scaled. */
 int eend_inproj_attn_packed_elems(void);
 int eend_inproj_attn_pack_f16(const void* W_in, void* packed_out, void* stream);
 int eend_inproj_attn_causal_packed_f16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16,
                                        int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
 
-/* In-projection + attention core of the speaker-axis self-attention in one launch (the [M][768] qkv
- * tensor never reaches HBM): qkv = x W_in^T + b_in, then the unmasked MHA over the C (<= 12) slots of each
- * frame as eend_spk_attn_f16 (nn.MultiheadAttention self_attn2 of the fusion layers, _sa_block2: FS
- * merge_tfm_encoder.py:388-394; LS merge_retnet_layer.py:301-306).  x f16 [B*C*Tp][ldx] (256 features,
- * row = (b*C + c)*Tp + t), W_in f16 [768][256] (in_proj_weight), b_in f32 [768] -> O f16 [B*C*Tp][256].
- * H = 4, dh = 64.  T_valid (0 = Tp): only frames t < T_valid of every slab are computed and written -- rows beyond are slab
- * padding whose O rows keep their previous contents (the model passes the real frame count: one tile round less at T = 500). */
-int eend_spk_qkv_attn_f16(const void* x_f16, int ldx, const void* W_in, const float* b_in, void* O_f16,
-                          int B, int C, int Tp, int T_valid, int H, float scale, void* stream);
 
 /* attractors / ||attractors||_2 and logits[b,t,c] = <emb[b,t], attractors[b,t,c]>
  * (FS model :43,:60 / :76,:79; LS model :89,:117).  emb f32 [B][Tp][D], attr f32 [B*C][Tp][D]

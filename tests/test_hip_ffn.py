@@ -159,34 +159,3 @@ def test_attnout_ffn_fused_split_weight_and_remainder(hip_lib, dev, M, Fh):
     h = (x.to(F16).float() @ w1.float().t() + b1).relu().to(F16).float()
     full = torch.nn.functional.layer_norm(h @ w2.float().t() + b2 + x, (256,), g2, be2, 1e-5)
     assert (o32 - full).abs().max().item() < 3e-3
-
-
-@pytest.mark.parametrize("B,C,Tp,Fh", [(1, 6, 64, 2048), (2, 4, 128, 2048), (1, 10, 64, 1024), (1, 12, 64, 2048), (3, 3, 64, 2048),
-                                        (1, 1, 64, 2048), (8, 6, 512, 2048)])
-def test_fusion_layer_tail(hip_lib, dev, B, C, Tp, Fh):
-    """one-launch layer tail == linear_res_ln -> spk_qkv_attn -> attnout_ffn_fused (three launches)."""
-    from fs_eend_amd import ops
-    M = B * C * Tp
-    a = rnd((M, 256), dev, 41, F16)
-    res = rnd((M, 256), dev, 42)
-    wo1, bo1 = rnd((256, 256), dev, 43, F16, 0.06), rnd((256,), dev, 44) * 0.2
-    win2, bin2 = rnd((768, 256), dev, 45, F16, 0.06), rnd((768,), dev, 46) * 0.2
-    wo2, bo2 = rnd((256, 256), dev, 47, F16, 0.06), rnd((256,), dev, 48) * 0.2
-    w1, b1 = rnd((Fh, 256), dev, 49, F16, 0.08), rnd((Fh,), dev, 50) * 0.3
-    w2, b2 = rnd((256, Fh), dev, 51, F16, 0.04), rnd((256,), dev, 52) * 0.3
-    ln = [(rnd((256,), dev, 60 + i) * 0.2 + 1, rnd((256,), dev, 70 + i) * 0.1) for i in range(3)]
-    # three launches
-    x32, x16 = torch.empty_like(res), torch.empty((M, 256), dtype=F16, device=dev)
-    o16 = torch.empty_like(x16)
-    ops.linear_res_ln(a, wo1, bo1, res, ln[0][0], ln[0][1], x32, x16, 1e-5)
-    ops.spk_qkv_attn(x16, win2, bin2, o16, B, C, Tp, 4)
-    want32, want16 = torch.empty_like(res), torch.empty_like(x16)
-    ops.attnout_ffn_fused(o16, wo2, bo2, x32, ln[1][0], ln[1][1], 1e-5, w1, b1, w2, b2, ln[2][0], ln[2][1], 1e-5, want32, want16)
-    # one launch (stream updated in place)
-    stream = res.clone()
-    got16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
-    ops.fusion_layer_tail(a, stream, got16, wo1, bo1, ln[0][0], ln[0][1], 1e-5, win2, bin2, wo2, bo2, ln[1][0], ln[1][1], 1e-5,
-                          w1, b1, w2, b2, ln[2][0], ln[2][1], 1e-5, B, C, Tp)
-    assert torch.isfinite(stream).all() and torch.isfinite(got16).all()
-    assert (stream - want32).abs().max().item() < 4e-3
-    assert (got16.float() - want16.float()).abs().max().item() < 8e-3

@@ -5,6 +5,17 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_stream_debug_hooks():
+    """The tile-size / rows-per-launch test hooks are process-wide: back to the defaults after every test."""
+    yield
+    try:
+        from fs_eend_amd import ops
+        ops.debug_ffn_stream_set(0, 0)
+    except Exception:
+        pass
 F16, F32 = torch.float16, torch.float32
 
 
@@ -173,9 +184,9 @@ def test_stream_entries_split_large_row_counts(hip_lib, dev, monkeypatch):
     outs = []
     for cap in (None, "768"):
         if cap is None:
-            monkeypatch.delenv("EEND_FFN_STREAM_MAX_ROWS", raising=False)
+            ops.debug_ffn_stream_set(0, 0)
         else:
-            monkeypatch.setenv("EEND_FFN_STREAM_MAX_ROWS", cap)
+            ops.debug_ffn_stream_set(0, int(cap))
             assert ops.ffn_stream_max_rows() == 768
         o32, o16 = torch.empty((M, 256), dtype=F32, device=dev), torch.empty((M, 256), dtype=F16, device=dev)
         ops.attnout_ffn_stream(a, ws, bo, res, None, g1, be1, 1e-5, b1, b2, g1, be1, 1e-5, o32, o16)
@@ -192,7 +203,7 @@ def test_stream_entries_split_large_row_counts(hip_lib, dev, monkeypatch):
 @pytest.mark.parametrize("M,with32", [(300, False), (1000, True), (70000, False)])
 def test_attnout_ffn_stream_tile_sizes_agree(hip_lib, dev, M, with32, monkeypatch):
     """128- and 192-row tiles (NJ = 2 / 3) are the same arithmetic per row -- bit-identical outputs whichever the launcher's cost model
-    (or EEND_FS_NJ) picks, including ragged last tiles and in place.  (Round 5 tried 256-row tiles, NJ = 4: this test caught a variant that
+    (or the eend_debug_ffn_stream_set test hook) picks, including ragged last tiles and in place.  (Round 5 tried 256-row tiles, NJ = 4: this test caught a variant that
     was 4 % faster because it skipped one activation part; done right it was no faster than NJ = 3 and was removed -- OPTIMISATION_LOG.)"""
     from fs_eend_amd import ops
     Fh = 2048
@@ -206,7 +217,7 @@ def test_attnout_ffn_stream_tile_sizes_agree(hip_lib, dev, M, with32, monkeypatc
     ws = ops.ffn_stream_pack(wo, w1, w2)
     outs = {}
     for nj in ("2", "3"):
-        monkeypatch.setenv("EEND_FS_NJ", nj)
+        ops.debug_ffn_stream_set(int(nj), 0)
         o32 = torch.full((M, 256), float("nan"), dtype=F32, device=dev) if with32 else None
         o16 = torch.full((M, 256), float("nan"), dtype=F16, device=dev)
         ops.attnout_ffn_stream(a, ws, bo, None, r16, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, o32, o16)
@@ -217,7 +228,7 @@ def test_attnout_ffn_stream_tile_sizes_agree(hip_lib, dev, M, with32, monkeypatc
     if with32:
         assert torch.equal(outs["2"][1], outs["3"][1])
     # in place (out16 over the residual stream, as fs_model calls it)
-    monkeypatch.setenv("EEND_FS_NJ", "2")
+    ops.debug_ffn_stream_set(2, 0)
     a2, r2 = a.clone(), r16.clone()
     ops.attnout_ffn_stream(a2, ws, bo, None, r2, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, None, r2)
     torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 """attnout_spk_stream (spk_stream.hip): LN11(A Wo1^T + bo1 + res) + speaker-axis MHA in one launch, against a torch fp32
-restatement of the same operator and against the two-launch path it replaces (linear_res16_ln + spk_qkv_attn)."""
+restatement of the same operator and against the un-fused launches (linear_res16_ln + linear + spk_attn)."""
 import importlib
 
 import pytest
@@ -49,10 +49,12 @@ def test_attnout_spk_stream_vs_torch(B, C, Tp):
     assert torch.isfinite(o16).all() and torch.isfinite(x16).all()
     assert (x16.float() - xr).abs().max().item() < 2e-2
     assert (o16.float() - orf).abs().max().item() < 2e-2
-    # the two-launch path it replaces
+    # the un-fused launches
     x2 = torch.empty_like(res); o2 = torch.empty_like(a)
     ops.linear_res16_ln(a, wo, bo, res, g1, be1, None, x2, 1e-5)
-    ops.spk_qkv_attn(x2, win, bin_, o2, B, C, Tp, 4)
+    qkv2 = torch.empty(a.shape[0], 768, dtype=a.dtype, device=a.device)
+    ops.linear(x2, win, bin_, qkv2)
+    ops.spk_attn(qkv2, o2, B, C, Tp, 4)
     torch.cuda.synchronize()
     assert (x16.float() - x2.float()).abs().max().item() < 1e-2
     assert (o16.float() - o2.float()).abs().max().item() < 2e-2
@@ -94,10 +96,12 @@ def test_attnout_spk_stream_res32_vs_torch(B, C, Tp):
     assert torch.isfinite(o16).all() and torch.isfinite(x32).all()
     assert (x32 - xr).abs().max().item() < 2e-4                               # f32 rows: accumulation order only
     assert (o16.float() - orf).abs().max().item() < 2e-2
-    # the two launches it replaces in ls_model._decode_span
+    # the un-fused launches
     x2 = torch.empty_like(res); x2h = torch.empty_like(a); o2 = torch.empty_like(a)
     ops.linear_res_ln(a, wo, bo, res, g1, be1, x2, x2h, 1e-5)
-    ops.spk_qkv_attn(x2h, win, bin_, o2, B, C, Tp, 4)
+    qkv2 = torch.empty(a.shape[0], 768, dtype=a.dtype, device=a.device)
+    ops.linear(x2h, win, bin_, qkv2)
+    ops.spk_attn(qkv2, o2, B, C, Tp, 4)
     torch.cuda.synchronize()
     assert (x32 - x2).abs().max().item() < 2e-4
     assert (o16.float() - o2.float()).abs().max().item() < 2e-2

@@ -16,7 +16,11 @@ for nseq in (384, 64):
     x = torch.randn(nseq * Tp, 256, generator=g).to(dev).half()
     qs = torch.empty(nseq * Tp * 256, dtype=torch.bfloat16, device=dev)
     o0 = torch.empty_like(x); o1 = torch.empty_like(x)
-    fns = {"attn_fused": lambda: ops.inproj_attn_causal(x, w, b, qs, o0, nseq, 4, Tp, 0, 500),
+    kq, kk, kv = (torch.empty(nseq * Tp * 256, dtype=torch.bfloat16, device=dev) for _ in range(3))
+    def two_kernels():
+        ops.inproj_heads(x, w, b, kq, kk, kv, nseq, Tp, 4)
+        ops.attn_causal(kq, kk, kv, o0, nseq, 4, Tp, 0, 500, scale=ops.LN2)
+    fns = {"inproj_heads + attn_causal": two_kernels,
            "attn_stream": lambda: ops.inproj_attn_causal_packed(x, wp, b, o1, nseq, 4, Tp, 0, 500)}
     res = {k: [] for k in fns}
     for _ in range(5):

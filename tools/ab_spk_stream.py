@@ -1,4 +1,4 @@
-"""Same-box timing of attnout_spk_stream against the two launches it replaces (linear_res16_ln + spk_qkv_attn) at the
+"""Same-box timing of attnout_spk_stream against the two launches it replaces (linear_res16_ln + linear + spk_attn) at the
 FS model.test decoder shape (B=64, C=6, Tp=512).  Usage: python tools/ab_spk_stream.py [reps]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,14 +21,15 @@ def main():
     bo = r(256, sc=0.1); g1 = 1 + r(256, sc=0.1); be1 = r(256, sc=0.1); bin_ = r(768, sc=0.3)
     ws = ops.spk_stream_pack(wo, win)
     x1 = torch.empty_like(res); o1 = torch.empty_like(a)
-    x2 = torch.empty_like(res); o2 = torch.empty_like(a)
+    x2 = torch.empty_like(res); o2 = torch.empty_like(a); qkv2 = torch.empty(M, 768, dtype=torch.float16, device=dev)
 
     def new():
         ops.attnout_spk_stream(a, ws, bo, res, g1, be1, 1e-5, x1, bin_, o1, B, C, Tp)
 
     def old():
         ops.linear_res16_ln(a, wo, bo, res, g1, be1, None, x2, 1e-5)
-        ops.spk_qkv_attn(x2, win, bin_, o2, B, C, Tp, 4, t_valid=500)
+        ops.linear(x2, win, bin_, qkv2)
+        ops.spk_attn(qkv2, o2, B, C, Tp, 4)
 
     def timed(fn):
         for _ in range(3):
