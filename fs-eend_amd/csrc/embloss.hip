@@ -2,110 +2,166 @@
 //     A[b,i,j] = <e_i, e_j> / (|e_i| |e_j| + 1e-6)        e = frame embeddings (B, T, 256)
 //     L[b,i,j] = <y_i, y_j> / (|y_i| |y_j| + 1e-6)        y = zero-padded speaker labels (B, T, C)
 //     loss     = mean over (b, i, j) of (A - L)^2
-// The reference materialises both (B,T,T) maps; here a block owns one 64 x 64 tile of one utterance,
-// forms it with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: the reference is an fp32 matmul and this is a
-// loss value, so no reduced-precision operands), adds the label map on the VALU (C <= 16) and reduces the
-// squared difference to one partial per block.  A second, single-block launch sums the partials in a fixed
-// order (deterministic, no atomics) and applies the normalisation (1 / (B T T) for FS-EEND's mse_loss; the LS
-// model zeroes the embeddings of frames beyond each utterance's length and divides by sum(len^2)).
+// The reference materialises both (B,T,T) maps; here a block forms 64 x 64 tiles of one utterance's maps in registers and reduces the
+// squared difference to one partial; a second, single-block launch sums the partials in a fixed order (deterministic, no atomics) and applies
+// the normalisation (1 / (B T T) for FS-EEND's mse_loss; the LS model zeroes the embeddings of frames beyond each utterance's length and
+// divides by sum(len^2)).
+// Round 6 (the round-1 kernel ran the map on the exact-f32 MFMA, 16x16x4, staged 32-wide k chunks with scalar loads and formed the
+// label map with 16 VALU FMAs per element: 856 us at 64 x T = 1000, 4 % of the LS training step):
+//   * both maps are symmetric: only the tiles on and above the diagonal are computed, the others count twice;
+//   * A on the f16 MFMA at f32 accuracy: e = hi + 2^-11 lo' with hi = f16(e), lo' = f16((e - hi) * 2^11) (scaled so that the remainder
+//     of a ~0.06-magnitude component is a normal f16 number), A = hi hi^T + 2^-11 (hi lo'^T + lo' hi^T) -- three 16x16x32 products,
+//     the dropped lo lo^T term is 2^-22 relative; the whole K = 256 of both row sets resident in LDS (4 x 32 KB);
+//   * L on the f16 MFMA too (16x16x16: labels are 0 / 1, products and sums exact);
+//   * row norms from the f32 values while staging.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int TS = 64;            // tile side
-constexpr int KC = 32;            // k chunk staged per step
-constexpr int LDE = KC + 1;       // padded row stride (floats)
 constexpr int CMAX = 16;
+constexpr int DM = 256;
+constexpr int L_EIH = 0, L_EIL = 32768, L_EJH = 65536, L_EJL = 98304;          // [64][256] f16 images, 512-byte rows
+constexpr int L_YI = 131072, L_YJ = L_YI + TS * CMAX * 2;                       // [64][16] f16
+constexpr int L_N = L_YJ + TS * CMAX * 2;                                       // |e_i| [64], |e_j| [64], |y_i| [64], |y_j| [64], red[4]
+constexpr int EMB_SMEM = L_N + (4 * TS + 4) * 4;
 
+// 16-byte chunk c (0..31) of row r at c ^ (r & 15): the 16 rows of an MFMA fragment read land in 16 distinct slots of the bank row
+DEV int swzRow(int row, int c) { return row * 512 + ((c ^ (row & 15)) << 4); }
+
+// A block owns the tile rows `it` and `nt - 1 - it` of one utterance (together nt + 1 tiles on and above the diagonal: equal work for
+// every block) and walks their column tiles: the 64 x 256 row set E_i is staged (split into hi / lo', norms) once per tile row, E_j once
+// per tile.  One partial per block.
 __global__ __launch_bounds__(256)
 void emb_consistency_tile_kernel(const float* __restrict__ emb, const float* __restrict__ tgt, const int* __restrict__ lens,
-                                 float* __restrict__ partial, int T, int Tp, int D, int C) {
-    __shared__ float Ei[TS * LDE], Ej[TS * LDE];
-    __shared__ float Yi[TS * CMAX], Yj[TS * CMAX];
-    __shared__ float n2i[TS], n2j[TS], ny2i[TS], ny2j[TS];
-    __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+                                 float* __restrict__ partial, int T, int Tp, int D, int C, int nt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
     const float* __restrict__ E = emb + (size_t)b * Tp * D;
     const float* __restrict__ Y = tgt + (size_t)b * T * C;
     const int elen = lens ? (lens[b] < T ? lens[b] : T) : T;     // LS variant: embeddings of frames >= len count as zero (model :100)
+    float* nrm = (float*)(smem + L_N);
 
-    // labels of the two row sets (zero beyond T) and their squared norms
-    for (int q = tid; q < 2 * TS * CMAX; q += 256) {
-        const int which = q / (TS * CMAX), r = (q % (TS * CMAX)) / CMAX, c = q % CMAX;
-        const int t = (which ? j0 : i0) + r;
-        const float v = (t < T && c < C) ? Y[(size_t)t * C + c] : 0.f;
-        (which ? Yj : Yi)[r * CMAX + c] = v;
-    }
-    if (tid < TS) { n2i[tid] = 0.f; n2j[tid] = 0.f; }
-    __syncthreads();
-    if (tid < 2 * TS) {
-        const float* y = (tid < TS ? Yi : Yj) + (tid & (TS - 1)) * CMAX;
-        float sum = 0.f;
+    // ---- staging of one row set: unit = 8 consecutive features of one row (32 B of f32 -> 16 B hi + 16 B lo'); 32 lanes cover a row
+    const int chunk = tid & 31, rsub = tid >> 5;
+    auto stage = [&](int which, int r0) __attribute__((always_inline)) {
+        char* dh = smem + (which ? L_EJH : L_EIH);
+        char* dl = smem + (which ? L_EJL : L_EIL);
+        float4 v0[8], v1[8];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) sum += y[c] * y[c];
-        (tid < TS ? ny2i : ny2j)[tid & (TS - 1)] = sum;
-    }
-
-    // A tile: wave w owns rows i0 + 16 w .. +16, all 64 columns (4 MFMA column tiles)
-    f32x4 acc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fk = lane >> 4;
-    for (int k0 = 0; k0 < D; k0 += KC) {
-        __syncthreads();
-        for (int q = tid; q < 2 * TS * KC; q += 256) {          // stage [64][32] chunks of both row sets
-            const int which = q / (TS * KC), r = (q % (TS * KC)) / KC, k = q % KC;
-            const int t = (which ? j0 : i0) + r;
-            const float v = t < elen ? E[(size_t)t * D + k0 + k] : 0.f;
-            (which ? Ej : Ei)[r * LDE + k] = v;
-        }
-        __syncthreads();
-        if (tid < 2 * TS) {                                      // running squared norms of the rows
-            const float* e = (tid < TS ? Ei : Ej) + (tid & (TS - 1)) * LDE;
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < KC; ++k) sum += e[k] * e[k];
-            (tid < TS ? n2i : n2j)[tid & (TS - 1)] += sum;
+        for (int k = 0; k < 8; ++k) {                            // all 16 loads of this thread in flight first
+            const int t = r0 + k * 8 + rsub;
+            v0[k] = make_float4(0, 0, 0, 0); v1[k] = v0[k];
+            if (t < elen) {
+                v0[k] = *(const float4*)(E + (size_t)t * D + chunk * 8);
+                v1[k] = *(const float4*)(E + (size_t)t * D + chunk * 8 + 4);
+            }
         }
 #pragma unroll
-        for (int ks = 0; ks < KC; ks += 4) {
-            const float a = Ei[(wave * 16 + frow) * LDE + ks + fk];
+        for (int k = 0; k < 8; ++k) {
+            const int row = k * 8 + rsub;
+            const float x[8] = {v0[k].x, v0[k].y, v0[k].z, v0[k].w, v1[k].x, v1[k].y, v1[k].z, v1[k].w};
+            f16x8 h, l;
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = (_Float16)x[e];
+                l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.0f);
+                ss = __builtin_fmaf(x[e], x[e], ss);
+            }
+            *(f16x8*)(dh + swzRow(row, chunk)) = h;
+            *(f16x8*)(dl + swzRow(row, chunk)) = l;
+            ss = wave_xor16_add(row16_allreduce_add(ss));        // the 32 lanes of this row (DPP + one permlane swap: no LDS round trip)
+            if (chunk == 0) nrm[which * TS + row] = __builtin_sqrtf(ss);
+        }
+        if (tid < TS) {                                           // labels (zero beyond T / C) as f16 and their norms
+            const int t = r0 + tid;
+            _Float16* yd = (_Float16*)(smem + (which ? L_YJ : L_YI)) + tid * CMAX;
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                const float v = (t < T && c < C) ? Y[(size_t)t * C + c] : 0.f;
+                yd[c] = (_Float16)v;
+                ss = __builtin_fmaf(v, v, ss);
+            }
+            nrm[(2 + which) * TS + tid] = __builtin_sqrtf(ss);
+        }
+    };
+
+    const int frow = lane & 15, g = lane >> 4;
+    const int il_a = wave * 16 + frow;
+    float sq = 0.f;
+    for (int half = 0; half < 2; ++half) {
+        const int it = half == 0 ? (int)blockIdx.x : nt - 1 - (int)blockIdx.x;
+        if (half == 1 && it <= (int)blockIdx.x) break;           // (odd nt: the middle row once)
+        const int i0 = it * TS;
+        __syncthreads();                                          // the previous row's readers are done
+        stage(0, i0);
+        for (int jt = it; jt < nt; ++jt) {
+            const int j0 = jt * TS;
+            if (jt > it) {
+                __syncthreads();                                  // the previous tile's readers are done
+                stage(1, j0);
+            }
+            __syncthreads();
+            // the diagonal tile reads E_i as both operands
+            const int jh0 = jt > it ? L_EJH : L_EIH, jl0 = jt > it ? L_EJL : L_EIL, yj0 = jt > it ? L_YJ : L_YI, nj0 = jt > it ? TS : 0;
+            // wave w: rows i0 + 16 w .. + 16, all 64 columns (4 column tiles); hi hi^T and the scaled cross terms apart
+            f32x4 ahh[4], acr[4], lac[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { ahh[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acr[ct] = ahh[ct]; lac[ct] = ahh[ct]; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f16x8 ih = *(const f16x8*)(smem + L_EIH + swzRow(il_a, ks * 4 + g));
+                const f16x8 ilo = *(const f16x8*)(smem + L_EIL + swzRow(il_a, ks * 4 + g));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const f16x8 jh = *(const f16x8*)(smem + jh0 + swzRow(ct * 16 + frow, ks * 4 + g));
+                    const f16x8 jl = *(const f16x8*)(smem + jl0 + swzRow(ct * 16 + frow, ks * 4 + g));
+                    ahh[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ih, jh, ahh[ct], 0, 0, 0);
+                    acr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ih, jl, acr[ct], 0, 0, 0);
+                    acr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ilo, jh, acr[ct], 0, 0, 0);
+                }
+            }
+            {
+                const f16x4 yi = *(const f16x4*)(smem + L_YI + il_a * 32 + g * 8);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const f16x4 yj = *(const f16x4*)(smem + yj0 + (ct * 16 + frow) * 32 + g * 8);
+                    lac[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(yi, yj, lac[ct], 0, 0, 0);
+                }
+            }
+            // D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+            float sqt = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const float bv = Ej[(ct * 16 + frow) * LDE + ks + fk];
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[ct], 0, 0, 0);
+                const int jl = ct * 16 + (lane & 15);
+                const float nj = nrm[nj0 + jl], nyj = nrm[2 * TS + nj0 + jl];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = wave * 16 + (lane >> 4) * 4 + r;
+                    if (i0 + il < T && j0 + jl < T) {
+                        const float a = __builtin_fmaf(acr[ct][r], 1.0f / 2048.0f, ahh[ct][r]);
+                        const float am = a / __builtin_fmaf(nrm[il], nj, 1e-6f);
+                        const float lm = lac[ct][r] / __builtin_fmaf(nrm[2 * TS + il], nyj, 1e-6f);
+                        const float d = am - lm;
+                        sqt = __builtin_fmaf(d, d, sqt);
+                    }
+                }
             }
-        }
-    }
-    __syncthreads();
-
-    // D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
-    float sq = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int jl = ct * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int il = wave * 16 + (lane >> 4) * 4 + r;
-            if (i0 + il < T && j0 + jl < T) {
-                const float am = acc[ct][r] / (__builtin_sqrtf(n2i[il]) * __builtin_sqrtf(n2j[jl]) + 1e-6f);
-                float dot = 0.f;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) dot = __builtin_fmaf(Yi[il * CMAX + c], Yj[jl * CMAX + c], dot);
-                const float lm = dot / (__builtin_sqrtf(ny2i[il]) * __builtin_sqrtf(ny2j[jl]) + 1e-6f);
-                const float d = am - lm;
-                sq = __builtin_fmaf(d, d, sq);
-            }
+            sq += jt > it ? 2.0f * sqt : sqt;                     // the tile below the diagonal is this one transposed
         }
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) sq = wave_xor_add(sq, m);
+    float* red = nrm + 4 * TS;
+    __syncthreads();
     if (lane == 0) red[wave] = sq;
     __syncthreads();
-    if (tid == 0)
-        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256)
@@ -126,12 +182,15 @@ void emb_consistency_sum_kernel(const float* __restrict__ partial, float* __rest
 
 int eend_launch_emb_consistency(const float* emb, const float* tgt, const int* lens, float inv_count, float* partial_ws, float* out,
                                 int B, int T, int Tp, int D, int C, hipStream_t stream) {
-    if (!emb || !tgt || !partial_ws || !out || B <= 0 || T <= 0 || Tp < T || D <= 0 || (D % KC) != 0 || C < 1 || C > CMAX)
+    if (!emb || !tgt || !partial_ws || !out || B <= 0 || B > 65535 || T <= 0 || Tp < T || D != DM || C < 1 || C > CMAX ||
+        ((size_t)emb & 15))
         return EEND_EINVAL;
-    const int nt = (T + TS - 1) / TS;
-    hipLaunchKernelGGL(emb_consistency_tile_kernel, dim3(nt, nt, B), dim3(256), 0, stream, emb, tgt, lens, partial_ws, T, Tp, D, C);
+    const int nt = (T + TS - 1) / TS, nrow = (nt + 1) / 2;                      // blocks per utterance: tile rows (it, nt - 1 - it)
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)emb_consistency_tile_kernel, EMB_SMEM)) return EEND_ELAUNCH;
+    hipLaunchKernelGGL(emb_consistency_tile_kernel, dim3(nrow, B), dim3(256), EMB_SMEM, stream, emb, tgt, lens, partial_ws, T, Tp, D, C, nt);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
     const float inv = inv_count > 0.f ? inv_count : 1.0f / ((float)B * (float)T * (float)T);
-    hipLaunchKernelGGL(emb_consistency_sum_kernel, dim3(1), dim3(256), 0, stream, partial_ws, out, nt * nt * B, inv);
+    hipLaunchKernelGGL(emb_consistency_sum_kernel, dim3(1), dim3(256), 0, stream, partial_ws, out, nrow * B, inv);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }

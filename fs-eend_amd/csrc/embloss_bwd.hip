@@ -8,7 +8,7 @@
 //
 // Structure: a flash-attention-shaped double product without a softmax.  A block owns 64 rows i of one utterance
 // and walks the 64-row tiles j: S^T = E_j E_i^T (f16 MFMA, K = 256), E' = (S/(1+eps) - L)/(1+eps) on the VALU (labels,
-// C <= 16, from LDS), G^T += E_j^T E'^T (f16 MFMA).  E_j^T is produced while staging (8x8 register transposes), and
+// C <= 16: one more small MFMA), G^T += E_j^T E'^T (f16 MFMA).  E_j^T is produced while staging (8x8 register transposes), and
 // the rows of E_j are fed to the first product in an order that makes the 8 j's a lane holds afterwards contiguous,
 // so E' is the B operand of the second product straight from registers.  The (T, T) maps never exist in memory.
 // Output: de[b, i, :] += 4 c * G (f32, each element owned by one lane -- no atomics).
@@ -30,9 +30,9 @@ void emb_consistency_bwd_kernel(const _Float16* __restrict__ emb16, const float*
     char* Ei = smem;                       // [64][256] f16
     char* Ej = smem + 32768;
     char* EjT = smem + 65536;              // [256 d][64 j] f16 (128-byte rows, swzT)
-    float* Yi = (float*)(smem + 98304);    // [64][16]
-    float* Yj = Yi + TS * CMAX;
-    float* nyi = Yj + TS * CMAX;           // [64]
+    _Float16* Yi = (_Float16*)(smem + 98304);   // [64][16] f16 (labels are 0 / 1: exact)
+    _Float16* Yj = Yi + TS * CMAX;
+    float* nyi = (float*)(Yj + TS * CMAX);      // [64]
     float* nyj = nyi + TS;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,16 +54,16 @@ void emb_consistency_bwd_kernel(const _Float16* __restrict__ emb16, const float*
             *(u32x4*)(dst + swzRow(row, dch)) = v;
         }
     };
-    auto stage_labels = [&](float* Yd, float* nyd, int r0) __attribute__((always_inline)) {
-        for (int q = tid; q < TS * CMAX; q += 256) {
-            const int r = q / CMAX, c = q % CMAX, t = r0 + r;
-            Yd[q] = (t < T && c < C) ? Y[(size_t)t * C + c] : 0.f;
-        }
-        __syncthreads();
+    auto stage_labels = [&](_Float16* Yd, float* nyd, int r0) __attribute__((always_inline)) {
         if (tid < TS) {
+            const int t = r0 + tid;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) s += Yd[tid * CMAX + c] * Yd[tid * CMAX + c];
+            for (int c = 0; c < CMAX; ++c) {
+                const float v = (t < T && c < C) ? Y[(size_t)t * C + c] : 0.f;
+                Yd[tid * CMAX + c] = (_Float16)v;
+                s = __builtin_fmaf(v, v, s);
+            }
             nyd[tid] = __builtin_sqrtf(s);
         }
     };
@@ -72,9 +72,7 @@ void emb_consistency_bwd_kernel(const _Float16* __restrict__ emb16, const float*
     stage_labels(Yi, nyi, i0);
     __syncthreads();
     const int il = wave * 16 + frow;                              // this lane's row i (B-operand column)
-    float yi[CMAX];
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) yi[c] = Yi[il * CMAX + c];
+    const f16x4 yi = *(const f16x4*)(Yi + il * CMAX + g * 4);   // B operand of the label product (column i, labels 4g .. 4g+3)
     const float nyi_l = nyi[il];
 
     f32x4 acc[16];
@@ -117,6 +115,14 @@ void emb_consistency_bwd_kernel(const _Float16* __restrict__ emb16, const float*
                     s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aj, bi, s[jb], 0, 0, 0);
                 }
             }
+            // the label map of the same (j, i) pairs on the MFMA (16x16x16 f16, exact: 0 / 1 labels), rows in the same order
+            f32x4 ls[2];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int jr = 32 * kk + 8 * (frow >> 2) + 4 * jb + (frow & 3);
+                const f16x4 yj = *(const f16x4*)(Yj + jr * CMAX + g * 4);
+                ls[jb] = __builtin_amdgcn_mfma_f32_16x16x16f16(yj, yi, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
             // lane (i = il, g): reg r of s[jb] <-> j = 32kk + 8g + 4jb + r
             f16x8 ef;
 #pragma unroll
@@ -124,10 +130,7 @@ void emb_consistency_bwd_kernel(const _Float16* __restrict__ emb16, const float*
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jl = 32 * kk + 8 * g + 4 * jb + r;
-                    float dot = 0.f;
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c) dot = __builtin_fmaf(yi[c], Yj[jl * CMAX + c], dot);
-                    const float lm = dot / (nyi_l * nyj[jl] + 1e-6f);
+                    const float lm = ls[jb][r] / (nyi_l * nyj[jl] + 1e-6f);
                     float e = (s[jb][r] * inv1 - lm) * inv1;
                     if (j0 + jl >= T || i0 + il >= T) e = 0.f;
                     ef[jb * 4 + r] = (_Float16)e;
@@ -156,7 +159,7 @@ void emb_consistency_bwd_kernel(const _Float16* __restrict__ emb16, const float*
 int eend_launch_emb_consistency_bwd(const void* emb16, const float* tgt, const int* lens, float inv_count, float* de,
                                     int B, int T, int Tp, int D, int C, hipStream_t stream) {
     if (!emb16 || !tgt || !de || B <= 0 || B > 65535 || T <= 0 || Tp < T || D != DM || C < 1 || C > CMAX) return EEND_EINVAL;
-    const int smem = 98304 + (2 * TS * CMAX + 2 * TS) * 4;
+    const int smem = 98304 + 2 * TS * CMAX * 2 + 2 * TS * 4;
     static EendOncePerDevice attr_once;
     if (!eend_set_dynamic_lds(attr_once, (const void*)emb_consistency_bwd_kernel, smem)) return EEND_ELAUNCH;
     const float inv = inv_count > 0.f ? inv_count : 1.0f / ((float)B * (float)T * (float)T);
