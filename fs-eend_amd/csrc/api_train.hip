@@ -116,6 +116,34 @@ int eend_ffn_bwd_data_bf16(const void* dY, int ldy, const void* W2T, const void*
     return eend_launch_ffn_fused(p, 0, FFN_EPI_RES_LN, (hipStream_t)stream);
 }
 
+int eend_ffn_train_stream_elems(int F) { return (F < 64 || (F % 64) != 0 || F > 2048) ? 0 : (int)eend_ffn_train_stream_nelems(F); }
+
+int eend_ffn_train_stream_ok(int M, int F, int ldx) { return eend_ffn_train_stream_fits(M, F, ldx) ? 1 : 0; }
+
+int eend_ffn_train_stream_pack(const void* W1, const void* W2, void* stream_out, int F, void* stream) {
+    return eend_launch_ffn_train_stream_pack(W1, W2, stream_out, F, (hipStream_t)stream);
+}
+
+int eend_ffn_train_stream_f16(const void* X, int ldx, const void* wstream, const float* b1, const float* b2, const float* res, float alpha,
+                              const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* hid_f16, void* xhat_f16,
+                              float* rstd, int M, int F, const eend_dropout* drop_hidden, const eend_dropout* drop_out, void* stream) {
+    FfnTrainStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = X; p.ldx = ldx; p.wstream = wstream; p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.res = res; p.alpha = alpha; p.eps = eps;
+    p.out32 = out_f32; p.out16 = out_f16; p.xhat16 = xhat_f16; p.rstat = rstd; p.hid = hid_f16; p.M = M; p.F = F;
+    p.drop1 = drop_spec(drop_hidden); p.drop2 = drop_spec(drop_out);
+    return eend_launch_ffn_train_stream(p, 1, (hipStream_t)stream);
+}
+
+int eend_ffn_bwd_data_stream_bf16(const void* dY, int ldy, const void* wstream, const void* hid_f16, float drop_scale, void* dH_bf16,
+                                  float* g_f32, int M, int F, void* stream) {
+    FfnTrainStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = dY; p.ldx = ldy; p.wstream = wstream; p.res = g_f32; p.out32 = g_f32; p.hid = (void*)hid_f16; p.dH = dH_bf16; p.alpha = 1.0f;
+    p.M = M; p.F = F; p.drop1 = DropSpec{0u, 0u, drop_scale > 0.f ? drop_scale : 1.0f};
+    return eend_launch_ffn_train_stream(p, 2, (hipStream_t)stream);
+}
+
 int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                             const eend_dropout* drop, void* stream) {
     if (!qkv || !O_f16 || H != 4) return EEND_EINVAL;
@@ -137,13 +165,15 @@ int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bia
 
 int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const float* bias, void* Q, void* Qt,
                                  void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream) {
-    if (!A || !W || !bias || !Q || !Qt || !K || !Kt || !V || !Vt) return EEND_EINVAL;
+    // Qt / Kt may be NULL: the one-launch backward (windows up to 512 frames, attn_bwd_fused.hip) reads its transposed operands from the
+    // row-major head images through the LDS, so the [d][t] copies need not exist
+    if (!A || !W || !bias || !Q || !K || !V || !Vt) return EEND_EINVAL;
     if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || H != 4) return EEND_EINVAL;
     ProjParams q;
     memset(&q, 0, sizeof(q));
     q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = nseq * Tp; q.N = 768; q.Tp = Tp; q.H = H;
-    q.kind[0] = PROJ_HEADS_BOTH; q.out[0] = Q; q.out2[0] = Qt;
-    q.kind[1] = PROJ_HEADS_BOTH; q.out[1] = K; q.out2[1] = Kt;
+    q.kind[0] = Qt ? PROJ_HEADS_BOTH : PROJ_HEADS; q.out[0] = Q; q.out2[0] = Qt;
+    q.kind[1] = Kt ? PROJ_HEADS_BOTH : PROJ_HEADS; q.out[1] = K; q.out2[1] = Kt;
     q.kind[2] = PROJ_HEADS_BOTH; q.out[2] = V; q.out2[2] = Vt;
     q.is_bf16[0] = q.is_bf16[1] = q.is_bf16[2] = 1;
     return eend_launch_proj_xres(q, (hipStream_t)stream);
@@ -218,7 +248,8 @@ int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f1
     if (!dY || !X || !ws || !out || M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return EEND_EINVAL;
     WgradParams p;
     memset(&p, 0, sizeof(p));
-    p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.b_is_f16 = x_is_f16 ? 1 : 0;
+    p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+    p.b_is_f16 = (x_is_f16 & 1) ? 1 : 0; p.b_blocked = (x_is_f16 & 2) ? 1 : 0; p.a_blocked = (x_is_f16 & 4) ? 1 : 0;
     int rc = plan_wgrad(M, N, K, 0, ws_floats, &p.tile, &p.nsplit, &p.m_per_split);
     if (rc != EEND_OK) return rc;
     rc = eend_launch_wgrad(p, (hipStream_t)stream);
@@ -231,7 +262,8 @@ int eend_wgrad_bias_bf16(const void* dY, int lda, const void* X, int ldb, int x_
     if (!dY || !X || !ws || !out || !bias_out || M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return EEND_EINVAL;
     WgradParams p;
     memset(&p, 0, sizeof(p));
-    p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.b_is_f16 = x_is_f16 ? 1 : 0;
+    p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+    p.b_is_f16 = (x_is_f16 & 1) ? 1 : 0; p.b_blocked = (x_is_f16 & 2) ? 1 : 0; p.a_blocked = (x_is_f16 & 4) ? 1 : 0;
     int rc = plan_wgrad(M, N, K, 0, ws_floats, &p.tile, &p.nsplit, &p.m_per_split, true);
     if (rc != EEND_OK) return rc;
     p.bias_partial = ws + (size_t)p.nsplit * N * K;

@@ -426,13 +426,14 @@ void heads_transpose_kernel(const unsigned short* __restrict__ in, int ld, unsig
 }  // namespace
 
 int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
-    if (!p.Q || !p.Qt || !p.K || !p.Kt || !p.V || !p.dO || !p.dOt || !p.Lse || !p.Dh || !p.dQKV) return EEND_EINVAL;
+    if (!p.Q || !p.K || !p.V || !p.dO || !p.dOt || !p.Lse || !p.Dh || !p.dQKV) return EEND_EINVAL;
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) || (p.ldo & 7) || (p.ldg & 3) || p.kv_len <= 0 ||
         p.kv_len > p.Tp || p.q_len <= 0)
         return EEND_EINVAL;
 #ifndef EEND_ATTN_BWD_TWO_KERNELS                       // (study build: the round-2 two-kernel form at every size)
     if (eend_attn_bwd_fused_ok(p, false)) return eend_launch_attn_bwd_fused(p, false, stream);
 #endif
+    if (!p.Qt || !p.Kt) return EEND_EINVAL;             // the two-kernel form reads the [d][t] copies
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
     static EendOncePerDevice attr_once;

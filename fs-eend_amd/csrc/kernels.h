@@ -265,6 +265,30 @@ long eend_ffn_stream_nelems(int F, int with_wo);
 long eend_ffn_stream_debug_row_cap();                    // test hook (eend_debug_ffn_stream_set), 0 = none
 int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
 int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream);
+// ffn_train_stream.hip: training forward (tr = 1) / data gradient (tr = 2) of the post-norm ReLU FFN block on a packed weight stream
+struct FfnTrainStreamParams {
+    const void* X;        // tr 1: x f16 [M][ldx]; tr 2: dY bf16 [M][ldx]
+    int ldx;
+    const void* wstream;  // eend_ffn_train_stream_pack output (tr 1: of W1, W2 f16; tr 2: of W2^T, W1^T bf16)
+    const float* b1;      // tr 1: [F]
+    const float* b2;      // tr 1: [256]
+    const float* gamma;   // tr 1: LayerNorm affine
+    const float* beta;
+    const float* res;     // f32 [M][256]: tr 1 the residual, tr 2 the incoming gradient stream
+    float alpha, eps;
+    float* out32;         // f32 [M][256]: tr 1 LayerNorm output, tr 2 the outgoing gradient stream (may alias res)
+    void* out16;          // tr 1: f16 [M][256]
+    void* xhat16;         // tr 1: f16 [M][256] normalised pre-affine rows
+    float* rstat;         // tr 1: [M] 1/sigma
+    void* hid;            // f16 [M][F]: tr 1 written (saved activations), tr 2 read (their zeros are the mask)
+    void* dH;             // tr 2: bf16 [M][F], written
+    DropSpec drop1, drop2; // tr 1: hidden / output dropout; tr 2: drop1.scale only
+    int M, F;
+};
+long eend_ffn_train_stream_nelems(int F);
+bool eend_ffn_train_stream_fits(int M, int F, int ldx);
+int eend_launch_ffn_train_stream_pack(const void* W1, const void* W2, void* out, int F, hipStream_t stream);
+int eend_launch_ffn_train_stream(const FfnTrainStreamParams& p, int tr, hipStream_t stream);
 // spk_stream.hip: x1 = LN11(A Wo1^T + bo1 + res16), O = speaker-axis MHA(x1 Win2^T + bin2) in one launch (C in {3, 6, 12})
 struct SpkStreamParams {
     const void* A;        // time-axis attention output f16 [B*C*Tp][lda], row = (b*C + c)*Tp + t
@@ -379,6 +403,7 @@ struct WgradParams {          // wgrad.hip: partial[s][n][k] = sum_{m in split s
     long m_per_split;         // multiple of 64
     int tile;                 // output tile edge: 128 or 256 (N, K, conv_cin multiples of it)
     int b_is_f16;
+    int a_blocked, b_blocked; // the operand is stored [M/16][ld/32][16 rows][32 features] (hid / dH of ffn_train_stream.hip; ld = its full row width)
     // Conv1d weight gradient: B rows of k-tile (tap, c_in block) are read at frame t + tap - conv_pad (zero outside [0, ilen))
     int conv, conv_cin, conv_pad, Tp;
     const int* ilens;

@@ -152,10 +152,17 @@ void wgrad_tr_kernel(const WgradParams p) {
     }
     const bool convB = CONV && isB;
     const int ld = isB ? p.ldb : p.lda;
+    const bool blocked = !CONV && (isB ? p.b_blocked : p.a_blocked) != 0;      // (wave-uniform)
     __amdgpu_buffer_rsrc_t rs;
     if (convB) {
         // absolute rows (the shifted rows of the first / last stage of a split lie outside the split)
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned)((size_t)p.M * p.ldb * 2)), 0x00020000);
+    } else if (blocked) {
+        // [M/16][ld/32][16][32] operand (ffn_train_stream.hip): the 16-row groups are as large as 16 row-major rows, so the split's base and
+        // the stage step are the row-major ones; whole groups are in bounds (rows of the last group beyond M hold finite values written
+        // by the producer and meet zero rows of the other, row-major, operand)
+        const char* base = (isB ? (const char*)p.B : (const char*)p.A) + (size_t)m_begin * ld * 2;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)((size_t)((m_len + 15) & ~15) * ld * 2)), 0x00020000);
     } else {
         const char* base = isB ? (const char*)p.B + ((size_t)m_begin * p.ldb + k0) * 2 : (const char*)p.A + ((size_t)m_begin * p.lda + n0) * 2;
         // rows >= m_len are out of bounds -> zeros (the last row's reach, n0 * 2 + BT * 2 <= ld * 2, stays inside)
@@ -168,7 +175,10 @@ void wgrad_tr_kernel(const WgradParams p) {
         const int r = (dl0 + e) * RPI + rl;                           // token row inside the stage
         const int q16 = (((p16 >> 2) ^ (r & 3)) << 2) | (p16 & 3);   // the 16-byte chunk that lives at position p16 of row r
         vrow[e] = r;
-        voff[e] = convB ? (unsigned)(conv_c0 * 2 + q16 * 16) : (unsigned)(r * ld * 2 + q16 * 16);
+        if (blocked)       // feature col0 + 8 q16 of token r: block (r >> 4, feature >> 5), row r & 15, 16-byte piece q16 & 3
+            voff[e] = (unsigned)((r >> 4) * (16 * ld * 2) + (((isB ? k0 : n0) >> 5) + (q16 >> 2)) * 1024 + (r & 15) * 64 + (q16 & 3) * 16);
+        else
+            voff[e] = convB ? (unsigned)(conv_c0 * 2 + q16 * 16) : (unsigned)(r * ld * 2 + q16 * 16);
     }
     const unsigned stage_step = (unsigned)(TR_TS * ld * 2);
     // CONV: sequence / frame of the next stage to be requested, and that sequence's length (loaded one stage ahead)
@@ -498,6 +508,7 @@ int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if ((p.N % bt) || (p.K % bt) || (p.lda & 7) || (p.ldb & 7) || p.nsplit <= 0 || p.m_per_split <= 0 || (p.m_per_split % 64))
         return EEND_EINVAL;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return EEND_EINVAL;
+    if ((p.a_blocked && (p.conv || (p.lda & 31) || p.N > p.lda)) || (p.b_blocked && (p.conv || (p.ldb & 31) || p.K > p.ldb))) return EEND_EINVAL;
     if (p.conv && (!p.ilens || p.conv_cin <= 0 || (p.conv_cin % bt) || p.Tp <= 0 || (p.Tp % 64))) return EEND_EINVAL;
     // 32-bit byte offsets inside a split (inside the whole X tensor for the Conv1d form), four stages of run-ahead included
     const size_t reach_a = ((size_t)p.m_per_split + 256) * p.lda * 2, reach_b = ((size_t)(p.conv ? p.M : p.m_per_split) + 256) * p.ldb * 2;

@@ -94,6 +94,11 @@ PROTOTYPES = {
     "eend_ffn_swish_train_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "eend_ffn_bwd_data_bf16": [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_ffn_train_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "eend_ffn_train_stream_elems": [_i],
+    "eend_ffn_train_stream_ok": [_i, _i, _i],
+    "eend_ffn_train_stream_pack": [_vp, _vp, _vp, _i, _vp],
+    "eend_ffn_train_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "eend_ffn_bwd_data_stream_bf16": [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_spk_attn_train_f16": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "eend_conv1d_l2norm_train_f16": [_vp] * 7 + [_i] * 5 + [_vp],
     "eend_inproj_heads_train_bf16": [_vp, _i, _vp, _vp] + [_vp] * 6 + [_i, _i, _i, _vp],

@@ -136,7 +136,9 @@ class _Site:
 class _AttnSave:
     def __init__(self, dev, nseq, Tp):
         n = nseq * Tp * D
-        self.q, self.qt, self.k, self.kt, self.v, self.vt = (torch.empty(n, dtype=BF16, device=dev) for _ in range(6))
+        self.q, self.k, self.v, self.vt = (torch.empty(n, dtype=BF16, device=dev) for _ in range(4))
+        # [d][t] copies of Q, K: read only by the two-kernel backward of windows beyond 512 frames (attn_bwd.hip)
+        self.qt, self.kt = ((torch.empty(n, dtype=BF16, device=dev) for _ in range(2)) if Tp > 512 else (None, None))
         self.lse = torch.empty(nseq * H * Tp, dtype=F32, device=dev)
         self.ctx = torch.empty(nseq * Tp, D, dtype=F16, device=dev)
 
@@ -260,10 +262,31 @@ class TrainStepBase:
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self._table = raw.to(self.dev)
         self._n_entries = len(self._entries)
+        # post-norm ReLU FFN blocks (keys X.w1 / X.w2 / X.w1T / X.w2T): packed weight streams of ffn_train_stream.hip, re-packed from the
+        # operand copies after every parameter update -- (W1, W2) f16 for the forward, (W2^T, W1^T) bf16 for the data gradient
+        self._ffn_streams = {}
+        for key in list(self.W):
+            if key.endswith(".w1") and all(key[:-3] + sfx in self.W for sfx in (".w2", ".w1T", ".w2T")):
+                pre = key[:-3]
+                Fh = self.W[key].shape[0]
+                n = _lib.load().eend_ffn_train_stream_elems(Fh)
+                if n > 0 and self.W[key].shape[1] == D:
+                    self._ffn_streams[pre] = (torch.empty(n, dtype=F16, device=self.dev), torch.empty(n, dtype=BF16, device=self.dev), Fh)
+        self._stream_of_w1 = {self.W[pre + ".w1"].data_ptr(): pre for pre in self._ffn_streams}
 
     def prep_weights(self):
-        """f32 parameters -> MFMA operand copies (one launch)."""
+        """f32 parameters -> MFMA operand copies (one launch), then the packed FFN streams."""
         _call("eend_prep_weights", self._table, self._n_entries)
+        for pre, (fw, bw, Fh) in self._ffn_streams.items():
+            _call("eend_ffn_train_stream_pack", self.W[pre + ".w1"], self.W[pre + ".w2"], fw, Fh)
+            _call("eend_ffn_train_stream_pack", self.W[pre + ".w2T"], self.W[pre + ".w1T"], bw, Fh)
+
+    def _ffn_stream_for(self, w1, M, F):
+        """Key of the packed streams serving this FFN at M rows, or None (the un-packed, row-major entries then)."""
+        pre = self._stream_of_w1.get(w1.data_ptr())
+        if pre is None or M % 16 != 0 or not _lib.load().eend_ffn_train_stream_ok(M, F, D):
+            return None
+        return pre
 
     # ------------------------------------------------------------------ helpers
     def _table_for(self, srcs, T):
@@ -302,6 +325,12 @@ class TrainStepBase:
         """linear1 + ReLU + dropout + linear2 + dropout + residual + LayerNorm of a post-norm block.  One launch (ffn.hip MODE 3: the hidden
         activations are written once for the backward and never re-read) where the shape allows, else the two GEMM launches."""
         F = hid.shape[1]
+        pre = self._ffn_stream_for(w1, M, F) if x16.shape[1] == 256 and x16.stride(0) == 256 else None
+        if pre is not None:
+            # packed weight stream (ffn_train_stream.hip): hid is written in the BLOCKED layout its two consumers read (_ffn_bwd)
+            _call("eend_ffn_train_stream_f16", x16, 256, self._ffn_streams[pre][0], b1, b2, res, 1.0, self._P(ln + ".weight"), self._P(ln + ".bias"),
+                  1e-5, out32, site.out16, hid, site.xhat, site.rstd, M, F, drop_hidden, drop_out)
+            return
         if F % 64 == 0 and (M + 128) * F * 2 < (1 << 32) and x16.shape[1] == 256:
             _call("eend_ffn_train_f16", x16, x16.stride(0), w1, b1, w2, b2, res, 1.0, self._P(ln + ".weight"), self._P(ln + ".bias"), 1e-5,
                   out32, site.out16, hid, site.xhat, site.rstd, M, F, drop_hidden, drop_out)
@@ -339,6 +368,15 @@ class TrainStepBase:
         W = self.W
         Fh = hid.shape[1]
         dh = dh16[:M * Fh].view(M, Fh)
+        pre = self._ffn_stream_for(W[wkey + ".w1"], M, Fh) if x_in16.stride(0) == 256 else None      # the same predicate as the forward's
+        if pre is not None:
+            # hid and dH in the blocked layout: flags 2 (X blocked) / 4 (dY blocked) of the weight-gradient entries
+            g2 = self._G(p_ + "linear2.weight").view(-1)
+            _call("eend_wgrad_bf16", ds16, D, hid, Fh, 1 | 2, M, D, Fh, self.ws, WS_FLOATS, g2, Fh, Fh, 1.0, 0)
+            _call("eend_ffn_bwd_data_stream_bf16", ds16, D, self._ffn_streams[pre][1], hid, drop_scale, dh, g32, M, Fh)
+            _call("eend_wgrad_bias_bf16", dh, Fh, x_in16, D, 1 | 4, M, Fh, D, self.ws, WS_FLOATS, self._G(p_ + "linear1.weight"), D, D,
+                  self._G(p_ + "linear1.bias"), 1.0, 0)
+            return
         self._wgrad(ds16, hid, M, D, Fh, p_ + "linear2.weight")
         if Fh % 64 == 0 and (M + 128) * Fh * 2 < (1 << 32):
             # dH = scale * (dY W2) under the saved mask, and g += dH W1, in one launch (ffn.hip MODE 4): dH is written once for the weight

@@ -524,6 +524,25 @@ int eend_ffn_swish_train_f16(const void* X, int ldx, const void* W1, const float
  * F a multiple of 64, M * F * 2 < 2^32 bytes, 16-byte aligned buffers; EEND_EINVAL outside that. */
 int eend_ffn_bwd_data_bf16(const void* dY, int ldy, const void* W2T, const void* hid_f16, const void* W1T, float drop_scale,
                            void* dH_bf16, float* g_f32, int M, int F, void* stream);
+/* Round 6: eend_ffn_train_f16 / eend_ffn_bwd_data_bf16 on a PACKED WEIGHT STREAM (ffn_train_stream.hip; same reference sites): one
+ * wave owns 32 / 48 token rows end to end, the hidden units stay in its registers and leave (hid, dH) / arrive (the mask) as 16-byte
+ * accesses per lane.  eend_ffn_train_stream_pack re-orders two 16-bit matrices A [F][256], B [256][F] into the fragment sequence the
+ * kernel consumes (eend_ffn_train_stream_elems(F) elements; F a multiple of 64, at most 2048): (W1, W2) in f16 for the forward,
+ * (W2^T, W1^T) in bf16 for the data gradient.  Pack once per parameter version.  Results, saved tensors and dropout masks as the
+ * un-packed entries (up to fp32 summation order), EXCEPT the layout of hid_f16 and dH_bf16: BLOCKED [ceil(M/16)][F/32][16 rows][32 units]
+ * (element (m, u) at ((m>>4) * (F/32) + (u>>5)) * 512 + (m&15) * 32 + (u&31); allocate ceil(M/16) * 16 rows) -- a wave then writes its 16
+ * rows as one sequential stream of whole cache lines, where row-major rows made the launch write-pattern-bound (594 -> 488 us forward,
+ * 812 -> 493 us data gradient at [196608, 2048]).  The only consumers are eend_ffn_bwd_data_stream_bf16 (the mask) and the weight
+ * gradients (eend_wgrad[_bias]_bf16 with x_is_f16 & 2 / & 4).  eend_ffn_train_stream_ok: the row count one launch can address (32-bit
+ * offsets); outside it -> EEND_EINVAL, the caller keeps the un-packed, row-major entries. */
+int eend_ffn_train_stream_elems(int F);
+int eend_ffn_train_stream_ok(int M, int F, int ldx);
+int eend_ffn_train_stream_pack(const void* A, const void* B, void* stream_out, int F, void* stream);
+int eend_ffn_train_stream_f16(const void* X, int ldx, const void* wstream, const float* b1, const float* b2, const float* res, float alpha,
+                              const float* gamma, const float* beta, float eps, float* out_f32, void* out_f16, void* hid_f16, void* xhat_f16,
+                              float* rstd, int M, int F, const eend_dropout* drop_hidden, const eend_dropout* drop_out, void* stream);
+int eend_ffn_bwd_data_stream_bf16(const void* dY, int ldy, const void* wstream, const void* hid_f16, float drop_scale, void* dH_bf16,
+                                  float* g_f32, int M, int F, void* stream);
 /* eend_spk_attn_f16 with dropout of the attention probabilities. */
 int eend_spk_attn_train_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale,
                             const eend_dropout* drop, void* stream);
@@ -534,7 +553,8 @@ int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bia
                                  void* stream);
 
 /* Packed MHA in-projection for training: Q, K, V in BOTH head layouts (bf16 [nseq][H][Tp][64] and
- * [nseq][H][64][Tp]) -- the forward attention reads Q, K, Vt, its backward Q, Qt, K, Kt, V.  K = 256. */
+ * [nseq][H][64][Tp]) -- the forward attention reads Q, K, Vt, its backward Q, K, V and, for windows beyond 512 frames
+ * (the two-kernel form), Qt, Kt.  Qt / Kt may be NULL (not written) when Tp <= 512.  K = 256. */
 int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const float* bias, void* Q, void* Qt,
                                  void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream);
 
@@ -575,7 +595,8 @@ int eend_conv1d_dgrad_bf16(const void* dY, const void* Wd, const int* src_lens, 
                            int nseq, int Tp, int cout, int ktaps, int pad, void* stream);
 
 /* Weight gradient out[n][k] (row stride ld_out, k < K_out) (+)= scale * sum_m dY[m][n] X[m][k]; dY bf16 [M][lda],
- * X f16 (x_is_f16) or bf16 [M][ldb]; N, K % 128 == 0. */
+ * X f16 (x_is_f16 & 1) or bf16 [M][ldb]; N, K % 128 == 0.  x_is_f16 & 2: X is stored in the blocked layout of
+ * eend_ffn_train_stream_f16's hid (ldb = its full width F); x_is_f16 & 4: dY is (eend_ffn_bwd_data_stream_bf16's dH, lda = F). */
 int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
                     long ws_floats, float* out, int ld_out, int K_out, float scale, int accumulate, void* stream);
 /* The same with the bias gradient on the side: bias_out[n] = scale * sum_m dY[m][n] (+ bias_out if accumulate), accumulated

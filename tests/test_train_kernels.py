@@ -65,10 +65,56 @@ def test_gemm_relu_bwd(T, dev, M, F):
     assert (out[act == 0] == 0).all()
 
 
+
+def _stream_of(T, dev, a, b, F):
+    """eend_ffn_train_stream_pack of two 16-bit matrices a [F][256], b [256][F] (f16 forward operands / bf16 transposed copies)."""
+    from fs_eend_amd import lib as L
+    n = L.load().eend_ffn_train_stream_elems(F)
+    assert n == 2 * (F // 32) * 8192
+    out = torch.empty(n, dtype=a.dtype, device=dev)
+    T._call("eend_ffn_train_stream_pack", a, b, out, F)
+    return out
+
+
+def _to_blocked(t, pad=0.0):
+    """row-major [M][F] -> the blocked layout of the stream entries, [ceil(M/16)*16][F] storage (padding rows = pad)."""
+    M, F = t.shape
+    Mp = (M + 15) // 16 * 16
+    tp = torch.full((Mp, F), pad, dtype=t.dtype, device=t.device)
+    tp[:M] = t
+    return tp.view(Mp // 16, 16, F // 32, 32).permute(0, 2, 1, 3).contiguous().view(Mp, F)
+
+
+def _from_blocked(tb, M):
+    Mp, F = tb.shape
+    return tb.view(Mp // 16, F // 32, 16, 32).permute(0, 2, 1, 3).contiguous().view(Mp, F)[:M]
+
+
+def _ffn_train_call(T, dev, impl, x, w1, b1, w2, b2, res, gm, be, o32, o16, hid, xh, rs, M, F, r1, r2):
+    if impl == "stream":
+        hb = torch.full(((M + 15) // 16 * 16, F), float("nan"), dtype=F16, device=dev)
+        T._call("eend_ffn_train_stream_f16", x, 256, _stream_of(T, dev, w1, w2, F), b1, b2, res, 1.0, gm, be, 1e-5, o32, o16, hb, xh, rs, M, F, r1, r2)
+        assert torch.isfinite(hb).all()                      # the padding rows of the last block too: the weight gradient multiplies them by zero rows
+        hid.copy_(_from_blocked(hb, M))
+    else:
+        T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res, 1.0, gm, be, 1e-5, o32, o16, hid, xh, rs, M, F, r1, r2)
+
+
+def _ffn_bwd_call(T, dev, impl, dy, w2t, act, w1t, scale, dh, gout, M, F):
+    if impl == "stream":
+        db = torch.full(((M + 15) // 16 * 16, F), float("nan"), dtype=BF16, device=dev)
+        T._call("eend_ffn_bwd_data_stream_bf16", dy, 256, _stream_of(T, dev, w2t, w1t, F), _to_blocked(act), scale, db, gout, M, F)
+        assert torch.isfinite(db.float()).all()
+        dh.copy_(_from_blocked(db, M))
+    else:
+        T._call("eend_ffn_bwd_data_bf16", dy, 256, w2t, act, w1t, scale, dh, gout, M, F)
+
+@pytest.mark.parametrize("impl", ["fused", "stream"])
 @pytest.mark.parametrize("M,F,scale", [(1000, 1024, 1.0 / 0.75), (300, 2048, 1.0), (70001, 2048, 1.0 / 0.9), (64, 64, 1.0)])
-def test_ffn_bwd_data_fused(T, dev, M, F, scale):
+def test_ffn_bwd_data_fused(T, dev, M, F, scale, impl):
     """eend_ffn_bwd_data_bf16 (ffn.hip MODE 4, round 5) == eend_gemm_relu_bwd_bf16 + eend_gemm_acc_bf16: dH bit-comparable (same bf16
-    operands, f32 accumulation in a different k order), the residual-gradient stream accumulated in place; both == torch fp32."""
+    operands, f32 accumulation in a different k order), the residual-gradient stream accumulated in place; both == torch fp32.
+    impl "stream": the same operator on the packed weight stream (eend_ffn_bwd_data_stream_bf16, ffn_train_stream.hip, round 6)."""
     gen = g(dev, M + F)
     dy = (torch.randn(M, 256, device=dev, generator=gen) * 1e-4).to(BF16)
     w2t = (torch.randn(F, 256, device=dev, generator=gen) / 16).to(BF16)        # [F][256] = W2^T
@@ -77,7 +123,7 @@ def test_ffn_bwd_data_fused(T, dev, M, F, scale):
     g32 = torch.randn(M, 256, device=dev, generator=gen) * 1e-4
     dh = torch.full((M, F), 3.0, dtype=BF16, device=dev)
     gout = g32.clone()
-    T._call("eend_ffn_bwd_data_bf16", dy, 256, w2t, act, w1t, scale, dh, gout, M, F)
+    _ffn_bwd_call(T, dev, impl, dy, w2t, act, w1t, scale, dh, gout, M, F)
     torch.cuda.synchronize()
     want_dh = (dy.float() @ w2t.float().t()) * scale * (act > 0)
     assert torch.isfinite(dh.float()).all() and torch.isfinite(gout).all()
@@ -155,6 +201,20 @@ def test_wgrad(T, dev, ws, M, N, K, f16):
         out3 = torch.full((N, K), 1.0, dtype=F32, device=dev)
         T._call("eend_wgrad_bf16", wide_dy[:, 2 * N:], 4 * N, wide_x[:, K:], 2 * K, 1 if f16 else 0, M, N, K, ws, ws.numel(), out3, K, K, 1.0, 0)
         assert (out3 == out).all()
+    # an operand in the blocked layout of the stream FFN entries ([M/16][F/32][16][32], x_is_f16 & 2: X, & 4: dY), incl. a partial last
+    # block whose padding rows hold finite garbage (they meet zero rows of the row-major operand): bit-identical to the row-major call
+    if K % 32 == 0 and N % 32 == 0:
+        xb = _to_blocked(x, pad=3.0)
+        out4 = torch.full((N, K), 1.0, dtype=F32, device=dev)
+        T._call("eend_wgrad_bf16", dy, N, xb, K, (1 if f16 else 0) | 2, M, N, K, ws, ws.numel(), out4, K, K, 1.0, 0)
+        assert (out4 == out).all()
+        dyb = _to_blocked(dy, pad=1e-5)
+        out5 = torch.full((N, K), 1.0, dtype=F32, device=dev)
+        bias5 = torch.full((N,), 3.0, dtype=F32, device=dev)
+        T._call("eend_wgrad_bias_bf16", dyb, N, x, K, (1 if f16 else 0) | 4, M, N, K, ws, ws.numel(), out5, K, K, bias5, 1.0, 0)
+        assert (out5 == out2).all()
+        if M % 16 == 0:                                           # (the bias column sums see the padding rows of a blocked dY: whole blocks only)
+            assert (bias5 == bias).all()
     # transpose-detecting: an asymmetric case is already covered (N != K); accumulate + narrow destination
     if K == 384:
         dst = torch.ones(N, 345, dtype=F32, device=dev)
@@ -323,11 +383,13 @@ def test_ffn_hidden_dropout_fwd_bwd(T, dev):
     assert (out[h == 0] == 0).all()
 
 
+@pytest.mark.parametrize("impl", ["fused", "stream"])
 @pytest.mark.parametrize("M,F,pdrop", [(1000, 1024, 0.25), (300, 2048, 0.0), (70001, 2048, 0.1), (64, 64, 0.25)])
-def test_ffn_train_fused(T, dev, M, F, pdrop):
+def test_ffn_train_fused(T, dev, M, F, pdrop, impl):
     """eend_ffn_train_f16 (ffn.hip MODE 3, round 5): the FFN of a post-norm block in one launch == eend_linear_relu_train_f16 +
     eend_linear_res_ln_train_f16 with the same two dropout sites (same masks), and == torch on the kernels' masks: saved hidden activation
-    (its zeros are the ReLU-and-dropout mask of the backward), LayerNorm output, normalised rows, 1/sigma; in place on the residual stream."""
+    (its zeros are the ReLU-and-dropout mask of the backward), LayerNorm output, normalised rows, 1/sigma; in place on the residual stream.
+    impl "stream": the same operator on the packed weight stream (eend_ffn_train_stream_f16, ffn_train_stream.hip, round 6)."""
     import ctypes
     gen = g(dev, 33)
     x = torch.randn(M, 256, device=dev, generator=gen).to(F16)
@@ -346,7 +408,7 @@ def test_ffn_train_fused(T, dev, M, F, pdrop):
         r1 = r2 = None
     nan16 = lambda *sh: torch.full(sh, float("nan"), dtype=F16, device=dev)
     o32, o16, hid, xh, rs = torch.full((M, 256), float("nan"), device=dev), nan16(M, 256), nan16(M, F), nan16(M, 256), torch.full((M,), float("nan"), device=dev)
-    T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res, 1.0, gm, be, 1e-5, o32, o16, hid, xh, rs, M, F, r1, r2)
+    _ffn_train_call(T, dev, impl, x, w1, b1, w2, b2, res, gm, be, o32, o16, hid, xh, rs, M, F, r1, r2)
     torch.cuda.synchronize()
     for t in (o32, o16, hid, xh, rs):
         assert torch.isfinite(t).all()
@@ -381,7 +443,7 @@ def test_ffn_train_fused(T, dev, M, F, pdrop):
     # in place on the residual stream (out_f32 = res), as the training step calls it; deterministic
     res2 = res.clone()
     q16, qh, qxh, qrs = torch.empty_like(o16), torch.empty_like(hid), torch.empty_like(xh), torch.empty_like(rs)
-    T._call("eend_ffn_train_f16", x, 256, w1, b1, w2, b2, res2, 1.0, gm, be, 1e-5, res2, q16, qh, qxh, qrs, M, F, r1, r2)
+    _ffn_train_call(T, dev, impl, x, w1, b1, w2, b2, res2, gm, be, res2, q16, qh, qxh, qrs, M, F, r1, r2)
     torch.cuda.synchronize()
     assert torch.equal(res2, o32) and torch.equal(q16, o16) and torch.equal(qh, hid) and torch.equal(qxh, xh) and torch.equal(qrs, rs)
 
