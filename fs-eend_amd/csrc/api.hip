@@ -22,7 +22,7 @@ GemmParams base_params(const void* A, int lda, const void* W, int ldw, const flo
 
 extern "C" {
 
-int eend_abi_version(void) { return 4; }
+int eend_abi_version(void) { return 5; }
 
 int eend_bn_cast_pad_f16(const float* x, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                          const float* bn_var, float eps, void* out_f16, int B, int T, int Tp, int Fin,

@@ -116,13 +116,11 @@ void attn_bwd_fused_kernel(const AttnBwdParams p) {
             const int kc = db * 4 + (g16 & 1) * 2 + ((i16 & 3) >> 1);
             offT[db][rd] = lds0 + row * 128 + ((kc ^ gsw(row)) << 4) + (i16 & 1) * 8;
         }
-    // dropout hash: h = fmix32((a * G + b) ^ seed), a = (seq*H + h)*Tp + query, b = key (common.h drop_keep)
+    // dropout hash: h = drop_mix((a * G + b) ^ seed), a = (seq*H + h)*Tp + query, b = key (common.h drop_keep)
     const unsigned aG0 = (unsigned)(sh * p.Tp + t0) * 0x9E3779B1u;
     const unsigned thr8 = p.drop.thresh24 << 8;            // (h >> 8) >= thresh24  <=>  h >= thresh24 << 8
     auto hash_keep = [&](unsigned x) __attribute__((always_inline)) {          // x = a * G + b
-        unsigned hh = x ^ p.drop.seed;
-        hh ^= hh >> 16; hh *= 0x85EBCA6Bu; hh ^= hh >> 13; hh *= 0xC2B2AE35u; hh ^= hh >> 16;
-        return hh >= thr8;
+        return drop_mix(x ^ p.drop.seed) >= thr8;
     };
 
     f32x16 zero16;

@@ -85,16 +85,24 @@ DEV int xcd_remap(int bid, int nblocks) {
 
 // ---- dropout (training step): counter-based, stateless.  keep(a, b) is a pure function of (seed, a, b), so the
 // backward kernels regenerate the mask of any forward site instead of storing it.  a = row-like index, b = column-like.
-// murmur3 finaliser over a * golden + b; keep probability 1 - thresh24 / 2^24.
+// hash of a * golden + b (drop_mix below); keep probability 1 - thresh24 / 2^24.
 struct DropSpec {
     unsigned seed;        // per-site seed (host: step seed mixed with the site id)
     unsigned thresh24;    // round(p * 2^24); 0 = dropout off
     float scale;          // 1 / (1 - p)
 };
+// Round 6: two rounds of xor-shift + 24-bit multiply (v_mul_u32_u24: full rate; the 32-bit multiplies of the murmur3 finaliser used until
+// round 5 are quarter rate and were half of a mask bit's 18 issue slots in the VALU-bound training kernels -- 10 now).  The compare
+// reads the top 24 bits of the second product; keep rate, row / column spread, lag correlations and 2 x 2 block counts measure like the
+// murmur masks' (numbers in the test checker's restatement of this function).
+DEV unsigned drop_mix(unsigned x) {                  // x = (a * golden + b) ^ seed
+    x ^= x >> 16;
+    x = (x & 0xFFFFFFu) * 0x6B2F4Du;                   // hipcc emits v_mul_u32_u24 for this
+    x ^= x >> 13;
+    return (x & 0xFFFFFFu) * 0x9E3779u;
+}
 DEV bool drop_keep(const DropSpec d, unsigned a, unsigned b) {
-    unsigned h = (a * 0x9E3779B1u + b) ^ d.seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return (h >> 8) >= d.thresh24;
+    return drop_mix((a * 0x9E3779B1u + b) ^ d.seed) >= (d.thresh24 << 8);     // (h >> 8) >= thresh24
 }
 DEV float drop_apply(const DropSpec d, float v, unsigned a, unsigned b) {
     return d.thresh24 == 0 ? v : (drop_keep(d, a, b) ? v * d.scale : 0.f);

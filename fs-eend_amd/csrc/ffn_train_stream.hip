@@ -88,9 +88,7 @@ DEV bool keep_of(const DropSpec d, unsigned rowbase, unsigned col) {       // dr
 #ifdef FTS_NOHASH
     return (rowbase + col) != d.seed;
 #endif
-    unsigned h = (rowbase + col) ^ d.seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h >= (d.thresh24 << 8);
+    return drop_mix((rowbase + col) ^ d.seed) >= (d.thresh24 << 8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

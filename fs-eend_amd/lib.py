@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("EEND_HIP_LIB") or os.path.join(_HERE, "csrc", "libeen
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _l = ctypes.c_long
 
-ABI_VERSION = 4          # EEND_ABI_VERSION of include/eend_hip.h; load() refuses a library that reports another
+ABI_VERSION = 5          # EEND_ABI_VERSION of include/eend_hip.h; load() refuses a library that reports another
 
 # name -> argtypes, exactly the prototypes of include/eend_hip.h
 PROTOTYPES = {

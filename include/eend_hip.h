@@ -32,7 +32,10 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change).
  *   4 (round 6): eend_attnout_ffn_fused_f16 gained out_lo_f16 / Wo_lo and eend_convert_fanout_f32 gained out_lo_f16 (round 5, shipped
  *      under 3 by mistake); a caller built against the version-3 header must refuse this library. */
-#define EEND_ABI_VERSION 4
+/*   5 (round 6): the dropout mask function of eend_dropout changed (two 24-bit-multiply rounds instead of the murmur3 finaliser): a caller
+ *      that regenerates masks itself (as oracle/dropout_ref.py does) must follow; eend_inproj_heads_train_bf16 accepts NULL Qt / Kt;
+ *      x_is_f16 of eend_wgrad[_bias]_bf16 became a flag word (bits 1, 2: blocked operands); new eend_ffn_train_stream_* entries. */
+#define EEND_ABI_VERSION 5
 int eend_abi_version(void);
 
 /* Eval-mode BatchNorm1d over features + cast + zero pad to the frame slab.
@@ -475,7 +478,9 @@ int eend_head_l2dot_a16_f32(const float* emb, const void* attr_f16, float* attr_
  * nn.MultiheadAttention(dropout=p)).  The reference draws its masks from torch's Philox stream, which no other
  * implementation can reproduce; here a mask is a pure function of (seed, element index), so the backward recomputes it
  * instead of storing it and a step stays bit-reproducible:
- *   h = fmix32((a * 0x9E3779B1 + b) ^ seed)   (murmur3 finaliser),   keep <=> (h >> 8) >= thresh24
+ *   h = mix((a * 0x9E3779B1 + b) ^ seed),   keep <=> (h >> 8) >= thresh24,
+ *   mix(x): x ^= x >> 16; x = (x & 0xFFFFFF) * 0x6B2F4D; x ^= x >> 13; x = (x & 0xFFFFFF) * 0x9E3779   (32-bit wrap-around; ABI 5 --
+ *   versions up to 4 used the murmur3 finaliser, whose 32-bit multiplies are quarter rate on CDNA4)
  * with (a, b) = (row, column) of the element (attention: a = (seq*H + head)*Tp + query, b = key; speaker attention:
  * a = ((b*Tp + t)*4 + head)*16 + query slot, b = key slot).  thresh24 = round(p * 2^24), scale = 1/(1-p).
  * A null pointer or thresh24 == 0 means no dropout.  Host struct, read at call time. */

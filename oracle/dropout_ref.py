@@ -6,7 +6,12 @@ scales the kept elements by 1/(1-p).  No other implementation can reproduce THOS
 dropout is: given the same masks, the HIP forward/backward equals the oracle's.  This module produces the masks the
 kernels produce -- include/eend_hip.h `eend_dropout`:
 
-    h = fmix32((a * 0x9E3779B1 + b) ^ seed)   (murmur3 finaliser, 32-bit wrap-around),   keep <=> (h >> 8) >= thresh24
+    h = mix((a * 0x9E3779B1 + b) ^ seed),   keep <=> (h >> 8) >= thresh24
+    mix(x): x ^= x >> 16; x = mul24(x, 0x6B2F4D); x ^= x >> 13; x = mul24(x, 0x9E3779)
+            with mul24(x, c) = ((x & 0xFFFFFF) * c) mod 2^32  (v_mul_u32_u24: full rate on CDNA4; rounds 3 - 5 used the murmur3 finaliser,
+            whose two 32-bit multiplies are quarter rate).  Measured on 4096 x 2048 masks at p = 0.1 against the murmur masks: keep rate
+            0.89981 (0.89979), per-column / per-row spread 0.00467 / 0.00648 (binomial 0.00469 / 0.00663), lag-1..64 correlations within
+            1.5e-3 (1.0e-3), 2 x 2 block counts chi^2 = 23 (14) at 15 degrees of freedom.
 
 with (a, b) per site as documented there -- and hands them to oracle/fs_eend_ref.py's `drop` hook.  The statistical
 claim (keep rate 1-p, independence across sites) is tested separately (tests/test_train_step.py).
@@ -39,10 +44,9 @@ def keep_mask(a: torch.Tensor, b: torch.Tensor, seed: int, thresh24: int) -> tor
     """a, b: int64 tensors (broadcastable) of the element indices -> bool keep mask."""
     h = ((a * 0x9E3779B1 + b) & M32) ^ seed
     h = h ^ (h >> 16)
-    h = (h * 0x85EBCA6B) & M32
+    h = ((h & 0xFFFFFF) * 0x6B2F4D) & M32
     h = h ^ (h >> 13)
-    h = (h * 0xC2B2AE35) & M32
-    h = h ^ (h >> 16)
+    h = ((h & 0xFFFFFF) * 0x9E3779) & M32
     return (h >> 8) >= thresh24
 
 

@@ -36,7 +36,7 @@ def test_library_exports_every_symbol(hip_lib):
     raw = ctypes.CDLL(L.LIB_PATH)
     for name in _header_protos():
         assert hasattr(raw, name), f"libeend_hip.so does not export {name}"
-    assert hip_lib.eend_abi_version() == 4
+    assert hip_lib.eend_abi_version() == 5
 
 
 def test_no_torch_types_in_abi():

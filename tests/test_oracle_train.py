@@ -87,6 +87,10 @@ def test_dropout_hash_restatement_matches_host_seeds():
     # scalar reference of the hash for one element (the C expression of csrc/common.h drop_keep, 32-bit wrap-around)
     a, b, s = 123457, 201, DR.site_seed(d.base, 4)
     h = ((a * 0x9E3779B1 + b) & DR.M32) ^ s
-    keep = (DR.fmix32_int(h) >> 8) >= d.thresh24
+    h ^= h >> 16
+    h = ((h & 0xFFFFFF) * 0x6B2F4D) & DR.M32
+    h ^= h >> 13
+    h = ((h & 0xFFFFFF) * 0x9E3779) & DR.M32
+    keep = (h >> 8) >= d.thresh24
     got = DR.keep_mask(torch.tensor([a]), torch.tensor([b]), s, d.thresh24)
     assert bool(got[0]) == keep
