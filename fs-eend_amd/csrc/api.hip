@@ -173,7 +173,12 @@ int eend_convert_fanout_f32(const float* E_f32, const float* W_f32, int ldw, con
 int eend_ffn_stream_elems(int F, int with_wo) { return (int)eend_ffn_stream_nelems(F, with_wo); }
 
 int eend_ffn_stream_pack_f16(const void* Wo, const void* W1, const void* W2, void* stream_out, int F, void* stream) {
-    return eend_launch_ffn_stream_pack(Wo, W1, W2, stream_out, F, Wo ? 1 : 0, (hipStream_t)stream);
+    return eend_launch_ffn_stream_pack(Wo, nullptr, W1, W2, stream_out, F, Wo ? 1 : 0, (hipStream_t)stream);
+}
+
+int eend_ffn_stream_pack_lo_f16(const void* Wo, const void* Wo_lo, const void* W1, const void* W2, void* stream_out, int F, void* stream) {
+    if (!Wo || !Wo_lo) return EEND_EINVAL;
+    return eend_launch_ffn_stream_pack(Wo, Wo_lo, W1, W2, stream_out, F, 1, (hipStream_t)stream);
 }
 
 // The stream kernels address rows with 32-bit buffer offsets (and prefetch one grid of tiles ahead): a launch takes at most
@@ -197,6 +202,7 @@ static int ffn_stream_chunked(FfnStreamParams p, int mode, int act, int epi, hip
     const float* r32 = p.res32;
     float* o32 = p.out32;
     char* o16 = (char*)p.out16;
+    char* o16l = (char*)p.out16lo;
     const int M = p.M;
     for (int m0 = 0; m0 < M; m0 += cap) {
         FfnStreamParams q = p;
@@ -206,6 +212,7 @@ static int ffn_stream_chunked(FfnStreamParams p, int mode, int act, int epi, hip
         q.res32 = r32 ? r32 + (size_t)m0 * 256 : nullptr;
         q.out32 = o32 ? o32 + (size_t)m0 * 256 : nullptr;
         q.out16 = o16 + (size_t)m0 * 512;
+        q.out16lo = o16l ? o16l + (size_t)m0 * 512 : nullptr;
         const int rc = eend_launch_ffn_stream(q, mode, act, epi, stream);
         if (rc != EEND_OK) return rc;
     }
@@ -232,6 +239,18 @@ int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, con
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.wstream = wstream; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1; p.res32 = res; p.res16 = res_f16;
     p.b1 = b1; p.b2 = b2; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2; p.out32 = out_f32; p.out16 = out_f16;
+    p.M = M; p.F = F;
+    return ffn_stream_chunked(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
+}
+
+int eend_attnout_ffn_stream_lo_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res, const float* g1,
+                                   const float* be1, float eps1, const float* b1, const float* b2, const float* g2, const float* be2,
+                                   float eps2, float* out_f32, void* out_f16, void* out_lo_f16, int M, int F, void* stream) {
+    if (!res) return EEND_EINVAL;
+    FfnStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.wstream = wstream; p.bo = bo; p.g1 = g1; p.be1 = be1; p.eps1 = eps1; p.res32 = res; p.wo_lo = 1;
+    p.b1 = b1; p.b2 = b2; p.alpha = 1.0f; p.gamma = g2; p.beta = be2; p.eps = eps2; p.out32 = out_f32; p.out16 = out_f16; p.out16lo = out_lo_f16;
     p.M = M; p.F = F;
     return ffn_stream_chunked(p, 1, 1, FFN_EPI_RES_LN, (hipStream_t)stream);
 }

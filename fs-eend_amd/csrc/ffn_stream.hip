@@ -75,19 +75,19 @@ constexpr int INFL = 4 * (NSLOT - 3);   // this wave's DMA pieces younger than t
 //       W2h(k) fragment i           : W2[n(i,f)][k*32 + (e>>2)*16 + g*4 + (e&3)]
 //   with lane = (f = l & 15, g = l >> 4), n(i,f) = (f>>2)*64 + i*4 + (f&3), kcol = g*64 + 8s (after LayerNorm1's register
 //   layout) or s*32 + g*8 (X read from memory).
-__global__ void ffn_stream_pack_kernel(const _Float16* __restrict__ Wo, const _Float16* __restrict__ W1,
+__global__ void ffn_stream_pack_kernel(const _Float16* __restrict__ Wo, const _Float16* __restrict__ Wo_lo, const _Float16* __restrict__ W1,
                                        const _Float16* __restrict__ W2, _Float16* __restrict__ out, int F, int k_permuted) {
     const int U = F / 32;
-    const int nWo = Wo ? 8 : 0;
+    const int nWo = Wo ? (Wo_lo ? 16 : 8) : 0;             // with Wo_lo: the eight items of f16(Wo - f16(Wo)) follow those of Wo
     const long total = (long)(nWo + 2 * U) * (SLOT / 16);
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int item = (int)(t >> 10), w = (int)(t & 1023);
         const int pfrag = w >> 6, l = w & 63, f = l & 15, g = l >> 4;
         _Float16 v[8];
         if (item < nWo) {
-            const int kc = item >> 1, sl = item & 1, i = pfrag;
+            const int kc = (item & 7) >> 1, sl = item & 1, i = pfrag;
             const int n = (f >> 2) * 64 + i * 4 + (f & 3);
-            const _Float16* src = Wo + (size_t)n * 256 + kc * 64 + sl * 32 + g * 8;
+            const _Float16* src = (item < 8 ? Wo : Wo_lo) + (size_t)n * 256 + kc * 64 + sl * 32 + g * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = src[e];
         } else {
@@ -128,10 +128,14 @@ __device__ unsigned long long g_fs_trace[256 * 8 * 10];
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, int ACT, int EPI, bool RES16, int NJ>
+// LO (MODE 1 on f32 residual rows: the LS-EEND decoder layer tail): the out-projection is followed by a second product with the f16
+// remainder of its weight on the same input fragments (eight more stream items), and the rows also leave as an f16 hi / lo pair
+// (out16lo = f16(y - f16(y)): the second operand of the next retention's query path).
+template <int MODE, int ACT, int EPI, bool RES16, int NJ, bool LO = false>
 __global__ __launch_bounds__(256, 1)
 void ffn_stream_kernel(const FfnStreamParams p) {
     constexpr bool PRE = MODE == 1;
+    static_assert(!LO || (PRE && !RES16), "LO: out-projection form on f32 residual rows");
     constexpr int TM = 64 * NJ, WM = 16 * NJ;
     // VMEM operations of a wave that are certainly younger than the DMA pieces the first six barriers after an epilogue wait for:
     // the INFL pieces in between plus the epilogue's own f16 row stores (8 per token fragment) and, where they are issued in or
@@ -139,7 +143,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     constexpr int LOOSE = INFL + 8 * NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int U = p.F >> 5;                               // half-chunks of 32 hidden units
-    const int S = (PRE ? 8 : 0) + 2 * U;                  // stream items per tile
+    const int S = (PRE ? (LO ? 16 : 8) : 0) + 2 * U;      // stream items per tile
     const int ntiles = (p.M + TM - 1) / TM;
 
     // The thread index is laundered per tile so that everything derived from it (LDS addresses, row pointers, DMA offsets)
@@ -159,6 +163,7 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     const __amdgpu_buffer_rsrc_t rsR32 = __builtin_amdgcn_make_buffer_rsrc((void*)p.res32, 0, p.res32 ? p.M * 1024 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsO16 = __builtin_amdgcn_make_buffer_rsrc(p.out16, 0, p.M * 512, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsO32 = __builtin_amdgcn_make_buffer_rsrc((void*)p.out32, 0, p.out32 ? p.M * 1024 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO16L = __builtin_amdgcn_make_buffer_rsrc(p.out16lo, 0, LO && p.out16lo ? p.M * 512 : 0, 0x00020000);
     auto bload = [&](const __amdgpu_buffer_rsrc_t& r, int off) __attribute__((always_inline)) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
     int dvo = lane * 16 + wave * 4096;                    // this wave moves pieces wave*4 .. wave*4+3 of every item
     int nxt = 0;                                          // next stream item to request (0 .. S-1)
@@ -359,6 +364,16 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                     for (int i = 0; i < 16; ++i) t4[i] = __builtin_bit_cast(f32x4, bload(rsR32, off + i * 16));
                 }
             };
+            if constexpr (LO) {                              // the remainder weight's eight items on the same input fragments
+                step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<0>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<1>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<2>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<3>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<4>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<5>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+                step(IC<0>{}, IC<6>{}, Fa{}, Fa{}, T{}, IC<0>{}, false, 0, hbA, hbB);
+            }
             load_res(IC<0>{});
             step(IC<0>{}, IC<7>{}, Fa{}, Fa{}, Fa{}, IC<(!RES16 ? 16 : 0)>{}, false, 0, hbA, hbB);
             pin_acc(2);
@@ -503,6 +518,34 @@ void ffn_stream_kernel(const FfnStreamParams p) {
                 }
                 wave_lds_sync();
             }
+            if (LO && p.out16lo) {                           // the f16 remainder of the same rows, same way
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x4 g4 = vec4(4, i), gg = g4 * (rstd * p.alpha), bb = vec4(5, i) - g4 * (rstd * mean);
+                    const f32x4 a4 = acc[i][j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float y = __builtin_fmaf(a4[q], gg[q], bb[q]);
+                        o[i >> 1][(i & 1) * 4 + q] = (_Float16)(y - (float)o[i >> 1][(i & 1) * 4 + q]);
+                    }
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if ((frow >> 3) == half) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) *(f16x8*)(st + (frow & 7) * 512 + (((g * 8 + e) ^ (frow & 7)) << 4)) = o[e];
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int rr = 2 * q4 + (lane >> 5), cc = lane & 31;
+                        const f16x8 v = *(const f16x8*)(st + rr * 512 + ((cc ^ rr) << 4));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO16L, (rbase + half * 8 + rr) * 512 + cc * 16, 0, 0);
+                    }
+                    wave_lds_sync();
+                }
+            }
             if (o32) {
 #pragma unroll
                 for (int fh = 0; fh < 2; ++fh)              // features fo + 0..31 / fo + 32..63
@@ -540,17 +583,17 @@ void ffn_stream_kernel(const FfnStreamParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 }
 
-template <int MODE, int ACT, int EPI, bool RES16, int NJ>
+template <int MODE, int ACT, int EPI, bool RES16, int NJ, bool LO = false>
 int launch_nj(const FfnStreamParams& p, int ncu, hipStream_t stream) {
     static EendOncePerDevice attr_once;
-    auto kern = ffn_stream_kernel<MODE, ACT, EPI, RES16, NJ>;
+    auto kern = ffn_stream_kernel<MODE, ACT, EPI, RES16, NJ, LO>;
     if (!eend_set_dynamic_lds(attr_once, (const void*)kern, SMEM)) return EEND_ELAUNCH;
     const int ntiles = (p.M + 64 * NJ - 1) / (64 * NJ);
     hipLaunchKernelGGL(kern, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), SMEM, stream, p);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
-template <int MODE, int ACT, int EPI, bool RES16>
+template <int MODE, int ACT, int EPI, bool RES16, bool LO = false>
 int launch(const FfnStreamParams& p, hipStream_t stream) {
     const int ncu = eend_cu_count();
     // 192-row tiles reuse every weight fragment for three MFMAs; when they leave CUs idle in the only (or last of few) rounds,
@@ -559,7 +602,7 @@ int launch(const FfnStreamParams& p, hipStream_t stream) {
     const long c3 = ((t3 + ncu - 1) / ncu) * (3 * 10 + 9), c2 = ((t2 + ncu - 1) / ncu) * (2 * 10 + 9);     // per-tile cost model: rows + fixed part
     const int forced = g_debug_nj.load(std::memory_order_relaxed);              // tests only (eend_debug_ffn_stream_set)
     const int nj = forced ? forced : (c2 < c3 ? 2 : 3);
-    return nj == 2 ? launch_nj<MODE, ACT, EPI, RES16, 2>(p, ncu, stream) : launch_nj<MODE, ACT, EPI, RES16, 3>(p, ncu, stream);
+    return nj == 2 ? launch_nj<MODE, ACT, EPI, RES16, 2, LO>(p, ncu, stream) : launch_nj<MODE, ACT, EPI, RES16, 3, LO>(p, ncu, stream);
 }
 
 }  // namespace
@@ -570,13 +613,15 @@ extern "C" int eend_debug_fs_trace(void* dst, void* stream) {
 }
 #endif
 
-long eend_ffn_stream_nelems(int F, int with_wo) { return (long)((with_wo ? 8 : 0) + 2 * (F / 32)) * (SLOT / 2); }
+// with_wo: 0 = FFN only, 1 = Wo items in front, 2 = Wo and its f16 remainder (the LO form)
+long eend_ffn_stream_nelems(int F, int with_wo) { return (long)((with_wo == 2 ? 16 : with_wo ? 8 : 0) + 2 * (F / 32)) * (SLOT / 2); }
 
-int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream) {
-    if (!W1 || !W2 || !out || F < 64 || (F % 64) != 0) return EEND_EINVAL;
-    const long total = eend_ffn_stream_nelems(F, Wo != nullptr) / 8;
+int eend_launch_ffn_stream_pack(const void* Wo, const void* Wo_lo, const void* W1, const void* W2, void* out, int F, int k_permuted,
+                                hipStream_t stream) {
+    if (!W1 || !W2 || !out || F < 64 || (F % 64) != 0 || (Wo_lo && !Wo)) return EEND_EINVAL;
+    const long total = eend_ffn_stream_nelems(F, Wo ? (Wo_lo ? 2 : 1) : 0) / 8;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(ffn_stream_pack_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream, (const _Float16*)Wo,
+    hipLaunchKernelGGL(ffn_stream_pack_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream, (const _Float16*)Wo, (const _Float16*)Wo_lo,
                        (const _Float16*)W1, (const _Float16*)W2, (_Float16*)out, F, k_permuted);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
@@ -587,6 +632,11 @@ int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi,
         return EEND_EINVAL;
     if (mode == 1) {
         if (!p.bo || !p.g1 || !p.be1 || act != 1 || epi != FFN_EPI_RES_LN || (!p.res16 && !p.res32)) return EEND_EINVAL;
+        if (p.wo_lo) {                                       // LO form: the stream carries the remainder weight's items (caller's contract)
+            if (p.res16 || !p.res32 || ((size_t)p.out16lo & 15)) return EEND_EINVAL;
+            return launch<1, 1, FFN_EPI_RES_LN, false, true>(p, stream);
+        }
+        if (p.out16lo) return EEND_EINVAL;
         return p.res16 ? launch<1, 1, FFN_EPI_RES_LN, true>(p, stream) : launch<1, 1, FFN_EPI_RES_LN, false>(p, stream);
     }
     if (!p.res32) return EEND_EINVAL;

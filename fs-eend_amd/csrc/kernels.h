@@ -259,11 +259,13 @@ struct FfnStreamParams {
     float eps, alpha;
     float* out32;         // may be null in mode 1 / FFN_EPI_RES_LN
     void* out16;
+    int wo_lo;            // mode 1 on f32 residual rows only (LO form): the stream carries Wo's f16 remainder behind Wo (ffn_stream_pack with Wo_lo)
+    void* out16lo;        // LO form, optional: f16(y - f16(y))
     int M, F;
 };
 long eend_ffn_stream_nelems(int F, int with_wo);
 long eend_ffn_stream_debug_row_cap();                    // test hook (eend_debug_ffn_stream_set), 0 = none
-int eend_launch_ffn_stream_pack(const void* Wo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
+int eend_launch_ffn_stream_pack(const void* Wo, const void* Wo_lo, const void* W1, const void* W2, void* out, int F, int k_permuted, hipStream_t stream);
 int eend_launch_ffn_stream(const FfnStreamParams& p, int mode, int act, int epi, hipStream_t stream);
 // ffn_train_stream.hip: training forward (tr = 1) / data gradient (tr = 2) of the post-norm ReLU FFN block on a packed weight stream
 struct FfnTrainStreamParams {

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "eend_convert_fanout_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "eend_ffn_stream_elems": [_i, _i],
     "eend_ffn_stream_pack_f16": [_vp, _vp, _vp, _vp, _i, _vp],
+    "eend_ffn_stream_pack_lo_f16": [_vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "eend_attnout_ffn_stream_lo_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "eend_ffn_stream_f16": [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_conv_stream_elems": [_i],
     "eend_conv_stream_ok": [_i, _i, _i],

@@ -388,6 +388,8 @@ class OnlineConformerRetentionDADiarization(nn.Module):
         for Ld in dl:
             Ld["wrs"] = ops.retention_stream_pack(Ld["wqkvg32"])
             Ld["ws1"] = ops.spk_stream_pack(Ld["out1_w"], Ld["in2_w"])
+            Fd = Ld["w1"].shape[0]      # layer tail on the packed stream (LO form) where its shape allows, else the un-packed ffn.hip launch
+            Ld["ws2"] = ops.ffn_stream_pack_lo(Ld["out2_w"], Ld["out2_wlo"], Ld["w1"], Ld["w2"]) if (Fd % 64 == 0 and 64 <= Fd <= 2048) else None
         P["dec.layers"] = dl
         self._prep, self._prep_key, self._pc = P, key, {}
         return P
@@ -500,9 +502,14 @@ class OnlineConformerRetentionDADiarization(nn.Module):
             ops.attnout_spk_stream_res32(o16, Ld["ws1"], Ld["out1_b"], ws.a32, Ld["g11"], Ld["be11"], Ld["eps11"], ws.a32, Ld["in2_b"],
                                          o16, B, C, Tp)
             # out-projection (hi / lo f16 weight pair) + norm21 + FFN + norm22 in one launch; f32 rows out, plus their hi / lo f16 copies
-            ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
-                                  Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16,
-                                  out16lo=ws.a16lo if (xlo and j + 1 < nd) else None, wo_lo=Ld["out2_wlo"])
+            # (ffn_stream.hip LO form: one wave owns 32 / 48 rows end to end; [327680, 2048]: 797 us un-packed ffn.hip -> 674 us before the lo product)
+            lo_out = ws.a16lo if (xlo and j + 1 < nd) else None
+            if Ld["ws2"] is not None:
+                ops.attnout_ffn_stream_lo(o16, Ld["ws2"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["b1"], Ld["b2"],
+                                          Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16, lo_out)
+            else:
+                ops.attnout_ffn_fused(o16, Ld["out2_w"], Ld["out2_b"], ws.a32, Ld["g21"], Ld["be21"], Ld["eps21"], Ld["w1"], Ld["b1"],
+                                      Ld["w2"], Ld["b2"], Ld["g22"], Ld["be22"], Ld["eps22"], ws.a32, ws.a16, out16lo=lo_out, wo_lo=Ld["out2_wlo"])
 
     def _run(self, src: Sequence[Tensor], ilens: Sequence[int], C: int):
         P = self._prepare()

@@ -665,6 +665,35 @@ def ffn_stream_pack(wo, w1, w2):
     return out
 
 
+def ffn_stream_pack_lo(wo, wo_lo, w1, w2):
+    """ffn_stream_pack with the out-projection weight as an f16 hi / lo pair: the stream of attnout_ffn_stream_lo."""
+    L = _lib.load()
+    for n, t in (("wo", wo), ("wo_lo", wo_lo), ("w1", w1), ("w2", w2)):
+        _chk(t, F16, n)
+    Fh = w1.shape[0]
+    if (w1.shape[1] != 256 or w2.shape != (256, Fh) or Fh % 64 or Fh < 64 or wo.shape != (256, 256) or wo_lo.shape != (256, 256)
+            or not all(t.is_contiguous() for t in (wo, wo_lo, w1, w2))):
+        raise _lib.EendHipError("ffn_stream_pack_lo: expected contiguous Wo / Wo_lo [256][256], W1 [F][256], W2 [256][F], F a multiple of 64")
+    out = torch.empty(L.eend_ffn_stream_elems(Fh, 2), dtype=F16, device=w1.device)
+    _lib.check(L.eend_ffn_stream_pack_lo_f16(_p(wo), _p(wo_lo), _p(w1), _p(w2), _p(out), Fh, _stream()), "eend_ffn_stream_pack_lo_f16")
+    return out
+
+
+def attnout_ffn_stream_lo(a16, wstream, bo, res, g1, be1, eps1, b1, b2, g2, be2, eps2, out32, out16, out16lo):
+    """attnout_ffn_fused(..., out16lo, wo_lo) on a packed weight stream (ffn_stream_pack_lo): f32 residual rows in, f32 + f16 hi / lo out."""
+    L = _lib.load()
+    _chk(a16, F16, "a16"); _chk(wstream, F16, "wstream"); _chk(out16, F16, "out16"); _chk(out16lo, F16, "out16lo")
+    for n, t in (("bo", bo), ("res", res), ("g1", g1), ("be1", be1), ("b1", b1), ("b2", b2), ("g2", g2), ("be2", be2), ("out32", out32)):
+        _chk(t, F32, n)
+    M, K = a16.shape
+    Fh = b1.shape[0]
+    if K != 256 or wstream.numel() != L.eend_ffn_stream_elems(Fh, 2) or res is None:
+        raise _lib.EendHipError("attnout_ffn_stream_lo: expected d_model 256 and a stream packed with Wo / Wo_lo for this F")
+    _lib.check(L.eend_attnout_ffn_stream_lo_f16(_p(a16), a16.stride(0), _p(wstream), _p(bo), _p(res), _p(g1), _p(be1), eps1, _p(b1), _p(b2),
+                                                _p(g2), _p(be2), eps2, _p(out32), _p(out16), _p(out16lo), M, Fh, _stream()),
+               "eend_attnout_ffn_stream_lo_f16")
+
+
 def ffn_stream_max_rows(lda=256):
     """Rows one launch of the packed-stream layer-tail kernels takes; larger M is served in several launches inside the C ABI."""
     return int(_lib.load().eend_ffn_stream_max_rows(int(lda)))

@@ -217,6 +217,14 @@ int eend_ffn_stream_f16(const void* X, int ldx, const void* wstream, const float
                         const float* res, float alpha, const float* gamma, const float* beta, float eps,
                         float* out_f32, void* out_f16, int M, int F, int act, int residual_stream_unnormalised,
                         void* stream);
+/* The LO form (round 6; LS-EEND decoder layer tail, merge_retnet_layer.py:240-253 on the f32 attractor rows): the out-projection weight
+ * as an f16 hi / lo pair (Wo_lo = f16(Wo - f16(Wo)): a second product on the same input fragments; eend_ffn_stream_elems(F, 2) elements)
+ * and the rows leaving as f32 AND as an f16 hi / lo pair (out_lo_f16 = f16(y - f16(y)); may be NULL), as eend_attnout_ffn_fused_f16
+ * with Wo_lo / out_lo_f16 does on un-packed weights. */
+int eend_ffn_stream_pack_lo_f16(const void* Wo, const void* Wo_lo, const void* W1, const void* W2, void* stream_out, int F, void* stream);
+int eend_attnout_ffn_stream_lo_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res, const float* g1,
+                                   const float* be1, float eps1, const float* b1, const float* b2, const float* g2, const float* be2,
+                                   float eps2, float* out_f32, void* out_f16, void* out_lo_f16, int M, int F, void* stream);
 /* res (f32) or res_f16 (f16), exactly one non-null; out_f32 may be NULL */
 int eend_attnout_ffn_stream_f16(const void* A, int lda, const void* wstream, const float* bo, const float* res,
                                 const void* res_f16, const float* g1, const float* be1, float eps1, const float* b1,

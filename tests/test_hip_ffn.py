@@ -117,6 +117,49 @@ def test_attnout_ffn_fused(hip_lib, dev, M, Fh):
     assert torch.equal(res2, o32) and torch.equal(a2, o16)
 
 
+@pytest.mark.parametrize("M,Fh", [(128, 2048), (1500, 2048), (77, 1024), (20011, 2048)])
+def test_attnout_ffn_stream_lo_matches_unpacked(hip_lib, dev, M, Fh):
+    """Round 6: the LO form of the packed-stream layer tail (ffn_stream.hip: Wo hi / lo pair in the stream, f32 + f16 hi / lo rows out) ==
+    eend_attnout_ffn_fused_f16 with wo_lo / out16lo on un-packed weights (the launch it replaces in the LS-EEND decoder), up to f32
+    summation order; remainder rows exact; in place on the residual stream; optional lo output."""
+    from fs_eend_amd import ops
+    a = rnd((M, 256), dev, 61, F16)
+    wo32 = rnd((256, 256), dev, 62, F32, 0.06)
+    wo, bo = wo32.half(), rnd((256,), dev, 63) * 0.2
+    wlo = (wo32 - wo.float()).half()
+    w1, b1 = rnd((Fh, 256), dev, 64, F16, 0.08), rnd((Fh,), dev, 65) * 0.3
+    w2, b2 = rnd((256, Fh), dev, 66, F16, 0.04), rnd((256,), dev, 67) * 0.3
+    res = rnd((M, 256), dev, 68)
+    g1, be1 = rnd((256,), dev, 69) * 0.2 + 1, rnd((256,), dev, 70) * 0.1
+    g2, be2 = rnd((256,), dev, 71) * 0.2 + 1, rnd((256,), dev, 72) * 0.1
+    nan = lambda dt: torch.full((M, 256), float("nan"), dtype=dt, device=dev)
+    p32, p16, pl = nan(F32), nan(F16), nan(F16)
+    ops.attnout_ffn_fused(a, wo, bo, res, g1, be1, 1e-5, w1, b1, w2, b2, g2, be2, 1e-5, p32, p16, out16lo=pl, wo_lo=wlo)
+    ws = ops.ffn_stream_pack_lo(wo, wlo, w1, w2)
+    o32, o16, ol = nan(F32), nan(F16), nan(F16)
+    ops.attnout_ffn_stream_lo(a, ws, bo, res, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, o32, o16, ol)
+    for t in (o32, o16, ol):
+        assert torch.isfinite(t).all()
+    assert (o32 - p32).abs().max().item() < 3e-3                 # f16 roundings of x / h may flip: fp32 sum order differs
+    assert ((o16.float() + ol.float()) - o32).abs().max().item() < 2e-6 * max(1.0, o32.abs().max().item())
+    # against float64 on the f32 out-projection weight
+    x = torch.nn.functional.layer_norm(a.double() @ wo32.double().t() + bo.double() + res.double(), (256,), g1.double(), be1.double(), 1e-5).float()
+    h = (x.to(F16).float() @ w1.float().t() + b1).relu().to(F16).float()
+    full = torch.nn.functional.layer_norm(h @ w2.float().t() + b2 + x, (256,), g2, be2, 1e-5)
+    assert (o32 - full).abs().max().item() < 3e-3
+    # in place on the f32 stream (out32 = res, out16 = a), without the lo output: the same rows
+    res2, a2 = res.clone(), a.clone()
+    ops.attnout_ffn_stream_lo(a2, ws, bo, res2, g1, be1, 1e-5, b1, b2, g2, be2, 1e-5, res2, a2, None)
+    assert torch.equal(res2, o32) and torch.equal(a2, o16)
+    # the split weight matters: the single-product stream differs from the f32-weight result by the f16 weight rounding
+    z2, zb2 = torch.zeros_like(w2), torch.zeros_like(b2)
+    one, zero = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    s32, s16 = nan(F32), nan(F16)
+    ops.attnout_ffn_stream_lo(a, ops.ffn_stream_pack_lo(wo, wlo, w1, z2), bo, res, g1, be1, 1e-5, b1, zb2, one, zero, 1e-5, s32, s16, None)
+    want = torch.nn.functional.layer_norm(x.double(), (256,), None, None, 1e-5).float()
+    assert (s32 - want).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("M,Fh", [(128, 2048), (1500, 2048), (77, 1024)])
 def test_attnout_ffn_fused_split_weight_and_remainder(hip_lib, dev, M, Fh):
     """Round 5 (LS-EEND decoder): wo_lo = the f16 remainder of the f32 out-projection weight (second MFMA product in the
