@@ -167,14 +167,14 @@ int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const fl
                                  void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream) {
     // Qt / Kt may be NULL: the one-launch backward (windows up to 512 frames, attn_bwd_fused.hip) reads its transposed operands from the
     // row-major head images through the LDS, so the [d][t] copies need not exist
-    if (!A || !W || !bias || !Q || !K || !V || !Vt) return EEND_EINVAL;
+    if (!A || !W || !bias || !Q || !K || !V) return EEND_EINVAL;
     if (nseq <= 0 || Tp <= 0 || (Tp % 64) != 0 || H != 4) return EEND_EINVAL;
     ProjParams q;
     memset(&q, 0, sizeof(q));
     q.X = A; q.ldx = lda; q.W = W; q.bias = bias; q.M = nseq * Tp; q.N = 768; q.Tp = Tp; q.H = H;
     q.kind[0] = Qt ? PROJ_HEADS_BOTH : PROJ_HEADS; q.out[0] = Q; q.out2[0] = Qt;
     q.kind[1] = Kt ? PROJ_HEADS_BOTH : PROJ_HEADS; q.out[1] = K; q.out2[1] = Kt;
-    q.kind[2] = PROJ_HEADS_BOTH; q.out[2] = V; q.out2[2] = Vt;
+    q.kind[2] = Vt ? PROJ_HEADS_BOTH : PROJ_HEADS; q.out[2] = V; q.out2[2] = Vt;
     q.is_bf16[0] = q.is_bf16[1] = q.is_bf16[2] = 1;
     return eend_launch_proj_xres(q, (hipStream_t)stream);
 }
@@ -545,19 +545,26 @@ int eend_retention_bwd_bf16(const void* Q, const void* Qt, const void* K, const 
                             const float* dctx_f32, const void* g_f16, int ldg, const void* rhat_f16, const float* rc_in,
                             void* ot_ws, void* ott_ws, float* kv_ws, float* g_ws, void* St_ws, void* dqkvg_bf16, int ldq,
                             int nseq, int H, int Tp, int L, int T_valid, float sk, void* stream) {
-    if (!Q || !Qt || !K || !Kt || !V || !Vt || !dctx_f32 || !g_f16 || !rhat_f16 || !rc_in || !ot_ws || !ott_ws || !kv_ws || !g_ws ||
-        !St_ws || !dqkvg_bf16)
-        return EEND_EINVAL;
+    if (!Q || !K || !V || !dctx_f32 || !g_f16 || !rhat_f16 || !rc_in || !ot_ws || !kv_ws || !g_ws || !St_ws || !dqkvg_bf16) return EEND_EINVAL;
     if (H != 4 || L <= 0 || T_valid <= 0 || T_valid > Tp || (T_valid % L) != 0 || ldq < 1024 || (ldq & 7)) return EEND_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nc = T_valid / L;
+    AttnBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.H = H; p.nseq = nseq; p.Tp = Tp; p.ldo = 256; p.ldg = ldq; p.L = L; p.nc = nc;
+    // chunk lengths up to 512: the one-launch backward and the row-major state kernel read no [d][t] copies (Qt / Kt / Vt / ott_ws may be NULL)
+    const bool row_major = eend_attn_bwd_fused_ok(p, true);
+    if (!row_major && (!Qt || !Kt || !Vt || !ott_ws)) return EEND_EINVAL;
     int rc = eend_launch_ret_gate_gn_bwd(dctx_f32, g_f16, ldg, rhat_f16, rc_in, (__bf16*)dqkvg_bf16 + 768, ldq, ot_ws, nseq, Tp, T_valid, st);
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_heads_transpose(ot_ws, 256, ott_ws, nseq, H, Tp, st);
+    if (row_major) {
+        rc = eend_launch_ret_bwd_states_rm(K, V, Q, ot_ws, 256, kv_ws, g_ws, St_ws, nseq, H, Tp, L, nc, st);
+    } else {
+        rc = eend_launch_heads_transpose(ot_ws, 256, ott_ws, nseq, H, Tp, st);
+        if (rc != EEND_OK) return rc;
+        rc = eend_launch_ret_bwd_states(Kt, Vt, Qt, ott_ws, kv_ws, g_ws, St_ws, nseq, H, Tp, L, nc, st);
+    }
     if (rc != EEND_OK) return rc;
-    rc = eend_launch_ret_bwd_states(Kt, Vt, Qt, ott_ws, kv_ws, g_ws, St_ws, nseq, H, Tp, L, nc, st);
-    if (rc != EEND_OK) return rc;
-    AttnBwdParams p;
     memset(&p, 0, sizeof(p));
     p.Q = Q; p.Qt = Qt; p.K = K; p.Kt = Kt; p.V = V; p.dO = ot_ws; p.dOt = ott_ws; p.dQKV = dqkvg_bf16;
     p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = 256; p.ldg = ldq; p.mask_delay = 0; p.kv_len = T_valid; p.q_len = T_valid;

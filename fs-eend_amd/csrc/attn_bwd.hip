@@ -445,13 +445,14 @@ int eend_launch_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
 // Retention core backward (see the RET note above): p.dO = o~ (bf16 rows), p.dOt its head-transposed copy, p.St the
 // states of ret_bwd_scan_kernel, p.L / p.nc the chunking; only query / key tiles inside the nc * L valid frames run.
 int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream) {
-    if (!p.Q || !p.Qt || !p.K || !p.Kt || !p.V || !p.dO || !p.dOt || !p.St || !p.dQKV) return EEND_EINVAL;
+    if (!p.Q || !p.K || !p.V || !p.dO || !p.St || !p.dQKV) return EEND_EINVAL;
     if (p.nseq <= 0 || p.nseq > 65535 || p.H <= 0 || p.Tp <= 0 || (p.Tp % 64) || (p.ldo & 7) || (p.ldg & 3) || p.L <= 0 || p.nc <= 0 ||
         (long)p.nc * p.L > p.Tp || p.mask_delay != 0 || p.kv_len != p.nc * p.L || p.q_len != p.nc * p.L)
         return EEND_EINVAL;
 #ifndef EEND_ATTN_BWD_TWO_KERNELS
     if (eend_attn_bwd_fused_ok(p, true)) return eend_launch_attn_bwd_fused(p, true, stream);
 #endif
+    if (!p.Qt || !p.Kt || !p.dOt) return EEND_EINVAL;   // the two-kernel form reads the [d][t] copies
     // full-slab grids: the blocks beyond the nc * L valid frames only write the zero rows of dQKV
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((p.Tp + 127) / 128, p.H, p.nseq), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;

@@ -447,6 +447,8 @@ int eend_launch_ret_bwd(const AttnBwdParams& p, hipStream_t stream);
 int eend_launch_ret_bwd_states(const void* Kt, const void* Vt, const void* Qt, const void* dOt, float* kv_ws, float* g_ws, void* St,
                                int nseq, int H, int Tp, int L, int nc, hipStream_t stream);
 int eend_launch_heads_transpose(const void* in, int ld, void* out, int nseq, int H, int Tp, hipStream_t stream);
+int eend_launch_ret_bwd_states_rm(const void* K, const void* V, const void* Q, const void* dO, int ldo, float* kv_ws, float* g_ws, void* St,
+                                  int nseq, int H, int Tp, int L, int nc, hipStream_t stream);
 
 int eend_launch_ln_bwd(const float* g, const void* xhat16, const float* rstd, const float* gamma, float* ds32, void* ds16,
                        float* partial, int* nblocks_out, long M, DropSpec drop, hipStream_t stream);

@@ -54,9 +54,11 @@ class _RetSave:
     """Saved tensors of one retention module: bf16 head layouts for the backward products, gate pre-activation,
     normalised rows, per-(row, head) 1/sigma * detached scale, and the gated output (out_proj input)."""
 
-    def __init__(self, dev, nseq, Tp):
+    def __init__(self, dev, nseq, Tp, L):
         n = nseq * Tp * D
-        self.q, self.qt, self.k, self.kt, self.v, self.vt = (torch.empty(n, dtype=BF16, device=dev) for _ in range(6))
+        self.q, self.k, self.v = (torch.empty(n, dtype=BF16, device=dev) for _ in range(3))
+        # [d][t] copies: only the two-kernel backward of chunk lengths beyond 512 reads them (attn_bwd.hip, retention_bwd.hip)
+        self.qt, self.kt, self.vt = ((torch.empty(n, dtype=BF16, device=dev) for _ in range(3)) if L > 512 else (None, None, None))
         self.g = torch.empty(nseq * Tp, D, dtype=F16, device=dev)
         self.rhat = torch.zeros(nseq * Tp, D, dtype=F16, device=dev)        # rows of skipped padding chunks stay zero
         self.rc = torch.zeros(nseq * Tp, H, dtype=F32, device=dev)
@@ -79,14 +81,14 @@ class _LsBuffers:
         for _ in range(n_enc):
             self.enc.append(dict(
                 lnA=_Site(dev, Me), za=e(Me, F_enc, dt=F16), aa=e(Me, F_enc, dt=F16),
-                lnB=_Site(dev, Me), ret=_RetSave(dev, B, Tp),
+                lnB=_Site(dev, Me), ret=_RetSave(dev, B, Tp, L),
                 lnC=_Site(dev, Me), P=e(Me, 2 * D, dt=F16), c16=e(Me, D, dt=F16), s16=e(Me, D, dt=F16),
                 bn_mean=e(D, dt=F32), bn_var=e(D, dt=F32), bn_n=e(1, dt=F32),
                 lnD=_Site(dev, Me), zb=e(Me, F_enc, dt=F16), ab=e(Me, F_enc, dt=F16),
                 lnE=_Site(dev, Me)))
         self.emb32, self.emb16, self.inv_norm = e(Me, D, dt=F32), e(Me, D, dt=F16), e(Me, dt=F32)
         self.a32, self.a16 = e(Md, D, dt=F32), e(Md, D, dt=F16)
-        self.dec = [dict(ret=_RetSave(dev, B * C, Tp), s11=_Site(dev, Md), qkv=e(Md, 3 * D, dt=F16), o2=e(Md, D, dt=F16),
+        self.dec = [dict(ret=_RetSave(dev, B * C, Tp, L), s11=_Site(dev, Md), qkv=e(Md, 3 * D, dt=F16), o2=e(Md, D, dt=F16),
                          s21=_Site(dev, Md), hid=e(Md, F_dec, dt=F16), s22=_Site(dev, Md)) for _ in range(n_dec)]
         # forward transients (f16 operands of the retention forward kernels)
         self.fq, self.fk, self.fkt, self.fvt = (e(Mx * D, dt=F16) for _ in range(4))
@@ -105,7 +107,8 @@ class _LsBuffers:
         self.dh16 = e(max(Me * max(F_enc, 2 * D), Md * F_dec), dt=BF16)
         self.dqkvg = e(Mx, 4 * D, dt=BF16)
         self.dqkv16 = e(Md, 3 * D, dt=BF16)
-        self.ot, self.ott = e(Mx * D, dt=BF16), e(Mx * D, dt=BF16)
+        self.ot = e(Mx * D, dt=BF16)
+        self.ott = e(Mx * D, dt=BF16) if L > 512 else None      # head-transposed o~: the two-kernel backward only
         self.g_ws = e(nseq_max * H * nc * 4096, dt=F32)
         self.st_bwd = e(nseq_max * H * nc * 6 * 4096, dt=BF16)
         self.bn_sums = e(2 * D, dt=F32)

@@ -567,7 +567,8 @@ int eend_conv1d_l2norm_train_f16(const void* X, const void* Wr, const float* bia
 
 /* Packed MHA in-projection for training: Q, K, V in BOTH head layouts (bf16 [nseq][H][Tp][64] and
  * [nseq][H][64][Tp]) -- the forward attention reads Q, K, Vt, its backward Q, K, V and, for windows beyond 512 frames
- * (the two-kernel form), Qt, Kt.  Qt / Kt may be NULL (not written) when Tp <= 512.  K = 256. */
+ * (the two-kernel form), Qt, Kt.  Qt / Kt may be NULL (not written) when Tp <= 512; Vt may be NULL when no consumer reads it (the
+ * retention backward at chunk lengths <= 512).  K = 256. */
 int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const float* bias, void* Q, void* Qt,
                                  void* K, void* Kt, void* V, void* Vt, int nseq, int Tp, int H, void* stream);
 
@@ -779,7 +780,8 @@ int eend_retention_chunk_train_f16(const void* Q, const void* K, const void* Kt,
  * intra-chunk on bf16 MFMA tiles, across chunks through 64x64 prefix / suffix states.  Q..Vt: bf16 head layouts of
  * eend_inproj_heads_train_bf16 (k rows pre-scaled by dk^-1/2); dqkvg bf16 [nseq*Tp][ldq]: dq | sk*dk | dv | dg at
  * columns 0 / 256 / 512 / 768.  ot_ws, ott_ws: bf16 scratch [nseq*Tp*256]; kv_ws, g_ws: f32 [nseq*H*nc*4096];
- * St_ws: bf16 [nseq*H*nc*6*4096]. */
+ * St_ws: bf16 [nseq*H*nc*6*4096].  Chunk lengths L <= 512 read only the row-major head layouts (Q, K, V; the transposed
+ * fragments come out of the LDS reads): Qt, Kt, Vt and ott_ws may then be NULL, and eend_inproj_heads_train_bf16 need not write them. */
 int eend_retention_bwd_bf16(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* Vt,
                             const float* dctx_f32, const void* g_f16, int ldg, const void* rhat_f16, const float* rc,
                             void* ot_ws, void* ott_ws, float* kv_ws, float* g_ws, void* St_ws, void* dqkvg_bf16, int ldq,

@@ -236,6 +236,11 @@ def test_retention_core_backward_kernels(hip_lib, dev, nseq, Tv, L):
     _call("eend_retention_bwd_bf16", q, qt, k, kt, v, vt, dctx, gate, D, rhat, rc, ot, ott, kv_ws, g_ws, st, dq, 4 * D, nseq, H, Tp, L, Tv, 0.125)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(dq.float()).all())
+    # chunk lengths up to 512 (round 6): the [d][t] copies and the transposed o~ scratch are not read -- NULL is accepted, same bits
+    dq2 = torch.full((M, 4 * D), float("nan"), dtype=torch.bfloat16, device=dev)
+    _call("eend_retention_bwd_bf16", q, None, k, None, v, None, dctx, gate, D, rhat, rc, ot, None, kv_ws, g_ws, st, dq2, 4 * D, nseq, H, Tp, L, Tv, 0.125)
+    torch.cuda.synchronize()
+    assert torch.equal(dq2, dq)
     # expected o~ (fp64 from the same inputs): d_rhat = dctx * swish(g); d_r = rc * (d_rhat - mean_head(d_rhat))  [rhat = 0]
     gg = gate.double()
     drh = dctx.double() * gg * torch.sigmoid(gg)
