@@ -53,6 +53,9 @@ def flops_per_launch(name, shape, T):
         return 2.0 * shape[0] * 768 * 256
     if name == "attnout_spk_stream":   # out-projection + speaker-axis in-projection GEMMs (LayerNorm and attention are VALU work)
         return 2.0 * shape[0] * (256 + 768) * 256
+    if name == "attnout_ffn_stream_lo":    # the same with the out-projection's remainder product (the LS-EEND decoder layer tail)
+        M, F, K = shape
+        return 4.0 * M * F * K + 4.0 * M * K * K
     if name in ("attnout_ffn_fused", "attnout_ffn_stream"):    # out-projection (K x K) + the two FFN GEMMs
         M, F, K = shape
         return 4.0 * M * F * K + 2.0 * M * K * K
@@ -102,6 +105,19 @@ def pmc_traffic(kernel, shape):
         if any(t in k for t in tag[0]) and k.endswith("grid=" + tag[1]):
             return v["hbm_bytes"]
     return None
+
+
+def train_pmc_traffic(call, shape, flavour):
+    """HBM bytes per launch of a training-step call from the committed PMC passes of one step (profiles/rNN_train_{fs,ls}_pmc_traffic.json,
+    tools/gpu_r06_pmc_train.sh; the default workloads only) -> (bytes or None, file, sha256[:16])."""
+    path, sha = pmc_traffic_file(f"train_{flavour}_pmc_traffic")
+    tags = {"eend_ffn_train_stream_f16": "ffn_train_stream_kernel<1, true, 3>", "eend_ffn_bwd_data_stream_bf16": "ffn_train_stream_kernel<2, false, 3>",
+            "eend_attn_causal_bwd_bf16": "attn_bwd_fused_kernel<false, true>", "eend_retention_bwd_bf16": "attn_bwd_fused_kernel<true, false>"}
+    big = {"fs": 196608, "ls": 393216}[flavour]
+    if call not in tags or not path or not shape or (call.startswith("eend_ffn") and shape[0] != big):
+        return None, path, sha
+    cand = [v["hbm_bytes"] for k, v in json.load(open(path))["kernels"].items() if tags[call] in k]
+    return (max(cand) if cand else None), path, sha
 
 
 def ls_retention_traffic(nseq, H, Tv, L, fused=False):
@@ -155,6 +171,8 @@ class OpTimer:
                 shape = (a[0].shape[0], a[7].shape[0], a[0].shape[1])
             elif name == "attnout_ffn_stream":          # (a16, wstream, bo, res, res16, g1, be1, eps1, b1, ...)
                 shape = (a[0].shape[0], a[8].shape[0], a[0].shape[1])
+            elif name == "attnout_ffn_stream_lo":       # (a16, wstream, bo, res, g1, be1, eps1, b1, ...)
+                shape = (a[0].shape[0], a[7].shape[0], a[0].shape[1])
             elif name == "ffn_stream":                  # (x16, wstream, b1, ...)
                 shape = (a[0].shape[0], a[2].shape[0], a[0].shape[1])
             elif name == "inproj_heads":
@@ -176,7 +194,7 @@ class OpTimer:
         return w
 
     def __enter__(self):
-        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm", "conv1d_l2norm_stream",
+        for n in ("bn_cast_pad", "gather_bn_cast_pad", "encoder_input", "ffn_fused", "attnout_ffn_fused", "attnout_ffn_stream", "attnout_ffn_stream_lo", "attnout_spk_stream", "ffn_stream", "convert_fanout_f32", "linear", "inproj_heads", "linear_res_ln", "linear_res_scale", "conv1d_l2norm", "conv1d_l2norm_stream",
                   "convert_fanout", "attn_causal", "inproj_attn_causal_packed", "spk_attn", "head_l2dot", "retention_proj", "retention_chunk", "retention_stream", "linear_res_scale_ln16", "linear_glu",
                   "dwconv_bn_swish", "layernorm_f16"):
             if not hasattr(self.ops, n):
@@ -817,6 +835,10 @@ class TrainCallTimer:
                 shape = (int(a[16]), int(a[17]), 256)
             elif name == "eend_ffn_bwd_data_bf16":
                 shape = (int(a[8]), int(a[9]), 256)
+            elif name == "eend_ffn_train_stream_f16":         # the same two operators on the packed weight stream (round 6)
+                shape = (int(a[15]), int(a[16]), 256)
+            elif name == "eend_ffn_bwd_data_stream_bf16":
+                shape = (int(a[7]), int(a[8]), 256)
             else:
                 shape = ()
             self.rec.append((name, shape, s, e))
@@ -836,7 +858,7 @@ class TrainCallTimer:
                     "eend_linear_res_scale_ln_train_f16", "ops.linear", "ops.retention_proj", "ops.convert_fanout"):
             M, N, K = shape
             return 2.0 * M * N * K
-        if name in ("eend_ffn_train_f16", "eend_ffn_bwd_data_bf16"):           # two products of M x F x 256
+        if name in ("eend_ffn_train_f16", "eend_ffn_bwd_data_bf16", "eend_ffn_train_stream_f16", "eend_ffn_bwd_data_stream_bf16"):   # two products of M x F x 256
             M, F_, K = shape
             return 4.0 * M * F_ * K
         if name in ("eend_retention_bwd_bf16", "eend_retention_chunk_train_f16"):
@@ -1025,9 +1047,11 @@ def main():
             out["kernel_ms_per_step"] = tot
             top = next((c for c in calls if c["tflops"]), None)
             if top is not None:
+                tr_bytes, tr_file, tr_sha = train_pmc_traffic(top["call"], top["shape"], args.flavour)
                 out["roofline"] = {"kernel": f"{top['call']} {top['shape']}", "bound": "mfma", "achieved": top["tflops"],
                                    "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_MFMA_TFLOPS,
-                                   "traffic": None, "avg_launch_ms": top["avg_ms"],
+                                   "traffic": tr_bytes, "traffic_file": os.path.relpath(tr_file, ROOT) if tr_file else None,
+                                   "traffic_file_sha256_16": tr_sha, "avg_launch_ms": top["avg_ms"],
                                    "note": "largest time share among the step's MFMA calls; algorithmic flops 2*M*N*K (GEMM family) "
                                            "or 5*D*T*(T+1) per sequence (attention backward); in-situ HIP events on the launch stream"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
