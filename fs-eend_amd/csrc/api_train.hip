@@ -234,6 +234,20 @@ int eend_gemm_acc_bf16(const void* A, int lda, const void* W, int ldw, const flo
     return eend_launch_gemm(p, EPI_RES_SCALE, (hipStream_t)stream);
 }
 
+int eend_gemm_acc_lnbwd_bf16(const void* A, int lda, const void* W, int ldw, const float* g_f32, const void* xhat_f16, const float* rstd,
+                             const float* gamma, float* ds_f32, void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta,
+                             float* dbias, int M, int K, const eend_dropout* drop, void* stream) {
+    if (!A || !W || !g_f32 || !xhat_f16 || !rstd || !gamma || !ds_f32 || !ds_bf16 || !ws || !dgamma || !dbeta || M <= 0) return EEND_EINVAL;
+    const long nb = ((long)M + 63) / 64;
+    if (ws_floats < nb * 768) return EEND_EINVAL;
+    GemmParams p = gemm_base(A, lda, W, ldw, nullptr, M, 256, K);
+    p.bf16 = 1; p.res = g_f32; p.alpha = 1.0f; p.out32 = ds_f32; p.out16 = ds_bf16; p.ldo = 256;
+    p.xhat16 = (void*)xhat_f16; p.rstat = (float*)rstd; p.gamma = gamma; p.colpart = ws; p.drop = drop_spec(drop);
+    int rc = eend_launch_gemm(p, EPI_RES_LNBWD, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    return eend_launch_wgrad_reduce_multi(ws, 768, (int)nb, 256, dgamma, dbeta, dbias, (hipStream_t)stream);
+}
+
 int eend_conv1d_dgrad_bf16(const void* dY, const void* Wd, const int* src_lens, const int* mask_lens, float* out_f32,
                            int nseq, int Tp, int cout, int ktaps, int pad, void* stream) {
     if (!dY || !Wd || !src_lens || !mask_lens || !out_f32) return EEND_EINVAL;

@@ -67,7 +67,7 @@ template <> struct Mfma16<__bf16> {
 };
 
 template <class ET, int BM, int BN, int WGM, int WGN, bool SWAP, int ALOAD, int EPI, int PF>
-__global__ __launch_bounds__(WGM * WGN * 64)
+__global__ __launch_bounds__(WGM * WGN * 64, (EPI == EPI_RES_LNBWD ? 2 : 1))     // (the LayerNorm-backward epilogue must not cost the second workgroup per CU)
 void gemm_f16_kernel(const GemmParams p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -348,7 +348,7 @@ void gemm_f16_kernel(const GemmParams p) {
             }
         }
     } else if constexpr (EPI == EPI_RES_LN || EPI == EPI_L2NORM || EPI == EPI_RES_SCALE || EPI == EPI_RES_SCALE_LN16 ||
-                         EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN || EPI == EPI_RES_SCALE_LN16_TRAIN) {
+                         EPI == EPI_RES_LN_TRAIN || EPI == EPI_L2NORM_TRAIN || EPI == EPI_RES_SCALE_LN16_TRAIN || EPI == EPI_RES_LNBWD) {
         // The block owns complete rows (BN == N, WGM == 1): per-token statistics.
         static_assert(SWAP && WGM == 1, "row-stat epilogues expect SWAP and one wave row");
         constexpr bool LNK = (EPI == EPI_RES_LN || EPI == EPI_RES_LN_TRAIN || EPI == EPI_RES_SCALE_LN16 ||
@@ -393,30 +393,107 @@ void gemm_f16_kernel(const GemmParams p) {
             }
         }
         float mean[FL], scale[FL];
-        if constexpr (EPI == EPI_RES_SCALE) {
+        auto block_rowsum = [&](float (&part)[FL]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                part[j] = wave_xor_add(part[j], 16);
+                part[j] = wave_xor_add(part[j], 32);
+            }
+            __syncthreads();
+            if (fkg == 0) {
+#pragma unroll
+                for (int j = 0; j < FL; ++j) red[wn * BM + j * 16 + frow] = part[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGN; ++w) s += red[w * BM + j * 16 + frow];
+                part[j] = s;
+            }
+        };
+        // EPI_RES_LNBWD: the LayerNorm backward of the post-norm site in front of the branch, in the epilogue (train_rows.hip ln_bwd_kernel,
+        // same algebra).  acc = g, the gradient w.r.t. the LayerNorm output (the data-gradient GEMM's result + the incoming stream):
+        //   dz = rstd * (g gamma - mean(g gamma) - x_hat mean(g gamma x_hat))  -> out32 (the residual stream's gradient, unmasked)
+        //   out16 = bf16 of dz under the sub-layer output's dropout mask (the branch gradient)
+        //   colpart[m-tile][3][256] = sums over the tile's rows of g x_hat | g | the masked dz (d gamma, d beta, d bias partials; this wave's
+        //   64 columns, the 16 row lanes by DPP), summed over the tiles in fixed order by wgrad_reduce_multi_kernel
+        // (x_hat is read twice -- the second time from L1 / L2 -- and the column sums leave per feature fragment: the version that kept them
+        // in registers needed 344 and lost the second workgroup per CU)
+        constexpr bool LNB = EPI == EPI_RES_LNBWD;
+        float* __restrict__ cp = LNB ? p.colpart + (size_t)(m0 / BM) * 3 * 256 : nullptr;
+        if constexpr (LNB) {
+            const float invN = 1.0f / (float)p.N;
+            float p1[FL], p2[FL];
+#pragma unroll
+            for (int j = 0; j < FL; ++j) { p1[j] = 0.f; p2[j] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                const float4 gam = *(const float4*)(p.gamma + R0 + i * 16);
+                const float gk[4] = {gam.x, gam.y, gam.z, gam.w};
+                float cgx[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < FL; ++j) {
+                    const int m = L0 + j * 16;
+                    const bool ok = m < p.M;
+                    f16x4 h = f16x4{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+                    if (ok) h = *(const f16x4*)((const _Float16*)p.xhat16 + (size_t)m * p.ldo + R0 + i * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g_ = ok ? acc[i][j][r] : 0.f, x_ = (float)h[r], d_ = g_ * gk[r];
+                        acc[i][j][r] = d_;                     // g gamma
+                        p1[j] += d_; p2[j] += d_ * x_;
+                        cg[r] += g_; cgx[r] += g_ * x_;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = row16_allreduce_add(cgx[r]), b = row16_allreduce_add(cg[r]);
+                    if (frow == 0) { cp[R0 + i * 16 + r - n0] = a; cp[256 + R0 + i * 16 + r - n0] = b; }
+                }
+            }
+            // both row sums in ONE exchange (red: [2][WGN][BM] floats = the 2 KB in front of the staging tile); the rows' 1/sigma travel under it
+            float rsv[FL];
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int m = L0 + j * 16;
+                rsv[j] = m < p.M ? p.rstat[m] : 0.f;
+                p1[j] = wave_xor_add(p1[j], 16); p1[j] = wave_xor_add(p1[j], 32);
+                p2[j] = wave_xor_add(p2[j], 16); p2[j] = wave_xor_add(p2[j], 32);
+            }
+            __syncthreads();
+            if (fkg == 0) {
+#pragma unroll
+                for (int j = 0; j < FL; ++j) { red[wn * BM + j * 16 + frow] = p1[j]; red[(WGN + wn) * BM + j * 16 + frow] = p2[j]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGN; ++w) { s1 += red[w * BM + j * 16 + frow]; s2 += red[(WGN + w) * BM + j * 16 + frow]; }
+                p1[j] = s1; p2[j] = s2;
+            }
+#pragma unroll
+            for (int j = 0; j < FL; ++j) {
+                const int m = L0 + j * 16;
+                const bool ok = m < p.M;
+                const float rs = rsv[j];
+                const float c1 = p1[j] * invN, c2 = p2[j] * invN;
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    f16x4 h = f16x4{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+                    if (ok) h = *(const f16x4*)((const _Float16*)p.xhat16 + (size_t)m * p.ldo + R0 + i * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = rs * (acc[i][j][r] - c1 - (float)h[r] * c2);
+                }
+                mean[j] = 0.f; scale[j] = 1.f;
+            }
+        } else if constexpr (EPI == EPI_RES_SCALE) {
 #pragma unroll
             for (int j = 0; j < FL; ++j) { mean[j] = 0.f; scale[j] = 1.f; }
         } else {
-            auto block_rowsum = [&](float (&part)[FL]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = 0; j < FL; ++j) {
-                    part[j] = wave_xor_add(part[j], 16);
-                    part[j] = wave_xor_add(part[j], 32);
-                }
-                __syncthreads();
-                if (fkg == 0) {
-#pragma unroll
-                    for (int j = 0; j < FL; ++j) red[wn * BM + j * 16 + frow] = part[j];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < FL; ++j) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WGN; ++w) s += red[w * BM + j * 16 + frow];
-                    part[j] = s;
-                }
-            };
             const float invN = 1.0f / (float)p.N;
             float part[FL];
             if constexpr (LNK) {
@@ -463,8 +540,8 @@ void gemm_f16_kernel(const GemmParams p) {
             // instruction -- PMC WRITE_SIZE showed 1.5x the algorithmic bytes for this kernel.  Through LDS every
             // store instruction writes one whole 1 KB row (fp32) or two 512 B rows (f16).
             char* stg = smem + 2048;                          // clear of the row-statistics scratch
-            if constexpr (EPI == EPI_RES_SCALE) __syncthreads();   // (no statistics pass: nothing has fenced the main loop's LDS reads yet)
-            O16 h16[FR][FL];
+            if constexpr (EPI == EPI_RES_SCALE || LNB) __syncthreads();   // (no statistics pass / its scratch was just read: fence before the staging writes)
+            O16 h16[LNB ? 1 : FR][LNB ? 1 : FL];
             O16 xh16[TRAINK && LNK ? FR : 1][TRAINK && LNK ? FL : 1];
 #pragma unroll
             for (int i = 0; i < FR; ++i) {
@@ -479,7 +556,7 @@ void gemm_f16_kernel(const GemmParams p) {
                     v[1] = (acc[i][j][1] - mean[j]) * scale[j] * g.y + be.y;
                     v[2] = (acc[i][j][2] - mean[j]) * scale[j] * g.z + be.z;
                     v[3] = (acc[i][j][3] - mean[j]) * scale[j] * g.w + be.w;
-                    h16[i][j] = OutCvt<ET>::cvt(v[0], v[1], v[2], v[3]);
+                    if constexpr (!LNB) h16[i][j] = OutCvt<ET>::cvt(v[0], v[1], v[2], v[3]);      // (LNB: made in the 2-byte staging pass below)
                     if constexpr (TRAINK && LNK)            // normalised, pre-affine row: what LayerNorm backward needs
                         xh16[i][j] = OutCvt<ET>::cvt((acc[i][j][0] - mean[j]) * scale[j], (acc[i][j][1] - mean[j]) * scale[j],
                                                      (acc[i][j][2] - mean[j]) * scale[j], (acc[i][j][3] - mean[j]) * scale[j]);
@@ -500,10 +577,28 @@ void gemm_f16_kernel(const GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < FR; ++i) {
                     const int nl = R0 + i * 16 - n0;
+                    float cds[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < FL; ++j) {
                         const int row = j * 16 + frow;
-                        *(O16*)(stg + row * 512 + (((nl >> 3) ^ ((row >> 1) & 7)) << 4) + ((nl >> 2) & 1) * 8) = h16[i][j];
+                        O16 hv;
+                        if constexpr (LNB) {                 // the branch gradient carries the forward's (row, column) dropout mask
+                            const unsigned mm = (unsigned)(L0 + j * 16), nn = (unsigned)(R0 + i * 16);
+                            const float k0 = drop_apply(p.drop, acc[i][j][0], mm, nn), k1 = drop_apply(p.drop, acc[i][j][1], mm, nn + 1);
+                            const float k2 = drop_apply(p.drop, acc[i][j][2], mm, nn + 2), k3 = drop_apply(p.drop, acc[i][j][3], mm, nn + 3);
+                            hv = OutCvt<ET>::cvt(k0, k1, k2, k3);
+                            if (L0 + j * 16 < p.M) { cds[0] += k0; cds[1] += k1; cds[2] += k2; cds[3] += k3; }
+                        } else {
+                            hv = h16[i][j];
+                        }
+                        *(O16*)(stg + row * 512 + (((nl >> 3) ^ ((row >> 1) & 7)) << 4) + ((nl >> 2) & 1) * 8) = hv;
+                    }
+                    if constexpr (LNB) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float c = row16_allreduce_add(cds[r]);
+                            if (frow == 0) cp[512 + nl + r] = c;
+                        }
                     }
                 }
                 __syncthreads();
@@ -643,6 +738,9 @@ int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
             case EPI_RES_SCALE:
                 if (p.N != 256) return EEND_EINVAL;
                 return launch<B, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_SCALE>(p, stream);
+            case EPI_RES_LNBWD:
+                if (p.N != 256 || p.ldo != 256 || !p.res || !p.out32 || !p.out16 || !p.xhat16 || !p.rstat || !p.gamma || !p.colpart) return EEND_EINVAL;
+                return launch<B, 64, 256, 1, 4, true, ALOAD_PLAIN, EPI_RES_LNBWD>(p, stream);
             case EPI_F32_ROWMASK:
                 if (p.N != 256 || !p.ilens || !p.mask_lens || !p.out32) return EEND_EINVAL;
                 return launch<B, 64, 256, 1, 4, true, ALOAD_CONV, EPI_F32_ROWMASK>(p, stream);

@@ -29,6 +29,8 @@ enum GemmEpilogue {
     EPI_L2NORM_TRAIN = 17,   // EPI_L2NORM that also saves 1/||x|| (rstat)
     EPI_RES_SCALE_LN16_TRAIN = 18,  // EPI_RES_SCALE_LN16 (pre-norm residual blocks, LS-EEND Conformer) with dropout of
                                     // (acc + bias) and x_hat / 1/sigma of the LayerNorm saved
+    EPI_RES_LNBWD = 19,      // bf16 data-gradient GEMM into the f32 gradient stream (EPI_RES_SCALE) FOLLOWED by the LayerNorm backward of the
+                             // post-norm site in front of the branch: out32 = dz, out16 = bf16 masked branch gradient, colpart = d gamma | d beta | d bias partials
 };
 
 struct GemmParams {
@@ -60,6 +62,7 @@ struct GemmParams {
     const void* mask;   // EPI_MASK_BF16: saved forward activation, 2-byte floats [M][ldmask]
     int ldmask;
     const int* mask_lens; // EPI_F32_ROWMASK: frames per sequence that receive a gradient
+    float* colpart;     // EPI_RES_LNBWD: f32 [ceil(M/64)][3][256] column partials (x_hat, rstat, gamma, drop are inputs there)
     void* xhat16;       // EPI_RES_LN_TRAIN: normalised rows before the affine, [M][ldo]
     float* rstat;       // EPI_*_TRAIN: 1/sigma or 1/||x|| per row, [M]
     DropSpec drop;      // EPI_RES_LN_TRAIN: dropout of (acc + bias) before the residual add; EPI_PLAIN_RELU_F16: of the

@@ -363,6 +363,13 @@ class TrainStepBase:
         _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
               self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, drop)
 
+    def _gemm_acc_ln_bwd(self, a16, K, wT, g32, site, ln, ds16, M, drop=None, bias=None):
+        """g32 += a16 wT^T (the data gradient of a K -> 256 linear joining the residual-gradient stream), then the LayerNorm backward of the
+        post-norm site `site` that stream now stands in front of -- one launch (gemm.hip EPI_RES_LNBWD): `_ln_bwd`'s outputs, the f32 stream
+        read and written once instead of twice."""
+        _call("eend_gemm_acc_lnbwd_bf16", a16, K, wT, K, g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
+              self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, K, drop)
+
     def _ffn_bwd(self, g32, ds16, dh16, hid, x_in16, M, wkey, p_, norm, drop_scale=1.0):
         """backward of x -> LN(x + W2 relu(W1 x + b1) + b2); g32 in/out (gradient w.r.t. output -> w.r.t. x)."""
         W = self.W
@@ -675,7 +682,7 @@ class FsTrainStep(TrainStepBase):
 
     # ------------------------------------------------------------------ backward
     def _attn_bwd(self, g32, ds16, dctx16, dqkv16, sv: _AttnSave, x_in16, nseq, Tp, M, w_outT, w_inT, p_out, p_in, bf, delay,
-                  kv_len, T, drop=None):
+                  kv_len, T, drop=None, next_ln=None):
         """backward of x -> x + out_proj(causal_mha(in_proj x)) given ds16 = gradient w.r.t. that sum (bf16) and
         g32 = the same in f32 (residual path); g32 += gradient through the attention branch."""
         self._wgrad(ds16, sv.ctx, M, D, D, p_out + ".weight")
@@ -683,7 +690,11 @@ class FsTrainStep(TrainStepBase):
         _call("eend_attn_causal_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, dctx16, D, sv.ctx, D, sv.lse, bf.dot_ws, bf.dh_ws, dqkv16,
               3 * D, nseq, H, Tp, delay, kv_len, T, 1.0, 0.125, ops.LN2, drop)
         self._wgrad_bias(dqkv16, x_in16, M, 3 * D, D, p_in + "_weight", p_in + "_bias")
-        _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
+        if next_ln is not None:           # (site, LayerNorm name, dropout spec, bias name) of the LayerNorm whose output this block's input is
+            site, ln, ndrop, nbias = next_ln
+            self._gemm_acc_ln_bwd(dqkv16, 3 * D, w_inT, g32, site, ln, ds16, M, ndrop, nbias)
+        else:
+            _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
 
     def backward(self, bf: _Buffers, dlogits: Optional[Tensor] = None, emb_loss_grad: float = 1.0):
         """Gradients w.r.t. every parameter -> self.flat.grads.  After forward(fused_loss=True): of bce + emb_loss.
@@ -715,7 +726,8 @@ class FsTrainStep(TrainStepBase):
             x_in16 = bf.dec[i - 1]["s22"].out16 if i > 0 else bf.a16
             dsd = ds16[:Md]
             so = 4096 + 16 * i
-            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + self.SITE_FFOUT), p_ + "linear2.bias")
+            if i == len(bf.dec) - 1:      # (the other layers' norm22 backward ran in the epilogue of the layer above's last data-gradient GEMM)
+                self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + self.SITE_FFOUT), p_ + "linear2.bias")
             self._ffn_bwd(g32, dsd, bf.dh16, sv["hid"], sv["s21"].out16, Md, f"d{i}", p_, "norm22", ff_scale)
             # speaker-axis attention block (merge_tfm_encoder.py:373, :388-394)
             self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md, dr(so + self.SITE_OUT2), p_ + "self_attn2.out_proj.bias")
@@ -723,12 +735,17 @@ class FsTrainStep(TrainStepBase):
             _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
             _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125, dr(so + self.SITE_SPK))
             self._wgrad_bias(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight", p_ + "self_attn2.in_proj_bias")
-            _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
+            # ... its in-projection's data gradient joins the stream, and norm11's backward runs in the same launch
             # time-axis attention block (:364, :379-385)
-            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + self.SITE_OUT1), p_ + "self_attn1.out_proj.bias")
+            self._gemm_acc_ln_bwd(dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + self.SITE_OUT1),
+                                  p_ + "self_attn1.out_proj.bias")
+            below = None
+            if i > 0:                     # the layer below ends in norm22: its backward rides on this block's last GEMM
+                pb = f"dec.attractor_decoder.layers.{i - 1}."
+                below = (bf.dec[i - 1]["s22"], pb + "norm22", dr(so - 16 + self.SITE_FFOUT), pb + "linear2.bias")
             self._attn_bwd(g32, dsd, dctx16[:Md], dqkv16[:Md], sv["att"], x_in16, B * C, Tp, Md, W[f"d{i}.out1_wT"],
                            W[f"d{i}.in1_wT"], p_ + "self_attn1.out_proj", p_ + "self_attn1.in_proj", bf, dm, T, T,
-                           dr(so + self.SITE_ATT))
+                           dr(so + self.SITE_ATT), next_ln=below)
 
         # ---- convert fan-out (model :113-114, factored): g32 = gradient w.r.t. attr0
         _call("eend_convert_fanout_bwd_f32", g32, bf.gsum16, self.ws, WS_FLOATS, bf.dpc, B, Tp, C)
@@ -751,14 +768,21 @@ class FsTrainStep(TrainStepBase):
             p_ = f"enc.transformer_encoder.layers.{i}."
             x_in16 = bf.enc[i - 1]["s2"].out16 if i > 0 else bf.site0.out16
             so = 16 * i
-            self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me, dr(so + self.SITE_FFOUT), p_ + "linear2.bias")
+            if i == len(bf.enc) - 1:      # (the other layers' norm2 backward ran in the epilogue of the layer above's last data-gradient GEMM)
+                self._ln_bwd(g32, sv["s2"], p_ + "norm2", dse, Me, dr(so + self.SITE_FFOUT), p_ + "linear2.bias")
             self._ffn_bwd(g32, dse, bf.dh16, sv["hid"], sv["s1"].out16, Me, f"e{i}", p_, "norm2", ff_scale)
             self._ln_bwd(g32, sv["s1"], p_ + "norm1", dse, Me, dr(so + self.SITE_OUT1), p_ + "self_attn.out_proj.bias")
+            if i > 0:
+                pb = f"enc.transformer_encoder.layers.{i - 1}."
+                below = (bf.enc[i - 1]["s2"], pb + "norm2", dr(so - 16 + self.SITE_FFOUT), pb + "linear2.bias")
+            else:                         # the encoder's input LayerNorm (model :166)
+                below = (bf.site0, "enc.encoder_norm", None, "enc.encoder.bias")
             self._attn_bwd(g32, dse, dctx16[:Me], dqkv16[:Me], sv["att"], x_in16, B, Tp, Me, W[f"e{i}.out_wT"], W[f"e{i}.in_wT"],
-                           p_ + "self_attn.out_proj", p_ + "self_attn.in_proj", bf, bf.delay_e, bf.kv_e, T, dr(so + self.SITE_ATT))
+                           p_ + "self_attn.out_proj", p_ + "self_attn.in_proj", bf, bf.delay_e, bf.kv_e, T, dr(so + self.SITE_ATT), next_ln=below)
 
         # ---- input projection + LayerNorm + BatchNorm (model :166,:173-174)
-        self._ln_bwd(g32, bf.site0, "enc.encoder_norm", dse, Me, None, "enc.encoder.bias")
+        if len(bf.enc) == 0:
+            self._ln_bwd(g32, bf.site0, "enc.encoder_norm", dse, Me, None, "enc.encoder.bias")
         _call("eend_wgrad_bf16", dse, D, bf.xin16, self.Fin_pad, 1, Me, D, self.Fin_pad, self.ws, WS_FLOATS, self._G("enc.encoder.weight"),
               self.Fin, self.Fin, 1.0, 0)
         _call("eend_gemm_bf16", dse, D, W["enc.in.wT"], D, None, bf.dy_in, self.Fin_pad, Me, self.Fin_pad, D)

@@ -397,7 +397,7 @@ class LsTrainStep(TrainStepBase):
     def _resgrad(self, g32, ds16, alpha, bias, M, drop):
         _call("eend_resgrad_cast_bf16", g32, ds16, alpha, self.ws, WS_FLOATS, self._G(bias), M, drop)
 
-    def _ret_bwd(self, bf, g32, ds16, sv: _RetSave, x_in16, nseq, M, wkey, pfx, prenorm_site=None, prenorm_ln=None):
+    def _ret_bwd(self, bf, g32, ds16, sv: _RetSave, x_in16, nseq, M, wkey, pfx, prenorm_site=None, prenorm_ln=None, next_ln=None):
         """backward of x -> x + out_proj(retention(x')) given ds16 = gradient w.r.t. the branch output (bf16); x' = x
         (decoder, post-norm: the input gradient joins g32 directly) or x' = LN(x) (encoder: through the LayerNorm)."""
         W = self.W
@@ -413,7 +413,10 @@ class LsTrainStep(TrainStepBase):
             blk = dq[:, j * D:(j + 1) * D]
             _call("eend_wgrad_bias_bf16", blk, 4 * D, x_in16, x_in16.stride(0), 1, M, D, D, self.ws, WS_FLOATS,
                   self._G(pfx + nm + ".weight"), D, D, self._G(pfx + nm + ".bias"), 1.0, 0)
-        if prenorm_site is None:
+        if prenorm_site is None and next_ln is not None:
+            site, ln, ndrop, nbias = next_ln
+            self._gemm_acc_ln_bwd(dq, 4 * D, W[wkey + ".wqkvgT"], g32, site, ln, ds16, M, ndrop, nbias)
+        elif prenorm_site is None:
             _call("eend_gemm_acc_bf16", dq, 4 * D, W[wkey + ".wqkvgT"], 4 * D, g32, 1.0, g32, None, M, 4 * D)
         else:
             dy = bf.dy16[:M]
@@ -462,16 +465,22 @@ class LsTrainStep(TrainStepBase):
             x_in16 = bf.dec[i - 1]["s22"].out16 if i > 0 else bf.a16
             dsd = ds16[:Md]
             so = 4096 + 16 * i
-            self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + SITE_FFOUT), p_ + "linear2.bias")
+            if i == len(bf.dec) - 1:      # (the other layers' norm22 backward ran in the epilogue of the layer above's last data-gradient GEMM)
+                self._ln_bwd(g32, sv["s22"], p_ + "norm22", dsd, Md, dr(so + SITE_FFOUT), p_ + "linear2.bias")
             self._ffn_bwd(g32, dsd, bf.dh16, sv["hid"], sv["s21"].out16, Md, f"d{i}", p_, "norm22", ff_scale)
             self._ln_bwd(g32, sv["s21"], p_ + "norm21", dsd, Md, dr(so + SITE_OUT2), p_ + "self_attn2.out_proj.bias")
             self._wgrad(dsd, sv["o2"], Md, D, D, p_ + "self_attn2.out_proj.weight")
             _call("eend_gemm_bf16", dsd, D, W[f"d{i}.out2_wT"], D, None, dctx16[:Md], D, Md, D, D)
             _call("eend_spk_attn_bwd_bf16", sv["qkv"], dctx16[:Md], dqkv16[:Md], B, C, Tp, H, 0.125, dr(so + SITE_SPK))
             self._wgrad_bias(dqkv16[:Md], sv["s11"].out16, Md, 3 * D, D, p_ + "self_attn2.in_proj_weight", p_ + "self_attn2.in_proj_bias")
-            _call("eend_gemm_acc_bf16", dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], 3 * D, g32, 1.0, g32, None, Md, 3 * D)
-            self._ln_bwd(g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + SITE_OUT1), p_ + "self_attn1.out_proj.bias")
-            self._ret_bwd(bf, g32, dsd, sv["ret"], x_in16, B * C, Md, f"d{i}", p_ + "self_attn1.")
+            # the in-projection's data gradient joins the stream; norm11's backward in the same launch (train.TrainStepBase._gemm_acc_ln_bwd)
+            self._gemm_acc_ln_bwd(dqkv16[:Md], 3 * D, W[f"d{i}.in2_wT"], g32, sv["s11"], p_ + "norm11", dsd, Md, dr(so + SITE_OUT1),
+                                  p_ + "self_attn1.out_proj.bias")
+            below = None
+            if i > 0:                     # the layer below ends in norm22: its backward rides on this block's last GEMM
+                pb = f"dec.layers.{i - 1}."
+                below = (bf.dec[i - 1]["s22"], pb + "norm22", dr(so - 16 + SITE_FFOUT), pb + "linear2.bias")
+            self._ret_bwd(bf, g32, dsd, sv["ret"], x_in16, B * C, Md, f"d{i}", p_ + "self_attn1.", next_ln=below)
 
         # ---- convert fan-out (LS model :216-217, factored): g32 = gradient w.r.t. attr0
         _call("eend_convert_fanout_bwd_f32", g32, bf.gsum16, self.ws, WS_FLOATS, bf.dpc, B, Tp, C)

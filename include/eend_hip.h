@@ -602,6 +602,16 @@ int eend_gemm_relu_bwd_bf16(const void* A, int lda, const void* W, int ldw, cons
 int eend_gemm_acc_bf16(const void* A, int lda, const void* W, int ldw, const float* res_f32, float alpha,
                        float* out_f32, void* out_bf16, int M, int K, void* stream);
 
+/* eend_gemm_acc_bf16 FOLLOWED by eend_layernorm_bwd_f32 of the post-norm site in front of the branch, in one launch (round 6): the
+ * f32 gradient stream is read once and written once instead of twice each.
+ *   g   = A W^T + g_f32                  (the data gradient of a K -> 256 linear joining the gradient w.r.t. a LayerNorm OUTPUT)
+ *   dz  = rstd * (g gamma - mean(g gamma) - x_hat mean(g gamma x_hat))  -> ds_f32 (may alias g_f32), ds_bf16 = bf16 of dz under `drop`
+ *   dgamma = sum_rows g x_hat, dbeta = sum_rows g, dbias (optional) = sum_rows of the masked dz      (overwritten, fixed summation order)
+ * A bf16 [M][lda], W bf16 [256][ldw] (the transposed copy), x_hat f16 [M][256], ws >= ceil(M/64) * 768 floats. */
+int eend_gemm_acc_lnbwd_bf16(const void* A, int lda, const void* W, int ldw, const float* g_f32, const void* xhat_f16, const float* rstd,
+                             const float* gamma, float* ds_f32, void* ds_bf16, float* ws, long ws_floats, float* dgamma, float* dbeta,
+                             float* dbias, int M, int K, const eend_dropout* drop, void* stream);
+
 /* Conv1d(256,256,k) data gradient as an implicit GEMM over (tap, c_out) (autograd of FS model :40): dY bf16 slab,
  * Wd bf16 [c_in][k*c_out] with Wd[ci][tap'*c_out + co] = W[co][ci][k-1-tap']; frames >= src_lens[seq] of dY count as
  * zero; out_f32 rows t >= mask_lens[seq] are written as zero (the input was truncated to ilen, FS model :38-39). */

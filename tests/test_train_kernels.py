@@ -318,6 +318,57 @@ def test_layernorm_bwd(T, dev, ws):
     assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("M,K,pdrop", [(3001, 768, 0.25), (777, 256, 0.0), (70001, 768, 0.1), (64, 1024, 0.0)])
+def test_gemm_acc_layernorm_bwd_fused(T, dev, ws, M, K, pdrop):
+    """eend_gemm_acc_lnbwd_bf16 (round 6: the LayerNorm backward of a post-norm site in the epilogue of the data-gradient GEMM that
+    produces its input gradient) == eend_gemm_acc_bf16 followed by eend_layernorm_bwd_f32: same masks, same partial-sum semantics; in
+    place on the f32 gradient stream."""
+    import ctypes
+    gen = g(dev, M + K)
+    A = (torch.randn(M, K, device=dev, generator=gen) * 1e-4).to(BF16)
+    W = (torch.randn(256, K, device=dev, generator=gen) / math.sqrt(K)).to(BF16)
+    g0 = torch.randn(M, 256, device=dev, generator=gen) * 1e-4
+    xh = torch.randn(M, 256, device=dev, generator=gen).to(F16)
+    rs = 0.5 + torch.rand(M, device=dev, generator=gen)
+    gm = 1 + 0.2 * torch.randn(256, device=dev, generator=gen)
+    if pdrop > 0:
+        spec, _d = _drop_spec(pdrop, 64, site=3)
+        dr = ctypes.byref(spec)
+    else:
+        dr = None
+    # the two launches
+    g1 = g0.clone()
+    T._call("eend_gemm_acc_bf16", A, K, W, K, g1, 1.0, g1, None, M, K)
+    gsum = g1.clone()
+    d16a = torch.empty(M, 256, dtype=BF16, device=dev)
+    dga, dba, dbia = (torch.empty(256, device=dev) for _ in range(3))
+    T._call("eend_layernorm_bwd_f32", g1, xh, rs, gm, g1, d16a, ws, ws.numel(), dga, dba, dbia, M, dr)
+    # one launch, in place
+    g2 = g0.clone()
+    d16b = torch.full((M, 256), float("nan"), dtype=BF16, device=dev)
+    dgb, dbb, dbib = (torch.full((256,), float("nan"), device=dev) for _ in range(3))
+    T._call("eend_gemm_acc_lnbwd_bf16", A, K, W, K, g2, xh, rs, gm, g2, d16b, ws, ws.numel(), dgb, dbb, dbib, M, K, dr)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g2).all() and torch.isfinite(d16b.float()).all()
+    # dz cancels its two largest components: compare on the scale of its input gradient
+    scale = float((gsum * gm).abs().max() * rs.max())
+    assert float((g2 - g1).abs().max()) < 2e-5 * scale
+    assert ((d16b == 0) == (d16a == 0)).all()
+    assert float((d16b.float() - d16a.float()).abs().max()) < 1e-2 * float(d16a.float().abs().max())
+    assert rel(dgb, dga) < 1e-4 and rel(dbb, dba) < 1e-4 and rel(dbib, dbia) < 1e-3
+    # against float64 from the same operands
+    g64 = A.double() @ W.double().t() + g0.double()
+    dd = g64 * gm.double()
+    c1, c2 = dd.mean(-1, keepdim=True), (dd * xh.double()).mean(-1, keepdim=True)
+    dz = rs.double()[:, None] * (dd - c1 - xh.double() * c2)
+    assert float((g2.double() - dz).abs().max()) < 1e-4 * scale
+    assert rel(dgb, (g64 * xh.double()).sum(0).float()) < 2e-3 and rel(dbb, g64.sum(0).float()) < 2e-3
+    # without the optional bias gradient
+    g3 = g0.clone()
+    T._call("eend_gemm_acc_lnbwd_bf16", A, K, W, K, g3, xh, rs, gm, g3, d16b, ws, ws.numel(), dgb, dbb, None, M, K, dr)
+    assert torch.equal(g3, g2)
+
+
 def want_mask_sum(dgen, grad, rows):
     return dgen.rows(grad, 5, rows).sum(0)
 
