@@ -479,8 +479,8 @@ int eend_glu_dwconv_f16(const void* P_f16, const float* w, void* c_f16, int nseq
 int eend_bn_batch_stats_f16(const void* c_f16, float* ws, long ws_floats, float* stats, int nseq, int Tp, int Tv,
                             void* stream) {
     if (!c_f16 || !ws || !stats || nseq <= 0 || Tv <= 0) return EEND_EINVAL;
-    long nb = ((long)nseq * Tv + 127) / 128;
-    if (nb > 1024) nb = 1024;
+    long nb = ((long)nseq * Tv + 31) / 32;             // 32 rows per block: 8 iterations of four rows in flight per thread
+    if (nb > 4096) nb = 4096;
     if (ws_floats < (nb + 1) * 256L) return EEND_EINVAL;
     float* sum = ws + nb * 256L;
     const float n = (float)((long)nseq * Tv);
@@ -510,8 +510,8 @@ int eend_bn_swish_bwd_stats_bf16(const void* ds_bf16, const void* c_f16, const f
                                  const float* gamma, const float* beta, float* ws, long ws_floats, float* sums,
                                  float* dgamma, float* dbeta, int nseq, int Tp, int Tv, void* stream) {
     if (!ws || !sums || !dgamma || !dbeta || nseq <= 0 || Tv <= 0) return EEND_EINVAL;
-    long nb = ((long)nseq * Tv + 127) / 128;
-    if (nb > 1024) nb = 1024;
+    long nb = ((long)nseq * Tv + 31) / 32;             // 32 rows per block: 8 iterations of four rows in flight per thread
+    if (nb > 4096) nb = 4096;
     if (ws_floats < nb * 512L) return EEND_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int rc = eend_launch_bn_swish_bwd_stats(ds_bf16, c_f16, mean, var, eps, gamma, beta, ws, nseq, Tp, Tv, (int)nb, st);

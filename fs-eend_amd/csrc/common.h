@@ -97,9 +97,9 @@ struct DropSpec {
 // murmur masks' (numbers in the test checker's restatement of this function).
 DEV unsigned drop_mix(unsigned x) {                  // x = (a * golden + b) ^ seed
     x ^= x >> 16;
-    x = (x & 0xFFFFFFu) * 0x6B2F4Du;                   // hipcc emits v_mul_u32_u24 for this
+    x = __umul24(x, 0x6B2F4Du);                        // v_mul_u32_u24: (x & 0xFFFFFF) * C, low 32 bits (the explicit mask cost a v_and per use)
     x ^= x >> 13;
-    return (x & 0xFFFFFFu) * 0x9E3779u;
+    return __umul24(x, 0x9E3779u);
 }
 DEV bool drop_keep(const DropSpec d, unsigned a, unsigned b) {
     return drop_mix((a * 0x9E3779B1u + b) ^ d.seed) >= (d.thresh24 << 8);     // (h >> 8) >= thresh24

@@ -233,14 +233,21 @@ void bn_colstats16_kernel(const _Float16* __restrict__ c16, const float* __restr
     long r1 = r0 + rows_per_block;
     r1 = r1 < nrows ? r1 : nrows;
     const float mu = shift ? shift[ch] : 0.f;
-    float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        const long seq = r / Tv;
-        const int t = (int)(r - seq * Tv);
-        const float v = (float)c16[((size_t)seq * Tp + t) * D + ch];
-        acc += shift ? (v - mu) * (v - mu) : v;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    long seq = r0 / Tv;
+    int t = (int)(r0 - seq * Tv);
+    for (long r = r0; r < r1; r += 4) {                       // four rows in flight, (sequence, frame) advanced incrementally (round 6)
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = shift ? mu : 0.f;                          // (rows beyond the range contribute nothing)
+            if (r + k < r1) v[k] = (float)c16[((size_t)seq * Tp + t) * D + ch];
+            if (++t == Tv) { t = 0; ++seq; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += shift ? (v[k] - mu) * (v[k] - mu) : v[k];
     }
-    partial[(size_t)blockIdx.x * D + ch] = acc;
+    partial[(size_t)blockIdx.x * D + ch] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 // Merge the (mean, M2, n) triples of R ranks (R = 1: this rank alone) -- Chan's parallel variance -- into the batch
@@ -312,18 +319,31 @@ void bn_swish_bwd_stats_kernel(const __bf16* __restrict__ ds, const _Float16* __
     long r1 = r0 + rows_per_block;
     r1 = r1 < nrows ? r1 : nrows;
     const float mu = mean[ch], rs = 1.0f / __builtin_sqrtf(var[ch] + eps), g = gamma[ch], b = beta[ch];
-    float s1 = 0.f, s2 = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        const long seq = r / Tv;
-        const int t = (int)(r - seq * Tv);
-        const size_t off = ((size_t)seq * Tp + t) * D + ch;
-        const float ch_ = ((float)c16[off] - mu) * rs;
-        const float dy = (float)ds[off] * swish_grad(g * ch_ + b);
-        s1 += dy;
-        s2 += dy * ch_;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    long seq = r0 / Tv;
+    int t = (int)(r0 - seq * Tv);
+    for (long r = r0; r < r1; r += 4) {                       // four rows in flight (see bn_colstats16_kernel)
+        float cv[4], dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cv[k] = mu; dv[k] = 0.f;
+            if (r + k < r1) {
+                const size_t off = ((size_t)seq * Tp + t) * D + ch;
+                cv[k] = (float)c16[off];
+                dv[k] = (float)ds[off];
+            }
+            if (++t == Tv) { t = 0; ++seq; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float ch_ = (cv[k] - mu) * rs;
+            const float dy = dv[k] * swish_grad(g * ch_ + b);
+            a1[k] += dy;
+            a2[k] += dy * ch_;
+        }
     }
-    partial[((size_t)blockIdx.x * 2) * D + ch] = s1;
-    partial[((size_t)blockIdx.x * 2 + 1) * D + ch] = s2;
+    partial[((size_t)blockIdx.x * 2) * D + ch] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    partial[((size_t)blockIdx.x * 2 + 1) * D + ch] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
 }
 
 // pass 2: d_c = gamma * rstd * (d_y - S1/n - c_hat * S2/n) for the valid frames, zero elsewhere; in place over ds (bf16).

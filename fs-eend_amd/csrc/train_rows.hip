@@ -313,12 +313,27 @@ void bn_colstats_kernel(const float* const* __restrict__ x_ptrs, const int* __re
     long r1 = r0 + rows_per_split;
     if (r1 > (long)B * T) r1 = (long)B * T;
     const float sh = shift ? shift[c] : 0.f;
+    // sixteen rows in flight per iteration, (utterance, frame) advanced incrementally, summed IN ROW ORDER (round 6: the one-row loop with a
+    // division, a length and a pointer load per row was latency-bound -- 123 us per pass over 44 MB; same sums bit for bit)
     float s1 = 0.f, s2 = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        const int b = (int)(r / T), t = (int)(r - (long)b * T);
-        const float x = (t < lens[b] ? x_ptrs[b][(size_t)t * F + c] : pad_value) - sh;
-        s1 += x;
-        s2 = __builtin_fmaf(x, x, s2);
+    int b = (int)(r0 / T), t = (int)(r0 - (long)b * T);
+    for (long r = r0; r < r1; r += 16) {
+        float x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            // branch-free: a row beyond the split or the utterance loads from a harmless address (this thread's partial slot) and is replaced
+            const bool in = r + k < r1;
+            const int bb = in ? b : 0;
+            const bool real = in && t < lens[bb];
+            const float* src = real ? x_ptrs[bb] + (size_t)t * F + c : partial + c;
+            const float v = *src;
+            x[k] = real ? v : pad_value;
+            if (++t == T) { t = 0; ++b; }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (r + k < r1) { const float d = x[k] - sh; s1 += d; s2 = __builtin_fmaf(d, d, s2); }
+        }
     }
     partial[((size_t)blockIdx.y * 2 + 0) * F + c] = s1;
     partial[((size_t)blockIdx.y * 2 + 1) * F + c] = s2;
@@ -359,12 +374,24 @@ void bn_bwd_kernel(const float* const* __restrict__ x_ptrs, const int* __restric
     if (r1 > (long)B * T) r1 = (long)B * T;
     const float mu = mean[c], rs = 1.0f / __builtin_sqrtf(var[c] + eps);
     float s1 = 0.f, s2 = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        const int b = (int)(r / T), t = (int)(r - (long)b * T);
-        const float x = t < lens[b] ? x_ptrs[b][(size_t)t * F + c] : pad_value;
-        const float g = (float)dy[((size_t)b * Tp + t) * ld + c];
-        s1 = __builtin_fmaf(g, (x - mu) * rs, s1);
-        s2 += g;
+    int b = (int)(r0 / T), t = (int)(r0 - (long)b * T);
+    for (long r = r0; r < r1; r += 16) {                      // sixteen rows in flight, summed in row order (see bn_colstats_kernel)
+        float x[16], g[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool in = r + k < r1;                       // branch-free, as in bn_colstats_kernel
+            const int bb = in ? b : 0, tt = in ? t : 0;
+            const bool real = in && t < lens[bb];
+            const float* src = real ? x_ptrs[bb] + (size_t)t * F + c : mean + c;
+            const float v = *src;
+            x[k] = real ? v : pad_value;
+            g[k] = (float)dy[((size_t)bb * Tp + tt) * ld + c];
+            if (++t == T) { t = 0; ++b; }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (r + k < r1) { s1 = __builtin_fmaf(g[k], (x[k] - mu) * rs, s1); s2 += g[k]; }
+        }
     }
     partial[((size_t)blockIdx.y * 2 + 0) * F + c] = s1;
     partial[((size_t)blockIdx.y * 2 + 1) * F + c] = s2;

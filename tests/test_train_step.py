@@ -91,6 +91,7 @@ def test_train_step_vs_reference(hip_lib, dev, name):
             n_bad += int((d > 0.15 * lr * (s + 1) + 1e-6).sum())
             n_all += len(idx)
             assert d.max() < 2.5 * lr * (s + 1) + 1e-6, (k, d.max(), lr)
+        print(f"   step {s}: {n_bad} of {n_all} sampled parameter entries more than 0.15 lr off the reference's")
         assert n_bad <= 0.03 * n_all, (n_bad, n_all)
         bn = m.enc.bn
         assert np.abs(bn.running_mean.cpu().numpy() - arr[f"s{s}_bn_mean"]).max() < 1e-4

@@ -5,4 +5,3 @@ PMC_TARGET=cmd PMC_TAG=r06_train_fs_ PMC_PASSES=fetch,write,sq PMC_CMD="python b
 PMC_TARGET=cmd PMC_TAG=r06_train_ls_ PMC_PASSES=fetch,write,sq PMC_CMD="python bench.py --mode train --flavour ls --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown" bash tools/gpu_pmc.sh > gpurun_out/pmc/r06_train_ls.log 2>&1
 python tools/pmc_traffic.py gpurun_out/pmc/r06_train_fs_fetch.csv gpurun_out/pmc/r06_train_fs_write.csv gpurun_out/r06_train_fs_pmc_traffic.json "bench.py --mode train --steps 1, FS B=64 T=500 4 speakers"
 python tools/pmc_traffic.py gpurun_out/pmc/r06_train_ls_fetch.csv gpurun_out/pmc/r06_train_ls_write.csv gpurun_out/r06_train_ls_pmc_traffic.json "bench.py --mode train --flavour ls --steps 1, LS B=64 T=1000 4 speakers"
-tail -3 gpurun_out/pmc/r06_train_fs.log gpurun_out/pmc/r06_train_ls.log
