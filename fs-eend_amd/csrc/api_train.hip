@@ -288,6 +288,28 @@ int eend_wgrad_bias_bf16(const void* dY, int lda, const void* X, int ldb, int x_
     return eend_launch_wgrad_reduce(p.bias_partial, N, p.nsplit, 1, N, N, bias_out, N, scale, accumulate, (hipStream_t)stream);
 }
 
+int eend_wgrad_bias_grouped_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
+                                 long ws_floats, float* out, float* bias_out, int group_rows, long group_stride, float scale, void* stream) {
+    if (!dY || !X || !ws || !out || !bias_out || M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128) || group_rows <= 0 || (N % group_rows) ||
+        group_stride < (long)group_rows * K)
+        return EEND_EINVAL;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = dY; p.B = X; p.partial = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+    p.b_is_f16 = (x_is_f16 & 1) ? 1 : 0; p.b_blocked = (x_is_f16 & 2) ? 1 : 0; p.a_blocked = (x_is_f16 & 4) ? 1 : 0;
+    int rc = plan_wgrad(M, N, K, 0, ws_floats, &p.tile, &p.nsplit, &p.m_per_split, true);
+    if (rc != EEND_OK) return rc;
+    p.bias_partial = ws + (size_t)p.nsplit * N * K;
+    rc = eend_launch_wgrad(p, (hipStream_t)stream);
+    if (rc != EEND_OK) return rc;
+    rc = eend_launch_wgrad_reduce_tiles(ws, p.tile, p.nsplit, N, K, K, out, K, scale, 0, (hipStream_t)stream, group_rows,
+                                        group_stride - (long)group_rows * K);
+    if (rc != EEND_OK) return rc;
+    // bias_out[g * group_stride + r]: the column sums of dY as N / group_rows rows of group_rows
+    return eend_launch_wgrad_reduce(p.bias_partial, N, p.nsplit, N / group_rows, group_rows, group_rows, bias_out, (int)group_stride, scale, 0,
+                                    (hipStream_t)stream);
+}
+
 int eend_conv1d_wgrad_bf16(const void* dY, const void* X_f16, const int* ilens, int nseq, int Tp, int cin, int ktaps,
                            int pad, float* ws, long ws_floats, float* tmp, float* out, void* stream) {
     if (!dY || !X_f16 || !ilens || !ws || !tmp || !out || nseq <= 0 || Tp <= 0 || cin != 256 || ktaps <= 0 || pad < 0 || pad >= ktaps)

@@ -415,7 +415,7 @@ struct WgradParams {          // wgrad.hip: partial[s][n][k] = sum_{m in split s
 };
 int eend_launch_wgrad(const WgradParams& p, hipStream_t stream);
 int eend_launch_wgrad_reduce_tiles(const float* partial, int tile, int nsplit, int N, int K, int K_out, float* out, int ld_out,
-                                   float scale, int accumulate, hipStream_t stream);
+                                   float scale, int accumulate, hipStream_t stream, int group_rows = 0, long group_gap = 0);
 int eend_launch_wgrad_reduce(const float* partial, long split_stride, int nsplit, int N, int K, int K_out, float* out,
                              int ld_out, float scale, int accumulate, hipStream_t stream);
 int eend_launch_wgrad_reduce_multi(const float* partial, long split_stride, int nsplit, int W, float* out0, float* out1, float* out2,

@@ -333,7 +333,7 @@ void wgrad_tr_kernel(const WgradParams p) {
 template <int BT>
 __global__ __launch_bounds__(256)
 void wgrad_reduce_tr_kernel(const float* __restrict__ partial, long split_stride, int nsplit, int N, int K, int K_out,
-                            float* __restrict__ out, int ld_out, float scale, int accumulate) {
+                            float* __restrict__ out, int ld_out, float scale, int accumulate, int group_rows, long group_gap) {
     constexpr int NJ = BT / 64;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // f32x4 slot
     if (idx >= (long)N * K / 4) return;
@@ -359,7 +359,9 @@ void wgrad_reduce_tr_kernel(const float* __restrict__ partial, long split_stride
     }
     for (; s < nsplit; ++s) s0 += src[(size_t)s * ss4];
     const f32x4 v = ((s0 + s1) + (s2 + s3)) * scale;
-    float* o = out + (size_t)n * ld_out + k;
+    // (group_rows > 0: the rows belong to several equally spaced destination tensors -- the four projections of a retention module in the
+    // flat gradient buffer: group g = n / group_rows starts group_gap floats further than contiguous rows would)
+    float* o = out + (size_t)n * ld_out + k + (group_rows > 0 ? (long)(n / group_rows) * group_gap : 0L);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (k + e < K_out) o[e] = accumulate ? o[e] + v[e] : v[e];
@@ -536,16 +538,16 @@ int eend_launch_wgrad(const WgradParams& p, hipStream_t stream) {
 
 // the partial tiles of eend_launch_wgrad (accumulator order of its `tile`) -> out[n][k]
 int eend_launch_wgrad_reduce_tiles(const float* partial, int tile, int nsplit, int N, int K, int K_out, float* out, int ld_out,
-                                   float scale, int accumulate, hipStream_t stream) {
+                                   float scale, int accumulate, hipStream_t stream, int group_rows, long group_gap) {
     const int bt = tile == 256 ? 256 : 128;
     if (!partial || !out || nsplit <= 0 || N <= 0 || K <= 0 || (N % bt) || (K % bt) || K_out <= 0 || K_out > K || ld_out < K_out)
         return EEND_EINVAL;
     const long n4 = (long)N * K / 4;
     const dim3 grid((unsigned)((n4 + 255) / 256));
     if (bt == 256)
-        hipLaunchKernelGGL(wgrad_reduce_tr_kernel<256>, grid, dim3(256), 0, stream, partial, (long)N * K, nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_tr_kernel<256>, grid, dim3(256), 0, stream, partial, (long)N * K, nsplit, N, K, K_out, out, ld_out, scale, accumulate, group_rows, group_gap);
     else
-        hipLaunchKernelGGL(wgrad_reduce_tr_kernel<128>, grid, dim3(256), 0, stream, partial, (long)N * K, nsplit, N, K, K_out, out, ld_out, scale, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_tr_kernel<128>, grid, dim3(256), 0, stream, partial, (long)N * K, nsplit, N, K, K_out, out, ld_out, scale, accumulate, group_rows, group_gap);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 

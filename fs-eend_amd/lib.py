@@ -108,6 +108,7 @@ PROTOTYPES = {
     "eend_attn_causal_bwd_bf16": [_vp] * 5 + [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i] + [_i] * 6 + [_f, _f, _f, _vp, _vp],
     "eend_gemm_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "eend_gemm_relu_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp],
+    "eend_wgrad_bias_grouped_bf16": [_vp, _i, _vp, _i, _i, _l, _i, _i, _vp, _l, _vp, _vp, _i, _l, _f, _vp],
     "eend_gemm_acc_lnbwd_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "eend_gemm_acc_bf16": [_vp, _i, _vp, _i, _vp, _f, _vp, _vp, _i, _i, _vp],
     "eend_conv1d_dgrad_bf16": [_vp] * 5 + [_i] * 5 + [_vp],

@@ -409,10 +409,20 @@ class LsTrainStep(TrainStepBase):
         _call("eend_gemm_acc_bf16", ds16, D, W[wkey + ".woT" if wkey[0] == "e" else wkey + ".out1_wT"], D, None, 1.0, dctx, None, M, D)
         _call("eend_retention_bwd_bf16", sv.q, sv.qt, sv.k, sv.kt, sv.v, sv.vt, dctx, sv.g, D, sv.rhat, sv.rc, bf.ot, bf.ott, bf.kv_ws,
               bf.g_ws, bf.st_bwd, dq, 4 * D, nseq, H, Tp, self.L, bf.Tv, 0.125)
-        for j, nm in enumerate(("q_proj", "k_proj", "v_proj", "g_proj")):
-            blk = dq[:, j * D:(j + 1) * D]
-            _call("eend_wgrad_bias_bf16", blk, 4 * D, x_in16, x_in16.stride(0), 1, M, D, D, self.ws, WS_FLOATS,
-                  self._G(pfx + nm + ".weight"), D, D, self._G(pfx + nm + ".bias"), 1.0, 0)
+        projs = ("q_proj", "k_proj", "v_proj", "g_proj")
+        offw = [self.flat.offsets[pfx + nm + ".weight"] for nm in projs]
+        offb = [self.flat.offsets[pfx + nm + ".bias"] for nm in projs]
+        stride = offw[1] - offw[0]
+        if all(offw[j] - offw[0] == j * stride and offb[j] - offb[0] == j * stride for j in range(4)) and stride >= D * D:
+            # the four projections' (weight, bias) gradients are equally spaced in the flat buffer: ONE weight-gradient launch over dq's 1024
+            # columns (x read once instead of four times, two reductions instead of eight)
+            _call("eend_wgrad_bias_grouped_bf16", dq, 4 * D, x_in16, x_in16.stride(0), 1, M, 4 * D, D, self.ws, WS_FLOATS,
+                  self._G(pfx + "q_proj.weight"), self._G(pfx + "q_proj.bias"), D, stride, 1.0)
+        else:
+            for j, nm in enumerate(projs):
+                blk = dq[:, j * D:(j + 1) * D]
+                _call("eend_wgrad_bias_bf16", blk, 4 * D, x_in16, x_in16.stride(0), 1, M, D, D, self.ws, WS_FLOATS,
+                      self._G(pfx + nm + ".weight"), D, D, self._G(pfx + nm + ".bias"), 1.0, 0)
         if prenorm_site is None and next_ln is not None:
             site, ln, ndrop, nbias = next_ln
             self._gemm_acc_ln_bwd(dq, 4 * D, W[wkey + ".wqkvgT"], g32, site, ln, ds16, M, ndrop, nbias)

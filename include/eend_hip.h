@@ -623,6 +623,12 @@ int eend_conv1d_dgrad_bf16(const void* dY, const void* Wd, const int* src_lens, 
  * eend_ffn_train_stream_f16's hid (ldb = its full width F); x_is_f16 & 4: dY is (eend_ffn_bwd_data_stream_bf16's dH, lda = F). */
 int eend_wgrad_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
                     long ws_floats, float* out, int ld_out, int K_out, float scale, int accumulate, void* stream);
+/* eend_wgrad_bias_bf16 for N / group_rows linear layers that share the input X and whose (weight, bias) gradients sit equally spaced in
+ * one buffer (the q / k / v / g projections of a retention module in the flat gradient buffer): rows g * group_rows .. of dY's N columns go
+ * to out + g * group_stride (row stride K), their bias gradient to bias_out + g * group_stride.  One pass over X instead of N / group_rows,
+ * one reduction launch each for weights and biases.  Overwrites (no accumulate). */
+int eend_wgrad_bias_grouped_bf16(const void* dY, int lda, const void* X, int ldb, int x_is_f16, long M, int N, int K, float* ws,
+                                 long ws_floats, float* out, float* bias_out, int group_rows, long group_stride, float scale, void* stream);
 /* The same with the bias gradient on the side: bias_out[n] = scale * sum_m dY[m][n] (+ bias_out if accumulate), accumulated
  * from the dY tiles the kernel stages anyway instead of by a separate pass over dY (eend_colsum_f32).  ws needs
  * nsplit * (N*K + N) floats. */

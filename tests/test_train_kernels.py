@@ -318,6 +318,31 @@ def test_layernorm_bwd(T, dev, ws):
     assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("M", [4133, 140000])
+def test_wgrad_grouped(T, dev, ws, M):
+    """eend_wgrad_bias_grouped_bf16 (round 6): the weight and bias gradients of four linear layers sharing one input (the q / k / v / g
+    projections of a retention module), destinations equally spaced in one buffer, == four eend_wgrad_bias_bf16 calls on the column
+    blocks of dY; the floats between the destinations stay untouched."""
+    gen = g(dev, M)
+    dy = (torch.randn(M, 1024, device=dev, generator=gen) * 1e-5).to(BF16)
+    x = torch.randn(M, 256, device=dev, generator=gen).to(F16)
+    stride = 256 * 256 + 256 + 64                                  # weight, bias, and a gap that must survive
+    buf = torch.full((4 * stride,), 7.0, dtype=F32, device=dev)
+    T._call("eend_wgrad_bias_grouped_bf16", dy, 1024, x, 256, 1, M, 1024, 256, ws, ws.numel(), buf, buf[256 * 256:], 256, stride, 1.0)
+    torch.cuda.synchronize()
+    for j in range(4):
+        w1 = torch.empty(256, 256, dtype=F32, device=dev)
+        b1 = torch.empty(256, dtype=F32, device=dev)
+        T._call("eend_wgrad_bias_bf16", dy[:, j * 256:(j + 1) * 256], 1024, x, 256, 1, M, 256, 256, ws, ws.numel(), w1, 256, 256, b1, 1.0, 0)
+        got_w = buf[j * stride:j * stride + 65536].view(256, 256)
+        got_b = buf[j * stride + 65536:j * stride + 65536 + 256]
+        assert relnorm(got_w, w1) < 1e-5 and rel(got_w, w1) < 1e-3, j
+        assert rel(got_b, b1) < 1e-4, j
+        assert (buf[j * stride + 65536 + 256:(j + 1) * stride] == 7.0).all()
+    want = dy.float().t() @ x.to(BF16).float()
+    assert relnorm(buf[:65536].view(256, 256), want[:256]) < 2e-3
+
+
 @pytest.mark.parametrize("M,K,pdrop", [(3001, 768, 0.25), (777, 256, 0.0), (70001, 768, 0.1), (64, 1024, 0.0)])
 def test_gemm_acc_layernorm_bwd_fused(T, dev, ws, M, K, pdrop):
     """eend_gemm_acc_lnbwd_bf16 (round 6: the LayerNorm backward of a post-norm site in the epilogue of the data-gradient GEMM that
