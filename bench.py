@@ -312,7 +312,7 @@ def batch_sweep(dev, model, T, C, sizes=(1, 512)):
 
 def length_sweep(dev, model, C, lengths=(300, 500, 1000, 2000), frames_per_step=32000):
     """The same model.test at other chunk lengths (about the same number of frames per step): the packed-weight attention kernel
-    (attn_stream.hip) covers the padded length 512 only -- every other length runs the round-2/3 attention kernels (attn_fused.hip
+    (attn_stream.hip) covers the padded length 512 only -- every other length runs the round-2/3 attention kernels (proj.hip + attn_full.hip
     for Tp <= 512, the tiled kernel beyond), so the T = 500 headline does not transfer."""
     out = {}
     for T in lengths:
@@ -345,7 +345,7 @@ def length_sweep(dev, model, C, lengths=(300, 500, 1000, 2000), frames_per_step=
             ts = sorted(a.elapsed_time(b) for a, b in evs)
             dt = ts[n // 2] * 1e-3
             out[str(T)] = dict(batch=Bs, padded_frames=Tp, frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3, ms_per_step_max=ts[-1],
-                               attention_kernel="attn_stream.hip (packed weights)" if Tp == 512 else ("attn_fused.hip" if Tp <= 512 else "proj.hip + attn.hip (tiled)"))
+                               attention_kernel="attn_stream.hip (packed weights)" if Tp == 512 else ("proj.hip + attn_full.hip (chunk resident)" if Tp <= 512 else "proj.hip + attn.hip (tiled)"))
             del gr, keep, src
         except Exception as e:                                   # noqa: BLE001
             out[str(T)] = dict(error=str(e)[:200])
@@ -1155,7 +1155,7 @@ def main():
                            "traffic_file": os.path.relpath(pmc_traffic_file()[0], ROOT) if pmc_traffic_file()[0] else None,
                            "traffic_file_sha256_16": pmc_traffic_file()[1]}
         att = [k for k in ksum if k["kernel"] == "attn_causal" and k["shape"][0] == B]
-        # the encoder's time-axis attention launch (nseq = B): the packed-weight form at Tp = 512 (attn_stream.hip), else attn_fused.hip
+        # the encoder's time-axis attention launch (nseq = B): the packed-weight form at Tp = 512 (attn_stream.hip), else proj.hip + attn_full.hip / attn.hip
         fus = [k for k in ksum if k["kernel"] in ("inproj_attn_causal_packed", "inproj_attn_causal") and k["shape"][0] == B]
         dec = [k for k in ksum if k["kernel"] in ("inproj_attn_causal_packed", "inproj_attn_causal") and k["shape"][0] == B * C]
         if fus:
