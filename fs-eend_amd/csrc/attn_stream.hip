@@ -10,7 +10,8 @@
 // (Round 3's form of the operator, attn_fused.hip -- weight slices in registers split by FEATURE across the waves, X streamed through
 //  an LDS tile every wave read completely, Q through an L2 scratch -- was LDS-read-bound, 19 us of a 32-us decoder item; removed in
 //  round 6 together with its A/B switch.)
-// Tp = 512 only (eight waves x two query blocks); other chunk lengths take eend_inproj_heads_bf16 + eend_attn_causal_bf16.
+// Tp = 64 m <= 512 (eight waves x two query blocks of the 16 slots; round 6: shorter windows leave slots empty, see tokbase); longer chunk
+// lengths take eend_inproj_heads_bf16 + eend_attn_causal_bf16.
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
@@ -92,8 +93,15 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
             seq_ = L >> 2; h_ = L & 3;
         }
     };
-    // the wave's tokens: fragments 0, 1 = query block `wave`, fragments 2, 3 = query block 15 - wave
-    auto tokbase = [&](int jt) __attribute__((always_inline)) { return jt < 2 ? 32 * wave + 16 * jt : 32 * (15 - wave) + 16 * (jt - 2); };
+    // the wave's tokens: fragments 0, 1 = query block b1, fragments 2, 3 = query block b2.  Tp = 512: (wave, 15 - wave).  Round 6, shorter
+    // padded lengths (Tp = 64 m < 512, nblk = Tp / 32 real blocks): the first nblk / 2 waves take the causally balanced pairs
+    // (w, nblk - 1 - w) of real blocks, the others two each of the 16 - nblk block slots beyond Tp -- their rows read as zeros (buffer
+    // bounds), their K / V rows are finite and masked (key >= kv_len), their flash passes are skipped -- so that every slot of the LDS
+    // tiles is written exactly once as before
+    const int nblk = p.Tp >> 5;
+    const int b1 = wave < (nblk >> 1) ? wave : nblk + 2 * (wave - (nblk >> 1));
+    const int b2 = wave < (nblk >> 1) ? nblk - 1 - wave : b1 + 1;
+    auto tokbase = [&](int jt) __attribute__((always_inline)) { return jt < 2 ? 32 * b1 + 16 * jt : 32 * b2 + 16 * (jt - 2); };
     char* Ow = Xs + wave * OSTG;
     auto relaunder = [&]() __attribute__((always_inline)) {
         asm volatile("" : "+v"(tid));
@@ -106,8 +114,8 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     // has its rows in flight while it waits for the others (and nothing is carried in registers around the loop).
     u32x4 xr[4][8];
     auto request_x = [&](int seq_) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.X + (size_t)seq_ * TP * p.ldx), 0,
-                                                                            TP * p.ldx * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.X + (size_t)seq_ * p.Tp * p.ldx), 0,
+                                                                            p.Tp * p.ldx * 2, 0x00020000);      // rows >= Tp: zeros
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             const int off = (tokbase(jt) + (lane >> 5)) * p.ldx * 2 + (lane & 31) * 16;
@@ -349,7 +357,7 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
                 *(f16x4*)(Ow + lq * 128 + (((db * 4 + g) ^ (lq & 7)) << 4) + hi * 8) = o;
             }
         wave_lds_sync();
-        _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * TP + qw0) * p.ldo + h * 64;
+        _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * p.Tp + qw0) * p.ldo + h * 64;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
@@ -358,9 +366,9 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
         }
         wave_lds_sync();
     };
-    run_pass(15 - wave, std::integral_constant<int, 2>{});
+    if (b2 < nblk) run_pass(b2, std::integral_constant<int, 2>{});      // (wave-uniform: a pass has no workgroup barrier)
     AS_STAMP(9);
-    run_pass(wave, std::integral_constant<int, 0>{});
+    if (b1 < nblk) run_pass(b1, std::integral_constant<int, 0>{});
     AS_STAMP(10);
     AS_STAMP(11);
 #ifdef EEND_AS_TRACE
@@ -390,7 +398,7 @@ int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream) {
 
 // p.W = the packed weights (eend_launch_inproj_attn_pack)
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream) {
-    if (p.Tp != TP || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O) return EEND_EINVAL;
+    if (p.Tp <= 0 || p.Tp > TP || (p.Tp & 63) || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O) return EEND_EINVAL;
     static EendOncePerDevice attr_once;
     if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel, SMEM)) return EEND_ELAUNCH;
     int n_cu = eend_cu_count() & ~31;                // multiple of 32: a persistent workgroup keeps its head (and its XCD)

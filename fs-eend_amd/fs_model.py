@@ -28,7 +28,7 @@ _H_SUPPORTED = 4
 # One fast form + one general fallback per operator, selected by SHAPE (round 6: the A/B environment switches of rounds 1 - 5 are gone;
 # their questions are answered in profiles/OPTIMISATION_LOG.md):
 #   encoder input      encin.hip (320 < in_size <= 384)              | gather + BatchNorm + linear_res_ln
-#   time-axis MHA      attn_stream.hip (Tp = 512, packed weights)    | in-projection + attn_full.hip (Tp <= 512) / attn.hip (longer)
+#   time-axis MHA      attn_stream.hip (Tp <= 512, packed weights)   | in-projection + attn.hip (longer chunks)
 #   layer head         spk_stream.hip (C <= 12: the limit of every speaker-axis kernel)
 #   layer tail         ffn_stream.hip (F % 64 == 0)                  | attnout_ffn_fused_res16 (ffn.hip)
 #   look-ahead conv    conv_stream.hip (256 channels)                | implicit-GEMM epilogue (gemm.hip)
@@ -147,7 +147,7 @@ class _Workspace:
         self.xin16 = torch.zeros(Me, Fin_pad, dtype=f16, device=dev)
         self.h16 = e(Me, D, dt=f16)
         # bf16 Q / K / V^T of the un-packed attention path: only chunk lengths other than 512 frames read them
-        n_qkv = Mx * D if Tp != 512 else 0
+        n_qkv = Mx * D if Tp > 512 else 0
         self.q, self.k, self.vt = e(n_qkv, dt=bf16), e(n_qkv, dt=bf16), e(n_qkv, dt=bf16)
         self.o16 = e(Mx, D, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
@@ -350,9 +350,9 @@ class OnlineTransformerDADiarization(nn.Module):
         def time_attention(x16, Ly, wkey, bkey, nseq, delay, kv):
             """in-projection + causal MHA over the frames of `nseq` sequences -> ws.o16 rows (merge_tfm_encoder.py:379-385)"""
             o = ws.o16[:nseq * Tp]
-            if Tp == 512:            # token-owning waves, packed weights, Q in registers, K / V never leave the CU (attn_stream.hip)
+            if Tp <= 512:            # token-owning waves, packed weights, Q in registers, K / V never leave the CU (attn_stream.hip)
                 ops.inproj_attn_causal_packed(x16, Ly[wkey + "p"], Ly[bkey], o, nseq, H, Tp, delay, kv)
-            else:                    # other chunk lengths: bf16 Q / K / V^T through HBM, resident (<= 512) or tiled attention kernel
+            else:                    # longer chunks: bf16 Q / K / V^T through HBM, tiled attention kernel
                 n = nseq * Tp * D
                 ops.inproj_heads(x16, Ly[wkey], Ly[bkey], ws.q[:n], ws.k[:n], ws.vt[:n], nseq, Tp, H)
                 ops.attn_causal(ws.q[:n], ws.k[:n], ws.vt[:n], o, nseq, H, Tp, delay, kv, scale=ops.LN2)

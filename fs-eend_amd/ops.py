@@ -299,7 +299,7 @@ def inproj_attn_pack(w_in):
 
 
 def inproj_attn_causal_packed(x16, w_packed, b_in, o16, nseq, H, Tp, mask_delay=0, kv_len=None):
-    """Packed in-projection + causal attention in one launch (attn_stream.hip; Tp = 512, H = 4): Q, K, V never reach HBM."""
+    """Packed in-projection + causal attention in one launch (attn_stream.hip; Tp = 64 m <= 512, H = 4): Q, K, V never reach HBM."""
     L = _lib.load()
     _chk(x16, F16, "x16"); _chk(w_packed, F16, "w_packed"); _chk(b_in, F32, "b_in"); _chk(o16, F16, "o16")
     if w_packed.numel() != L.eend_inproj_attn_packed_elems() or b_in.numel() != 768 or x16.shape[0] < nseq * Tp or o16.shape[0] < nseq * Tp:

@@ -448,7 +448,7 @@ int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H,
 
 /* Packed in-projection + causal multi-head attention in one launch (nn.MultiheadAttention(x, x, x) on the time axis:
  * nn.TransformerEncoderLayer.self_attn, FS model :147; self_attn1 of the fusion layers, merge_tfm_encoder.py:379-385),
- * Tp = 512, H = 4, d_model = 256 (attn_stream.hip): the in-projection weights pre-packed in MFMA fragment order, a wave keeps
+ * Tp = 64 m <= 512 (round 6; rounds 4 - 5: 512 only), H = 4, d_model = 256 (attn_stream.hip): the in-projection weights pre-packed in MFMA fragment order, a wave keeps
  * the X rows of the 64 tokens whose queries it runs in registers, the head's 96 KB of weights arrive by LDS-DMA, Q, K and V never
  * reach HBM.  eend_inproj_attn_pack_f16 re-orders W_in f16 [768][256] (= in_proj_weight with the q rows pre-multiplied by
  * 1/sqrt(64) * log2(e)) into eend_inproj_attn_packed_elems() f16 elements, once per parameter version.  mask: key j visible to

@@ -1,5 +1,5 @@
-"""GPU: the packed in-projection + causal attention kernel (csrc/attn_stream.hip, Tp = 512) against the general two-kernel path
-(eend_inproj_heads_bf16 -> eend_attn_causal_bf16, every other chunk length) and against fp32 torch on the same f16 operands."""
+"""GPU: the packed in-projection + causal attention kernel (csrc/attn_stream.hip, Tp = 64 m <= 512) against the general two-kernel path
+(eend_inproj_heads_bf16 -> eend_attn_causal_bf16, longer or ragged chunk lengths) and against fp32 torch on the same f16 operands."""
 import math
 
 import pytest
@@ -52,11 +52,14 @@ def test_general_path_other_chunk_lengths(hip_lib, dev, nseq, Tp, delay, kv_len)
     assert (o.float() - want).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("nseq,delay,kv_len", [(1, 0, 512), (8, 0, 500), (5, 3, 470), (40, 0, 500), (2, 1000, 512), (300, 0, 500)])
-def test_inproj_attn_packed(hip_lib, dev, nseq, delay, kv_len):
+@pytest.mark.parametrize("nseq,delay,kv_len,Tp", [(1, 0, 512, 512), (8, 0, 500, 512), (5, 3, 470, 512), (40, 0, 500, 512), (2, 1000, 512, 512),
+                                                   (300, 0, 500, 512),
+                                                   # round 6: shorter padded lengths on the same kernel (block slots beyond Tp stay empty)
+                                                   (7, 0, 300, 320), (3, 0, 64, 64), (9, 2, 100, 128), (12, 0, 440, 448), (4, 1000, 380, 384),
+                                                   (5, 0, 192, 192), (130, 0, 250, 256)])
+def test_inproj_attn_packed(hip_lib, dev, nseq, delay, kv_len, Tp):
     """attn_stream.hip (token-owning waves, packed weights, Q in registers) against fp32 torch and against the two-kernel path."""
     from fs_eend_amd import ops
-    Tp = 512
     x, w, b = _case(dev, nseq, Tp, nseq * 11 + delay)
     wp = ops.inproj_attn_pack(w)
     o = torch.full((nseq * Tp, 256), float("nan"), dtype=F16, device=dev)
@@ -75,11 +78,13 @@ def test_inproj_attn_packed(hip_lib, dev, nseq, delay, kv_len):
 
 
 def test_inproj_attn_packed_rejects_other_lengths(hip_lib, dev):
+    """windows beyond the 512 frames the LDS tiles hold (and lengths that are not a multiple of 64): EEND_EINVAL, the caller keeps the two kernels"""
     from fs_eend_amd import ops, lib as _lib
-    x, w, b = _case(dev, 2, 256, 1)
-    wp = ops.inproj_attn_pack(w)
-    with pytest.raises(_lib.EendHipError):
-        ops.inproj_attn_causal_packed(x, wp, b, torch.empty_like(x), 2, 4, 256, 0, 256)
+    for Tp in (576, 1024, 96):
+        x, w, b = _case(dev, 2, Tp, 1)
+        wp = ops.inproj_attn_pack(w)
+        with pytest.raises(_lib.EendHipError):
+            ops.inproj_attn_causal_packed(x, wp, b, torch.empty_like(x), 2, 4, Tp, 0, Tp)
 
 
 @pytest.mark.parametrize("B,T,C", [(3, 130, 3), (5, 500, 6), (2, 512, 10), (2, 700, 4)])
