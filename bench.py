@@ -345,7 +345,7 @@ def length_sweep(dev, model, C, lengths=(300, 500, 1000, 2000), frames_per_step=
             ts = sorted(a.elapsed_time(b) for a, b in evs)
             dt = ts[n // 2] * 1e-3
             out[str(T)] = dict(batch=Bs, padded_frames=Tp, frames_per_s=Bs * T / dt, ms_per_step=dt * 1e3, ms_per_step_max=ts[-1],
-                               attention_kernel="attn_stream.hip (packed weights)" if Tp <= 512 else "proj.hip + attn.hip (tiled)")
+                               attention_kernel="attn_stream.hip (packed weights)" if Tp <= 512 else "attn_stream.hip (groups of 512 frames + combine)")
             del gr, keep, src
         except Exception as e:                                   # noqa: BLE001
             out[str(T)] = dict(error=str(e)[:200])

@@ -557,6 +557,24 @@ int eend_inproj_attn_causal_packed_f16(const void* X_f16, int ldx, const void* W
     return eend_launch_inproj_attn_stream(p, (hipStream_t)stream);
 }
 
+int eend_inproj_attn_long_scratch_elems(int nseq, int Tp, int mask_delay, int kv_len, long long* part_f16_elems, long long* lse_f32_elems) {
+    if (!part_f16_elems || !lse_f32_elems) return EEND_EINVAL;
+    long a = 0, b = 0;
+    const int rc = eend_inproj_attn_long_scratch(nseq, Tp, mask_delay, kv_len, &a, &b);
+    *part_f16_elems = a; *lse_f32_elems = b;
+    return rc;
+}
+
+int eend_inproj_attn_causal_long_f16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16, void* part_f16,
+                                     float* lse_f32, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream) {
+    if (!X_f16 || !W_packed || !b_in || !O_f16 || !lse_f32 || nseq > 16383) return EEND_EINVAL;
+    InprojAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = X_f16; p.ldx = ldx; p.W = W_packed; p.bias = b_in; p.O = O_f16; p.Opart = part_f16; p.lse = lse_f32;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.ldo = ldo; p.mask_delay = mask_delay; p.kv_len = kv_len;
+    return eend_launch_inproj_attn_long(p, (hipStream_t)stream);
+}
+
 int eend_spk_attn_f16(const void* qkv, void* O_f16, int B, int C, int Tp, int H, float scale, void* stream) {
     if (!qkv || !O_f16) return EEND_EINVAL;
     SpkAttnParams p;

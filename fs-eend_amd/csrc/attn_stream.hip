@@ -70,6 +70,13 @@ __device__ unsigned long long g_as_trace[256 * 6 * 12];
 #define AS_STAMP(k) do {} while (0)
 #endif
 
+// LONG (round 6, windows of more than 512 frames): an item is a (sequence, head, query group, key group) of the pair table in the
+// parameters -- groups of 512 frames, the last one shorter.  A diagonal item (key group = query group) is the item of the short form on
+// that group's rows and writes its rows of O; an off-diagonal item projects Q from the query group's rows, then K / V from the key
+// group's (the wave's X fragments are loaded a second time between the Q and the K items), runs the same flash passes with the causal
+// limit shifted by the distance of the groups and writes its normalised partial result into a scratch slot.  Every item also leaves the
+// log2 of its softmax denominators; attn_long_combine_kernel weighs the partial rows of a query group with them.
+template <bool LONG>
 __global__ __launch_bounds__(512)
 void inproj_attn_stream_kernel(const InprojAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +90,8 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int frow = lane & 15, fkg = lane >> 4;
-    const int nitems = p.nseq * 4;
+    const int nsh = p.nseq * 4;
+    const int nitems = LONG ? nsh * p.npairs : nsh;
     const bool xcd_map = (p.nseq & 7) == 0 && ((gridDim.x & 7) == 0 || (int)gridDim.x >= nitems);
     auto item_of = [&](int L, int& seq_, int& h_) __attribute__((always_inline)) {
         if (xcd_map) {
@@ -98,9 +106,12 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     // (w, nblk - 1 - w) of real blocks, the others two each of the 16 - nblk block slots beyond Tp -- their rows read as zeros (buffer
     // bounds), their K / V rows are finite and masked (key >= kv_len), their flash passes are skipped -- so that every slot of the LDS
     // tiles is written exactly once as before
-    const int nblk = p.Tp >> 5;
-    const int b1 = wave < (nblk >> 1) ? wave : nblk + 2 * (wave - (nblk >> 1));
-    const int b2 = wave < (nblk >> 1) ? nblk - 1 - wave : b1 + 1;
+    int nblk = p.Tp >> 5;
+    int b1 = wave < (nblk >> 1) ? wave : nblk + 2 * (wave - (nblk >> 1));
+    int b2 = wave < (nblk >> 1) ? nblk - 1 - wave : b1 + 1;
+    // item geometry (LONG: set per item): first row and row count of the query / key group, causal limit and valid keys in key-group terms
+    int qoff = 0, koff = 0, Tq = p.Tp, Tk = p.Tp, dl = p.mask_delay, kvl = p.kv_len, pair = 0;
+    bool offd = false;
     auto tokbase = [&](int jt) __attribute__((always_inline)) { return jt < 2 ? 32 * b1 + 16 * jt : 32 * b2 + 16 * (jt - 2); };
     char* Ow = Xs + wave * OSTG;
     auto relaunder = [&]() __attribute__((always_inline)) {
@@ -113,12 +124,13 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     // requested at the top of an item BEFORE the barrier that ends the previous one: a wave that has finished its two flash passes
     // has its rows in flight while it waits for the others (and nothing is carried in registers around the loop).
     u32x4 xr[4][8];
-    auto request_x = [&](int seq_) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.X + (size_t)seq_ * p.Tp * p.ldx), 0,
-                                                                            p.Tp * p.ldx * 2, 0x00020000);      // rows >= Tp: zeros
+    auto request_x = [&](int seq_, auto KEYS) __attribute__((always_inline)) {
+        constexpr bool keys = decltype(KEYS)::value;          // the key group's rows of an off-diagonal item: 64 consecutive tokens per wave
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.X + ((size_t)seq_ * p.Tp + (keys ? koff : qoff)) * p.ldx), 0,
+                                                                            (keys ? Tk : Tq) * p.ldx * 2, 0x00020000);      // rows beyond the group: zeros
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            const int off = (tokbase(jt) + (lane >> 5)) * p.ldx * 2 + (lane & 31) * 16;
+            const int off = ((keys ? 64 * wave + 16 * jt : tokbase(jt)) + (lane >> 5)) * p.ldx * 2 + (lane & 31) * 16;
 #pragma unroll
             for (int i = 0; i < 8; ++i) xr[jt][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + i * 2 * p.ldx * 2, 0, 0);
         }
@@ -126,9 +138,24 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     int seq, h;
-    item_of(item, seq, h);
+    if constexpr (LONG) {
+        pair = item / nsh;
+        item_of(item - pair * nsh, seq, h);
+        const int qg = p.pq[pair], kg = p.pk[pair];
+        qoff = qg * TP; koff = kg * TP;
+        Tq = p.Tp - qoff < TP ? p.Tp - qoff : TP;
+        Tk = p.Tp - koff < TP ? p.Tp - koff : TP;
+        offd = qg != kg;
+        dl = p.mask_delay + (qoff - koff);
+        kvl = p.kv_len - koff < Tk ? p.kv_len - koff : Tk;
+        nblk = Tq >> 5;
+        b1 = wave < (nblk >> 1) ? wave : nblk + 2 * (wave - (nblk >> 1));
+        b2 = wave < (nblk >> 1) ? nblk - 1 - wave : b1 + 1;
+    } else {
+        item_of(item, seq, h);
+    }
     relaunder();
-    request_x(seq);
+    request_x(seq, std::false_type{});
     // every wave is done with K / V^T / its staging tile of the previous item (not __syncthreads: its fence would wait for
     // the loads just issued)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -166,7 +193,7 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
         // (still unused) K region: 16 rows x 32 chunks of 16 bytes, chunk index XORed with the row so that both the row-major
         // writes and the fragment reads are conflict-free.  No barrier: a wave only touches its own tile.
         f16x8 x[4][8];
-        {
+        auto rows_to_fragments = [&]() __attribute__((always_inline)) {
             char* xt = Ks + wave * 8192;
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
@@ -180,9 +207,19 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
                 for (int ks = 0; ks < 8; ++ks) x[jt][ks] = __builtin_bit_cast(f16x8, *(const u32x4*)(xt + frow * 512 + (((ks * 4 + fkg) ^ frow) << 4)));
                 wave_lds_sync();
             }
-        }
+        };
+        rows_to_fragments();
         sfor<NITEM>([&](auto N) __attribute__((always_inline)) {
             constexpr int n = decltype(N)::value, kind = n >> 1, ffb = (n & 1) * 2;      // kind 0 q, 1 k, 2 v
+            if constexpr (LONG && n == 2) {
+                // off-diagonal item: Q is done with the query rows; the key group's rows take their place (the K region is still this
+                // wave's to use: the first K rows are written behind the barrier below)
+                if (offd) {
+                    relaunder();
+                    request_x(seq, std::true_type{});
+                    rows_to_fragments();
+                }
+            }
             // this wave's pieces of item n have landed (its X rows are older): the younger requests are 2 (5 - n) pieces
             __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NITEM - 1 - n)));
             __builtin_amdgcn_s_barrier();
@@ -226,10 +263,10 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
                     if constexpr (kind == 0) {
                         qpk[ffb + hf][jt] = v;
                     } else if constexpr (kind == 1) {
-                        const int key = tokbase(jt) + frow, d = (ffb + hf) * 16 + fkg * 4;
+                        const int key = (LONG && offd ? 64 * wave + 16 * jt : tokbase(jt)) + frow, d = (ffb + hf) * 16 + fkg * 4;
                         *(u32x2*)(Ks + (key >> 6) * TILE + swz128(key & 63, d >> 3) + (d & 7) * 2) = v;
                     } else {
-                        const int d = (ffb + hf) * 16 + frow, key = tokbase(jt) + fkg * 4;
+                        const int d = (ffb + hf) * 16 + frow, key = (LONG && offd ? 64 * wave + 16 * jt : tokbase(jt)) + fkg * 4;
                         *(u32x2*)(Vs + (key >> 6) * TILE + swz128(d, (key & 63) >> 3) + (key & 7) * 2) = v;
                     }
                 }
@@ -282,9 +319,9 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
                 const bf16x8 kf = *(const bf16x8*)(kb_ + swz128(kb * 32 + krow, ks * 2 + hi));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? mneg : s[kb], 0, 0, 0);
             }
-        const int wlim = qw0 + p.mask_delay < p.kv_len - 1 ? qw0 + p.mask_delay : p.kv_len - 1;
+        const int wlim = qw0 + dl < kvl - 1 ? qw0 + dl : kvl - 1;
         if (key0 + KB - 1 > wlim) {
-            const int lim = q + p.mask_delay < p.kv_len - 1 ? q + p.mask_delay : p.kv_len - 1;
+            const int lim = q + dl < kvl - 1 ? q + dl : kvl - 1;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -338,13 +375,17 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     };
     auto run_pass = [&](int qb, auto JT0) __attribute__((always_inline)) {
         begin_pass(qb, JT0);
-        int last_key = qw0 + 31 + p.mask_delay;
-        last_key = last_key < p.kv_len - 1 ? last_key : p.kv_len - 1;
+        int last_key = qw0 + 31 + dl;
+        last_key = last_key < kvl - 1 ? last_key : kvl - 1;
         const int jend = last_key < 0 ? 0 : last_key / KB + 1;
         for (int j = 0; j < jend; ++j) tile(j);
         // O[q][d] = O^T / l: stage the wave's 32 x 64 f16 tile, then 128-byte rows to HBM
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
+        // (LONG: a row with no key of this key group in reach contributes nothing)
+        const float inv = LONG ? (l_tot > 0.f ? 1.0f / l_tot : 0.f) : 1.0f / l_tot;
+        if constexpr (LONG) {
+            if (hi == 0) p.lse[((size_t)(pair * p.nseq + seq) * 4 + h) * TP + q] = l_tot > 0.f ? __builtin_amdgcn_logf(l_tot) - mneg[0] : -1e30f;
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -357,12 +398,16 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
                 *(f16x4*)(Ow + lq * 128 + (((db * 4 + g) ^ (lq & 7)) << 4) + hi * 8) = o;
             }
         wave_lds_sync();
-        _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * p.Tp + qw0) * p.ldo + h * 64;
+        _Float16* __restrict__ Og = (_Float16*)p.O + ((size_t)seq * p.Tp + qoff + qw0) * p.ldo + h * 64;
+        int ldo = p.ldo;
+        if constexpr (LONG) {
+            if (offd) { Og = (_Float16*)p.Opart + ((size_t)(p.pslot[pair] * p.nseq + seq) * TP + qw0) * 256 + h * 64; ldo = 256; }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
             const f16x8 v = __builtin_bit_cast(f16x8, *(const u32x4*)(Ow + row * 128 + ((ch ^ (row & 7)) << 4)));
-            *(f16x8*)(Og + (size_t)row * p.ldo + ch * 8) = v;
+            *(f16x8*)(Og + (size_t)row * ldo + ch * 8) = v;
         }
         wave_lds_sync();
     };
@@ -378,6 +423,47 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     }
 #endif                                 // every wave is done with K / V^T / its staging tile before the next item
     }
+}
+
+// O rows of the query groups that have off-diagonal items: O = sum_i 2^(lse_i - lse) O_i over the group's items (the diagonal item's rows are
+// in O itself).  Half a wave per row: lane -> (head, 8 features).
+__global__ __launch_bounds__(256)
+void attn_long_combine_kernel(const InprojAttnParams p) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);           // frame within the sequence
+    const int seq = blockIdx.y;
+    if (row >= p.Tp) return;
+    const int qg = row / TP, ql = row - qg * TP, l32 = threadIdx.x & 31, h = l32 >> 3, d8 = l32 & 7;
+    int idx[8], n = 0, pd = -1;
+    for (int i = 0; i < p.npairs; ++i)
+        if (p.pq[i] == qg) {
+            if (p.pk[i] == qg) pd = i;
+            else if (n < 8) idx[n++] = i;
+        }
+    if (n == 0 || pd < 0) return;
+    _Float16* o = (_Float16*)p.O + ((size_t)seq * p.Tp + row) * p.ldo + h * 64 + d8 * 8;
+    const float ld = p.lse[((size_t)(pd * p.nseq + seq) * 4 + h) * TP + ql];
+    float m = ld, lk[8];
+    for (int i = 0; i < n; ++i) {
+        lk[i] = p.lse[((size_t)(idx[i] * p.nseq + seq) * 4 + h) * TP + ql];
+        m = __builtin_fmaxf(m, lk[i]);
+    }
+    float wd = __builtin_amdgcn_exp2f(ld - m), wsum = wd;
+    const f16x8 od = *(const f16x8*)o;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = wd * (float)od[e];
+    for (int i = 0; i < n; ++i) {
+        const float w = __builtin_amdgcn_exp2f(lk[i] - m);
+        wsum += w;
+        const f16x8 v = *(const f16x8*)((const _Float16*)p.Opart + ((size_t)(p.pslot[idx[i]] * p.nseq + seq) * TP + ql) * 256 + h * 64 + d8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
+    }
+    const float inv = 1.0f / wsum;
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = to_f16_sat(acc[e] * inv);
+    *(f16x8*)o = r;
 }
 
 }  // namespace
@@ -400,10 +486,69 @@ int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream) {
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream) {
     if (p.Tp <= 0 || p.Tp > TP || (p.Tp & 63) || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O) return EEND_EINVAL;
     static EendOncePerDevice attr_once;
-    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel, SMEM)) return EEND_ELAUNCH;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<false>, SMEM)) return EEND_ELAUNCH;
     int n_cu = eend_cu_count() & ~31;                // multiple of 32: a persistent workgroup keeps its head (and its XCD)
     if (n_cu <= 0) n_cu = 32;
     const int nitems = p.nseq * 4;
-    hipLaunchKernelGGL(inproj_attn_stream_kernel, dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, p);
+    InprojAttnParams q = p;
+    q.npairs = 0; q.Opart = nullptr; q.lse = nullptr;
+    hipLaunchKernelGGL(inproj_attn_stream_kernel<false>, dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, q);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+// Windows of more than 512 frames (Tp = 64 m <= 512 * EEND_ATTN_LONG_MAX_GROUPS): the (query group, key group) items a mask reaches, the
+// off-diagonal ones first (they are the long ones).  Returns the number of items, 0 if the shape is not covered; *noff = scratch slots.
+static int attn_long_pairs(int Tp, int mask_delay, int kv_len, unsigned char* pq, unsigned char* pk, unsigned char* pslot, int* noff) {
+    if (Tp <= TP || (Tp & 63) || kv_len < 1 || kv_len > Tp || mask_delay < 0) return 0;
+    const int ng = (Tp + TP - 1) / TP;
+    int n = 0, slots = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int qg = 0; qg < ng; ++qg)
+            for (int kg = 0; kg < ng; ++kg) {
+                if ((pass == 0) == (qg == kg)) continue;
+                if (qg != kg) {
+                    const long qlast = (long)qg * TP + (Tp - qg * TP < TP ? Tp - qg * TP : TP) - 1;
+                    if ((long)kg * TP >= kv_len || (long)kg * TP > qlast + mask_delay) continue;
+                    int per_q = 0;
+                    for (int i = 0; i < n; ++i) per_q += pq[i] == qg;
+                    if (per_q >= 8) return 0;                       // the combine kernel's list
+                }
+                if (n >= EEND_ATTN_LONG_MAX_PAIRS) return 0;
+                pq[n] = (unsigned char)qg; pk[n] = (unsigned char)kg; pslot[n] = (unsigned char)(qg != kg ? slots++ : 0);
+                ++n;
+            }
+    *noff = slots;
+    return n;
+}
+
+int eend_inproj_attn_long_scratch(int nseq, int Tp, int mask_delay, int kv_len, long* part_elems, long* lse_elems) {
+    unsigned char a[EEND_ATTN_LONG_MAX_PAIRS], b[EEND_ATTN_LONG_MAX_PAIRS], c[EEND_ATTN_LONG_MAX_PAIRS];
+    int noff = 0;
+    const int n = attn_long_pairs(Tp, mask_delay, kv_len, a, b, c, &noff);
+    if (n == 0 || nseq <= 0) return EEND_EINVAL;
+    *part_elems = (long)noff * nseq * TP * 256;
+    *lse_elems = (long)n * nseq * 4 * TP;
+    return EEND_OK;
+}
+
+int eend_launch_inproj_attn_long(const InprojAttnParams& p0, hipStream_t stream) {
+    InprojAttnParams p = p0;
+    if ((p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O || !p.lse) return EEND_EINVAL;
+    if (p.mask_delay > (1 << 24)) p.mask_delay = 1 << 24;
+    int noff = 0;
+    p.npairs = attn_long_pairs(p.Tp, p.mask_delay, p.kv_len, p.pq, p.pk, p.pslot, &noff);
+    if (p.npairs == 0 || (noff > 0 && !p.Opart)) return EEND_EINVAL;
+    static EendOncePerDevice attr_once;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<true>, SMEM)) return EEND_ELAUNCH;
+    int n_cu = eend_cu_count() & ~31;
+    if (n_cu <= 0) n_cu = 32;
+    const long nitems = (long)p.nseq * 4 * p.npairs;
+    if (nitems > (1L << 30)) return EEND_EINVAL;
+    hipLaunchKernelGGL(inproj_attn_stream_kernel<true>, dim3(nitems < n_cu ? (int)nitems : n_cu), dim3(512), SMEM, stream, p);
+    if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
+    if (noff > 0) {
+        hipLaunchKernelGGL(attn_long_combine_kernel, dim3((p.Tp + 7) / 8, p.nseq), dim3(256), 0, stream, p);
+        if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
+    }
+    return EEND_OK;
 }

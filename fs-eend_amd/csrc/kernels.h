@@ -131,14 +131,22 @@ struct RetParams {
 int eend_launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 
 // attn_stream.hip: in-projection + causal attention in one launch, token-owning waves and fragment-packed weights (Tp = 512, H = 4)
+#define EEND_ATTN_LONG_MAX_PAIRS 64
 struct InprojAttnParams {
     const void* X; int ldx;      // f16 [nseq*Tp][ldx], 256 model dims
     const void* W;               // f16 packed in_proj_weight (eend_launch_inproj_attn_pack), q rows pre-scaled (ops.QSCALE_LOG2)
     const float* bias;           // [768]
     void* O;                     // f16 [nseq*Tp][ldo]
     int nseq, H, Tp, ldo, mask_delay, kv_len;
+    // windows of more than 512 frames (eend_launch_inproj_attn_long fills the table): items = (query group, key group) of 512 frames
+    int npairs;
+    void* Opart;                 // f16 [off-diagonal slot][nseq][512][256]: normalised partial rows
+    float* lse;                  // [item of the table][nseq][4][512]: log2 of the softmax denominators
+    unsigned char pq[EEND_ATTN_LONG_MAX_PAIRS], pk[EEND_ATTN_LONG_MAX_PAIRS], pslot[EEND_ATTN_LONG_MAX_PAIRS];
 };
 long eend_inproj_attn_packed_nelems();
+int eend_inproj_attn_long_scratch(int nseq, int Tp, int mask_delay, int kv_len, long* part_elems, long* lse_elems);
+int eend_launch_inproj_attn_long(const InprojAttnParams& p, hipStream_t stream);
 int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream);
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream);
 

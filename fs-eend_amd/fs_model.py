@@ -146,9 +146,11 @@ class _Workspace:
         e = lambda *s, dt: torch.empty(*s, dtype=dt, device=dev)
         self.xin16 = torch.zeros(Me, Fin_pad, dtype=f16, device=dev)
         self.h16 = e(Me, D, dt=f16)
-        # bf16 Q / K / V^T of the un-packed attention path: only chunk lengths other than 512 frames read them
-        n_qkv = Mx * D if Tp > 512 else 0
-        self.q, self.k, self.vt = e(n_qkv, dt=bf16), e(n_qkv, dt=bf16), e(n_qkv, dt=bf16)
+        # windows of more than 512 frames: partial rows + softmax denominators of the grouped form (attn_stream.hip), or -- where that form
+        # does not cover the shape -- bf16 Q / K / V^T of the un-packed path; both allocated at first use (grow-only)
+        self.Mx, self.D = Mx, D
+        self.q = self.k = self.vt = None
+        self.attn_part, self.attn_lse = e(0, dt=f16), e(0, dt=f32)
         self.o16 = e(Mx, D, dt=f16)
         self.emb16 = e(Me, D, dt=f16)
         self.a16 = e(Md, D, dt=f16)
@@ -352,8 +354,20 @@ class OnlineTransformerDADiarization(nn.Module):
             o = ws.o16[:nseq * Tp]
             if Tp <= 512:            # token-owning waves, packed weights, Q in registers, K / V never leave the CU (attn_stream.hip)
                 ops.inproj_attn_causal_packed(x16, Ly[wkey + "p"], Ly[bkey], o, nseq, H, Tp, delay, kv)
-            else:                    # longer chunks: bf16 Q / K / V^T through HBM, tiled attention kernel
+                return o
+            # (same-box A/B, 163840 frames: Tp 1024 326 vs 454 us, 2048 586 vs 664 us, 4096 1098 vs 1090 us -- an item re-projects its key
+            #  group's K / V, so the grouped form stops paying at about six groups)
+            need = ops.inproj_attn_long_scratch(nseq, Tp, delay, kv) if Tp <= 3072 else None
+            if need is not None:     # the same kernel on (query group, key group) items of 512 frames + a combine pass over the partial rows
+                if ws.attn_part.numel() < need[0]:
+                    ws.attn_part = torch.empty(need[0], dtype=torch.float16, device=o.device)
+                if ws.attn_lse.numel() < need[1]:
+                    ws.attn_lse = torch.empty(need[1], dtype=torch.float32, device=o.device)
+                ops.inproj_attn_causal_long(x16, Ly[wkey + "p"], Ly[bkey], o, ws.attn_part, ws.attn_lse, nseq, H, Tp, delay, kv)
+            else:                    # bf16 Q / K / V^T through HBM, tiled attention kernel
                 n = nseq * Tp * D
+                if ws.q is None:
+                    ws.q, ws.k, ws.vt = (torch.empty(ws.Mx * ws.D, dtype=torch.bfloat16, device=o.device) for _ in range(3))
                 ops.inproj_heads(x16, Ly[wkey], Ly[bkey], ws.q[:n], ws.k[:n], ws.vt[:n], nseq, Tp, H)
                 ops.attn_causal(ws.q[:n], ws.k[:n], ws.vt[:n], o, nseq, H, Tp, delay, kv, scale=ops.LN2)
             return o

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "eend_inproj_attn_packed_elems": [],
     "eend_inproj_attn_pack_f16": [_vp, _vp, _vp],
     "eend_inproj_attn_causal_packed_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "eend_inproj_attn_long_scratch_elems": [_i, _i, _i, _i, _vp, _vp],
+    "eend_inproj_attn_causal_long_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "eend_spk_stream_elems": [],
     "eend_spk_stream_ok": [_i, _i],
     "eend_spk_stream_pack_f16": [_vp, _vp, _vp, _vp],

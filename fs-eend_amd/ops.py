@@ -309,6 +309,31 @@ def inproj_attn_causal_packed(x16, w_packed, b_in, o16, nseq, H, Tp, mask_delay=
                "eend_inproj_attn_causal_packed_f16")
 
 
+def inproj_attn_long_scratch(nseq, Tp, mask_delay=0, kv_len=None):
+    """(partial-row f16 elements, lse f32 elements) eend_inproj_attn_causal_long_f16 needs for this shape, or None if it does not cover it."""
+    import ctypes
+    L = _lib.load()
+    a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    rc = L.eend_inproj_attn_long_scratch_elems(nseq, Tp, mask_delay, Tp if kv_len is None else kv_len, ctypes.byref(a), ctypes.byref(b))
+    return None if rc != 0 else (a.value, b.value)
+
+
+def inproj_attn_causal_long(x16, w_packed, b_in, o16, part16, lse32, nseq, H, Tp, mask_delay=0, kv_len=None):
+    """Packed in-projection + causal attention for windows of more than 512 frames (attn_stream.hip, groups of 512 frames + combine)."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(w_packed, F16, "w_packed"); _chk(b_in, F32, "b_in"); _chk(o16, F16, "o16"); _chk(part16, F16, "part16"); _chk(lse32, F32, "lse32")
+    kv = Tp if kv_len is None else kv_len
+    need = inproj_attn_long_scratch(nseq, Tp, mask_delay, kv)
+    if need is None:
+        raise _lib.EendHipError("inproj_attn_causal_long: shape not covered")
+    if (w_packed.numel() != L.eend_inproj_attn_packed_elems() or b_in.numel() != 768 or x16.shape[0] < nseq * Tp or o16.shape[0] < nseq * Tp
+            or part16.numel() < need[0] or lse32.numel() < need[1]):
+        raise _lib.EendHipError("inproj_attn_causal_long: shape mismatch")
+    _lib.check(L.eend_inproj_attn_causal_long_f16(_p(x16), x16.stride(0), _p(w_packed), _p(b_in), _p(o16), _p(part16), _p(lse32), nseq, H, Tp,
+                                                  o16.stride(0), mask_delay, kv, _stream()),
+               "eend_inproj_attn_causal_long_f16")
+
+
 def spk_stream_pack(wo16, win16):
     """Pack Wo1 [256][256] + in_proj_weight [768][256] (f16) into the weight stream of attnout_spk_stream."""
     L = _lib.load()

@@ -460,6 +460,18 @@ int eend_inproj_attn_pack_f16(const void* W_in, void* packed_out, void* stream);
 int eend_inproj_attn_causal_packed_f16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16,
                                        int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
 
+/* The same operator for windows of more than 512 frames (round 6; Tp = 64 m, 1 <= kv_len <= Tp, mask_delay >= 0; whole recordings at
+ * test time, FS model :147 on an un-chunked sequence): the frames are cut into groups of 512 and the launch runs one item of the kernel
+ * above per (sequence, head, query group, key group the mask reaches).  The item of a group with itself writes its rows of O; an item
+ * of two different groups projects Q from the query group's rows and K / V from the key group's, and leaves normalised partial rows in
+ * part_f16; every item leaves the log2 of its softmax denominators in lse_f32, and a second launch weighs the partial rows of a query
+ * group with them (O = sum_i 2^(lse_i - lse) O_i).  Scratch sizes from eend_inproj_attn_long_scratch_elems (EEND_EINVAL for a shape
+ * this form does not cover: Tp <= 512 -- use the entry above --, more than 64 items or 9 key groups per query group; the caller
+ * keeps eend_inproj_heads_bf16 + eend_attn_causal_bf16 there).  Same weights, bias and mask convention as the entry above. */
+int eend_inproj_attn_long_scratch_elems(int nseq, int Tp, int mask_delay, int kv_len, long long* part_f16_elems, long long* lse_f32_elems);
+int eend_inproj_attn_causal_long_f16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16, void* part_f16,
+                                     float* lse_f32, int nseq, int H, int Tp, int ldo, int mask_delay, int kv_len, void* stream);
+
 
 /* attractors / ||attractors||_2 and logits[b,t,c] = <emb[b,t], attractors[b,t,c]>
  * (FS model :43,:60 / :76,:79; LS model :89,:117).  emb f32 [B][Tp][D], attr f32 [B*C][Tp][D]

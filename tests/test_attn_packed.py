@@ -107,3 +107,44 @@ def test_model_chunk_lengths_agree_with_oracle(hip_lib, dev, B, T, C):
     for x, y in zip(got[0], want[0]):
         assert x.shape == y.shape and torch.isfinite(x).all()
         assert (x.cpu() - y).abs().max() < 1e-3, float((x.cpu() - y).abs().max())
+
+
+@pytest.mark.parametrize("nseq,delay,kv_len,Tp", [(3, 0, 1000, 1024), (2, 0, 600, 640), (5, 3, 1500, 1536), (2, 0, 2040, 2048), (1, 5000, 1000, 1024),
+                                                   (2, 700, 1100, 1152), (40, 0, 1024, 1024), (2, 0, 520, 1024), (1, 0, 4000, 4096), (3, 600, 300, 1024)])
+def test_inproj_attn_long(hip_lib, dev, nseq, delay, kv_len, Tp):
+    """Windows of more than 512 frames on attn_stream.hip's (query group, key group) items + combine pass, against fp32 torch and the
+    two-kernel path (in-projection, tiled attn.hip); covers look-ahead masks that reach later key groups, key groups cut by kv_len
+    (rows without a key in reach of an item) and a last group shorter than 512 frames."""
+    from fs_eend_amd import ops
+    x, w, b = _case(dev, nseq, Tp, nseq * 13 + delay + Tp)
+    wp = ops.inproj_attn_pack(w)
+    need = ops.inproj_attn_long_scratch(nseq, Tp, delay, kv_len)
+    assert need is not None
+    part = torch.full((need[0],), float("nan"), dtype=F16, device=dev)
+    lse = torch.full((need[1],), float("nan"), dtype=F32, device=dev)
+    o = torch.full((nseq * Tp, 256), float("nan"), dtype=F16, device=dev)
+    ops.inproj_attn_causal_long(x, wp, b, o, part, lse, nseq, 4, Tp, delay, kv_len)
+    o1 = _two_kernel(x, w, b, nseq, Tp, delay, kv_len)
+    assert torch.isfinite(o).all()
+    e_old = (o.float() - o1.float()).abs().max().item()
+    if nseq * Tp <= 8192:
+        want = _fp32(x, w, b, nseq, Tp, delay, kv_len)
+        e_ref = (o.float() - want).abs().max().item()
+        e_ref_old = (o1.float() - want).abs().max().item()
+        print(f"long vs fp32 {e_ref:.2e} (two kernels vs fp32 {e_ref_old:.2e}); long vs two kernels {e_old:.2e}")
+        assert e_ref < 2e-2
+    assert e_old < 3e-2
+
+
+def test_inproj_attn_long_scratch_shapes(hip_lib, dev):
+    """the scratch query is the shape predicate: windows <= 512 frames, ragged lengths and more than 64 items are not covered"""
+    from fs_eend_amd import ops
+    assert ops.inproj_attn_long_scratch(4, 512) is None
+    assert ops.inproj_attn_long_scratch(4, 1000) is None
+    assert ops.inproj_attn_long_scratch(4, 1024, 0, 0) is None
+    assert ops.inproj_attn_long_scratch(4, 1024) == (1 * 4 * 512 * 256, 3 * 4 * 4 * 512)
+    assert ops.inproj_attn_long_scratch(4, 1024, 10000) == (2 * 4 * 512 * 256, 4 * 4 * 4 * 512)
+    assert ops.inproj_attn_long_scratch(1, 4096) is not None               # 36 items
+    assert ops.inproj_attn_long_scratch(1, 4096, 10000) is not None        # 64 items
+    assert ops.inproj_attn_long_scratch(1, 4608, 10000) is None            # 81 items
+    assert ops.inproj_attn_long_scratch(1, 6144) is None                   # 78 items (and 11 key groups for the last query group)
