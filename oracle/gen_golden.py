@@ -56,6 +56,12 @@ FS_CASES = [
     # 12 speaker slots = max_speakers 10 + 2 (the dihard configs of LS-EEND; the largest slot count the kernels dispatch),
     # full-size model, ragged
     dict(name="fs_c12_T500", cfg=fs_cfg(), lengths=[500, 317], C=12, seed=8, pseed=19, xseed=787),
+    # whole recordings at test time (the infer configs set chunk_size to the recording length): windows of more than 512 frames,
+    # three groups of the grouped attention form with a ragged last one (Tp = 1344), full-size model
+    dict(name="fs_long_T1300_c4", cfg=fs_cfg(), lengths=[1300, 900], C=4, seed=9, pseed=20, xseed=788),
+    # ... and with look-ahead in the masks (keys of the next group in reach of a group's last queries), two groups (Tp = 704)
+    dict(name="fs_long_delay2_T700", cfg=fs_cfg(enc_n_layers=1, dec_n_layers=1, dec_dim_feedforward=256, mask_delay=2),
+         lengths=[700, 520], C=5, seed=10, pseed=21, xseed=789),
 ]
 
 FS_FWD_CASES = [

@@ -1,2 +1,2 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
-timeout 600 python tools/ab_attn_long.py 2>&1 | tail -12
+timeout 1500 python -m pytest tests/test_fs_parity.py -q -s -p no:cacheprovider -k "long" 2>&1 | grep -v "^$" | tail -12
