@@ -260,15 +260,20 @@ def test_bn_cast_pad(hip_lib, dev):
     close(out2.view(B, Tp, Fpad), want2, 1e-3, 1e-3, "cast+pad")
 
 
-def test_head_l2dot(hip_lib, dev):
+@pytest.mark.parametrize("B,T,Tp,C,D,a16", [(2, 50, 64, 6, 256, False), (1, 7, 64, 3, 256, False), (3, 61, 64, 5, 256, True), (1, 1, 64, 1, 256, True),
+                                             (2, 130, 192, 10, 256, False), (2, 33, 64, 4, 128, False), (2, 33, 64, 4, 512, True)])
+def test_head_l2dot(hip_lib, dev, B, T, Tp, C, D, a16):
+    """rows-in-flight form (d_model 256, four rows per wave, ragged last wave) and the general one-row-per-wave form"""
     from fs_eend_amd import ops
-    B, T, Tp, C, D = 2, 50, 64, 6, 256
     emb = rnd((B, Tp, D), dev, 55)
     emb = emb / emb.norm(dim=-1, keepdim=True)
     attr = rnd((B * C, Tp, D), dev, 56) * 3
-    ao = torch.empty((B, T, C, D), dtype=F32, device=dev)
-    lg = torch.empty((B, T, C), dtype=F32, device=dev)
+    if a16:
+        attr = attr.to(F16)
+    ao = torch.full((B, T, C, D), float("nan"), dtype=F32, device=dev)
+    lg = torch.full((B, T, C), float("nan"), dtype=F32, device=dev)
     ops.head_l2dot(emb.view(-1, D), attr.view(-1, D), ao, lg, B, T, Tp, C, D)
+    attr = attr.float()
     a = attr.view(B, C, Tp, D)[:, :, :T].permute(0, 2, 1, 3)
     a = a / a.norm(dim=-1, keepdim=True)
     close(ao, a, 1e-6, 1e-5, "attractor l2norm")
