@@ -179,6 +179,37 @@ int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const fl
     return eend_launch_proj_xres(q, (hipStream_t)stream);
 }
 
+int eend_proj_stream_elems(int N) { return (int)eend_proj_stream_nelems(N); }
+
+int eend_proj_stream_pack_f16(const void* W, void* stream_out, int N, void* stream) {
+    return eend_launch_proj_stream_pack(W, stream_out, N, (hipStream_t)stream);
+}
+
+static bool proj_stream_params(ProjStreamParams& p, const void* X, int ldx, const void* wstream, const float* bias, int M, int N, int Tp, int H,
+                               const eend_proj_group* groups) {
+    if (!groups || N <= 0 || (N % 256) != 0 || N > 1024) return false;
+    memset(&p, 0, sizeof(p));
+    p.X = X; p.ldx = ldx; p.wstream = wstream; p.bias = bias; p.M = M; p.N = N; p.Tp = Tp; p.H = H;
+    for (int g = 0; g < N / 256; ++g) {
+        p.kind_a[g] = groups[g].rows ? groups[g].rows_kind : 0; p.bf_a[g] = groups[g].rows_bf16; p.ld_a[g] = groups[g].rows_ld;
+        p.out_a[g] = groups[g].rows; p.out_b[g] = groups[g].rows2_bf16_heads; p.out_t[g] = groups[g].heads_t; p.bf_t[g] = groups[g].heads_t_bf16;
+    }
+    return true;
+}
+
+int eend_proj_stream_ok(int ldx, int M, int N, int Tp, int H, const eend_proj_group* groups) {
+    ProjStreamParams p;
+    if (!proj_stream_params(p, (const void*)16, ldx, (const void*)16, (const float*)16, M, N, Tp, H, groups)) return 0;
+    return eend_proj_stream_fits(p) ? 1 : 0;
+}
+
+int eend_proj_stream_f16(const void* X, int ldx, const void* wstream, const float* bias, int M, int N, int Tp, int H,
+                         const eend_proj_group* groups, void* stream) {
+    ProjStreamParams p;
+    if (!proj_stream_params(p, X, ldx, wstream, bias, M, N, Tp, H, groups)) return EEND_EINVAL;
+    return eend_launch_proj_stream(p, (hipStream_t)stream);
+}
+
 int eend_attn_causal_lse_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, float* lse, int nseq, int H,
                               int Tp, int ldo, int mask_delay, int kv_len, float scale, const eend_dropout* drop,
                               void* stream) {

@@ -377,6 +377,24 @@ struct ProjParams {       // proj.hip: up to four 256-feature output groups
     int ld[4];
 };
 int eend_launch_proj_xres(const ProjParams& p, hipStream_t stream);
+// proj_stream.hip (round 6): the same projections on a packed weight stream, wave-owned rows, up to three destinations per 256-feature group
+struct ProjStreamParams {
+    const void* X; int ldx;   // f16 [M][ldx], 256 features
+    const void* wstream;      // eend_launch_proj_stream_pack output for W f16 [N][256]
+    const float* bias;        // [N]
+    int M, N, Tp, H;
+    int kind_a[4];            // 0 none, 1 row-major [M][ld_a] (pointer at the group's first column), 2 head rows [seq][H][Tp][64]
+    int bf_a[4];              // element type of out_a (else f16)
+    int ld_a[4];
+    void* out_a[4];
+    void* out_b[4];           // optional: bf16 head rows (second copy)
+    void* out_t[4];           // optional: transposed head rows [seq][H][64][Tp]
+    int bf_t[4];
+};
+long eend_proj_stream_nelems(int N);
+int eend_launch_proj_stream_pack(const void* W, void* out, int N, hipStream_t stream);
+bool eend_proj_stream_fits(const ProjStreamParams& p);
+int eend_launch_proj_stream(const ProjStreamParams& p, hipStream_t stream);
 int eend_launch_ret_chunk_full(const RetParams& p, hipStream_t stream);
 
 // ret_stream.hip (round 5): the retention with its q / k / v / g projections fused on chip (pass 1: chunk K^T V products, pass 2: rows)

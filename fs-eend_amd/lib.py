@@ -43,6 +43,10 @@ PROTOTYPES = {
     "eend_inproj_attn_packed_elems": [],
     "eend_inproj_attn_pack_f16": [_vp, _vp, _vp],
     "eend_inproj_attn_causal_packed_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "eend_proj_stream_elems": [_i],
+    "eend_proj_stream_pack_f16": [_vp, _vp, _i, _vp],
+    "eend_proj_stream_ok": [_i, _i, _i, _i, _i, _vp],
+    "eend_proj_stream_f16": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "eend_inproj_attn_long_scratch_elems": [_i, _i, _i, _i, _vp, _vp],
     "eend_inproj_attn_causal_long_f16": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "eend_spk_stream_elems": [],
@@ -156,6 +160,12 @@ class PrepEntry(ctypes.Structure):
                 ("A", ctypes.c_int), ("B", ctypes.c_int), ("C", ctypes.c_int), ("Cpad", ctypes.c_int),
                 ("sa", ctypes.c_long), ("sb", ctypes.c_long), ("sc", ctypes.c_long),
                 ("dtype", ctypes.c_int), ("nscale", ctypes.c_int), ("scale", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+class ProjGroup(ctypes.Structure):
+    """eend_proj_group of include/eend_hip.h."""
+    _fields_ = [("rows", ctypes.c_void_p), ("rows_kind", ctypes.c_int), ("rows_bf16", ctypes.c_int), ("rows_ld", ctypes.c_int),
+                ("rows2_bf16_heads", ctypes.c_void_p), ("heads_t", ctypes.c_void_p), ("heads_t_bf16", ctypes.c_int)]
 
 
 class Dropout(ctypes.Structure):

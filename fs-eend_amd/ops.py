@@ -334,6 +334,50 @@ def inproj_attn_causal_long(x16, w_packed, b_in, o16, part16, lse32, nseq, H, Tp
                "eend_inproj_attn_causal_long_f16")
 
 
+def proj_stream_pack(w16, out=None):
+    """Re-order W f16 [N][256] (N = 256 n <= 1024) into the packed weight stream of proj_stream; None if the shape has no stream form."""
+    L = _lib.load()
+    _chk(w16, F16, "w16")
+    n = L.eend_proj_stream_elems(int(w16.shape[0])) if (w16.dim() == 2 and w16.shape[1] == 256) else 0
+    if n <= 0:
+        return None
+    if out is None:
+        out = torch.empty(n, dtype=F16, device=w16.device)
+    _lib.check(L.eend_proj_stream_pack_f16(_p(w16), _p(out), int(w16.shape[0]), _stream()), "eend_proj_stream_pack_f16")
+    return out
+
+
+def _proj_groups(groups):
+    arr = (_lib.ProjGroup * len(groups))()
+    for a, gd in zip(arr, groups):
+        rows, kind, t = gd.get("rows"), gd.get("kind", 0), gd.get("heads_t")
+        a.rows = _p(rows); a.rows_kind = kind if rows is not None else 0
+        a.rows_bf16 = 1 if (rows is not None and rows.dtype == BF16) else 0
+        a.rows_ld = int(gd.get("ld", 0))
+        a.rows2_bf16_heads = _p(gd.get("rows2"))
+        a.heads_t = _p(t); a.heads_t_bf16 = 1 if (t is not None and t.dtype == BF16) else 0
+    return arr
+
+
+def proj_stream_ok(ldx, M, N, Tp, H, groups):
+    return bool(_lib.load().eend_proj_stream_ok(int(ldx), int(M), int(N), int(Tp), int(H), _proj_groups(groups)))
+
+
+def proj_stream(x16, wstream, bias, M, N, Tp, H, groups):
+    """Y = x16 W^T + bias on the packed stream; groups: one dict per 256 output features with rows (+ kind 1 row-major / 2 head rows, ld),
+    rows2 (bf16 head rows), heads_t (transposed head rows) -- see eend_proj_stream_f16."""
+    L = _lib.load()
+    _chk(x16, F16, "x16"); _chk(wstream, F16, "wstream"); _chk(bias, F32, "bias")
+    if wstream.numel() != L.eend_proj_stream_elems(N) or bias.numel() != N or len(groups) != N // 256 or x16.shape[0] < M:
+        raise _lib.EendHipError("proj_stream: shape mismatch")
+    for gd in groups:
+        for k in ("rows2",):
+            if gd.get(k) is not None:
+                _chk(gd[k], BF16, k)
+    _lib.check(L.eend_proj_stream_f16(_p(x16), x16.stride(0), _p(wstream), _p(bias), M, N, Tp, H, _proj_groups(groups), _stream()),
+               "eend_proj_stream_f16")
+
+
 def spk_stream_pack(wo16, win16):
     """Pack Wo1 [256][256] + in_proj_weight [768][256] (f16) into the weight stream of attnout_spk_stream."""
     L = _lib.load()

@@ -273,6 +273,14 @@ class TrainStepBase:
                 if n > 0 and self.W[key].shape[1] == D:
                     self._ffn_streams[pre] = (torch.empty(n, dtype=F16, device=self.dev), torch.empty(n, dtype=BF16, device=self.dev), Fh)
         self._stream_of_w1 = {self.W[pre + ".w1"].data_ptr(): pre for pre in self._ffn_streams}
+        # K = 256 input projections with a packed-stream form (proj_stream.hip): the retention q / k / v / g operand copies (X.wqkvg)
+        self._proj_streams = {}
+        for key in list(self.W):
+            w = self.W[key]
+            if key.endswith(".wqkvg") and w.dtype == F16 and w.dim() == 2 and w.shape[1] == D:
+                n = _lib.load().eend_proj_stream_elems(int(w.shape[0]))
+                if n > 0:
+                    self._proj_streams[key] = torch.empty(n, dtype=F16, device=self.dev)
 
     def prep_weights(self):
         """f32 parameters -> MFMA operand copies (one launch), then the packed FFN streams."""
@@ -280,6 +288,8 @@ class TrainStepBase:
         for pre, (fw, bw, Fh) in self._ffn_streams.items():
             _call("eend_ffn_train_stream_pack", self.W[pre + ".w1"], self.W[pre + ".w2"], fw, Fh)
             _call("eend_ffn_train_stream_pack", self.W[pre + ".w2T"], self.W[pre + ".w1T"], bw, Fh)
+        for key, buf in self._proj_streams.items():
+            _call("eend_proj_stream_pack_f16", self.W[key], buf, int(self.W[key].shape[0]))
 
     def _ffn_stream_for(self, w1, M, F):
         """Key of the packed streams serving this FFN at M rows, or None (the un-packed, row-major entries then)."""

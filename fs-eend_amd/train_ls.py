@@ -234,13 +234,24 @@ class LsTrainStep(TrainStepBase):
         _call("eend_linear_res_scale_ln_train_f16", a16, a16.stride(0), w, w.stride(0), bias, h32, alpha, self._P(ln + ".weight"),
               self._P(ln + ".bias"), 1e-5, h32, site.out16, site.xhat, site.rstd, M, K, drop)
 
+    proj_stream_min_rows = 49152        # rows from which the packed-stream projection beats the two launches (tests set 0 to force it)
+
     def _ret_fwd(self, bf, x16, wkey, sv: _RetSave, nseq, Tp, Tv):
         W = self.W
         n = nseq * Tp * D
         q, k, kt, vt = bf.fq[:n], bf.fk[:n], bf.fkt[:n], bf.fvt[:n]
-        ops.retention_proj(x16, W[wkey + ".wqkvg"], W[wkey + ".bqkvg"], q, k, kt, vt, sv.g, nseq, Tp, H)
-        _call("eend_inproj_heads_train_bf16", x16, x16.stride(0), W[wkey + ".wqkvg"], W[wkey + ".bqkvg"], sv.q, sv.qt, sv.k, sv.kt,
-              sv.v, sv.vt, nseq, Tp, H)
+        ws = self._proj_streams.get(wkey + ".wqkvg")
+        groups = [dict(rows=q, kind=2, rows2=sv.q), dict(rows=k, kind=2, rows2=sv.k, heads_t=kt), dict(rows2=sv.v, heads_t=vt),
+                  dict(rows=sv.g, kind=1, ld=D)]
+        if ws is not None and sv.qt is None and nseq * Tp >= self.proj_stream_min_rows and ops.proj_stream_ok(x16.stride(0), nseq * Tp, 4 * D, Tp, H, groups):
+            # one pass over the rows for the f16 operands of the forward kernel AND the bf16 head rows the backward keeps (proj_stream.hip:
+            # [393216, 1024] 526 us against 803 us for the two projections below, [65536, 1024] 101 against 149 us; below about 48 k rows
+            # the 256-row tiles leave CUs idle and the two launches win)
+            ops.proj_stream(x16, ws, W[wkey + ".bqkvg"], nseq * Tp, 4 * D, Tp, H, groups)
+        else:
+            ops.retention_proj(x16, W[wkey + ".wqkvg"], W[wkey + ".bqkvg"], q, k, kt, vt, sv.g, nseq, Tp, H)
+            _call("eend_inproj_heads_train_bf16", x16, x16.stride(0), W[wkey + ".wqkvg"], W[wkey + ".bqkvg"], sv.q, sv.qt, sv.k, sv.kt,
+                  sv.v, sv.vt, nseq, Tp, H)
         _call("eend_retention_chunk_train_f16", q, k, kt, vt, sv.g, sv.ctx, sv.rhat, sv.rc, bf.st, bf.kv_ws, bf.cscale, bf.sexp, nseq, H,
               Tp, self.L, D, D, 1e-6, Tv)
 

@@ -510,6 +510,32 @@ typedef struct eend_dropout {
     float scale;
 } eend_dropout;
 
+/* K = 256 input projections on a packed weight stream (proj_stream.hip, round 6): nn.MultiheadAttention's in_proj (FS model :147,
+ * merge_tfm_encoder.py:379-385) and MultiScaleRetention's q / k / v / g projections (LS retention.py:146-160) in the training forward,
+ * where the f16 operands of the forward kernel and the bf16 Q / K / V the hand-written backward keeps used to be two projections of the
+ * same rows.  Y = X W^T + bias, X f16 [M][ldx] (256 features), W f16 [N][256], N = 256 n <= 1024, re-ordered once per parameter version
+ * by eend_proj_stream_pack_f16 into eend_proj_stream_elems(N) f16 elements.  Each 256-feature output group g names up to three
+ * destinations, all written from one pass over the rows:
+ *   rows            rows_kind 1: [M][rows_ld] row-major (pointer at the group's first column); 2: head rows [seq][H][Tp][64];
+ *                   f16, or bf16 with rows_bf16
+ *   rows2_bf16_heads  a second copy as bf16 head rows
+ *   heads_t         transposed head rows [seq][H][64][Tp] (f16, or bf16 with heads_t_bf16)
+ * Head destinations need H = 4, Tp a multiple of 64 and M a multiple of Tp.  eend_proj_stream_ok is the shape predicate (pointers of
+ * `groups` only tested for null / alignment); EEND_EINVAL on anything else -- the caller keeps eend_inproj_heads_train_bf16 /
+ * eend_retention_proj_f16 / eend_gemm_f16 there. */
+typedef struct eend_proj_group {
+    void* rows;
+    int rows_kind, rows_bf16, rows_ld;
+    void* rows2_bf16_heads;
+    void* heads_t;
+    int heads_t_bf16;
+} eend_proj_group;
+int eend_proj_stream_elems(int N);
+int eend_proj_stream_pack_f16(const void* W, void* stream_out, int N, void* stream);
+int eend_proj_stream_ok(int ldx, int M, int N, int Tp, int H, const eend_proj_group* groups);
+int eend_proj_stream_f16(const void* X, int ldx, const void* wstream, const float* bias, int M, int N, int Tp, int H,
+                         const eend_proj_group* groups, void* stream);
+
 /* eend_linear_res_ln_f16 that also saves what LayerNorm backward needs: xhat_f16 [M][256] = the normalised
  * row before the affine, rstd [M] = 1/sigma.  (torch.nn.LayerNorm inside nn.TransformerEncoderLayer, FS model
  * :147,:174; merge_tfm_encoder.py:364,373-374.)  `drop` acts on (A W^T + bias) before the residual (dropout1 /
