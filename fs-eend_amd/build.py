@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["gemm.hip", "ffn.hip", "ffn_stream.hip", "convert_f32.hip", "convert_rows.hip", "encin.hip", "conv_stream.hip", "proj.hip", "attn.hip", "attn_full.hip", "attn_stream.hip", "spk_stream.hip", "embloss.hip", "postproc.hip", "feature.hip", "pit.hip", "misc.hip", "retention.hip", "retention_full.hip", "ret_stream.hip", "stream.hip", "skinny.hip", "gemm_f32.hip", "api.hip",
            # training step: backward kernels, optimiser
-           "wgrad.hip", "ffn_train_stream.hip", "proj_stream.hip", "attn_bwd.hip", "attn_bwd_fused.hip", "train_rows.hip", "embloss_bwd.hip", "optim.hip", "api_train.hip",
+           "wgrad.hip", "ffn_train_stream.hip", "proj_stream.hip", "gemm_acc_stream.hip", "attn_bwd.hip", "attn_bwd_fused.hip", "train_rows.hip", "embloss_bwd.hip", "optim.hip", "api_train.hip",
            # LS-EEND training step
            "ls_train.hip", "retention_bwd.hip"]
 LIB = os.path.join(CSRC, "libeend_hip.so")

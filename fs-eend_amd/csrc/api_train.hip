@@ -179,6 +179,21 @@ int eend_inproj_heads_train_bf16(const void* A, int lda, const void* W, const fl
     return eend_launch_proj_xres(q, (hipStream_t)stream);
 }
 
+int eend_gemm_acc_stream_elems(int K) { return (int)eend_gemm_acc_stream_nelems(K); }
+
+int eend_gemm_acc_stream_ok(int M, int K, int lda) { return eend_gemm_acc_stream_fits(M, K, lda) ? 1 : 0; }
+
+int eend_gemm_acc_stream_pack_bf16(const void* Wt, int ldw, void* stream_out, int K, void* stream) {
+    return eend_launch_gemm_acc_stream_pack(Wt, ldw, stream_out, K, (hipStream_t)stream);
+}
+
+int eend_gemm_acc_stream_bf16(const void* A, int lda, const void* wstream, float* g_f32, int M, int K, void* stream) {
+    GemmAccStreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.wstream = wstream; p.g = g_f32; p.M = M; p.K = K;
+    return eend_launch_gemm_acc_stream(p, (hipStream_t)stream);
+}
+
 int eend_proj_stream_elems(int N) { return (int)eend_proj_stream_nelems(N); }
 
 int eend_proj_stream_pack_f16(const void* W, void* stream_out, int N, void* stream) {

@@ -391,6 +391,17 @@ struct ProjStreamParams {
     void* out_t[4];           // optional: transposed head rows [seq][H][64][Tp]
     int bf_t[4];
 };
+// gemm_acc_stream.hip (round 6): g[M][256] += A[M][K] Wt^T on a packed weight stream (data gradient of a K -> 256 linear layer)
+struct GemmAccStreamParams {
+    const void* A; int lda;   // bf16 [M][lda]
+    const void* wstream;      // eend_launch_gemm_acc_stream_pack output for Wt bf16 [256][K]
+    float* g;                 // f32 [M][256], in place
+    int M, K;
+};
+long eend_gemm_acc_stream_nelems(int K);
+int eend_launch_gemm_acc_stream_pack(const void* Wt, int ldw, void* out, int K, hipStream_t stream);
+bool eend_gemm_acc_stream_fits(int M, int K, int lda);
+int eend_launch_gemm_acc_stream(const GemmAccStreamParams& p, hipStream_t stream);
 long eend_proj_stream_nelems(int N);
 int eend_launch_proj_stream_pack(const void* W, void* out, int N, hipStream_t stream);
 bool eend_proj_stream_fits(const ProjStreamParams& p);

@@ -281,6 +281,16 @@ class TrainStepBase:
                 n = _lib.load().eend_proj_stream_elems(int(w.shape[0]))
                 if n > 0:
                     self._proj_streams[key] = torch.empty(n, dtype=F16, device=self.dev)
+        # data gradients g += dY W of the K -> 256 projections with a large K (attention in-projections X.in_wT / X.in2_wT: K = 768, retention
+        # projections X.wqkvgT: K = 1024): packed streams of gemm_acc_stream.hip from the transposed bf16 operand copies [256][K]
+        self._gacc_streams = {}
+        for key in list(self.W):
+            w = self.W[key]
+            if (key.endswith(".in_wT") or key.endswith(".in2_wT") or key.endswith(".wqkvgT")) and w.dtype == BF16 and w.dim() == 2 and w.shape[0] == D:
+                n = _lib.load().eend_gemm_acc_stream_elems(int(w.shape[1]))
+                if n > 0:
+                    self._gacc_streams[key] = torch.empty(n, dtype=BF16, device=self.dev)
+        self._gacc_of_w = {self.W[k].data_ptr(): k for k in self._gacc_streams}
 
     def prep_weights(self):
         """f32 parameters -> MFMA operand copies (one launch), then the packed FFN streams."""
@@ -290,6 +300,9 @@ class TrainStepBase:
             _call("eend_ffn_train_stream_pack", self.W[pre + ".w2T"], self.W[pre + ".w1T"], bw, Fh)
         for key, buf in self._proj_streams.items():
             _call("eend_proj_stream_pack_f16", self.W[key], buf, int(self.W[key].shape[0]))
+        for key, buf in self._gacc_streams.items():
+            w = self.W[key]
+            _call("eend_gemm_acc_stream_pack_bf16", w, w.stride(0), buf, int(w.shape[1]))
 
     def _ffn_stream_for(self, w1, M, F):
         """Key of the packed streams serving this FFN at M rows, or None (the un-packed, row-major entries then)."""
@@ -373,10 +386,28 @@ class TrainStepBase:
         _call("eend_layernorm_bwd_f32", g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
               self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, drop)
 
+    def _gemm_acc(self, a16, K, wT, g32, M):
+        """g32 += a16 wT^T in place: the packed-stream kernel where it pays (see _gemm_acc_ln_bwd), else gemm.hip's tiles."""
+        key = self._gacc_of_w.get(wT.data_ptr())
+        if key is not None and M >= self.gacc_stream_min_rows and _lib.load().eend_gemm_acc_stream_ok(M, K, K):
+            _call("eend_gemm_acc_stream_bf16", a16, K, self._gacc_streams[key], g32, M, K)
+        else:
+            _call("eend_gemm_acc_bf16", a16, K, wT, K, g32, 1.0, g32, None, M, K)
+
+    gacc_stream_min_rows = 98304        # rows from which gemm_acc_stream.hip + eend_layernorm_bwd_f32 beat the fused tiled launch (tests set 0)
+
     def _gemm_acc_ln_bwd(self, a16, K, wT, g32, site, ln, ds16, M, drop=None, bias=None):
         """g32 += a16 wT^T (the data gradient of a K -> 256 linear joining the residual-gradient stream), then the LayerNorm backward of the
         post-norm site `site` that stream now stands in front of -- one launch (gemm.hip EPI_RES_LNBWD): `_ln_bwd`'s outputs, the f32 stream
         read and written once instead of twice."""
+        key = self._gacc_of_w.get(wT.data_ptr())
+        if key is not None and M >= self.gacc_stream_min_rows and _lib.load().eend_gemm_acc_stream_ok(M, K, K):
+            # from about 100 k rows the packed-stream GEMM (wave-owned rows, no k-tile barriers) + the LayerNorm backward as its own pass beat
+            # the tiled GEMM with the LayerNorm backward in its epilogue: [196608, 256, 768] 172 + 95 us against 314 us, [393216, 256, 1024]
+            # 363 + 192 against 665 us (same box)
+            _call("eend_gemm_acc_stream_bf16", a16, K, self._gacc_streams[key], g32, M, K)
+            self._ln_bwd(g32, site, ln, ds16, M, drop, bias)
+            return
         _call("eend_gemm_acc_lnbwd_bf16", a16, K, wT, K, g32, site.xhat, site.rstd, self._P(ln + ".weight"), g32, ds16, self.ws, WS_FLOATS,
               self._G(ln + ".weight"), self._G(ln + ".bias"), None if bias is None else self._G(bias), M, K, drop)
 
@@ -704,7 +735,7 @@ class FsTrainStep(TrainStepBase):
             site, ln, ndrop, nbias = next_ln
             self._gemm_acc_ln_bwd(dqkv16, 3 * D, w_inT, g32, site, ln, ds16, M, ndrop, nbias)
         else:
-            _call("eend_gemm_acc_bf16", dqkv16, 3 * D, w_inT, 3 * D, g32, 1.0, g32, None, M, 3 * D)
+            self._gemm_acc(dqkv16, 3 * D, w_inT, g32, M)
 
     def backward(self, bf: _Buffers, dlogits: Optional[Tensor] = None, emb_loss_grad: float = 1.0):
         """Gradients w.r.t. every parameter -> self.flat.grads.  After forward(fused_loss=True): of bce + emb_loss.

@@ -438,7 +438,7 @@ class LsTrainStep(TrainStepBase):
             site, ln, ndrop, nbias = next_ln
             self._gemm_acc_ln_bwd(dq, 4 * D, W[wkey + ".wqkvgT"], g32, site, ln, ds16, M, ndrop, nbias)
         elif prenorm_site is None:
-            _call("eend_gemm_acc_bf16", dq, 4 * D, W[wkey + ".wqkvgT"], 4 * D, g32, 1.0, g32, None, M, 4 * D)
+            self._gemm_acc(dq, 4 * D, W[wkey + ".wqkvgT"], g32, M)
         else:
             dy = bf.dy16[:M]
             _call("eend_gemm_bf16", dq, 4 * D, W[wkey + ".wqkvgT"], 4 * D, None, dy, D, M, D, 4 * D)

@@ -510,6 +510,17 @@ typedef struct eend_dropout {
     float scale;
 } eend_dropout;
 
+/* g_f32[M][256] += A[M][K] Wt^T in place on a packed weight stream (gemm_acc_stream.hip, round 6): eend_gemm_acc_bf16(res = out = g,
+ * alpha = 1) for the data gradients whose K is large -- autograd of nn.MultiheadAttention's in_proj (K = 768; FS model :147,
+ * merge_tfm_encoder.py:379-385) and of MultiScaleRetention's projections (K = 1024; LS retention.py:146-160).  A bf16 [M][lda],
+ * Wt bf16 [256][ldw] (the transposed weight, as eend_gemm_acc_bf16 takes it), K a multiple of 128 in 256 .. 2048, re-ordered once per
+ * parameter version by eend_gemm_acc_stream_pack_bf16 into eend_gemm_acc_stream_elems(K) 16-bit elements.  eend_gemm_acc_stream_ok is
+ * the shape predicate; EEND_EINVAL otherwise (the caller keeps eend_gemm_acc_bf16 / eend_gemm_acc_lnbwd_bf16). */
+int eend_gemm_acc_stream_elems(int K);
+int eend_gemm_acc_stream_ok(int M, int K, int lda);
+int eend_gemm_acc_stream_pack_bf16(const void* Wt, int ldw, void* stream_out, int K, void* stream);
+int eend_gemm_acc_stream_bf16(const void* A, int lda, const void* wstream, float* g_f32, int M, int K, void* stream);
+
 /* K = 256 input projections on a packed weight stream (proj_stream.hip, round 6): nn.MultiheadAttention's in_proj (FS model :147,
  * merge_tfm_encoder.py:379-385) and MultiScaleRetention's q / k / v / g projections (LS retention.py:146-160) in the training forward,
  * where the f16 operands of the forward kernel and the bf16 Q / K / V the hand-written backward keeps used to be two projections of the

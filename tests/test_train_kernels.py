@@ -804,3 +804,30 @@ def test_prep_weights_table(T, dev):
     flat = w.reshape(40, -1)[:, :300].clone()
     flat[:8] *= 2.0
     assert torch.equal(d2[:, :300], flat.to(F16)) and (d2[:, 300:] == 0).all()
+
+
+@pytest.mark.parametrize("M,K", [(192, 768), (1000, 1024), (4096 + 48, 256), (131, 768), (50000, 768), (30000, 2048)])
+def test_gemm_acc_stream(hip_lib, dev, M, K):
+    """g += A Wt^T on the packed weight stream (gemm_acc_stream.hip) against float64 and against eend_gemm_acc_bf16 on the same operands;
+    ragged M (rows beyond M neither read into the result nor written), both tile heights"""
+    from fs_eend_amd import train as T, lib as L
+    g_ = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g_) * 0.5).to(dev).to(BF16)
+    wt = (torch.randn(256, K, generator=g_) / 16).to(dev).to(BF16)
+    g0 = torch.randn(M, 256, generator=g_).to(dev)
+    n = L.load().eend_gemm_acc_stream_elems(K)
+    assert n > 0 and L.load().eend_gemm_acc_stream_ok(M, K, K)
+    ws = torch.empty(n, dtype=BF16, device=dev)
+    T._call("eend_gemm_acc_stream_pack_bf16", wt, K, ws, K)
+    pad = torch.full((M + 256, 256), float("nan"), dtype=torch.float32, device=dev)
+    pad[:M] = g0
+    T._call("eend_gemm_acc_stream_bf16", a, K, ws, pad, M, K)
+    want = g0.double() + a.double() @ wt.double().t()
+    assert torch.isnan(pad[M:]).all()
+    err = (pad[:M].double() - want).abs().max().item()
+    g1 = g0.clone()
+    T._call("eend_gemm_acc_bf16", a, K, wt, K, g1, 1.0, g1, None, M, K)
+    err_old = (g1.double() - want).abs().max().item()
+    print(f"stream vs float64 {err:.2e} (tiled GEMM {err_old:.2e})")
+    assert err < 2e-4 * (K / 256) ** 0.5 + 1e-5
+    assert not L.load().eend_gemm_acc_stream_ok(M, 320, 320) and not L.load().eend_gemm_acc_stream_ok(M, 4096, 4096)

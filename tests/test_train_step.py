@@ -35,8 +35,14 @@ def _module(meta, dev):
                               None, pit=meta["pit"]), m
 
 
+@pytest.mark.parametrize("force_gacc_stream", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_train_step_vs_reference(hip_lib, dev, name):
+def test_train_step_vs_reference(hip_lib, dev, name, force_gacc_stream, monkeypatch):
+    if force_gacc_stream:
+        # the packed-stream data-gradient GEMM of the attention in-projections (gemm_acc_stream.hip + eend_layernorm_bwd_f32 in place of the
+        # tiled GEMM with the LayerNorm backward in its epilogue) is taken from 96 k rows; the goldens are smaller: same bars with it forced on
+        from fs_eend_amd.train import TrainStepBase
+        monkeypatch.setattr(TrainStepBase, "gacc_stream_min_rows", 0)
     meta, arr = FX.load_case(name)
     mod, m = _module(meta, dev)
     feats = [f.to(dev) for f in FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])]

@@ -58,6 +58,7 @@ def test_ls_train_step_vs_reference(hip_lib, dev, name, force_proj_stream, monke
         # rows) is taken from 48 k rows; the goldens are smaller, so the same bars are checked with it forced on
         from fs_eend_amd.train_ls import LsTrainStep
         monkeypatch.setattr(LsTrainStep, "proj_stream_min_rows", 0)
+        monkeypatch.setattr(LsTrainStep, "gacc_stream_min_rows", 0)          # ... and the packed-stream data-gradient GEMM (gemm_acc_stream.hip)
     meta, arr = FX.load_case(name)
     mod, m = _module(meta, dev)
     feats = [f.to(dev) for f in FX.make_src(meta["lengths"], meta["in_size"], meta["xseed"])]

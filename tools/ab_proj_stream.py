@@ -37,6 +37,12 @@ for nseq, Tp in ((384, 512), (64, 512), (768, 512), (128, 512)):
     ws = ops.proj_stream_pack(w)
     gr = [dict(rows=qb, kind=2), dict(rows=kb, kind=2), dict(rows=vb, kind=2)]
     t_new = timeit(lambda: ops.proj_stream(x, ws, b, M, 768, Tp, 4, gr))
+    # ... as the FS step calls it: with V^T for the forward attention kernel
+    vtb = torch.empty(n, dtype=BF16, device=dev)
+    t_old_vt = timeit(lambda: T._call("eend_inproj_heads_train_bf16", x, x.stride(0), w, b, qb, None, kb, None, vb, vtb, nseq, Tp, 4))
+    gr_vt = [dict(rows=qb, kind=2), dict(rows=kb, kind=2), dict(rows=vb, kind=2, heads_t=vtb)]
+    t_new_vt = timeit(lambda: ops.proj_stream(x, ws, b, M, 768, Tp, 4, gr_vt))
+    print(f"M {M}: FS in-proj heads + V^T {t_old_vt:.1f} -> {t_new_vt:.1f} us")
     # row-major [M][768] f16 (speaker-axis in-projection)
     o = torch.empty(M, 768, dtype=F16, device=dev)
     t_lin = timeit(lambda: ops.linear(x, w, b, o))
