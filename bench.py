@@ -784,7 +784,9 @@ class TrainCallTimer:
                 "eend_linear_relu_train_f16": (7, 8, 9)}
     # ops.* forward wrappers the LS step calls directly (not through _call): name -> shape extractor on the positional args
     OPS = {"linear": lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]),
-           "retention_proj": lambda a: (a[0].shape[0], 1024, 256), "convert_fanout": lambda a: (a[0].shape[0], 256, 256)}
+           "retention_proj": lambda a: (a[0].shape[0], 1024, 256), "convert_fanout": lambda a: (a[0].shape[0], 256, 256),
+           # one pass for the forward's f16 operands and the backward's bf16 head rows (proj_stream.hip): (rows, N, 256)
+           "proj_stream": lambda a: (int(a[3]), int(a[4]), 256)}
 
     def __init__(self, T):
         self.T, self.rec = T, []
@@ -839,6 +841,8 @@ class TrainCallTimer:
                 shape = (int(a[15]), int(a[16]), 256)
             elif name == "eend_ffn_bwd_data_stream_bf16":
                 shape = (int(a[7]), int(a[8]), 256)
+            elif name == "eend_gemm_acc_stream_bf16":         # (rows, 256 output features, K) on the packed weight stream (round 6)
+                shape = (int(a[4]), 256, int(a[5]))
             else:
                 shape = ()
             self.rec.append((name, shape, s, e))
