@@ -225,6 +225,17 @@ int eend_proj_stream_f16(const void* X, int ldx, const void* wstream, const floa
     return eend_launch_proj_stream(p, (hipStream_t)stream);
 }
 
+int eend_inproj_attn_train_bf16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16, int ldo, void* Q_bf16,
+                                void* K_bf16, void* V_bf16, float* lse, int nseq, int H, int Tp, int mask_delay, int kv_len,
+                                const eend_dropout* drop, void* stream) {
+    if (!X_f16 || !W_packed || !b_in || !O_f16 || !Q_bf16 || !K_bf16 || !V_bf16 || !lse || nseq > 16383) return EEND_EINVAL;
+    InprojAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.X = X_f16; p.ldx = ldx; p.W = W_packed; p.bias = b_in; p.O = O_f16; p.ldo = ldo; p.Qh = Q_bf16; p.Kh = K_bf16; p.Vh = V_bf16; p.lse = lse;
+    p.nseq = nseq; p.H = H; p.Tp = Tp; p.mask_delay = mask_delay; p.kv_len = kv_len; p.drop = drop_spec(drop);
+    return eend_launch_inproj_attn_train(p, (hipStream_t)stream);
+}
+
 int eend_attn_causal_lse_bf16(const void* Q, const void* K, const void* Vt, void* O_f16, float* lse, int nseq, int H,
                               int Tp, int ldo, int mask_delay, int kv_len, float scale, const eend_dropout* drop,
                               void* stream) {

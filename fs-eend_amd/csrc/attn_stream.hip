@@ -76,9 +76,17 @@ __device__ unsigned long long g_as_trace[256 * 6 * 12];
 // group's (the wave's X fragments are loaded a second time between the Q and the K items), runs the same flash passes with the causal
 // limit shifted by the distance of the groups and writes its normalised partial result into a scratch slot.  Every item also leaves the
 // log2 of its softmax denominators; attn_long_combine_kernel weighs the partial rows of a query group with them.
-template <bool LONG>
+// TRAIN (round 6, windows up to 512 frames): the training forward of the same operator -- what eend_inproj_heads_train_bf16 +
+// eend_attn_causal_lse_bf16 did in two launches with Q / K / V^T through HBM in between.  The key bias is applied (the saved K is the
+// reference's K), Q / K / V also leave as bf16 head rows [seq][H][Tp][64] for the hand-written backward (V a second time in the other
+// MFMA orientation: a lane then owns 4 features of a token), the probabilities are dropped by the counter hash of eend_dropout (element
+// (a, b) = ((seq H + head) Tp + query, key); the row sums stay un-dropped) and the log2-domain log-sum-exp of every row is kept.
+// FULL: Tp = 512 known at compile time (the block map is (wave, 15 - wave) and no pass is skipped: the round-4 kernel, register for register)
+template <bool LONG, bool TRAIN = false, bool FULL = false>
 __global__ __launch_bounds__(512)
 void inproj_attn_stream_kernel(const InprojAttnParams p) {
+    static_assert(!(LONG && TRAIN), "the training form covers windows up to 512 frames");
+    static_assert(!(LONG && FULL), "groups of a long window have their own lengths");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem + L_K;                           // [8][64 keys][128 B]
     char* Vs = smem + L_V;                           // [8][64 d][128 B]; before that: weight items 0..3
@@ -106,9 +114,9 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
     // (w, nblk - 1 - w) of real blocks, the others two each of the 16 - nblk block slots beyond Tp -- their rows read as zeros (buffer
     // bounds), their K / V rows are finite and masked (key >= kv_len), their flash passes are skipped -- so that every slot of the LDS
     // tiles is written exactly once as before
-    int nblk = p.Tp >> 5;
-    int b1 = wave < (nblk >> 1) ? wave : nblk + 2 * (wave - (nblk >> 1));
-    int b2 = wave < (nblk >> 1) ? nblk - 1 - wave : b1 + 1;
+    int nblk = FULL ? 16 : p.Tp >> 5;
+    int b1 = FULL ? wave : (wave < (nblk >> 1) ? wave : nblk + 2 * (wave - (nblk >> 1)));
+    int b2 = FULL ? 15 - wave : (wave < (nblk >> 1) ? nblk - 1 - wave : b1 + 1);
     // item geometry (LONG: set per item): first row and row count of the query / key group, causal limit and valid keys in key-group terms
     int qoff = 0, koff = 0, Tq = p.Tp, Tk = p.Tp, dl = p.mask_delay, kvl = p.kv_len, pair = 0;
     bool offd = false;
@@ -174,11 +182,18 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
         // bias is dropped: q . b_k is the same for every key of a query and cancels in the softmax.
         f32x4 bq4[4];
         float bv1[4];
+        f32x4 bk4[TRAIN ? 4 : 1], bv4[TRAIN ? 4 : 1];
 #pragma unroll
         for (int ff = 0; ff < 4; ++ff) {
             const float4 t4 = *(const float4*)(p.bias + h * 64 + ff * 16 + fkg * 4);
             bq4[ff] = f32x4{t4.x, t4.y, t4.z, t4.w};
             bv1[ff] = p.bias[512 + h * 64 + ff * 16 + frow];
+            if constexpr (TRAIN) {
+                const float4 k4 = *(const float4*)(p.bias + 256 + h * 64 + ff * 16 + fkg * 4);
+                const float4 v4 = *(const float4*)(p.bias + 512 + h * 64 + ff * 16 + fkg * 4);
+                bk4[ff] = f32x4{k4.x, k4.y, k4.z, k4.w};
+                bv4[ff] = f32x4{v4.x, v4.y, v4.z, v4.w};
+            }
         }
         // the head's six weight items: this wave moves pieces 2 wave, 2 wave + 1 of each
 #pragma unroll
@@ -227,13 +242,18 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
             relaunder();
             const char* wi = smem + lane * 16 + (n < 4 ? L_V + n * WITEM : L_X + (n - 4) * WITEM);
             f32x4 acc[2][4];
+            f32x4 accv[TRAIN && kind == 2 ? 2 : 1][4];            // TRAIN: V a second time with the token as the lane's column (head rows for the backward)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (kind == 2) b4 = f32x4{bv1[ffb + hf], bv1[ffb + hf], bv1[ffb + hf], bv1[ffb + hf]};      // V^T: the feature is the lane's column
                 else if constexpr (kind == 0) b4 = bq4[ffb + hf];
+                else if constexpr (TRAIN) b4 = bk4[ffb + hf];
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) acc[hf][jt] = b4;
+                for (int jt = 0; jt < 4; ++jt) {
+                    acc[hf][jt] = b4;
+                    if constexpr (TRAIN && kind == 2) accv[hf][jt] = bv4[ffb + hf];
+                }
             }
             // 16 fragments, 4 MFMAs each; fragment reads run PD ahead in a rotation of NB registers, pinned per fragment pair
             // (left to itself the scheduler hoists every read of the item to its top and the register file overflows)
@@ -249,6 +269,7 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
                     for (int jt = 0; jt < 4; ++jt) {
                         if constexpr (kind == 2) acc[hf][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[jt][ks], w, acc[hf][jt], 0, 0, 0);    // rows = key
                         else acc[hf][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x[jt][ks], acc[hf][jt], 0, 0, 0);                        // rows = d
+                        if constexpr (TRAIN && kind == 2) accv[hf][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x[jt][ks], accv[hf][jt], 0, 0, 0);
                     }
                     if constexpr (pi + PD < 16) wf[(pi + PD) % NB] = *(const f16x8*)(wi + (pi + PD) * 1024);
                 });
@@ -260,6 +281,15 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     const u32x2 v = pack_bf16x4(acc[hf][jt]);
+                    if constexpr (TRAIN) {
+                        // bf16 head rows for the backward: 4 features of a token per lane (block slots beyond Tp hold no frames)
+                        const int tok = tokbase(jt) + frow;
+                        if (tok < p.Tp) {
+                            __bf16* dst = (__bf16*)(kind == 0 ? p.Qh : kind == 1 ? p.Kh : p.Vh) + (((size_t)(seq * 4 + h) * p.Tp + tok) * 64 + (ffb + hf) * 16 + fkg * 4);
+                            if constexpr (kind == 2) *(u32x2*)dst = pack_bf16x4(accv[hf][jt]);
+                            else *(u32x2*)dst = v;
+                        }
+                    }
                     if constexpr (kind == 0) {
                         qpk[ffb + hf][jt] = v;
                     } else if constexpr (kind == 1) {
@@ -359,6 +389,16 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
             lsum1 += s[1][i];
         }
         l_run += lsum0 + lsum1;
+        if constexpr (TRAIN) {                         // dropout of the probabilities (the row sum stays un-dropped)
+            if (p.drop.thresh24) {
+                const unsigned da = (unsigned)((seq * 4 + h) * p.Tp + q);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s[kb][i] = drop_apply(p.drop, s[kb][i], da, (unsigned)(key0 + kb * 32 + (i & 7) + 8 * hi + 16 * (i >> 3)));
+            }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -386,6 +426,9 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
         if constexpr (LONG) {
             if (hi == 0) p.lse[((size_t)(pair * p.nseq + seq) * 4 + h) * TP + q] = l_tot > 0.f ? __builtin_amdgcn_logf(l_tot) - mneg[0] : -1e30f;
         }
+        if constexpr (TRAIN) {                         // log2-domain log-sum-exp of the row, for the backward
+            if (hi == 0) p.lse[(size_t)(seq * 4 + h) * p.Tp + q] = __builtin_amdgcn_logf(l_tot) - mneg[0];
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -411,9 +454,9 @@ void inproj_attn_stream_kernel(const InprojAttnParams p) {
         }
         wave_lds_sync();
     };
-    if (b2 < nblk) run_pass(b2, std::integral_constant<int, 2>{});      // (wave-uniform: a pass has no workgroup barrier)
+    if (FULL || b2 < nblk) run_pass(b2, std::integral_constant<int, 2>{});      // (wave-uniform: a pass has no workgroup barrier)
     AS_STAMP(9);
-    if (b1 < nblk) run_pass(b1, std::integral_constant<int, 0>{});
+    if (FULL || b1 < nblk) run_pass(b1, std::integral_constant<int, 0>{});
     AS_STAMP(10);
     AS_STAMP(11);
 #ifdef EEND_AS_TRACE
@@ -486,13 +529,35 @@ int eend_launch_inproj_attn_pack(const void* W, void* out, hipStream_t stream) {
 int eend_launch_inproj_attn_stream(const InprojAttnParams& p, hipStream_t stream) {
     if (p.Tp <= 0 || p.Tp > TP || (p.Tp & 63) || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O) return EEND_EINVAL;
     static EendOncePerDevice attr_once;
-    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<false>, SMEM)) return EEND_ELAUNCH;
+    static EendOncePerDevice attr_once_full;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<false, false, false>, SMEM)) return EEND_ELAUNCH;
+    if (!eend_set_dynamic_lds(attr_once_full, (const void*)inproj_attn_stream_kernel<false, false, true>, SMEM)) return EEND_ELAUNCH;
     int n_cu = eend_cu_count() & ~31;                // multiple of 32: a persistent workgroup keeps its head (and its XCD)
     if (n_cu <= 0) n_cu = 32;
     const int nitems = p.nseq * 4;
     InprojAttnParams q = p;
     q.npairs = 0; q.Opart = nullptr; q.lse = nullptr;
-    hipLaunchKernelGGL(inproj_attn_stream_kernel<false>, dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, q);
+    if (p.Tp == TP) hipLaunchKernelGGL((inproj_attn_stream_kernel<false, false, true>), dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, q);
+    else hipLaunchKernelGGL((inproj_attn_stream_kernel<false, false, false>), dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, q);
+    return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
+}
+
+// training forward (Tp = 64 m <= 512): p.Qh / p.Kh / p.Vh bf16 head rows and p.lse [nseq][4][Tp] out, p.drop on the probabilities
+int eend_launch_inproj_attn_train(const InprojAttnParams& p, hipStream_t stream) {
+    if (p.Tp <= 0 || p.Tp > TP || (p.Tp & 63) || (p.ldo & 7) || (p.ldx & 7) || p.H != 4 || p.nseq <= 0 || !p.X || !p.W || !p.bias || !p.O || !p.Qh || !p.Kh ||
+        !p.Vh || !p.lse || p.kv_len < 1 || (long)p.nseq * 4 * p.Tp >= (1L << 31))
+        return EEND_EINVAL;
+    static EendOncePerDevice attr_once;
+    static EendOncePerDevice attr_once_full;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<false, true, false>, SMEM)) return EEND_ELAUNCH;
+    if (!eend_set_dynamic_lds(attr_once_full, (const void*)inproj_attn_stream_kernel<false, true, true>, SMEM)) return EEND_ELAUNCH;
+    int n_cu = eend_cu_count() & ~31;
+    if (n_cu <= 0) n_cu = 32;
+    const int nitems = p.nseq * 4;
+    InprojAttnParams q = p;
+    q.npairs = 0; q.Opart = nullptr;
+    if (p.Tp == TP) hipLaunchKernelGGL((inproj_attn_stream_kernel<false, true, true>), dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, q);
+    else hipLaunchKernelGGL((inproj_attn_stream_kernel<false, true, false>), dim3(nitems < n_cu ? nitems : n_cu), dim3(512), SMEM, stream, q);
     return hipGetLastError() == hipSuccess ? EEND_OK : EEND_ELAUNCH;
 }
 
@@ -539,12 +604,12 @@ int eend_launch_inproj_attn_long(const InprojAttnParams& p0, hipStream_t stream)
     p.npairs = attn_long_pairs(p.Tp, p.mask_delay, p.kv_len, p.pq, p.pk, p.pslot, &noff);
     if (p.npairs == 0 || (noff > 0 && !p.Opart)) return EEND_EINVAL;
     static EendOncePerDevice attr_once;
-    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<true>, SMEM)) return EEND_ELAUNCH;
+    if (!eend_set_dynamic_lds(attr_once, (const void*)inproj_attn_stream_kernel<true, false>, SMEM)) return EEND_ELAUNCH;
     int n_cu = eend_cu_count() & ~31;
     if (n_cu <= 0) n_cu = 32;
     const long nitems = (long)p.nseq * 4 * p.npairs;
     if (nitems > (1L << 30)) return EEND_EINVAL;
-    hipLaunchKernelGGL(inproj_attn_stream_kernel<true>, dim3(nitems < n_cu ? (int)nitems : n_cu), dim3(512), SMEM, stream, p);
+    hipLaunchKernelGGL((inproj_attn_stream_kernel<true, false>), dim3(nitems < n_cu ? (int)nitems : n_cu), dim3(512), SMEM, stream, p);
     if (hipGetLastError() != hipSuccess) return EEND_ELAUNCH;
     if (noff > 0) {
         hipLaunchKernelGGL(attn_long_combine_kernel, dim3((p.Tp + 7) / 8, p.nseq), dim3(256), 0, stream, p);

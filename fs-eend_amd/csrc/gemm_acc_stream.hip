@@ -103,10 +103,6 @@ void gemm_acc_stream_kernel(const GemmAccStreamParams p) {
             for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
     };
 
-#ifdef GAS_STAGGER
-    // timing study: workgroups start a quarter of a tile apart in four groups (s_sleep 127 = 8128 cycles)
-    for (int i = 0; i < (int)(blockIdx.x & 3) * GAS_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63; frow = lane & 15; g = lane >> 4; fo = g * 64;

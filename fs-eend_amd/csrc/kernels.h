@@ -143,7 +143,11 @@ struct InprojAttnParams {
     void* Opart;                 // f16 [off-diagonal slot][nseq][512][256]: normalised partial rows
     float* lse;                  // [item of the table][nseq][4][512]: log2 of the softmax denominators
     unsigned char pq[EEND_ATTN_LONG_MAX_PAIRS], pk[EEND_ATTN_LONG_MAX_PAIRS], pslot[EEND_ATTN_LONG_MAX_PAIRS];
+    // training forward (eend_launch_inproj_attn_train): bf16 head rows [seq][H][Tp][64] for the backward, lse [nseq][4][Tp], dropout of P
+    void* Qh; void* Kh; void* Vh;
+    DropSpec drop;
 };
+int eend_launch_inproj_attn_train(const InprojAttnParams& p, hipStream_t stream);
 long eend_inproj_attn_packed_nelems();
 int eend_inproj_attn_long_scratch(int nseq, int Tp, int mask_delay, int kv_len, long* part_elems, long* lse_elems);
 int eend_launch_inproj_attn_long(const InprojAttnParams& p, hipStream_t stream);

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "eend_inproj_attn_packed_elems": [],
     "eend_inproj_attn_pack_f16": [_vp, _vp, _vp],
     "eend_inproj_attn_causal_packed_f16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "eend_inproj_attn_train_bf16": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "eend_gemm_acc_stream_elems": [_i],
     "eend_gemm_acc_stream_ok": [_i, _i, _i],
     "eend_gemm_acc_stream_pack_bf16": [_vp, _i, _vp, _i, _vp],

@@ -291,6 +291,13 @@ class TrainStepBase:
                 if n > 0:
                     self._gacc_streams[key] = torch.empty(n, dtype=BF16, device=self.dev)
         self._gacc_of_w = {self.W[k].data_ptr(): k for k in self._gacc_streams}
+        # time-axis attention in-projections (X.in_w / X.in1_w, f16 [768][256]): packed for the one-launch training forward (attn_stream.hip)
+        self._attn_packed = {}
+        for key in list(self.W):
+            w = self.W[key]
+            if (key.endswith(".in_w") or key.endswith(".in1_w")) and w.dtype == F16 and tuple(w.shape) == (3 * D, D):
+                self._attn_packed[key] = torch.empty(_lib.load().eend_inproj_attn_packed_elems(), dtype=F16, device=self.dev)
+        self._attn_packed_of_w = {self.W[k].data_ptr(): k for k in self._attn_packed}
 
     def prep_weights(self):
         """f32 parameters -> MFMA operand copies (one launch), then the packed FFN streams."""
@@ -300,6 +307,8 @@ class TrainStepBase:
             _call("eend_ffn_train_stream_pack", self.W[pre + ".w2T"], self.W[pre + ".w1T"], bw, Fh)
         for key, buf in self._proj_streams.items():
             _call("eend_proj_stream_pack_f16", self.W[key], buf, int(self.W[key].shape[0]))
+        for key, buf in self._attn_packed.items():
+            _call("eend_inproj_attn_pack_f16", self.W[key], buf)
         for key, buf in self._gacc_streams.items():
             w = self.W[key]
             _call("eend_gemm_acc_stream_pack_bf16", w, w.stride(0), buf, int(w.shape[1]))
@@ -394,6 +403,7 @@ class TrainStepBase:
         else:
             _call("eend_gemm_acc_bf16", a16, K, wT, K, g32, 1.0, g32, None, M, K)
 
+    attn_train_fused = True             # (tests compare against the two-launch forward by clearing it)
     gacc_stream_min_rows = 98304        # rows from which gemm_acc_stream.hip + eend_layernorm_bwd_f32 beat the fused tiled launch (tests set 0)
 
     def _gemm_acc_ln_bwd(self, a16, K, wT, g32, site, ln, ds16, M, drop=None, bias=None):
@@ -611,6 +621,12 @@ class FsTrainStep(TrainStepBase):
     SITE_ATT, SITE_OUT1, SITE_SPK, SITE_OUT2, SITE_FF, SITE_FFOUT = 0, 1, 2, 3, 4, 5
 
     def _attn_fwd(self, x16, w, bias, sv: _AttnSave, nseq, Tp, mask_delay, kv_len, drop=None):
+        key = self._attn_packed_of_w.get(w.data_ptr())
+        if key is not None and Tp <= 512 and H == 4 and self.attn_train_fused:
+            # in-projection + attention in one launch, Q / K / V^T on chip in between; bf16 head rows + lse saved for the backward
+            _call("eend_inproj_attn_train_bf16", x16, x16.stride(0), self._attn_packed[key], bias, sv.ctx, D, sv.q, sv.k, sv.v, sv.lse, nseq, H, Tp,
+                  mask_delay, kv_len, drop)
+            return
         _call("eend_inproj_heads_train_bf16", x16, x16.stride(0), w, bias, sv.q, sv.qt, sv.k, sv.kt, sv.v, sv.vt, nseq, Tp, H)
         _call("eend_attn_causal_lse_bf16", sv.q, sv.k, sv.vt, sv.ctx, sv.lse, nseq, H, Tp, D, mask_delay, kv_len, ops.LN2, drop)
 

@@ -510,6 +510,17 @@ typedef struct eend_dropout {
     float scale;
 } eend_dropout;
 
+/* Training forward of nn.MultiheadAttention(x, x, x) on the time axis in one launch (attn_stream.hip, round 6; windows Tp = 64 m <= 512,
+ * H = 4): eend_inproj_heads_train_bf16 + eend_attn_causal_lse_bf16 with Q / K / V^T staying on chip between projection and attention.
+ * W_packed = eend_inproj_attn_pack_f16 of the f16 in-projection operand copy (q rows pre-scaled as for the two entries it replaces), b_in
+ * [768] (the key bias IS applied here: the saved K is the reference's).  Out: O_f16 [nseq*Tp][ldo] (the heads' context rows), Q / K / V
+ * bf16 head rows [nseq][H][Tp][64] and lse [nseq][H][Tp] (log2 domain) for eend_attn_causal_bwd_bf16; `drop` acts on the attention
+ * probabilities, element ((seq*H + head)*Tp + query, key), as in eend_attn_causal_lse_bf16.  EEND_EINVAL for longer windows: the caller
+ * keeps the two entries (and the [d][t] copies their backward reads). */
+int eend_inproj_attn_train_bf16(const void* X_f16, int ldx, const void* W_packed, const float* b_in, void* O_f16, int ldo, void* Q_bf16,
+                                void* K_bf16, void* V_bf16, float* lse, int nseq, int H, int Tp, int mask_delay, int kv_len,
+                                const eend_dropout* drop, void* stream);
+
 /* g_f32[M][256] += A[M][K] Wt^T in place on a packed weight stream (gemm_acc_stream.hip, round 6): eend_gemm_acc_bf16(res = out = g,
  * alpha = 1) for the data gradients whose K is large -- autograd of nn.MultiheadAttention's in_proj (K = 768; FS model :147,
  * merge_tfm_encoder.py:379-385) and of MultiScaleRetention's projections (K = 1024; LS retention.py:146-160).  A bf16 [M][lda],
