@@ -87,14 +87,15 @@ def pmc_traffic(kernel, shape):
     FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per MI355X_MICROARCH.md).  Only the
     default workload (B=64, T=500, C=6) was profiled; anything else -> None."""
     path = pmc_traffic_file()[0]
-    tags = {("attnout_ffn_stream", (196608, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 3>",), "65536"),
-            ("attnout_ffn_stream", (32768, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 2>",), "65536"),
+    # (alternatives; an alternative that is a tuple needs all its pieces in the kernel name: template lists grew over the rounds)
+    tags = {("attnout_ffn_stream", (196608, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 3",), "65536"),
+            ("attnout_ffn_stream", (32768, 2048, 256)): (("ffn_stream_kernel<1, 1, 0, true, 2",), "65536"),
             ("attnout_ffn_fused", (196608, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #hi", "ffn_fused_kernel<1, 0, true>(FfnParams) #hi"), "131072"),
             ("attnout_ffn_fused", (32768, 2048, 256)): (("ffn_fused_kernel<1, 0, 1>(FfnParams) #lo", "ffn_fused_kernel<1, 0, true>(FfnParams) #lo"), "131072"),
-            ("attnout_spk_stream", (196608,)): (("spk_stream_kernel<8>",), "65536"),
+            ("attnout_spk_stream", (196608,)): (("spk_stream_kernel<8",), "65536"),
             ("conv1d_l2norm_stream", (32768, 256, 4864)): (("conv_stream_kernel",), "65536"),
-            ("inproj_attn_causal_packed", (64, 4)): (("inproj_attn_stream_kernel(InprojAttnParams) #lo",), "131072"),
-            ("inproj_attn_causal_packed", (384, 4)): (("inproj_attn_stream_kernel(InprojAttnParams) #hi",), "131072"),
+            ("inproj_attn_causal_packed", (64, 4)): ((("inproj_attn_stream_kernel", " #lo"),), "131072"),
+            ("inproj_attn_causal_packed", (384, 4)): ((("inproj_attn_stream_kernel", " #hi"),), "131072"),
             ("attn_causal", (64, 4)): (("attn_causal_full_kernel",), "131072"),
             ("attn_causal", (384, 4)): (("attn_causal_full_kernel",), "786432"),
             ("linear_res_ln", (196608, 256, 256)): (("gemm_f16_kernel<64, 256, 1, 4, true, 0, 4", "gemm_f16_kernelIDF16_Li64ELi256ELi1ELi4ELb1ELi0ELi4ELi0E"), "786432")}
@@ -102,7 +103,7 @@ def pmc_traffic(kernel, shape):
     if tag is None or not os.path.exists(path):
         return None
     for k, v in json.load(open(path))["kernels"].items():
-        if any(t in k for t in tag[0]) and k.endswith("grid=" + tag[1]):
+        if any((all(u in k for u in t) if isinstance(t, tuple) else t in k) for t in tag[0]) and k.endswith("grid=" + tag[1]):
             return v["hbm_bytes"]
     return None
 
