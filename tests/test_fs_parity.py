@@ -138,3 +138,21 @@ def test_weights_update_is_seen(hip_lib, dev):
         m.dec.convert.bias.add_(0.5)
     b = m.test(src, meta["lengths"], 4)[0][0]
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("T", [1000, 2900, 4000])
+def test_whole_recording_windows_agree_with_the_chunk(hip_lib, dev, T):
+    """The three attention forms of model.test see the same frames: with causal masks and a 9-frame look-ahead conv the first 480 frames of
+    a long recording are the first 480 frames of its 500-frame prefix (packed kernel, Tp = 512) -- on the grouped form (512 < Tp <= 3072:
+    (query group, key group) items + combine pass) and on the tiled fallback beyond (in-projection through HBM + attn.hip), within the
+    logit tolerance of the reference parity tests."""
+    meta, _ = FX.load_case("fs_full_T500_c4")
+    m = build_fs_mirror(meta).to(dev)
+    C = 4
+    src = [s.to(dev) for s in FX.make_src([T, T - 137], 345, 4242)]
+    long_out = m.test(src, [T, T - 137], C)[0]
+    short_out = m.test([s[:500] for s in src], [500, 500], C)[0]
+    torch.cuda.synchronize()
+    for a, b in zip(long_out, short_out):
+        assert torch.isfinite(a).all()
+        assert max_abs(a[:480], b[:480].cpu()) < LOGIT_TOL
