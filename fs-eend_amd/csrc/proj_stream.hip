@@ -12,6 +12,8 @@
 // Reference sites: nn.MultiheadAttention in_proj (FS model :147, merge_tfm_encoder.py:379-385), MultiScaleRetention q / k / v / g
 // projections (LS retention.py:146-160).  proj.hip (X tile resident in LDS, two workgroup barriers per 64 features and destination)
 // stays as the general form: [196608, 768]: 189 us there.
+// Study switches (timing only, tools/build_variant.sh; several are not valid kernels): PS_NOSTORE no destination stores, PS_WAIT60 the item
+// barrier waits for (almost) nothing, PS_NOBARRIER no item barrier, PS_NODMA no weight DMA after the prologue.
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
